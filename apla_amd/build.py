@@ -1,0 +1,48 @@
+"""Build libapla_hip.so (gfx950 only) in-tree with hipcc.  No torch headers, no pybind: a plain C-ABI shared library
+that Python binds through ctypes (apla_amd/_lib.py).  ``python -m apla_amd.build`` or ``__graft_entry__.build()``."""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libapla_hip.so")
+SOURCES = ["errors.cpp", "gemm_nt.hip", "layernorm.hip", "attention.hip", "apla_dw.hip", "optim.hip", "misc.hip"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"]
+
+
+def _stale(obj, src):
+    if not os.path.exists(obj):
+        return True
+    deps = [src, os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "apla_hip.h")]
+    return any(os.path.getmtime(d) > os.path.getmtime(obj) for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    jobs = []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(objdir, s.rsplit(".", 1)[0] + ".o")
+        if force or _stale(obj, src):
+            cmd = [HIPCC] + FLAGS + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", src, "-o", obj]
+            jobs.append(cmd)
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed:\n{r.stdout}\n{r.stderr}")
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(run, jobs))
+    objs = [os.path.join(objdir, s.rsplit(".", 1)[0] + ".o") for s in SOURCES]
+    if jobs or not os.path.exists(OUT):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

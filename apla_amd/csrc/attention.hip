@@ -1,0 +1,423 @@
+// Fused multi-head attention (head_dim 64) forward + deterministic backward for gfx950.
+//
+// Data layout: the packed qkv activation [B*N, 3*H*64] exactly as the qkv Linear produces it ([.., 3, H, 64]);
+// o / do are [B*N, H*64] (heads already merged), so neither the reshape/permute copies of appla_attn.py:53-54 nor the
+// transpose(1,2).reshape of :60 exist.  The [B,H,N,N] score tensor is never written.
+//
+// All products use v_mfma_f32_32x32x16_bf16 in the "reduction-axis on the lane's registers" orientation:
+//   forward   S^T = K·Q^T (key rows, q on the lane) -> online softmax is lane-local (one lane^32 exchange per row op)
+//             O^T += V^T · P^T   with P^T taken straight from the accumulator as the B operand
+//   backward  kernel dQ   (one wave = 32 query rows): S^T, dP^T = V·dO^T, dQ^T += K^T · dS^T
+//             kernel dKdV (one wave = 32 keys):       S = Q·K^T, dP = dO·V^T, dV^T += dO^T · P, dK^T += Q^T · dS
+// The transposed operands (V^T, K^T, dO^T, Q^T) come from the SAME row-major LDS tile through ds_read_b64_tr_b16;
+// tiles use one XOR swizzle that is conflict-free for both the ds_read_b128 row reads and the transposed reads.
+// dQ and dK/dV are produced by separate kernels so that no cross-workgroup reduction (atomics) is needed: results are
+// bitwise reproducible.  delta = rowsum(dO*O) is produced by the dQ kernel and consumed by the dKdV kernel.
+#include "common.h"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+// 64-column bf16 tile (128-byte rows), 16-byte chunk index XOR f(row): conflict-free for ds_read_b128 row fragments
+// (32 rows x one chunk) and for ds_read_b64_tr_b16 blocks (4 rows x 64 bytes per half-wave).
+__device__ __forceinline__ int tile_off(int row, int chunk) {
+  const int f = (((row >> 1) & 1) << 2) | ((row >> 2) & 3);
+  return row * 128 + ((chunk ^ f) << 4);
+}
+
+// Stage a [ROWS x 64] bf16 tile: global (row stride ld elements, rows clamped to [0, nrows)) -> registers.
+template <int ROWS>
+struct TileRegs { bf16x8 v[ROWS * 8 / 256]; };
+
+template <int ROWS>
+__device__ __forceinline__ void tile_load(TileRegs<ROWS>& t, const bf16* base, long ld, int row0, int nrows, int tid) {
+#pragma unroll
+  for (int i = 0; i < ROWS * 8 / 256; ++i) {
+    const int e = tid + i * 256, row = e >> 3, chunk = e & 7;
+    int gr = row0 + row;
+    gr = gr < nrows ? gr : nrows - 1;
+    t.v[i] = *(const bf16x8*)(base + (long)gr * ld + chunk * 8);
+  }
+}
+template <int ROWS>
+__device__ __forceinline__ void tile_store(const TileRegs<ROWS>& t, char* lds, int tid) {
+#pragma unroll
+  for (int i = 0; i < ROWS * 8 / 256; ++i) {
+    const int e = tid + i * 256, row = e >> 3, chunk = e & 7;
+    *(bf16x8*)(lds + tile_off(row, chunk)) = t.v[i];
+  }
+}
+
+// Row fragment (A operand, 32 rows x 16 k): lane l holds tile[row0 + (l&31)][16*ks + 8*(l>>5) + 0..7]
+__device__ __forceinline__ bf16x8 row_frag(const char* lds, int row0, int ks, int lane) {
+  return *(const bf16x8*)(lds + tile_off(row0 + (lane & 31), 2 * ks + (lane >> 5)));
+}
+
+// Transposed fragment (A operand = tile^T, 32 "columns of the tile" x 16 "rows of the tile"):
+// element j of lane l = tile[rbase + 8*(j>>2) + 4*(l>>5) + (j&3)][c0 + (l&31)], matching the k-order in which a 32x32 f32
+// accumulator is consumed as the other operand (see cdna guide: accumulator tile as next MFMA operand).
+__device__ __forceinline__ bf16x8 tr_frag(const char* lds, int rbase, int c0, int lane) {
+  const int g = lane >> 4, i = lane & 15;
+  const int col = c0 + 16 * (g & 1) + 4 * (i & 3);  // this lane's address: 4 consecutive columns of one row
+  const int r = rbase + 4 * (g >> 1) + (i >> 2);
+  const int a0 = tile_off(r, col >> 3) + ((col & 4) << 1);
+  const int a1 = tile_off(r + 8, col >> 3) + ((col & 4) << 1);
+  bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(lds + a0));
+  bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(lds + a1));
+  bf16x8 out;
+  out[0] = lo[0]; out[1] = lo[1]; out[2] = lo[2]; out[3] = lo[3];
+  out[4] = hi[0]; out[5] = hi[1]; out[6] = hi[2]; out[7] = hi[3];
+  return out;
+}
+
+__device__ __forceinline__ bf16x8 acc_to_operand(const f32x16& a, int s) {
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (bf16)a[8 * s + j];
+  return o;
+}
+
+// row index (within a 32-row tile) of accumulator register `reg` for lane half h
+__device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+// Register fragment straight from global (B operand with the matrix row on the lane):
+// lane l holds M[row][16*ks + 8*(l>>5) + 0..7] for ks = 0..3
+__device__ __forceinline__ void load_row_frags(bf16x8 (&f)[4], const bf16* rowptr, int lane) {
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) f[ks] = *(const bf16x8*)(rowptr + 16 * ks + 8 * (lane >> 5));
+}
+
+// Store a transposed accumulator pair (acc[dt][reg] = X[d = 32dt + acc_row(reg,h)][row on lane]) as bf16 to a row-major
+// [rows, 64] slice: 8-byte pieces of 4 consecutive d.
+__device__ __forceinline__ void store_acc_T(const f32x16 (&acc)[2], bf16* rowptr, int h, float mul) {
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      bf16x4 v = pack4(acc[dt][4 * g] * mul, acc[dt][4 * g + 1] * mul, acc[dt][4 * g + 2] * mul, acc[dt][4 * g + 3] * mul);
+      *(bf16x4*)(rowptr + 32 * dt + 8 * g + 4 * h) = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
+                                                       float* __restrict__ lse, int N, int H, float scale) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * 8192];
+  char* Ks = smem;
+  char* Vs = smem + 8192;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h2 = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128;
+  const int D = H * 64;
+  const long ld = 3L * D;
+  const bf16* base = qkv + (long)b * N * ld + h * 64;
+  const float c = scale * LOG2E;
+
+  int q = q0 + wave * 32 + (lane & 31);
+  const bool qvalid = q < N;
+  if (!qvalid) q = N - 1;
+  bf16x8 qf[4];
+  load_row_frags(qf, base + (long)q * ld, lane);
+
+  f32x16 acc_o[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { acc_o[0][i] = 0.f; acc_o[1][i] = 0.f; }
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int nkb = (N + 63) / 64;
+  TileRegs<64> kr, vr;
+  tile_load<64>(kr, base + D, ld, 0, N, tid);
+  tile_load<64>(vr, base + 2 * D, ld, 0, N, tid);
+  for (int kb = 0; kb < nkb; ++kb) {
+    __syncthreads();
+    tile_store<64>(kr, Ks, tid);
+    tile_store<64>(vr, Vs, tid);
+    __syncthreads();
+    if (kb + 1 < nkb) {
+      tile_load<64>(kr, base + D, ld, (kb + 1) * 64, N, tid);
+      tile_load<64>(vr, base + 2 * D, ld, (kb + 1) * 64, N, tid);
+    }
+    f32x16 s[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s[kt][i] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Ks, kt * 32, ks, lane), qf[ks], s[kt], 0, 0, 0);
+    }
+    if (kb * 64 + 64 > N) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (kb * 64 + kt * 32 + acc_row(i, h2) >= N) s[kt][i] = -INFINITY;
+    }
+    float mx = s[0][0];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[kt][i]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = exp2f((m_run - m_new) * c);
+    const float mc = m_new * c;
+    float rs = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        s[kt][i] = exp2f(fmaf(s[kt][i], c, -mc));
+        rs += s[kt][i];
+      }
+    l_run = l_run * alpha + rs;
+    m_run = m_new;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc_o[0][i] *= alpha; acc_o[1][i] *= alpha; }
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int sk = 0; sk < 2; ++sk) {
+        const bf16x8 pb = acc_to_operand(s[kt], sk);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+          acc_o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Vs, kt * 32 + 16 * sk, 32 * dt, lane), pb, acc_o[dt], 0, 0, 0);
+      }
+  }
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  if (qvalid) {
+    store_acc_T(acc_o, o + ((long)b * N + q) * D + h * 64, h2, 1.0f / l_tot);
+    if (h2 == 0) lse[((long)b * H + h) * N + q] = m_run * scale + __logf(l_tot);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ backward: dQ (+delta)
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
+                                                          const bf16* __restrict__ dout, const float* __restrict__ lse,
+                                                          float* __restrict__ delta, bf16* __restrict__ dqkv, int N,
+                                                          int H, float scale) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * 8192];
+  char* Ks = smem;
+  char* Vs = smem + 8192;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h2 = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128;
+  const int D = H * 64;
+  const long ld = 3L * D;
+  const bf16* base = qkv + (long)b * N * ld + h * 64;
+  const float c = scale * LOG2E;
+
+  int q = q0 + wave * 32 + (lane & 31);
+  const bool qvalid = q < N;
+  if (!qvalid) q = N - 1;
+  bf16x8 qf[4], dof[4];
+  load_row_frags(qf, base + (long)q * ld, lane);
+  load_row_frags(dof, dout + ((long)b * N + q) * D + h * 64, lane);
+  float dl = 0.f;
+  {
+    bf16x8 of[4];
+    load_row_frags(of, o + ((long)b * N + q) * D + h * 64, lane);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dl += (float)dof[ks][j] * (float)of[ks][j];
+  }
+  dl += __shfl_xor(dl, 32, 64);
+  const long statidx = ((long)b * H + h) * N + q;
+  if (qvalid && h2 == 0) delta[statidx] = dl;
+  const float lse2 = lse[statidx] * LOG2E;
+
+  f32x16 acc_dq[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { acc_dq[0][i] = 0.f; acc_dq[1][i] = 0.f; }
+
+  const int nkb = (N + 63) / 64;
+  TileRegs<64> kr, vr;
+  tile_load<64>(kr, base + D, ld, 0, N, tid);
+  tile_load<64>(vr, base + 2 * D, ld, 0, N, tid);
+  for (int kb = 0; kb < nkb; ++kb) {
+    __syncthreads();
+    tile_store<64>(kr, Ks, tid);
+    tile_store<64>(vr, Vs, tid);
+    __syncthreads();
+    if (kb + 1 < nkb) {
+      tile_load<64>(kr, base + D, ld, (kb + 1) * 64, N, tid);
+      tile_load<64>(vr, base + 2 * D, ld, (kb + 1) * 64, N, tid);
+    }
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Ks, kt * 32, ks, lane), qf[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Vs, kt * 32, ks, lane), dof[ks], dp, 0, 0, 0);
+      }
+      const bool tail = kb * 64 + kt * 32 + 32 > N;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        float p = exp2f(fmaf(s[i], c, -lse2));
+        if (tail && kb * 64 + kt * 32 + acc_row(i, h2) >= N) p = 0.f;
+        s[i] = p * (dp[i] - dl);  // dS^T (unscaled)
+      }
+#pragma unroll
+      for (int sk = 0; sk < 2; ++sk) {
+        const bf16x8 dsb = acc_to_operand(s, sk);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+          acc_dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Ks, kt * 32 + 16 * sk, 32 * dt, lane), dsb, acc_dq[dt], 0, 0, 0);
+      }
+    }
+  }
+  if (qvalid) store_acc_T(acc_dq, dqkv + ((long)b * N + q) * ld + h * 64, h2, scale);
+}
+
+// ------------------------------------------------------------------------------------------------ backward: dK, dV
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ dout,
+                                                           const float* __restrict__ lse,
+                                                           const float* __restrict__ delta, bf16* __restrict__ dqkv,
+                                                           int N, int H, float scale) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * 8192 + 2 * 64 * 4];
+  char* Qs = smem;
+  char* dOs = smem + 8192;
+  float* lses = (float*)(smem + 16384);
+  float* dls = lses + 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h2 = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * 128;
+  const int D = H * 64;
+  const long ld = 3L * D;
+  const bf16* base = qkv + (long)b * N * ld + h * 64;
+  const bf16* dobase = dout + (long)b * N * D + h * 64;
+  const float* lsebase = lse + ((long)b * H + h) * N;
+  const float* dlbase = delta + ((long)b * H + h) * N;
+  const float c = scale * LOG2E;
+
+  int key = k0 + wave * 32 + (lane & 31);
+  const bool kvalid = key < N;
+  if (!kvalid) key = N - 1;
+  bf16x8 kf[4], vf[4];
+  load_row_frags(kf, base + D + (long)key * ld, lane);
+  load_row_frags(vf, base + 2 * D + (long)key * ld, lane);
+
+  f32x16 acc_dk[2], acc_dv[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { acc_dk[0][i] = 0.f; acc_dk[1][i] = 0.f; acc_dv[0][i] = 0.f; acc_dv[1][i] = 0.f; }
+
+  const int nqb = (N + 63) / 64;
+  TileRegs<64> qr, dr;
+  float lreg = 0.f, dreg = 0.f;
+  tile_load<64>(qr, base, ld, 0, N, tid);
+  tile_load<64>(dr, dobase, D, 0, N, tid);
+  if (tid < 64) { const int qq = tid < N ? tid : N - 1; lreg = lsebase[qq] * LOG2E; dreg = dlbase[qq]; }
+  for (int qb = 0; qb < nqb; ++qb) {
+    __syncthreads();
+    tile_store<64>(qr, Qs, tid);
+    tile_store<64>(dr, dOs, tid);
+    if (tid < 64) { lses[tid] = lreg; dls[tid] = dreg; }
+    __syncthreads();
+    if (qb + 1 < nqb) {
+      tile_load<64>(qr, base, ld, (qb + 1) * 64, N, tid);
+      tile_load<64>(dr, dobase, D, (qb + 1) * 64, N, tid);
+      if (tid < 64) { int qq = (qb + 1) * 64 + tid; qq = qq < N ? qq : N - 1; lreg = lsebase[qq] * LOG2E; dreg = dlbase[qq]; }
+    }
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Qs, qt * 32, ks, lane), kf[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(dOs, qt * 32, ks, lane), vf[ks], dp, 0, 0, 0);
+      }
+      const bool tail = qb * 64 + qt * 32 + 32 > N;
+      f32x16 ds;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int r0 = qt * 32 + 8 * g + 4 * h2;
+        const f32x4 l4 = *(const f32x4*)(lses + r0), d4 = *(const f32x4*)(dls + r0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int i = 4 * g + e;
+          float p = exp2f(fmaf(s[i], c, -l4[e]));
+          if (tail && qb * 64 + r0 + e >= N) p = 0.f;
+          s[i] = p;
+          ds[i] = p * (dp[i] - d4[e]);
+        }
+      }
+#pragma unroll
+      for (int sk = 0; sk < 2; ++sk) {
+        const bf16x8 pb = acc_to_operand(s, sk), dsb = acc_to_operand(ds, sk);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          acc_dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(dOs, qt * 32 + 16 * sk, 32 * dt, lane), pb, acc_dv[dt], 0, 0, 0);
+          acc_dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Qs, qt * 32 + 16 * sk, 32 * dt, lane), dsb, acc_dk[dt], 0, 0, 0);
+        }
+      }
+    }
+  }
+  if (kvalid) {
+    bf16* orow = dqkv + ((long)b * N + key) * ld + h * 64;
+    store_acc_T(acc_dk, orow + D, h2, scale);
+    store_acc_T(acc_dv, orow + 2 * D, h2, 1.0f);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ attention matrix on demand
+// attn[b,h,q,k] = exp(q·k*scale - lse[q]).  Visualisation path only (Block.forward(return_attention=True)); plain VALU.
+__global__ __launch_bounds__(256) void attn_probs_kernel(const bf16* __restrict__ qkv, const float* __restrict__ lse,
+                                                         float* __restrict__ attn, int N, int H, float scale) {
+  const int b = blockIdx.z, h = blockIdx.y, q = blockIdx.x;
+  const int D = H * 64;
+  const long ld = 3L * D;
+  const bf16* qrow = qkv + ((long)b * N + q) * ld + h * 64;
+  __shared__ float qs[64];
+  if (threadIdx.x < 64) qs[threadIdx.x] = (float)qrow[threadIdx.x];
+  __syncthreads();
+  const float l = lse[((long)b * H + h) * N + q];
+  for (int k = threadIdx.x; k < N; k += 256) {
+    const bf16* krow = qkv + ((long)b * N + k) * ld + D + h * 64;
+    float acc = 0.f;
+#pragma unroll
+    for (int d8 = 0; d8 < 8; ++d8) {
+      const bf16x8 kv = *(const bf16x8*)(krow + d8 * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc += qs[d8 * 8 + j] * (float)kv[j];
+    }
+    attn[(((long)b * H + h) * N + q) * N + k] = __expf(acc * scale - l);
+  }
+}
+
+}  // namespace
+
+extern "C" int apla_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, float scale,
+                             hipStream_t stream) {
+  APLA_REQUIRE(qkv && o && lse && B > 0 && N > 0 && H > 0, "apla_attn_fwd: bad arguments");
+  APLA_REQUIRE(apla_aligned16(qkv) && apla_aligned16(o), "apla_attn_fwd: pointers must be 16-byte aligned");
+  APLA_REQUIRE(B <= 65535 && H <= 65535, "apla_attn_fwd: B/H exceed grid limits");
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3((N + 127) / 128, H, B), dim3(256), 0, stream, (const bf16*)qkv, (bf16*)o, lse, N, H, scale);
+  APLA_CHECK_LAUNCH("apla_attn_fwd");
+  return APLA_OK;
+}
+
+extern "C" int apla_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta,
+                             void* dqkv, int B, int N, int H, float scale, hipStream_t stream) {
+  APLA_REQUIRE(qkv && o && d_o && lse && delta && dqkv && B > 0 && N > 0 && H > 0, "apla_attn_bwd: bad arguments");
+  APLA_REQUIRE(apla_aligned16(qkv) && apla_aligned16(o) && apla_aligned16(d_o) && apla_aligned16(dqkv), "apla_attn_bwd: pointers must be 16-byte aligned");
+  APLA_REQUIRE(B <= 65535 && H <= 65535, "apla_attn_bwd: B/H exceed grid limits");
+  dim3 grid((N + 127) / 128, H, B);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, stream, (const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse, delta, (bf16*)dqkv, N, H, scale);
+  APLA_CHECK_LAUNCH("apla_attn_bwd[dq]");
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, stream, (const bf16*)qkv, (const bf16*)d_o, lse, delta, (bf16*)dqkv, N, H, scale);
+  APLA_CHECK_LAUNCH("apla_attn_bwd[dkv]");
+  return APLA_OK;
+}
+
+extern "C" int apla_attn_probs(const void* qkv, const float* lse, float* attn, int B, int N, int H, float scale,
+                               hipStream_t stream) {
+  APLA_REQUIRE(qkv && lse && attn && B > 0 && N > 0 && H > 0 && B <= 65535 && H <= 65535, "apla_attn_probs: bad arguments");
+  hipLaunchKernelGGL(attn_probs_kernel, dim3(N, H, B), dim3(256), 0, stream, (const bf16*)qkv, lse, attn, N, H, scale);
+  APLA_CHECK_LAUNCH("apla_attn_probs");
+  return APLA_OK;
+}

@@ -1,0 +1,83 @@
+// Shared device/host helpers for the APLA gfx950 kernels (CDNA4 only; no other target is supported).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/apla_hip.h"
+
+typedef __bf16 bf16;
+typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define LDSP(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLBP(p) ((const __attribute__((address_space(1))) void*)(p))
+
+// ---- host-side error plumbing (thread-local message, C-ABI returns negative errno-style codes) ----
+void apla_set_error(const char* fmt, ...);
+
+#define APLA_REQUIRE(cond, ...)            \
+  do {                                     \
+    if (!(cond)) {                         \
+      apla_set_error(__VA_ARGS__);         \
+      return APLA_EINVAL;                  \
+    }                                      \
+  } while (0)
+
+#define APLA_CHECK_LAUNCH(name)                                                  \
+  do {                                                                           \
+    hipError_t e__ = hipGetLastError();                                          \
+    if (e__ != hipSuccess) {                                                     \
+      apla_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));     \
+      return APLA_EIO;                                                           \
+    }                                                                            \
+  } while (0)
+
+static inline bool apla_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// ---- device helpers ----
+__device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }
+__device__ __forceinline__ bf16 f2bf(float x) { return (bf16)x; }
+
+__device__ __forceinline__ bf16x4 pack4(float a, float b, float c, float d) {
+  bf16x4 r;
+  r[0] = (bf16)a; r[1] = (bf16)b; r[2] = (bf16)c; r[3] = (bf16)d;
+  return r;
+}
+
+// residual-stream element access: ResT is float or bf16; 4 consecutive elements
+template <typename T> struct Vec4IO;
+template <> struct Vec4IO<float> {
+  static __device__ __forceinline__ f32x4 load(const float* p) { return *(const f32x4*)p; }
+  static __device__ __forceinline__ void store(float* p, f32x4 v) { *(f32x4*)p = v; }
+};
+template <> struct Vec4IO<bf16> {
+  static __device__ __forceinline__ f32x4 load(const bf16* p) {
+    bf16x4 t = *(const bf16x4*)p;
+    f32x4 r = {(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
+    return r;
+  }
+  static __device__ __forceinline__ void store(bf16* p, f32x4 v) { *(bf16x4*)p = pack4(v[0], v[1], v[2], v[3]); }
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// bijective XCD-aware block remap: blocks b and b+8 share an XCD (round-robin dispatch), so give each
+// XCD a contiguous run of logical tile ids -> neighbouring tiles (same A panel) hit the same L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}

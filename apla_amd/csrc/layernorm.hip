@@ -1,0 +1,199 @@
+// LayerNorm forward / backward-dX for gfx950.  HBM-bound row kernels: one wave per token row, the row lives in
+// registers (<= 2048 features), 8/16-byte vector loads, two-pass statistics in fp32.
+//
+// Backward computes only dX (gamma/beta are frozen under APLA) and fuses (a) the residual-gradient add and (b) the
+// gather of the r APLA-trainable columns of the result (bf16) that the column-masked dW1 kernel consumes.
+#include "common.h"
+
+namespace {
+
+constexpr int MAXC = 8;  // row chunks of 4 elements per lane: D <= 64*4*MAXC = 2048
+constexpr int ROWS_PER_BLOCK = 4;
+
+template <typename ResT, typename YT>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const ResT* __restrict__ x, long xs, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, YT* __restrict__ y, int ldy,
+                                                     float* __restrict__ mean_o, float* __restrict__ rstd_o, int M,
+                                                     int D, float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nchunk = D >> 2;
+  for (int m = blockIdx.x * ROWS_PER_BLOCK + wave; m < M; m += gridDim.x * ROWS_PER_BLOCK) {
+    const ResT* xr = x + (size_t)m * xs;
+    f32x4 v[MAXC];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int ch = lane + c * 64;
+      if (ch < nchunk) {
+        v[c] = Vec4IO<ResT>::load(xr + ch * 4);
+        s += v[c][0] + v[c][1] + v[c][2] + v[c][3];
+      }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int ch = lane + c * 64;
+      if (ch < nchunk) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = v[c][e] - mean; q += d * d; }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+    if (lane == 0) { mean_o[m] = mean; rstd_o[m] = rstd; }
+    YT* yr = y + (size_t)m * ldy;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int ch = lane + c * 64;
+      if (ch < nchunk) {
+        const f32x4 g = *(const f32x4*)(gamma + ch * 4), b = *(const f32x4*)(beta + ch * 4);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (v[c][e] - mean) * rstd * g[e] + b[e];
+        Vec4IO<YT>::store(yr + ch * 4, o);
+      }
+    }
+  }
+}
+
+// dx_out = dres_in + ((dy*g) - mean(dy*g) - xhat*mean(dy*g*xhat)) * rstd ; optional gather of trainable columns.
+template <typename ResT, typename DYT, bool GATHER>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const DYT* __restrict__ dy, int lddy, const ResT* __restrict__ x,
+                                                     long xs, const float* __restrict__ gamma,
+                                                     const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
+                                                     const ResT* dres, ResT* dx, long dxs,
+                                                     const int32_t* __restrict__ inds, int r, bf16* __restrict__ gout,
+                                                     int M, int D) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* rowbuf = (float*)smem_raw;  // [ROWS_PER_BLOCK][D] when GATHER
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nchunk = D >> 2;
+  for (int m0 = blockIdx.x * ROWS_PER_BLOCK; m0 < M; m0 += gridDim.x * ROWS_PER_BLOCK) {
+    const int m = m0 + wave;
+    if (m < M) {
+      const ResT* xr = x + (size_t)m * xs;
+      const DYT* dyr = dy + (size_t)m * lddy;
+      const float mean = mean_i[m], rstd = rstd_i[m];
+      f32x4 xh[MAXC], w[MAXC];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c) {
+        const int ch = lane + c * 64;
+        if (ch < nchunk) {
+          const f32x4 xv = Vec4IO<ResT>::load(xr + ch * 4);
+          const f32x4 dv = Vec4IO<DYT>::load(dyr + ch * 4);
+          const f32x4 g = *(const f32x4*)(gamma + ch * 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            xh[c][e] = (xv[e] - mean) * rstd;
+            w[c][e] = dv[e] * g[e];
+            s1 += w[c][e];
+            s2 += w[c][e] * xh[c][e];
+          }
+        }
+      }
+      const float c1 = wave_sum(s1) / (float)D, c2 = wave_sum(s2) / (float)D;
+      ResT* dxr = dx + (size_t)m * dxs;
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c) {
+        const int ch = lane + c * 64;
+        if (ch < nchunk) {
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (w[c][e] - c1 - xh[c][e] * c2) * rstd;
+          if (dres != nullptr) o += Vec4IO<ResT>::load(dres + (size_t)m * dxs + ch * 4);
+          Vec4IO<ResT>::store(dxr + ch * 4, o);
+          if constexpr (GATHER) *(f32x4*)(rowbuf + wave * D + ch * 4) = o;
+        }
+      }
+    }
+    if constexpr (GATHER) {
+      __syncthreads();
+      if (m < M) {
+        for (int j = lane; j < r; j += 64) gout[(size_t)m * r + j] = (bf16)rowbuf[wave * D + inds[j]];
+      }
+      __syncthreads();
+    }
+  }
+}
+
+template <typename ResT>
+__global__ __launch_bounds__(256) void gather_cols_kernel(const ResT* __restrict__ src, long ss,
+                                                          const int32_t* __restrict__ inds, int r,
+                                                          bf16* __restrict__ out, int M) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int m = blockIdx.x * ROWS_PER_BLOCK + wave; m < M; m += gridDim.x * ROWS_PER_BLOCK)
+    for (int j = lane; j < r; j += 64) out[(size_t)m * r + j] = (bf16)(float)src[(size_t)m * ss + inds[j]];
+}
+
+inline int ln_grid(int M) {
+  int g = (M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+  return g < 4096 ? g : 4096;
+}
+
+}  // namespace
+
+extern "C" int apla_layernorm_fwd(const void* x, int res_dtype, long x_row_stride, const float* gamma,
+                                  const float* beta, void* y, int y_dtype, int ldy, float* mean, float* rstd, int M,
+                                  int D, float eps, hipStream_t stream) {
+  APLA_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 256 * MAXC, "apla_layernorm_fwd: need D%%4==0 and D<=2048 (D=%d)", D);
+  APLA_REQUIRE(x && y && gamma && beta && mean && rstd, "apla_layernorm_fwd: null pointer");
+  APLA_REQUIRE(x_row_stride % 4 == 0 && ldy % 4 == 0 && x_row_stride >= D && ldy >= D, "apla_layernorm_fwd: strides must be >= D and multiples of 4");
+  APLA_REQUIRE(apla_aligned16(x) && apla_aligned16(gamma) && apla_aligned16(beta) && (((uintptr_t)y) & 7) == 0, "apla_layernorm_fwd: alignment");
+#define LN_FWD(T, Y) hipLaunchKernelGGL((ln_fwd_kernel<T, Y>), dim3(ln_grid(M)), dim3(256), 0, stream, (const T*)x, x_row_stride, gamma, beta, (Y*)y, ldy, mean, rstd, M, D, eps)
+  if (res_dtype == APLA_F32 && y_dtype == APLA_BF16) LN_FWD(float, bf16);
+  else if (res_dtype == APLA_F32 && y_dtype == APLA_F32) LN_FWD(float, float);
+  else if (res_dtype == APLA_BF16 && y_dtype == APLA_BF16) LN_FWD(bf16, bf16);
+  else if (res_dtype == APLA_BF16 && y_dtype == APLA_F32) LN_FWD(bf16, float);
+  else {
+    apla_set_error("apla_layernorm_fwd: bad res_dtype %d / y_dtype %d", res_dtype, y_dtype);
+    return APLA_ENOSYS;
+  }
+#undef LN_FWD
+  APLA_CHECK_LAUNCH("apla_layernorm_fwd");
+  return APLA_OK;
+}
+
+extern "C" int apla_layernorm_bwd(const void* dy, int dy_dtype, int lddy, const void* x, int res_dtype, long x_row_stride,
+                                  const float* gamma, const float* mean, const float* rstd, const void* dres_in,
+                                  void* dx_out, long dx_row_stride, const int32_t* inds, int r, void* gather_out, int M,
+                                  int D, hipStream_t stream) {
+  APLA_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 256 * MAXC, "apla_layernorm_bwd: need D%%4==0 and D<=2048 (D=%d)", D);
+  APLA_REQUIRE(dy && x && gamma && mean && rstd && dx_out, "apla_layernorm_bwd: null pointer");
+  APLA_REQUIRE(lddy % 4 == 0 && x_row_stride % 4 == 0 && dx_row_stride % 4 == 0 && lddy >= D && x_row_stride >= D && dx_row_stride >= D, "apla_layernorm_bwd: bad strides");
+  APLA_REQUIRE(gather_out == nullptr || (inds != nullptr && r > 0 && r <= D), "apla_layernorm_bwd: gather needs inds and 0<r<=D");
+  const bool gather = gather_out != nullptr;
+  const size_t lds = gather ? (size_t)ROWS_PER_BLOCK * D * sizeof(float) : 0;
+#define LN_BWD(T, Y, G)                                                                                                \
+  hipLaunchKernelGGL((ln_bwd_kernel<T, Y, G>), dim3(ln_grid(M)), dim3(256), lds, stream, (const Y*)dy, lddy,           \
+                     (const T*)x, x_row_stride, gamma, mean, rstd, (const T*)dres_in, (T*)dx_out, dx_row_stride, inds, \
+                     r, (bf16*)gather_out, M, D)
+#define LN_BWD_G(T, Y) do { if (gather) LN_BWD(T, Y, true); else LN_BWD(T, Y, false); } while (0)
+  if (res_dtype == APLA_F32 && dy_dtype == APLA_BF16) LN_BWD_G(float, bf16);
+  else if (res_dtype == APLA_F32 && dy_dtype == APLA_F32) LN_BWD_G(float, float);
+  else if (res_dtype == APLA_BF16 && dy_dtype == APLA_BF16) LN_BWD_G(bf16, bf16);
+  else if (res_dtype == APLA_BF16 && dy_dtype == APLA_F32) LN_BWD_G(bf16, float);
+  else {
+    apla_set_error("apla_layernorm_bwd: bad res_dtype %d / dy_dtype %d", res_dtype, dy_dtype);
+    return APLA_ENOSYS;
+  }
+#undef LN_BWD_G
+#undef LN_BWD
+  APLA_CHECK_LAUNCH("apla_layernorm_bwd");
+  return APLA_OK;
+}
+
+extern "C" int apla_gather_cols(const void* src, int res_dtype, long src_row_stride, const int32_t* inds, int r,
+                                void* out, int M, int D, hipStream_t stream) {
+  APLA_REQUIRE(src && inds && out && M > 0 && r > 0 && r <= D, "apla_gather_cols: bad arguments");
+  if (res_dtype == APLA_F32)
+    hipLaunchKernelGGL(gather_cols_kernel<float>, dim3(ln_grid(M)), dim3(256), 0, stream, (const float*)src, src_row_stride, inds, r, (bf16*)out, M);
+  else if (res_dtype == APLA_BF16)
+    hipLaunchKernelGGL(gather_cols_kernel<bf16>, dim3(ln_grid(M)), dim3(256), 0, stream, (const bf16*)src, src_row_stride, inds, r, (bf16*)out, M);
+  else {
+    apla_set_error("apla_gather_cols: bad res_dtype %d", res_dtype);
+    return APLA_ENOSYS;
+  }
+  APLA_CHECK_LAUNCH("apla_gather_cols");
+  return APLA_OK;
+}

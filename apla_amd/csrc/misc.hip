@@ -1,0 +1,188 @@
+// Front end (patchify / token assembly) and classifier-head kernels.  All are forward-only or tiny: the patch embedding
+// never sees a gradient under APLA (first trainable leaf is block 0's projection) and the head is [B,D]x[D,C] in fp32.
+#include "common.h"
+
+namespace {
+
+// images fp32 [B,3,S,S] -> cols bf16 [B*Np, Kp]; column order (c, py, px) == conv weight.reshape(D, 3*p*p)
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, bf16* __restrict__ cols, int S,
+                                                       int patch, int grid_w, int Np, int Kp) {
+  const int row = blockIdx.x;  // b*Np + t
+  const int b = row / Np, t = row - b * Np;
+  const int gy = t / grid_w, gx = t - gy * grid_w;
+  const int pp = patch * patch, K = 3 * pp;
+  for (int k = threadIdx.x; k < Kp; k += 256) {
+    float v = 0.f;
+    if (k < K) {
+      const int c = k / pp, rem = k - c * pp, py = rem / patch, px = rem - py * patch;
+      v = img[(((size_t)b * 3 + c) * S + gy * patch + py) * S + gx * patch + px];
+    }
+    cols[(size_t)row * Kp + k] = (bf16)v;
+  }
+}
+
+template <typename ResT>
+__global__ __launch_bounds__(256) void assemble_tokens_kernel(const bf16* __restrict__ patches, int ldp,
+                                                              const float* __restrict__ cls,
+                                                              const float* __restrict__ pos, ResT* __restrict__ tok,
+                                                              int Np, int D) {
+  const int row = blockIdx.x;  // b*(Np+1) + n
+  const int N = Np + 1;
+  const int b = row / N, n = row - b * N;
+  for (int c4 = threadIdx.x; c4 < D / 4; c4 += 256) {
+    f32x4 v = *(const f32x4*)(pos + (size_t)n * D + c4 * 4);
+    if (n == 0) v += *(const f32x4*)(cls + c4 * 4);
+    else v += Vec4IO<bf16>::load(patches + ((size_t)b * Np + n - 1) * ldp + c4 * 4);
+    Vec4IO<ResT>::store(tok + (size_t)row * D + c4 * 4, v);
+  }
+}
+
+// C[i,j] (+)= sum_k A[i*sai + k*sak] * B[k*sbk + j*sbj] (+ bias[j]); 32x32 tile per workgroup, fp32 FMA.
+__global__ __launch_bounds__(256) void sgemm_small_kernel(const float* __restrict__ A, long sai, long sak,
+                                                          const float* __restrict__ Bm, long sbk, long sbj,
+                                                          const float* __restrict__ bias, float* __restrict__ C,
+                                                          long ldc, int M, int N, int K, int accumulate) {
+  __shared__ float As[32][33], Bs[32][33];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;  // 16 x 16 threads, 2x2 outputs each
+  const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+  float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+  for (int k0 = 0; k0 < K; k0 += 32) {
+    for (int e = threadIdx.x; e < 1024; e += 256) {
+      const int a = e >> 5, c = e & 31;
+      // A tile: As[i][k]; pick the faster-varying global index for the inner thread index
+      {
+        const int i = sak <= sai ? a : c, k = sak <= sai ? c : a;
+        As[i][k] = (i0 + i < M && k0 + k < K) ? A[(long)(i0 + i) * sai + (long)(k0 + k) * sak] : 0.f;
+      }
+      {
+        const int k = sbj <= sbk ? a : c, j = sbj <= sbk ? c : a;
+        Bs[k][j] = (j0 + j < N && k0 + k < K) ? Bm[(long)(k0 + k) * sbk + (long)(j0 + j) * sbj] : 0.f;
+      }
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int k = 0; k < 32; ++k) {
+      const float a0 = As[ty][k], a1 = As[ty + 16][k], b0 = Bs[k][tx], b1 = Bs[k][tx + 16];
+      acc[0][0] += a0 * b0; acc[0][1] += a0 * b1; acc[1][0] += a1 * b0; acc[1][1] += a1 * b1;
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+      const int i = i0 + ty + 16 * u, j = j0 + tx + 16 * w;
+      if (i < M && j < N) {
+        float v = acc[u][w];
+        if (bias != nullptr) v += bias[j];
+        if (accumulate) v += C[(long)i * ldc + j];
+        C[(long)i * ldc + j] = v;
+      }
+    }
+}
+
+// one workgroup per sample: softmax cross-entropy, dlogits = (softmax - onehot) / B, row loss
+__global__ __launch_bounds__(256) void cross_entropy_kernel(const float* __restrict__ logits, int ldl,
+                                                            const int32_t* __restrict__ labels,
+                                                            float* __restrict__ dlogits, float* __restrict__ row_loss,
+                                                            int B, int C) {
+  __shared__ float red[4];
+  __shared__ float bc;
+  const int b = blockIdx.x;
+  const float* lr = logits + (size_t)b * ldl;
+  float mx = -INFINITY;
+  for (int c = threadIdx.x; c < C; c += 256) mx = fmaxf(mx, lr[c]);
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) bc = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  mx = bc;
+  float s = 0.f;
+  for (int c = threadIdx.x; c < C; c += 256) s += __expf(lr[c] - mx);
+  s = wave_sum(s);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) bc = red[0] + red[1] + red[2] + red[3];
+  __syncthreads();
+  const float lse = mx + __logf(bc);
+  const int y = labels[b];
+  const float invB = 1.0f / (float)B;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float pr = __expf(lr[c] - lse);
+    dlogits[(size_t)b * ldl + c] = (pr - (c == y ? 1.0f : 0.0f)) * invB;
+  }
+  if (threadIdx.x == 0) row_loss[b] = lse - lr[y];
+}
+
+__global__ __launch_bounds__(256) void mean_kernel(const float* __restrict__ v, float* __restrict__ out, int n) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += v[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (red[0] + red[1] + red[2] + red[3]) / (float)n;
+}
+
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, long ld, float* __restrict__ out,
+                                                     int M, int N) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= N) return;
+  float s = 0.f;
+  for (int i = 0; i < M; ++i) s += X[(long)i * ld + j];
+  out[j] = s;
+}
+
+}  // namespace
+
+extern "C" int apla_patchify(const float* images, void* cols, int B, int S, int patch, int Kp, hipStream_t stream) {
+  APLA_REQUIRE(images && cols && B > 0 && S > 0 && patch > 0 && S >= patch, "apla_patchify: bad arguments");
+  APLA_REQUIRE(Kp >= 3 * patch * patch && Kp % 64 == 0, "apla_patchify: Kp must be >= 3*p*p and a multiple of 64");
+  const int gw = S / patch, Np = gw * gw;
+  hipLaunchKernelGGL(patchify_kernel, dim3(B * Np), dim3(256), 0, stream, images, (bf16*)cols, S, patch, gw, Np, Kp);
+  APLA_CHECK_LAUNCH("apla_patchify");
+  return APLA_OK;
+}
+
+extern "C" int apla_assemble_tokens(const void* patches, int ldp, const float* cls_token, const float* pos_embed,
+                                    void* tokens, int res_dtype, int B, int Np, int D, hipStream_t stream) {
+  APLA_REQUIRE(patches && cls_token && pos_embed && tokens && B > 0 && Np > 0 && D % 4 == 0 && ldp % 4 == 0, "apla_assemble_tokens: bad arguments");
+  if (res_dtype == APLA_F32)
+    hipLaunchKernelGGL(assemble_tokens_kernel<float>, dim3(B * (Np + 1)), dim3(256), 0, stream, (const bf16*)patches, ldp, cls_token, pos_embed, (float*)tokens, Np, D);
+  else if (res_dtype == APLA_BF16)
+    hipLaunchKernelGGL(assemble_tokens_kernel<bf16>, dim3(B * (Np + 1)), dim3(256), 0, stream, (const bf16*)patches, ldp, cls_token, pos_embed, (bf16*)tokens, Np, D);
+  else {
+    apla_set_error("apla_assemble_tokens: bad res_dtype %d", res_dtype);
+    return APLA_ENOSYS;
+  }
+  APLA_CHECK_LAUNCH("apla_assemble_tokens");
+  return APLA_OK;
+}
+
+extern "C" int apla_sgemm_small(const float* A, long sai, long sak, const float* Bm, long sbk, long sbj,
+                                const float* bias, float* C, long ldc, int M, int N, int K, int accumulate,
+                                hipStream_t stream) {
+  APLA_REQUIRE(A && Bm && C && M > 0 && N > 0 && K > 0, "apla_sgemm_small: bad arguments");
+  hipLaunchKernelGGL(sgemm_small_kernel, dim3((N + 31) / 32, (M + 31) / 32), dim3(256), 0, stream, A, sai, sak, Bm, sbk, sbj, bias, C, ldc, M, N, K, accumulate);
+  APLA_CHECK_LAUNCH("apla_sgemm_small");
+  return APLA_OK;
+}
+
+extern "C" int apla_cross_entropy(const float* logits, int ldl, const int32_t* labels, float* dlogits,
+                                  float* row_loss, float* loss, int B, int C, hipStream_t stream) {
+  APLA_REQUIRE(logits && labels && dlogits && row_loss && loss && B > 0 && C > 0 && ldl >= C, "apla_cross_entropy: bad arguments");
+  hipLaunchKernelGGL(cross_entropy_kernel, dim3(B), dim3(256), 0, stream, logits, ldl, labels, dlogits, row_loss, B, C);
+  APLA_CHECK_LAUNCH("apla_cross_entropy");
+  hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, stream, (const float*)row_loss, loss, B);
+  APLA_CHECK_LAUNCH("apla_cross_entropy[mean]");
+  return APLA_OK;
+}
+
+extern "C" int apla_colsum(const float* X, long ld, float* out, int M, int N, hipStream_t stream) {
+  APLA_REQUIRE(X && out && M > 0 && N > 0, "apla_colsum: bad arguments");
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, X, ld, out, M, N);
+  APLA_CHECK_LAUNCH("apla_colsum");
+  return APLA_OK;
+}

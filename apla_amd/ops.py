@@ -1,0 +1,325 @@
+"""Thin torch-tensor front ends of the C-ABI kernels (include/apla_hip.h).
+
+PyTorch is used here for device memory and streams only: every function checks its operands on the host (device,
+dtype, contiguity, shapes — a mis-shaped launch can fault the GPU), passes raw pointers and the current HIP stream to
+libapla_hip.so and raises on a non-zero return code.  No function has a CPU path.
+"""
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import (APLA_BF16, APLA_F32, EPI_GELU, EPI_MUL, EPI_RESIDUAL, EPI_STORE, EPI_SWIGLU,  # noqa: F401
+                   EPI_SWIGLU_BWD, check, lib)
+
+_DT = {torch.bfloat16: APLA_BF16, torch.float32: APLA_F32}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _req(t: torch.Tensor, dtype, name: str, ndim: Optional[int] = None):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.AplaHipError(f"{name}: expected a CUDA/HIP tensor (the APLA kernels have no CPU path)")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if ndim is not None and t.ndim != ndim:
+        raise ValueError(f"{name}: expected {ndim}-D, got shape {tuple(t.shape)}")
+    if t.stride(-1) != 1:
+        raise ValueError(f"{name}: innermost dimension must be contiguous")
+    return t
+
+
+def _rows2d(t: torch.Tensor, name: str):
+    """2-D view metadata (rows, cols, leading dimension) of a row-major matrix."""
+    if t.ndim != 2:
+        raise ValueError(f"{name}: expected 2-D, got {tuple(t.shape)}")
+    return t.shape[0], t.shape[1], t.stride(0)
+
+
+def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, epilogue: int = EPI_STORE,
+            out: Optional[torch.Tensor] = None, out_dtype=torch.bfloat16, aux_in: Optional[torch.Tensor] = None,
+            aux_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[M,Nout] = epilogue(a[M,K] @ w[N,K]^T + bias).  See include/apla_hip.h:apla_gemm_nt."""
+    _req(a, torch.bfloat16, "a", 2), _req(w, torch.bfloat16, "w", 2)
+    M, K, lda = _rows2d(a, "a")
+    N, Kw, ldw = _rows2d(w, "w")
+    if K != Kw:
+        raise ValueError(f"gemm_nt: K mismatch {K} vs {Kw}")
+    if bias is not None:
+        _req(bias, torch.float32, "bias", 1)
+        if bias.numel() != N:
+            raise ValueError("gemm_nt: bias length != N")
+    n_out = {EPI_SWIGLU: N // 2, EPI_SWIGLU_BWD: 2 * N}.get(epilogue, N)
+    if out is None:
+        out = torch.empty(M, n_out, device=a.device, dtype=out_dtype)
+    _req(out, None, "out", 2)
+    if out.shape != (M, n_out):
+        raise ValueError(f"gemm_nt: out shape {tuple(out.shape)} != {(M, n_out)}")
+    ld_in = ld_out = 0
+    if aux_in is not None:
+        _req(aux_in, None, "aux_in", 2)
+        need = {EPI_RESIDUAL: (M, N), EPI_MUL: (M, N), EPI_SWIGLU_BWD: (M, 2 * N)}.get(epilogue)
+        if need is None or tuple(aux_in.shape) != need:
+            raise ValueError(f"gemm_nt: aux_in shape {tuple(aux_in.shape)} invalid for epilogue {epilogue}")
+        if epilogue == EPI_RESIDUAL and aux_in.dtype != out.dtype:
+            raise TypeError("gemm_nt: residual and output dtypes differ")
+        if epilogue in (EPI_MUL, EPI_SWIGLU_BWD) and aux_in.dtype != torch.bfloat16:
+            raise TypeError("gemm_nt: aux_in must be bf16")
+        ld_in = aux_in.stride(0)
+    if aux_out is not None:
+        _req(aux_out, torch.bfloat16, "aux_out", 2)
+        if tuple(aux_out.shape) != (M, N):
+            raise ValueError("gemm_nt: aux_out shape")
+        ld_out = aux_out.stride(0)
+    if epilogue in (EPI_GELU, EPI_SWIGLU) and aux_out is None:
+        raise ValueError("gemm_nt: epilogue needs aux_out")
+    if epilogue in (EPI_RESIDUAL, EPI_MUL, EPI_SWIGLU_BWD) and aux_in is None:
+        raise ValueError("gemm_nt: epilogue needs aux_in")
+    if epilogue not in (EPI_STORE, EPI_RESIDUAL) and out.dtype != torch.bfloat16:
+        raise TypeError("gemm_nt: this epilogue writes bf16")
+    rc = lib().apla_gemm_nt(a.data_ptr(), lda, w.data_ptr(), ldw, _ptr(bias), out.data_ptr(), out.stride(0), M, N, K,
+                            epilogue, _DT[out.dtype], _ptr(aux_in), ld_in, _ptr(aux_out), ld_out, _stream())
+    check(rc, "apla_gemm_nt")
+    return out
+
+
+def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-6, *,
+                  out_dtype=torch.bfloat16, rows: Optional[int] = None, row_stride: Optional[int] = None):
+    """x: [M,D] residual stream (fp32|bf16).  With rows/row_stride given, x is a flat buffer and row m starts at
+    m*row_stride (CLS-row selection).  Returns (y [M,D], mean [M], rstd [M])."""
+    _req(x, None, "x")
+    D = gamma.numel()
+    if rows is None:
+        M, Dx, xs = _rows2d(x, "x")
+        if Dx != D:
+            raise ValueError("layernorm_fwd: feature size mismatch")
+    else:
+        M, xs = rows, row_stride
+        if (M - 1) * xs + D > x.numel():
+            raise ValueError("layernorm_fwd: strided rows exceed the buffer")
+    _req(gamma, torch.float32, "gamma", 1), _req(beta, torch.float32, "beta", 1)
+    y = torch.empty(M, D, device=x.device, dtype=out_dtype)
+    mean = torch.empty(M, device=x.device, dtype=torch.float32)
+    rstd = torch.empty_like(mean)
+    rc = lib().apla_layernorm_fwd(x.data_ptr(), _DT[x.dtype], xs, gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
+                                  _DT[out_dtype], D, mean.data_ptr(), rstd.data_ptr(), M, D, float(eps), _stream())
+    check(rc, "apla_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor, *,
+                  dres: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                  inds: Optional[torch.Tensor] = None, r: int = 0, rows: Optional[int] = None,
+                  row_stride: Optional[int] = None):
+    """dx = dres + LN_bwd_dx(dy).  Returns (dx, gathered | None).  With rows/row_stride: x and out are flat buffers
+    whose row m starts at m*row_stride (only those rows are read/written)."""
+    _req(dy, None, "dy", 2), _req(x, None, "x")
+    M, D, lddy = _rows2d(dy, "dy")
+    if rows is None:
+        Mx, Dx, xs = _rows2d(x, "x")
+        if (Mx, Dx) != (M, D):
+            raise ValueError("layernorm_bwd: x/dy shape mismatch")
+        if out is None:
+            out = torch.empty(M, D, device=x.device, dtype=x.dtype)
+        dxs = out.stride(0)
+    else:
+        if rows != M or out is None:
+            raise ValueError("layernorm_bwd: strided mode needs rows == dy rows and an out buffer")
+        xs = dxs = row_stride
+        if (M - 1) * xs + D > x.numel() or (M - 1) * dxs + D > out.numel():
+            raise ValueError("layernorm_bwd: strided rows exceed the buffer")
+    if out.dtype != x.dtype or (dres is not None and (dres.dtype != x.dtype or dres.shape != out.shape)):
+        raise TypeError("layernorm_bwd: dres/out must match x dtype and out shape")
+    gathered = None
+    if inds is not None:
+        _req(inds, torch.int32, "inds", 1)
+        if not (0 < r <= D) or inds.numel() < r:
+            raise ValueError("layernorm_bwd: bad r")
+        gathered = torch.empty(M, r, device=x.device, dtype=torch.bfloat16)
+    rc = lib().apla_layernorm_bwd(dy.data_ptr(), _DT[dy.dtype], lddy, x.data_ptr(), _DT[x.dtype], xs, gamma.data_ptr(),
+                                  mean.data_ptr(), rstd.data_ptr(), _ptr(dres), out.data_ptr(), dxs, _ptr(inds), r,
+                                  _ptr(gathered), M, D, _stream())
+    check(rc, "apla_layernorm_bwd")
+    return out, gathered
+
+
+def gather_cols(src: torch.Tensor, inds: torch.Tensor, r: int) -> torch.Tensor:
+    _req(src, None, "src", 2), _req(inds, torch.int32, "inds", 1)
+    M, D, ss = _rows2d(src, "src")
+    out = torch.empty(M, r, device=src.device, dtype=torch.bfloat16)
+    check(lib().apla_gather_cols(src.data_ptr(), _DT[src.dtype], ss, inds.data_ptr(), r, out.data_ptr(), M, D,
+                                 _stream()), "apla_gather_cols")
+    return out
+
+
+def attn_fwd(qkv: torch.Tensor, B: int, N: int, H: int, scale: float):
+    """qkv: [B*N, 3*H*64] bf16 contiguous.  Returns (o [B*N, H*64] bf16, lse [B,H,N] fp32)."""
+    _req(qkv, torch.bfloat16, "qkv", 2)
+    if tuple(qkv.shape) != (B * N, 3 * H * 64) or not qkv.is_contiguous():
+        raise ValueError(f"attn_fwd: qkv must be contiguous [{B * N}, {3 * H * 64}], got {tuple(qkv.shape)}")
+    o = torch.empty(B * N, H * 64, device=qkv.device, dtype=torch.bfloat16)
+    lse = torch.empty(B, H, N, device=qkv.device, dtype=torch.float32)
+    check(lib().apla_attn_fwd(qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), B, N, H, float(scale), _stream()),
+          "apla_attn_fwd")
+    return o, lse
+
+
+def attn_bwd(qkv: torch.Tensor, o: torch.Tensor, do: torch.Tensor, lse: torch.Tensor, B: int, N: int, H: int,
+             scale: float, *, dqkv: Optional[torch.Tensor] = None, delta: Optional[torch.Tensor] = None):
+    _req(qkv, torch.bfloat16, "qkv", 2), _req(o, torch.bfloat16, "o", 2), _req(do, torch.bfloat16, "do", 2)
+    _req(lse, torch.float32, "lse", 3)
+    if tuple(qkv.shape) != (B * N, 3 * H * 64) or tuple(o.shape) != (B * N, H * 64) or o.shape != do.shape \
+            or tuple(lse.shape) != (B, H, N):
+        raise ValueError("attn_bwd: shape mismatch")
+    if not (qkv.is_contiguous() and o.is_contiguous() and do.is_contiguous() and lse.is_contiguous()):
+        raise ValueError("attn_bwd: operands must be contiguous")
+    if dqkv is None:
+        dqkv = torch.empty_like(qkv)
+    if delta is None:
+        delta = torch.empty(B, H, N, device=qkv.device, dtype=torch.float32)
+    if dqkv.shape != qkv.shape or not dqkv.is_contiguous() or delta.numel() < B * H * N:
+        raise ValueError("attn_bwd: bad dqkv/delta buffers")
+    check(lib().apla_attn_bwd(qkv.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(), delta.data_ptr(),
+                              dqkv.data_ptr(), B, N, H, float(scale), _stream()), "apla_attn_bwd")
+    return dqkv
+
+
+def attn_probs(qkv: torch.Tensor, lse: torch.Tensor, B: int, N: int, H: int, scale: float) -> torch.Tensor:
+    _req(qkv, torch.bfloat16, "qkv", 2), _req(lse, torch.float32, "lse", 3)
+    if tuple(qkv.shape) != (B * N, 3 * H * 64) or not qkv.is_contiguous() or tuple(lse.shape) != (B, H, N):
+        raise ValueError("attn_probs: shape mismatch")
+    attn = torch.empty(B, H, N, N, device=qkv.device, dtype=torch.float32)
+    check(lib().apla_attn_probs(qkv.data_ptr(), lse.data_ptr(), attn.data_ptr(), B, N, H, float(scale), _stream()),
+          "apla_attn_probs")
+    return attn
+
+
+def dw_workspace(M: int, r: int, D: int, device) -> torch.Tensor:
+    nbytes = lib().apla_dw_workspace_bytes(M, r, D)
+    if nbytes < 0:
+        raise ValueError(f"apla_proj_dw needs r%64==0 and D%128==0 (r={r}, D={D})")
+    return torch.empty(nbytes // 4, device=device, dtype=torch.float32)
+
+
+def proj_dw(dyg: torch.Tensor, x: torch.Tensor, dW1: torch.Tensor, db1: torch.Tensor, *,
+            row_scale: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None,
+            accumulate: bool = False):
+    """dW1[r,D] (+)= row_scale * dyg[M,r]^T @ x[M,D]; db1[r] (+)= row_scale * colsum(dyg)."""
+    _req(dyg, torch.bfloat16, "dyg", 2), _req(x, torch.bfloat16, "x", 2)
+    _req(dW1, torch.float32, "dW1", 2), _req(db1, torch.float32, "db1", 1)
+    M, r = dyg.shape
+    Mx, D, ldx = _rows2d(x, "x")
+    if Mx != M or tuple(dW1.shape) != (r, D) or db1.numel() != r or not dyg.is_contiguous() or not dW1.is_contiguous():
+        raise ValueError("proj_dw: shape mismatch")
+    if row_scale is not None:
+        _req(row_scale, torch.float32, "row_scale", 1)
+        if row_scale.numel() != r:
+            raise ValueError("proj_dw: row_scale length != r")
+    if workspace is None:
+        workspace = dw_workspace(M, r, D, x.device)
+    if workspace.numel() * 4 < lib().apla_dw_workspace_bytes(M, r, D):
+        raise ValueError("proj_dw: workspace too small")
+    check(lib().apla_proj_dw(dyg.data_ptr(), x.data_ptr(), ldx, _ptr(row_scale), dW1.data_ptr(), db1.data_ptr(),
+                             workspace.data_ptr(), M, r, D, int(accumulate), _stream()), "apla_proj_dw")
+
+
+def pack_proj_rows(W1: torch.Tensor, b1: Optional[torch.Tensor], inds: torch.Tensor, gamma: Optional[torch.Tensor],
+                   Wnat: torch.Tensor, WnatT: torch.Tensor, bnat: Optional[torch.Tensor]):
+    _req(W1, torch.float32, "W1", 2), _req(inds, torch.int32, "inds", 1)
+    _req(Wnat, torch.bfloat16, "Wnat", 2), _req(WnatT, torch.bfloat16, "WnatT", 2)
+    r, D = W1.shape
+    if tuple(Wnat.shape) != (D, D) or tuple(WnatT.shape) != (D, D) or inds.numel() < r \
+            or not (W1.is_contiguous() and Wnat.is_contiguous() and WnatT.is_contiguous()):
+        raise ValueError("pack_proj_rows: shape mismatch")
+    if b1 is not None and (bnat is None or bnat.numel() != D or b1.numel() != r):
+        raise ValueError("pack_proj_rows: bias buffers")
+    if gamma is not None and gamma.numel() != D:
+        raise ValueError("pack_proj_rows: gamma length")
+    check(lib().apla_pack_proj_rows(W1.data_ptr(), _ptr(b1), inds.data_ptr(), _ptr(gamma), Wnat.data_ptr(),
+                                    WnatT.data_ptr(), _ptr(bnat), r, D, _stream()), "apla_pack_proj_rows")
+
+
+def adamw_step(params, grads, exp_avg, exp_avg_sq, decay_mask, *, lr, weight_decay, betas=(0.9, 0.999), eps=1e-8,
+               step: int, max_norm: float = 0.0, grad_scale: float = 1.0, norm_ws: torch.Tensor):
+    for t_, nm in ((params, "params"), (grads, "grads"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+        _req(t_, torch.float32, nm, 1)
+    _req(decay_mask, torch.uint8, "decay_mask", 1), _req(norm_ws, torch.float32, "norm_ws", 1)
+    n = params.numel()
+    if not (grads.numel() == exp_avg.numel() == exp_avg_sq.numel() == decay_mask.numel() == n) or norm_ws.numel() < 512:
+        raise ValueError("adamw_step: buffer sizes")
+    check(lib().apla_adamw_step(params.data_ptr(), grads.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
+                                decay_mask.data_ptr(), n, float(lr), float(weight_decay), float(betas[0]),
+                                float(betas[1]), float(eps), int(step), float(max_norm), float(grad_scale),
+                                norm_ws.data_ptr(), _stream()), "apla_adamw_step")
+
+
+def patchify(images: torch.Tensor, patch: int, Kp: int) -> torch.Tensor:
+    _req(images, torch.float32, "images", 4)
+    B, C, S, S2 = images.shape
+    if C != 3 or S != S2 or not images.is_contiguous():
+        raise ValueError("patchify: expected contiguous [B,3,S,S]")
+    Np = (S // patch) ** 2
+    cols = torch.empty(B * Np, Kp, device=images.device, dtype=torch.bfloat16)
+    check(lib().apla_patchify(images.data_ptr(), cols.data_ptr(), B, S, patch, Kp, _stream()), "apla_patchify")
+    return cols
+
+
+def assemble_tokens(patches: torch.Tensor, cls_token: torch.Tensor, pos: torch.Tensor, B: int, Np: int,
+                    res_dtype=torch.float32, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _req(patches, torch.bfloat16, "patches", 2), _req(cls_token, torch.float32, "cls"), _req(pos, torch.float32, "pos", 2)
+    D = patches.shape[1]
+    if patches.shape[0] != B * Np or cls_token.numel() != D or tuple(pos.shape) != (Np + 1, D) or not pos.is_contiguous():
+        raise ValueError("assemble_tokens: shape mismatch")
+    if out is None:
+        out = torch.empty(B * (Np + 1), D, device=patches.device, dtype=res_dtype)
+    check(lib().apla_assemble_tokens(patches.data_ptr(), patches.stride(0), cls_token.data_ptr(), pos.data_ptr(),
+                                     out.data_ptr(), _DT[out.dtype], B, Np, D, _stream()), "apla_assemble_tokens")
+    return out
+
+
+def sgemm_small(A: torch.Tensor, Bm: torch.Tensor, *, trans_a=False, trans_b=False, bias=None, out=None,
+                accumulate=False) -> torch.Tensor:
+    """fp32: out[M,N] (+)= op(A) @ op(Bm) (+bias); op = transpose when trans_* is set."""
+    _req(A, torch.float32, "A", 2), _req(Bm, torch.float32, "B", 2)
+    M, K = (A.shape[1], A.shape[0]) if trans_a else A.shape
+    Kb, N = (Bm.shape[1], Bm.shape[0]) if trans_b else Bm.shape
+    if K != Kb:
+        raise ValueError("sgemm_small: inner dimension mismatch")
+    sai, sak = (1, A.stride(0)) if trans_a else (A.stride(0), 1)
+    sbk, sbj = (1, Bm.stride(0)) if trans_b else (Bm.stride(0), 1)
+    if out is None:
+        out = torch.empty(M, N, device=A.device, dtype=torch.float32)
+    if tuple(out.shape) != (M, N) or out.dtype != torch.float32 or out.stride(1) != 1:
+        raise ValueError("sgemm_small: bad out")
+    check(lib().apla_sgemm_small(A.data_ptr(), sai, sak, Bm.data_ptr(), sbk, sbj, _ptr(bias), out.data_ptr(),
+                                 out.stride(0), M, N, K, int(accumulate), _stream()), "apla_sgemm_small")
+    return out
+
+
+def cross_entropy(logits: torch.Tensor, labels: torch.Tensor):
+    """Returns (loss [1], dlogits [B,C], row_loss [B]); mean reduction."""
+    _req(logits, torch.float32, "logits", 2), _req(labels, torch.int32, "labels", 1)
+    B, C = logits.shape
+    if labels.numel() != B or not logits.is_contiguous():
+        raise ValueError("cross_entropy: labels length / logits must be contiguous")
+    dlogits = torch.empty(B, C, device=logits.device, dtype=torch.float32)
+    row_loss = torch.empty(B, device=logits.device, dtype=torch.float32)
+    loss = torch.empty(1, device=logits.device, dtype=torch.float32)
+    check(lib().apla_cross_entropy(logits.data_ptr(), logits.stride(0), labels.data_ptr(), dlogits.data_ptr(),
+                                   row_loss.data_ptr(), loss.data_ptr(), B, C, _stream()), "apla_cross_entropy")
+    return loss, dlogits, row_loss
+
+
+def colsum(X: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _req(X, torch.float32, "X", 2)
+    M, N = X.shape
+    if out is None:
+        out = torch.empty(N, device=X.device, dtype=torch.float32)
+    check(lib().apla_colsum(X.data_ptr(), X.stride(0), out.data_ptr(), M, N, _stream()), "apla_colsum")
+    return out

@@ -1,0 +1,141 @@
+/* apla_hip.h — C-ABI of libapla_hip.so: the MI355X (gfx950) kernels behind the APLA fine-tuning hot path.
+ *
+ * Conventions:
+ *   - every entry point is `extern "C" int fn(..., hipStream_t stream)`; 0 = OK, negative = error
+ *     (APLA_EINVAL shape/alignment, APLA_ENOSYS unsupported configuration, APLA_EIO HIP launch error);
+ *     a human-readable message for the calling thread is available from apla_last_error().
+ *   - stateless and re-entrant: no allocation, no synchronisation, no global state; all buffers (including
+ *     workspaces) are owned by the caller; kernels are enqueued on `stream` only (hipGraph-capturable).
+ *   - activations / frozen weights are bf16 (raw uint16 storage), trainable masters / statistics / gradients fp32,
+ *     index vectors int32 on device.  "res" buffers (the residual stream and its gradient) are fp32 or bf16,
+ *     selected by `res_dtype` (APLA_F32 / APLA_BF16).
+ *   - matrices are row-major with an explicit leading dimension in ELEMENTS.
+ *
+ * Each declaration cites the reference interface it replaces (paths relative to /root/reference/src).
+ */
+#ifndef APLA_HIP_H
+#define APLA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef __HIP_PLATFORM_AMD__
+typedef struct ihipStream_t* hipStream_t;
+#endif
+
+enum { APLA_OK = 0, APLA_EIO = -5, APLA_EINVAL = -22, APLA_ENOSYS = -38 };
+enum { APLA_BF16 = 0, APLA_F32 = 2 };
+
+/* GEMM epilogues */
+enum {
+  APLA_EPI_STORE = 0,     /* C = acc (+bias)                                 -> out_dtype (bf16|f32)            */
+  APLA_EPI_GELU = 1,      /* a = acc+bias; C = gelu(a) bf16; aux_out = gelu'(a) bf16 (exact erf GELU)           */
+  APLA_EPI_RESIDUAL = 2,  /* C = aux_in + acc (+bias); aux_in/C are residual-stream dtype (may alias)           */
+  APLA_EPI_MUL = 3,       /* C = (acc (+bias)) * aux_in; aux_in bf16 [M,N]                      -> bf16         */
+  APLA_EPI_SWIGLU = 4,    /* weight rows interleaved (x1_i,x2_i): C[:, i] = silu(x1)*x2 bf16 [M,N/2];
+                             aux_out = (acc+bias) bf16 [M,N] (saved for backward)                               */
+  APLA_EPI_SWIGLU_BWD = 5 /* acc = dh [M,N]; aux_in = saved x12 interleaved [M,2N];
+                             C[:,2i] = dh*x2*silu'(x1), C[:,2i+1] = dh*silu(x1)       -> bf16 [M,2N]            */
+};
+
+const char* apla_last_error(void);
+int apla_version(void);
+
+/* C[M,N] = A[M,K] · W[N,K]^T (+bias) with a fused epilogue; bf16 MFMA, fp32 accumulate.
+ * Replaces every frozen nn.Linear on the path — qkv (apla/appla_attn.py:53), the merged APLA projection
+ * (appla_attn.py:64-79, scatter folded into the natural-order weight), Mlp.fc1/fc2 (utils/transformers/vit.py:152-168),
+ * SwiGLU w12/w3 (vit.py:108-149) — and their dX backward (same kernel on the transposed frozen weight).
+ * Requires N % 128 == 0, K % 64 == 0, lda/ldw % 8 == 0, 16-byte aligned pointers. */
+int apla_gemm_nt(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int M, int N,
+                 int K, int epilogue, int out_dtype, const void* aux_in, int ld_aux_in, void* aux_out,
+                 int ld_aux_out, hipStream_t stream);
+
+/* y = LayerNorm(x)*gamma+beta (y_dtype bf16, or f32 for the classifier-head input), saving mean/rstd (fp32).  x rows are `x_row_stride` elements apart so
+ * the final-norm-on-CLS-rows case (vit.py:416-419) needs no gather.  Replaces nn.LayerNorm(eps=1e-6)
+ * (vit.py:251,261,554). */
+int apla_layernorm_fwd(const void* x, int res_dtype, long x_row_stride, const float* gamma, const float* beta,
+                       void* y, int y_dtype, int ldy, float* mean, float* rstd, int M, int D, float eps,
+                       hipStream_t stream);
+
+/* dx_out = dres_in + LN_backward_dx(dy; x, gamma, mean, rstd)   (gamma/beta frozen: apla/apla_vit.py:80-81).
+ * dres_in may be NULL (treated as 0) and may alias dx_out.  If `gather_out` != NULL also writes the APLA-trainable
+ * columns of dx_out: gather_out[m, j] = dx_out[m, inds[j]] for j < r (bf16) — the only part of the projection's
+ * output gradient that the column-masked dW1 needs (autograd of the scatter at appla_attn.py:70-74). */
+int apla_layernorm_bwd(const void* dy, int dy_dtype, int lddy, const void* x, int res_dtype, long x_row_stride, const float* gamma,
+                       const float* mean, const float* rstd, const void* dres_in, void* dx_out, long dx_row_stride,
+                       const int32_t* inds, int r, void* gather_out, int M, int D, hipStream_t stream);
+
+/* Gather only (used when the projection output gradient is already materialised): out[m,j] = src[m,inds[j]] bf16. */
+int apla_gather_cols(const void* src, int res_dtype, long src_row_stride, const int32_t* inds, int r, void* out,
+                     int M, int D, hipStream_t stream);
+
+/* Fused multi-head attention forward on the packed qkv activations [B*N, 3*H*64] (layout [.., 3, H, 64], exactly the
+ * output of the qkv Linear): o[B*N, H*64] = softmax(q k^T * scale) v, lse[B,H,N] = log-sum-exp of the scaled scores.
+ * Replaces appla_attn.py:53-60 without materialising attn[B,H,N,N].  head_dim must be 64. */
+int apla_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, float scale, hipStream_t stream);
+
+/* Attention backward from (qkv, o, do, lse): dqkv[B*N, 3*H*64].  `delta` is a caller workspace of B*H*N floats.
+ * Deterministic (no atomics).  Autograd of appla_attn.py:53-60. */
+int apla_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv, int B,
+                  int N, int H, float scale, hipStream_t stream);
+
+/* Materialise attn[B,H,N,N] (fp32) on demand — the second return value of APLA_Attention.forward (appla_attn.py:83),
+ * used only by Block.forward(return_attention=True) (vit.py:279-287). */
+int apla_attn_probs(const void* qkv, const float* lse, float* attn, int B, int N, int H, float scale,
+                    hipStream_t stream);
+
+/* Column-masked weight gradient of the APLA projection:
+ *   dW1[j,:] (+)= row_scale[j] * sum_m dyg[m,j] * x[m,:]     dW1 fp32 [r,D]
+ *   db1[j]   (+)= row_scale[j] * sum_m dyg[m,j]              db1 fp32 [r]
+ * dyg bf16 [M,r] (gathered trainable columns), x bf16 [M,D] (projection input = attention output).
+ * The (D-r) frozen columns of dW are never formed.  Replaces autograd of F.linear(x, proj_weight1, proj_bias1)
+ * (appla_attn.py:64).  `partial` is a caller workspace of apla_dw_workspace_bytes(M,r,D) bytes.
+ * accumulate != 0 adds into dW1/db1.  row_scale may be NULL (=1).  Deterministic (slab reduction). */
+long apla_dw_workspace_bytes(int M, int r, int D);
+int apla_proj_dw(const void* dyg, const void* x, int ldx, const float* row_scale, float* dW1, float* db1,
+                 void* partial, int M, int r, int D, int accumulate, hipStream_t stream);
+
+/* Refresh the engine-layout copies of the projection after W1/b1 changed:
+ *   Wnat[inds[j], :]  = bf16(gamma[inds[j]] * W1[j, :])         natural-order forward weight  [D,D]
+ *   WnatT[:, inds[j]] = bf16(gamma[inds[j]] * W1[j, :])         transposed copy for dX         [D,D]
+ *   bnat[inds[j]]     = gamma[inds[j]] * b1[j]                                                 [D] fp32
+ * for j < r (gamma may be NULL).  This is where the reference's two scatter_ calls (appla_attn.py:70-79) go:
+ * applied once per step to r rows of weights instead of every forward to M rows of activations. */
+int apla_pack_proj_rows(const float* W1, const float* b1, const int32_t* inds, const float* gamma, void* Wnat,
+                        void* WnatT, float* bnat, int r, int D, hipStream_t stream);
+
+/* Fused global-norm clip + AdamW over the flat trainable buffer (defaults/trainer.py:127-138,
+ * defaults/wrappers.py:205-221): grads are first multiplied by grad_scale (1/world for DDP mean), the global L2
+ * norm is reduced on device (no host sync), clip coefficient = min(1, max_norm/(norm+1e-6)) (max_norm <= 0 disables),
+ * weight decay applies to elements with decay_mask[i] != 0 (uint8).  `norm_ws` = 512 floats workspace:
+ * [0] sum of squares, [1] resulting grad norm (pre-clip), [2..257] per-workgroup partials (deterministic reduction).
+ * Grads are overwritten with the scaled+clipped values (as clip_grad_norm_ does in place). */
+int apla_adamw_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, const uint8_t* decay_mask,
+                    long n, float lr, float weight_decay, float beta1, float beta2, float eps, int step,
+                    float max_norm, float grad_scale, float* norm_ws, hipStream_t stream);
+
+/* Patch embedding front end (vit.py:291-307, 387-396): images fp32 [B,3,S,S] -> im2col bf16 [B*Np, Kp] with
+ * Kp = round_up(3*p*p, 64) (zero padded); then (after the GEMM) tokens[b,0] = cls+pos[0], tokens[b,1+t] =
+ * patches[b,t] + pos[1+t] in residual dtype. */
+int apla_patchify(const float* images, void* cols, int B, int S, int patch, int Kp, hipStream_t stream);
+int apla_assemble_tokens(const void* patches, int ldp, const float* cls_token, const float* pos_embed, void* tokens,
+                         int res_dtype, int B, int Np, int D, hipStream_t stream);
+
+/* Classifier head on the normalised CLS features (defaults/models.py:64-65,86-87) and mean cross-entropy
+ * (defaults/wrappers.py:312-316), fp32 throughout.  The head is [B,D]x[D,C] (0.2 GFLOP): plain fp32 FMA kernels.
+ *   apla_sgemm_small : C[i,j] (+)= sum_k A[i*sai + k*sak] * B[k*sbk + j*sbj] (+ bias[j])   (any strides: NT/NN/TN)
+ *   apla_cross_entropy: dlogits = (softmax(logits) - onehot(labels)) / B ; row_loss[b] ; loss = mean(row_loss)
+ *   apla_colsum      : out[j] = sum_i X[i*ld + j]                                           (bias gradient) */
+int apla_sgemm_small(const float* A, long sai, long sak, const float* Bm, long sbk, long sbj, const float* bias,
+                     float* C, long ldc, int M, int N, int K, int accumulate, hipStream_t stream);
+int apla_cross_entropy(const float* logits, int ldl, const int32_t* labels, float* dlogits, float* row_loss,
+                       float* loss, int B, int C, hipStream_t stream);
+int apla_colsum(const float* X, long ld, float* out, int M, int N, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* APLA_HIP_H */

@@ -1,0 +1,327 @@
+"""Kernel-level parity: every HIP kernel (through the C-ABI, apla_amd.ops) against the CPU oracle evaluated in fp64 on
+the SAME bf16-rounded inputs.  Tolerances are stated per test: bf16 outputs carry one rounding (2^-9 relative) on top
+of fp32 accumulation-order differences; fp32 outputs are compared much tighter."""
+import math
+
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import apla_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+BF16_OUT = 6e-3   # max-abs error / max-abs reference for a bf16-rounded output of O(1) dynamic range
+F32_OUT = 2e-5
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from apla_amd import ops as _ops
+    return _ops
+
+
+def dev(t, dtype=None):
+    return t.to("cuda", dtype) if dtype else t.to("cuda")
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def bf(t):
+    """round to bf16 and return (bf16 tensor, its exact fp64 value)"""
+    b = t.to(torch.bfloat16)
+    return b, b.double()
+
+
+# ------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(300, 256, 192), (1000, 384, 768), (128, 128, 64), (1, 128, 64), (25216, 768, 768)])
+def test_gemm_store_bias(ops, M, N, K):
+    a, ad = bf(rnd(M, K, seed=1))
+    w, wd = bf(rnd(N, K, scale=K ** -0.5, seed=2))
+    bias = rnd(N, seed=3)
+    ref = ad @ wd.t() + bias.double()
+    out = ops.gemm_nt(dev(a), dev(w), dev(bias))
+    assert rel_err(out.cpu(), ref) < BF16_OUT
+    out32 = ops.gemm_nt(dev(a), dev(w), dev(bias), out_dtype=torch.float32)
+    assert rel_err(out32.cpu(), ref) < F32_OUT
+    nob = ops.gemm_nt(dev(a), dev(w), None, out_dtype=torch.float32)
+    assert rel_err(nob.cpu(), ad @ wd.t()) < F32_OUT
+
+
+def test_gemm_strided_a_and_tail(ops):
+    """A given as a column slice of a wider buffer (lda > K), M not a multiple of the tile."""
+    M, N, K = 333, 128, 128
+    big, bigd = bf(rnd(M, 3 * K, seed=4))
+    w, wd = bf(rnd(N, K, scale=K ** -0.5, seed=5))
+    A = dev(big)[:, K:2 * K]
+    out = ops.gemm_nt(A, dev(w), None, out_dtype=torch.float32)
+    assert rel_err(out.cpu(), bigd[:, K:2 * K] @ wd.t()) < F32_OUT
+
+
+def test_gemm_gelu(ops):
+    M, N, K = 515, 256, 128
+    a, ad = bf(rnd(M, K, seed=6))
+    w, wd = bf(rnd(N, K, scale=2 * K ** -0.5, seed=7))
+    bias = rnd(N, scale=0.3, seed=8)
+    pre = ad @ wd.t() + bias.double()
+    g = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    h = ops.gemm_nt(dev(a), dev(w), dev(bias), epilogue=ops.EPI_GELU, aux_out=g)
+    assert rel_err(h.cpu(), O.gelu_fwd(pre)) < BF16_OUT
+    assert rel_err(g.cpu(), O.gelu_grad(pre)) < BF16_OUT
+
+
+@pytest.mark.parametrize("res_dtype", [torch.float32, torch.bfloat16])
+def test_gemm_residual(ops, res_dtype):
+    M, N, K = 260, 128, 192
+    a, ad = bf(rnd(M, K, seed=9))
+    w, wd = bf(rnd(N, K, scale=K ** -0.5, seed=10))
+    bias = rnd(N, seed=11)
+    res = rnd(M, N, seed=12).to(res_dtype)
+    ref = res.double() + ad @ wd.t() + bias.double()
+    r_dev = dev(res)
+    out = ops.gemm_nt(dev(a), dev(w), dev(bias), epilogue=ops.EPI_RESIDUAL, aux_in=r_dev, out_dtype=res_dtype)
+    assert rel_err(out.cpu(), ref) < (F32_OUT if res_dtype == torch.float32 else BF16_OUT)
+    # in place (aux_in aliases out)
+    ops.gemm_nt(dev(a), dev(w), dev(bias), epilogue=ops.EPI_RESIDUAL, aux_in=r_dev, out=r_dev)
+    assert rel_err(r_dev.cpu(), ref) < (F32_OUT if res_dtype == torch.float32 else BF16_OUT)
+
+
+def test_gemm_mul(ops):
+    M, N, K = 130, 256, 64
+    a, ad = bf(rnd(M, K, seed=13))
+    w, wd = bf(rnd(N, K, scale=K ** -0.5, seed=14))
+    g, gd = bf(rnd(M, N, seed=15))
+    out = ops.gemm_nt(dev(a), dev(w), None, epilogue=ops.EPI_MUL, aux_in=dev(g))
+    assert rel_err(out.cpu(), (ad @ wd.t()) * gd) < BF16_OUT
+
+
+def test_gemm_swiglu_fwd_bwd(ops):
+    M, Fh, K = 200, 128, 64  # hidden Fh; interleaved weight has 2*Fh rows
+    a, ad = bf(rnd(M, K, seed=16))
+    w12, w12d = bf(rnd(2 * Fh, K, scale=2 * K ** -0.5, seed=17))  # rows [w1; w2]
+    b12 = rnd(2 * Fh, scale=0.2, seed=18)
+    inter = torch.stack([w12[:Fh], w12[Fh:]], 1).reshape(2 * Fh, K).contiguous()
+    binter = torch.stack([b12[:Fh], b12[Fh:]], 1).reshape(2 * Fh).contiguous()
+    x12 = ad @ w12d.t() + b12.double()
+    x1, x2 = x12[:, :Fh], x12[:, Fh:]
+    saved = torch.empty(M, 2 * Fh, device="cuda", dtype=torch.bfloat16)
+    h = ops.gemm_nt(dev(a), dev(inter), dev(binter), epilogue=ops.EPI_SWIGLU, aux_out=saved)
+    assert rel_err(h.cpu(), O.silu(x1) * x2) < BF16_OUT
+    assert rel_err(saved.cpu().double().reshape(M, Fh, 2)[:, :, 0], x1) < BF16_OUT
+    # backward: dh = g @ w3t^T ; dx12 interleaved
+    Dout = 64
+    gup, gupd = bf(rnd(M, Dout, seed=19))
+    w3t, w3td = bf(rnd(Fh, Dout, scale=Dout ** -0.5, seed=20))  # [Fh, Dout] = w3^T layout for the NT kernel
+    dh = gupd @ w3td.t()
+    sv = saved.cpu().double().reshape(M, Fh, 2)
+    s1, s2 = sv[:, :, 0], sv[:, :, 1]
+    ref = torch.stack([dh * s2 * O.silu_grad(s1), dh * O.silu(s1)], 2).reshape(M, 2 * Fh)
+    dx12 = ops.gemm_nt(dev(gup), dev(w3t), None, epilogue=ops.EPI_SWIGLU_BWD, aux_in=saved)
+    assert rel_err(dx12.cpu(), ref) < BF16_OUT
+
+
+def test_gemm_rejects_bad_shapes(ops):
+    from apla_amd._lib import AplaHipError
+    a = torch.zeros(16, 96, device="cuda", dtype=torch.bfloat16)
+    w = torch.zeros(128, 96, device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(AplaHipError):
+        ops.gemm_nt(a, w)  # K % 64 != 0
+    with pytest.raises(AplaHipError):
+        ops.gemm_nt(torch.zeros(4, 64), torch.zeros(128, 64))  # CPU tensors: no CPU path
+
+
+# ------------------------------------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize("res_dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,D", [(37, 64), (1001, 384), (515, 768), (64, 1536)])
+def test_layernorm_fwd_bwd(ops, res_dtype, M, D):
+    x = (rnd(M, D, seed=21) * 1.5 + 0.3).to(res_dtype)
+    gamma, beta = 1 + 0.2 * rnd(D, seed=22), 0.1 * rnd(D, seed=23)
+    xd = x.double()
+    yref, mref, rref = O.layernorm_fwd(xd, gamma.double(), beta.double(), 1e-6)
+    y, mean, rstd = ops.layernorm_fwd(dev(x), dev(gamma), dev(beta), 1e-6)
+    assert rel_err(y.cpu(), yref) < BF16_OUT
+    assert rel_err(mean.cpu(), mref) < 1e-5 and rel_err(rstd.cpu(), rref) < 1e-5
+    y32, _, _ = ops.layernorm_fwd(dev(x), dev(gamma), dev(beta), 1e-6, out_dtype=torch.float32)
+    assert rel_err(y32.cpu(), yref) < F32_OUT
+    dy, dyd = bf(rnd(M, D, seed=24))
+    dres = rnd(M, D, seed=25).to(res_dtype)
+    ref = dres.double() + O.layernorm_bwd_dx(dyd, xd, gamma.double(), mref, rref)
+    r = min(64, D // 2)
+    inds = torch.randperm(D, generator=torch.Generator().manual_seed(1)).int()
+    dx, gathered = ops.layernorm_bwd(dev(dy), dev(x), dev(gamma), mean, rstd, dres=dev(dres), inds=dev(inds), r=r)
+    tol = F32_OUT * 5 if res_dtype == torch.float32 else BF16_OUT
+    assert rel_err(dx.cpu(), ref) < tol
+    assert rel_err(gathered.cpu(), ref[:, inds[:r].long()]) < BF16_OUT
+    dx2, none = ops.layernorm_bwd(dev(dy), dev(x), dev(gamma), mean, rstd)
+    assert none is None
+    assert rel_err(dx2.cpu(), ref - dres.double()) < tol
+    g2 = ops.gather_cols(dx, dev(inds), r)
+    assert torch.equal(g2.cpu(), dx.cpu()[:, inds[:r].long()].to(torch.bfloat16))
+
+
+def test_layernorm_cls_rows_strided(ops):
+    """final norm on CLS rows only: row m at offset m*N*D of the residual buffer (vit.py:416-419)."""
+    B, N, D = 5, 7, 128
+    x = rnd(B * N, D, seed=26)
+    gamma, beta = 1 + 0.2 * rnd(D, seed=27), 0.1 * rnd(D, seed=28)
+    xdev = dev(x)
+    y, mean, rstd = ops.layernorm_fwd(xdev, dev(gamma), dev(beta), 1e-6, out_dtype=torch.float32, rows=B, row_stride=N * D)
+    yref, mref, rref = O.layernorm_fwd(x.double()[::N], gamma.double(), beta.double(), 1e-6)
+    assert rel_err(y.cpu(), yref) < F32_OUT
+    dy = rnd(B, D, seed=29)
+    out = torch.zeros(B * N, D, device="cuda")
+    ops.layernorm_bwd(dev(dy), xdev, dev(gamma), mean, rstd, out=out, rows=B, row_stride=N * D)
+    ref = torch.zeros(B * N, D, dtype=torch.float64)
+    ref[::N] = O.layernorm_bwd_dx(dy.double(), x.double()[::N], gamma.double(), mref, rref)
+    assert rel_err(out.cpu(), ref) < 5 * F32_OUT
+
+
+# ------------------------------------------------------------------------------------------- attention
+@pytest.mark.parametrize("B,N,H", [(2, 197, 2), (1, 64, 1), (3, 300, 3), (1, 1, 1), (2, 129, 2), (1, 1370, 1)])
+def test_attention_fwd_bwd(ops, B, N, H):
+    D = 64 * H
+    scale = 64 ** -0.5
+    qkv, qkvd = bf(rnd(B, N, 3 * D, seed=31))
+    oref, lref, aref = O.attention_fwd(qkvd, H, scale, return_attn=True)
+    o, lse = ops.attn_fwd(dev(qkv).reshape(B * N, 3 * D), B, N, H, scale)
+    assert rel_err(o.cpu().reshape(B, N, D), oref) < BF16_OUT
+    assert float((lse.cpu().double() - lref).abs().max()) < 2e-4
+    do, dod = bf(rnd(B, N, D, seed=32))
+    # reference backward evaluated at the bf16-rounded o that the kernel actually saved
+    o_saved = o.cpu().double().reshape(B, N, D)
+    dref = O.attention_bwd(dod, qkvd, o_saved, lref, H, scale)
+    dqkv = ops.attn_bwd(dev(qkv).reshape(B * N, 3 * D), o, dev(do).reshape(B * N, D), lse, B, N, H, scale)
+    got = dqkv.cpu().reshape(B, N, 3 * D)
+    for i, nm in enumerate(("dq", "dk", "dv")):
+        e = rel_err(got[..., i * D:(i + 1) * D], dref[..., i * D:(i + 1) * D])
+        assert e < 2e-2, (nm, e)   # P and dS are rounded to bf16 before the second product
+    attn = ops.attn_probs(dev(qkv).reshape(B * N, 3 * D), lse, B, N, H, scale)
+    assert rel_err(attn.cpu(), aref) < 1e-4
+
+
+def test_attention_online_softmax_rescale_branch(ops):
+    """Force the running max to jump at a later key block (guide rule 26): one key spikes against every query."""
+    B, N, H = 1, 200, 1
+    scale = 64 ** -0.5
+    qkv = rnd(B, N, 192, seed=33)
+    qkv[0, 150, 64:128] = qkv[0, :, 0:64].mean(0) * 0 + 6.0 * torch.sign(qkv[0, 3, 0:64])  # big key in block 2
+    qkvb, qkvd = bf(qkv)
+    oref, lref = O.attention_fwd(qkvd, H, scale)
+    o, lse = ops.attn_fwd(dev(qkvb).reshape(N, 192), B, N, H, scale)
+    assert rel_err(o.cpu().reshape(B, N, 64), oref) < BF16_OUT
+    assert float((lse.cpu().double() - lref).abs().max()) < 1e-3
+
+
+# ------------------------------------------------------------------------------------------- APLA dW / pack
+@pytest.mark.parametrize("M,r,D", [(1000, 64, 128), (197 * 8, 64, 384), (64, 128, 256), (25216, 192, 768)])
+def test_proj_dw(ops, M, r, D):
+    dyg, dygd = bf(rnd(M, r, seed=41))
+    x, xd = bf(rnd(M, D, seed=42))
+    scale = 0.5 + torch.rand(r, generator=torch.Generator().manual_seed(43))
+    ref_w = scale.double()[:, None] * (dygd.t() @ xd)
+    ref_b = scale.double() * dygd.sum(0)
+    dW = torch.full((r, D), 7.0, device="cuda")
+    db = torch.full((r,), 7.0, device="cuda")
+    ops.proj_dw(dev(dyg), dev(x), dW, db, row_scale=dev(scale))
+    assert rel_err(dW.cpu(), ref_w) < 5e-5 and rel_err(db.cpu(), ref_b) < 5e-5
+    ops.proj_dw(dev(dyg), dev(x), dW, db, row_scale=dev(scale), accumulate=True)
+    assert rel_err(dW.cpu(), 2 * ref_w) < 5e-5 and rel_err(db.cpu(), 2 * ref_b) < 5e-5
+    # determinism: bitwise identical on a re-run
+    dW2, db2 = torch.empty_like(dW), torch.empty_like(db)
+    ops.proj_dw(dev(dyg), dev(x), dW2, db2, row_scale=dev(scale))
+    dW3, db3 = torch.empty_like(dW), torch.empty_like(db)
+    ops.proj_dw(dev(dyg), dev(x), dW3, db3, row_scale=dev(scale))
+    assert torch.equal(dW2, dW3) and torch.equal(db2, db3)
+
+
+def test_pack_proj_rows_equals_reference_scatter(ops):
+    """Weight-side scatter == the reference's activation-side scatter (appla_attn.py:64-79)."""
+    D, r, M = 128, 32, 50
+    torch.manual_seed(5)
+    W, b = rnd(D, D, scale=0.1, seed=44), rnd(D, scale=0.1, seed=45)
+    inds = O.sample_indices(D)
+    W1, W2, b1, b2 = O.split_proj(W, b, inds, r)
+    gamma = 0.5 + torch.rand(D, generator=torch.Generator().manual_seed(46))
+    # frozen part prepared on the host once; trainable rows packed by the kernel
+    Wn = torch.zeros(D, D)
+    Wn[inds[r:]] = gamma[inds[r:], None] * W2
+    bn = torch.zeros(D)
+    bn[inds[r:]] = gamma[inds[r:]] * b2
+    Wnat, WnatT, bnat = dev(Wn, torch.bfloat16), dev(Wn.t().contiguous(), torch.bfloat16), dev(bn)
+    ops.pack_proj_rows(dev(W1), dev(b1), dev(inds.int()), dev(gamma), Wnat, WnatT, bnat)
+    full = (gamma[:, None] * W).to(torch.bfloat16)
+    assert torch.equal(Wnat.cpu(), full)
+    assert torch.equal(WnatT.cpu(), full.t())
+    assert rel_err(bnat.cpu(), gamma * b) < 1e-6
+    x, xd = bf(rnd(M, D, seed=47))
+    y = ops.gemm_nt(dev(x), Wnat, bnat, out_dtype=torch.float32)
+    ref = gamma.double() * O.apla_proj_fwd(xd, W1.to(torch.bfloat16).double() * 1.0, b1.double(), W2.double(), b2.double(), inds)
+    assert rel_err(y.cpu(), ref) < 1e-2  # gamma*W rounded once to bf16 vs W rounded then scaled
+
+
+# ------------------------------------------------------------------------------------------- optimizer
+def test_adamw_clip_matches_oracle(ops):
+    n = 5000
+    p0, g0 = rnd(n, seed=51), rnd(n, scale=0.05, seed=52)
+    mask = (torch.arange(n) % 3 != 0)
+    p = {"w": p0[mask].clone(), "b.bias": p0[~mask].clone()}
+    g = {"w": g0[mask].clone() * 0.5, "b.bias": g0[~mask].clone() * 0.5}
+    p["w"] = p["w"].reshape(-1, 1)  # ndim 2 -> decayed
+    g["w"] = g["w"].reshape(-1, 1)
+    state = {}
+    P, G = dev(p0.clone()), dev(g0.clone())
+    m, v = torch.zeros_like(P), torch.zeros_like(P)
+    ws = torch.zeros(512, device="cuda")
+    decay = dev(mask.to(torch.uint8))
+    for step in (1, 2, 3):
+        gn = O.clip_grad_norm(g, 1.0)
+        O.adamw_step(p, g, state, lr=1e-2, wd=0.1)
+        ops.adamw_step(P, G, m, v, decay, lr=1e-2, weight_decay=0.1, step=step, max_norm=1.0, grad_scale=0.5, norm_ws=ws)
+        assert abs(float(ws[1]) - float(gn)) < 1e-5 * float(gn)
+        got = P.cpu()
+        assert rel_err(got[mask], p["w"].flatten()) < 2e-6 and rel_err(got[~mask], p["b.bias"]) < 2e-6
+        g = {"w": (g0[mask] * 0.5).reshape(-1, 1).clone(), "b.bias": (g0[~mask] * 0.5).clone()}
+        G.copy_(dev(g0))
+
+
+# ------------------------------------------------------------------------------------------- front end / head
+@pytest.mark.parametrize("S,patch,D", [(32, 16, 128), (28, 14, 128)])
+def test_patch_embed_tokens(ops, S, patch, D):
+    B = 3
+    img = rnd(B, 3, S, S, seed=61)
+    Wc, bc = rnd(D, 3, patch, patch, scale=0.05, seed=62), rnd(D, scale=0.1, seed=63)
+    Np = (S // patch) ** 2
+    cls, pos = rnd(1, 1, D, scale=0.1, seed=64), rnd(1, Np + 1, D, scale=0.1, seed=65)
+    K = 3 * patch * patch
+    Kp = (K + 63) // 64 * 64
+    Wp = torch.zeros(D, Kp)
+    Wp[:, :K] = Wc.reshape(D, K)
+    cols = ops.patchify(dev(img), patch, Kp)
+    patches = ops.gemm_nt(cols, dev(Wp, torch.bfloat16), dev(bc))
+    tok = ops.assemble_tokens(patches, dev(cls.flatten()), dev(pos[0].contiguous()), B, Np)
+    p = {"patch_embed.proj.weight": Wc.to(torch.bfloat16).double(), "patch_embed.proj.bias": bc.double(),
+         "cls_token": cls.double(), "pos_embed": pos.double()}
+    ref = O.embed_tokens(img.to(torch.bfloat16).double(), p, patch)
+    assert rel_err(tok.cpu().reshape(B, Np + 1, D), ref) < BF16_OUT
+
+
+def test_head_and_cross_entropy(ops):
+    B, D, C = 37, 96, 1000
+    xn, W, b = rnd(B, D, seed=71), rnd(C, D, scale=0.05, seed=72), rnd(C, scale=0.1, seed=73)
+    labels = torch.randint(0, C, (B,), generator=torch.Generator().manual_seed(74))
+    logits = ops.sgemm_small(dev(xn), dev(W), trans_b=True, bias=dev(b))
+    ref_logits = xn.double() @ W.double().t() + b.double()
+    assert rel_err(logits.cpu(), ref_logits) < 1e-5
+    loss, dlogits, _ = ops.cross_entropy(logits, dev(labels.int()))
+    rl, rdl = O.cross_entropy_fwd_bwd(ref_logits, labels)
+    assert abs(float(loss) - float(rl)) < 1e-5 and rel_err(dlogits.cpu(), rdl) < 1e-5
+    dW = ops.sgemm_small(dlogits, dev(xn), trans_a=True)
+    dxn = ops.sgemm_small(dlogits, dev(W))
+    db = ops.colsum(dlogits)
+    assert rel_err(dW.cpu(), rdl.t() @ xn.double()) < 1e-5
+    assert rel_err(dxn.cpu(), rdl @ W.double()) < 1e-5
+    assert rel_err(db.cpu(), rdl.sum(0)) < 1e-5
