@@ -22,7 +22,8 @@ SIGNATURES = {
     "apla_layernorm_fwd": (c_int, [c_void_p, c_int, c_long, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                    c_void_p, c_int, c_int, c_float, c_void_p]),
     "apla_layernorm_bwd": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_long, c_void_p, c_void_p, c_void_p,
-                                   c_void_p, c_void_p, c_long, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
+                                   c_void_p, c_void_p, c_int, c_long, c_void_p, c_long, c_void_p, c_int, c_void_p,
+                                   c_int, c_int, c_void_p]),
     "apla_gather_cols": (c_int, [c_void_p, c_int, c_long, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     "apla_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "apla_attn_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,

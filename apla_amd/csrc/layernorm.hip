@@ -56,12 +56,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const ResT* __restrict__ x,
   }
 }
 
-// dx_out = dres_in + ((dy*g) - mean(dy*g) - xhat*mean(dy*g*xhat)) * rstd ; optional gather of trainable columns.
-template <typename ResT, typename DYT, bool GATHER>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const DYT* __restrict__ dy, int lddy, const ResT* __restrict__ x,
+// dx_out = dres_in + ((dy*g) - mean(dy*g) - xhat*mean(dy*g*xhat)) * rstd ; optional bf16 copy of dx_out (GEMM operand
+// when the gradient stream is fp32) and optional gather of the APLA-trainable columns.
+template <typename XT, typename DYT, typename GT, bool GATHER>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const DYT* __restrict__ dy, int lddy, const XT* __restrict__ x,
                                                      long xs, const float* __restrict__ gamma,
                                                      const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
-                                                     const ResT* dres, ResT* dx, long dxs,
+                                                     const GT* dres, GT* dx, long dxs, bf16* __restrict__ dxb, long dbs,
                                                      const int32_t* __restrict__ inds, int r, bf16* __restrict__ gout,
                                                      int M, int D) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const DYT* __restrict__ dy,
   for (int m0 = blockIdx.x * ROWS_PER_BLOCK; m0 < M; m0 += gridDim.x * ROWS_PER_BLOCK) {
     const int m = m0 + wave;
     if (m < M) {
-      const ResT* xr = x + (size_t)m * xs;
+      const XT* xr = x + (size_t)m * xs;
       const DYT* dyr = dy + (size_t)m * lddy;
       const float mean = mean_i[m], rstd = rstd_i[m];
       f32x4 xh[MAXC], w[MAXC];
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const DYT* __restrict__ dy,
       for (int c = 0; c < MAXC; ++c) {
         const int ch = lane + c * 64;
         if (ch < nchunk) {
-          const f32x4 xv = Vec4IO<ResT>::load(xr + ch * 4);
+          const f32x4 xv = Vec4IO<XT>::load(xr + ch * 4);
           const f32x4 dv = Vec4IO<DYT>::load(dyr + ch * 4);
           const f32x4 g = *(const f32x4*)(gamma + ch * 4);
 #pragma unroll
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const DYT* __restrict__ dy,
         }
       }
       const float c1 = wave_sum(s1) / (float)D, c2 = wave_sum(s2) / (float)D;
-      ResT* dxr = dx + (size_t)m * dxs;
+      GT* dxr = dx + (size_t)m * dxs;
 #pragma unroll
       for (int c = 0; c < MAXC; ++c) {
         const int ch = lane + c * 64;
@@ -101,8 +102,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const DYT* __restrict__ dy,
           f32x4 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = (w[c][e] - c1 - xh[c][e] * c2) * rstd;
-          if (dres != nullptr) o += Vec4IO<ResT>::load(dres + (size_t)m * dxs + ch * 4);
-          Vec4IO<ResT>::store(dxr + ch * 4, o);
+          if (dres != nullptr) o += Vec4IO<GT>::load(dres + (size_t)m * dxs + ch * 4);
+          Vec4IO<GT>::store(dxr + ch * 4, o);
+          if (dxb != nullptr) Vec4IO<bf16>::store(dxb + (size_t)m * dbs + ch * 4, o);
           if constexpr (GATHER) *(f32x4*)(rowbuf + wave * D + ch * 4) = o;
         }
       }
@@ -154,29 +156,39 @@ extern "C" int apla_layernorm_fwd(const void* x, int res_dtype, long x_row_strid
   return APLA_OK;
 }
 
-extern "C" int apla_layernorm_bwd(const void* dy, int dy_dtype, int lddy, const void* x, int res_dtype, long x_row_stride,
+extern "C" int apla_layernorm_bwd(const void* dy, int dy_dtype, int lddy, const void* x, int x_dtype, long x_row_stride,
                                   const float* gamma, const float* mean, const float* rstd, const void* dres_in,
-                                  void* dx_out, long dx_row_stride, const int32_t* inds, int r, void* gather_out, int M,
-                                  int D, hipStream_t stream) {
+                                  void* dx_out, int grad_dtype, long dx_row_stride, void* dx_bf16_copy,
+                                  long copy_row_stride, const int32_t* inds, int r, void* gather_out, int M, int D,
+                                  hipStream_t stream) {
   APLA_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 256 * MAXC, "apla_layernorm_bwd: need D%%4==0 and D<=2048 (D=%d)", D);
   APLA_REQUIRE(dy && x && gamma && mean && rstd && dx_out, "apla_layernorm_bwd: null pointer");
   APLA_REQUIRE(lddy % 4 == 0 && x_row_stride % 4 == 0 && dx_row_stride % 4 == 0 && lddy >= D && x_row_stride >= D && dx_row_stride >= D, "apla_layernorm_bwd: bad strides");
+  APLA_REQUIRE(dx_bf16_copy == nullptr || (copy_row_stride % 4 == 0 && copy_row_stride >= D), "apla_layernorm_bwd: bad copy stride");
   APLA_REQUIRE(gather_out == nullptr || (inds != nullptr && r > 0 && r <= D), "apla_layernorm_bwd: gather needs inds and 0<r<=D");
   const bool gather = gather_out != nullptr;
   const size_t lds = gather ? (size_t)ROWS_PER_BLOCK * D * sizeof(float) : 0;
-#define LN_BWD(T, Y, G)                                                                                                \
-  hipLaunchKernelGGL((ln_bwd_kernel<T, Y, G>), dim3(ln_grid(M)), dim3(256), lds, stream, (const Y*)dy, lddy,           \
-                     (const T*)x, x_row_stride, gamma, mean, rstd, (const T*)dres_in, (T*)dx_out, dx_row_stride, inds, \
-                     r, (bf16*)gather_out, M, D)
-#define LN_BWD_G(T, Y) do { if (gather) LN_BWD(T, Y, true); else LN_BWD(T, Y, false); } while (0)
-  if (res_dtype == APLA_F32 && dy_dtype == APLA_BF16) LN_BWD_G(float, bf16);
-  else if (res_dtype == APLA_F32 && dy_dtype == APLA_F32) LN_BWD_G(float, float);
-  else if (res_dtype == APLA_BF16 && dy_dtype == APLA_BF16) LN_BWD_G(bf16, bf16);
-  else if (res_dtype == APLA_BF16 && dy_dtype == APLA_F32) LN_BWD_G(bf16, float);
-  else {
-    apla_set_error("apla_layernorm_bwd: bad res_dtype %d / dy_dtype %d", res_dtype, dy_dtype);
+#define LN_BWD(X, Y, G, GA)                                                                                            \
+  hipLaunchKernelGGL((ln_bwd_kernel<X, Y, G, GA>), dim3(ln_grid(M)), dim3(256), lds, stream, (const Y*)dy, lddy,       \
+                     (const X*)x, x_row_stride, gamma, mean, rstd, (const G*)dres_in, (G*)dx_out, dx_row_stride,       \
+                     (bf16*)dx_bf16_copy, copy_row_stride, inds, r, (bf16*)gather_out, M, D)
+#define LN_BWD_G(X, Y, G) do { if (gather) LN_BWD(X, Y, G, true); else LN_BWD(X, Y, G, false); } while (0)
+#define LN_BWD_Y(X, G)                                           \
+  do {                                                           \
+    if (dy_dtype == APLA_BF16) LN_BWD_G(X, bf16, G);             \
+    else LN_BWD_G(X, float, G);                                  \
+  } while (0)
+  const bool ok = (x_dtype == APLA_F32 || x_dtype == APLA_BF16) && (dy_dtype == APLA_F32 || dy_dtype == APLA_BF16) &&
+                  (grad_dtype == APLA_F32 || grad_dtype == APLA_BF16);
+  if (!ok) {
+    apla_set_error("apla_layernorm_bwd: bad dtypes x=%d dy=%d grad=%d", x_dtype, dy_dtype, grad_dtype);
     return APLA_ENOSYS;
   }
+  if (x_dtype == APLA_F32 && grad_dtype == APLA_F32) LN_BWD_Y(float, float);
+  else if (x_dtype == APLA_F32 && grad_dtype == APLA_BF16) LN_BWD_Y(float, bf16);
+  else if (x_dtype == APLA_BF16 && grad_dtype == APLA_F32) LN_BWD_Y(bf16, float);
+  else LN_BWD_Y(bf16, bf16);
+#undef LN_BWD_Y
 #undef LN_BWD_G
 #undef LN_BWD
   APLA_CHECK_LAUNCH("apla_layernorm_bwd");

@@ -1,0 +1,390 @@
+"""Fused APLA training step for MI355X: explicit forward + backward + gradient exchange + optimizer over the HIP kernels.
+
+This replaces, for the hot path only, what the reference runs through autograd/DDP/torch.optim
+(defaults/trainer.py:106-151 -> Classifier.forward -> VisionTransformer.forward_features -> Block.forward ->
+APLA_Attention.forward, plus DDP's bucketed all-reduce, clip_grad_norm_ and AdamW).  Design points:
+
+* No autograd graph.  Under APLA every weight except {proj_weight1, proj_bias1} x L and the head is frozen, so the
+  backward is a fixed dX chain plus L column-masked dW1 products and the head.  It is written out as a static launch
+  sequence on one HIP stream and captured into hipGraphs (torch.cuda.CUDAGraph drives hipStreamBeginCapture).
+* Engine weight layout (built once, 288 GB of HBM makes duplicates free): every frozen Linear is kept as bf16 [out,in]
+  for the forward and as a transposed bf16 copy [in,out] for the dX backward, so that all dense work is the same
+  "NT" MFMA kernel.  LayerScale (frozen) is folded into the following weight/bias in both directions.  The APLA
+  projection is kept in NATURAL feature order: its r trainable rows are re-scattered from the fp32 masters once per
+  step (apla_pack_proj_rows), which removes the two activation-side scatter_ calls of appla_attn.py:70-79.
+* Activations bf16, accumulation fp32, residual stream fp32 (default) or bf16, LN statistics / softmax / LSE fp32.
+  Saved per block for backward: block input, mid residual, LN stats, qkv, attention output, LSE, gelu'(pre-activation).
+* Trainable state is ONE flat fp32 buffer (params / grads / Adam moments) in ``named_parameters`` order; the module's
+  Parameters are views into it, so ``state_dict()`` and checkpoints keep the reference layout.
+* Data parallel: one process per GPU; after backward the flat gradient buffer is all-reduced (RCCL, SUM) on a side
+  stream in two chunks following backward order (head + upper blocks first, overlapped with the rest of backward);
+  the mean (1/world) is folded into the fused clip+AdamW kernel.  No per-step barrier, no buffer broadcast
+  (SURVEY.md §2.3 C1/C2).
+"""
+from dataclasses import dataclass
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import AplaHipError
+from .apla.appla_attn import APLA_Attention
+
+_BF = torch.bfloat16
+
+
+@dataclass
+class OptimConfig:
+    lr: float = 1e-4
+    weight_decay: float = 1e-5
+    betas: tuple = (0.9, 0.999)
+    eps: float = 1e-8
+    grad_clipping: float = 1.0   # defaults/trainer.py:130 (0 disables)
+
+
+class _BlockState:
+    pass
+
+
+def _bf(t):
+    return t.detach().to(_BF).contiguous()
+
+
+def _bf_t(t):
+    return t.detach().t().contiguous().to(_BF)
+
+
+def _interleave_rows(w):
+    h = w.shape[0] // 2
+    return torch.stack([w[:h], w[h:]], 1).reshape(w.shape).contiguous()
+
+
+class AplaTrainEngine:
+    def __init__(self, model: nn.Module, batch_size: int, img_size: int, device="cuda", res_dtype=torch.float32,
+                 grad_dtype=_BF, optim: Optional[OptimConfig] = None, process_group=None, use_graphs: bool = True):
+        if not torch.cuda.is_available():
+            raise AplaHipError("AplaTrainEngine needs an MI355X (no CPU fallback)")
+        self.device = torch.device(device)
+        self.model = model.to(self.device)
+        bb = model.backbone
+        self.B, self.S = batch_size, img_size
+        self.patch = bb.patch_size
+        self.D, self.L, self.H = bb.embed_dim, bb.depth, bb.num_heads
+        if self.D != 64 * self.H:
+            raise NotImplementedError("HIP attention kernel needs head_dim == 64")
+        self.Np = (img_size // self.patch) ** 2
+        self.N = self.Np + 1
+        self.M = self.B * self.N
+        self.eps = bb.eps
+        self.swiglu = bb.use_swiglu
+        self.res_dtype, self.grad_dtype = res_dtype, grad_dtype
+        self.optim = optim or OptimConfig()
+        self.pg = process_group
+        self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
+        self.use_graphs = use_graphs
+        self.scale = bb.blocks[0].attn.scale
+        self.step_count = 0
+        self._graphs = None
+        self._build_flat_params()
+        self._build_frozen_layout()
+        self._alloc_buffers()
+        self.refresh_weights()
+
+    # ------------------------------------------------------------------ trainable state
+    def _build_flat_params(self):
+        named = [(n, p) for n, p in self.model.named_parameters() if p.requires_grad]
+        expect = []
+        self.blocks_train = []
+        for i, blk in enumerate(self.model.backbone.blocks):
+            a = blk.attn
+            if isinstance(a, APLA_Attention):
+                W1, b1, inds, r = a.proj_weight1, a.proj_bias1, a.inds, a.partial_size
+                names = (f"backbone.blocks.{i}.attn.proj_weight1", f"backbone.blocks.{i}.attn.proj_bias1")
+            else:  # partial_size: full (apla_vit.py:66-75): full-rank projection, identity permutation
+                W1, b1, r = a.proj.weight, a.proj.bias, self.D
+                inds = torch.arange(self.D)
+                names = (f"backbone.blocks.{i}.attn.proj.weight", f"backbone.blocks.{i}.attn.proj.bias")
+            if r % 64 != 0 or self.D % 128 != 0:
+                raise NotImplementedError(f"engine needs partial_size % 64 == 0 and dim % 128 == 0 (r={r}, D={self.D})")
+            expect += list(names)
+            self.blocks_train.append((W1, b1, inds, r))
+        expect += ["fc.weight", "fc.bias"]
+        if [n for n, _ in named] != expect:
+            raise NotImplementedError("engine supports exactly the APLA trainable set (proj rows of every block + head); "
+                                      f"got {[n for n, _ in named][:6]}…")
+        n_total = sum(p.numel() for _, p in named)
+        dev = self.device
+        self.flat_params = torch.empty(n_total, device=dev, dtype=torch.float32)
+        self.flat_grads = torch.zeros(n_total, device=dev, dtype=torch.float32)
+        self.exp_avg = torch.zeros(n_total, device=dev, dtype=torch.float32)
+        self.exp_avg_sq = torch.zeros(n_total, device=dev, dtype=torch.float32)
+        self.decay_mask = torch.zeros(n_total, device=dev, dtype=torch.uint8)
+        self.norm_ws = torch.zeros(512, device=dev, dtype=torch.float32)
+        self.slices = {}
+        off = 0
+        for n, p in named:
+            k = p.numel()
+            self.flat_params[off:off + k].copy_(p.detach().reshape(-1).float())
+            p.data = self.flat_params[off:off + k].view(p.shape)      # module params become views of the flat buffer
+            p.grad = self.flat_grads[off:off + k].view(p.shape)
+            if not (n.endswith(".bias") or p.ndim == 1):             # defaults/wrappers.py:205-221
+                self.decay_mask[off:off + k] = 1
+            self.slices[n] = (off, k, tuple(p.shape))
+            off += k
+        self.n_trainable = n_total
+        self.names = [n for n, _ in named]
+        # all-reduce chunks in backward order: [second half of blocks + head] first, then the first half
+        half_name = self.names[2 * (self.L // 2)] if self.L > 1 else self.names[0]
+        split = self.slices[half_name][0]
+        self.chunks = [(split, n_total), (0, split)] if split > 0 else [(0, n_total)]
+
+    def _grad_view(self, name):
+        off, k, shape = self.slices[name]
+        return self.flat_grads[off:off + k].view(shape)
+
+    def _param_view(self, name):
+        off, k, shape = self.slices[name]
+        return self.flat_params[off:off + k].view(shape)
+
+    # ------------------------------------------------------------------ frozen weights in kernel layout
+    def _build_frozen_layout(self):
+        bb, dev, D = self.model.backbone, self.device, self.D
+        f32 = lambda t: t.detach().float().contiguous().to(dev)  # noqa: E731
+        K = 3 * self.patch * self.patch
+        self.Kp = (K + 63) // 64 * 64
+        wpe = torch.zeros(D, self.Kp, device=dev)
+        wpe[:, :K] = bb.patch_embed.proj.weight.detach().reshape(D, K).float()
+        self.Wpe, self.bpe = wpe.to(_BF), f32(bb.patch_embed.proj.bias)
+        self.cls = f32(bb.cls_token).reshape(D)
+        with torch.no_grad():
+            self.pos = f32(bb.interpolate_pos_encoding(self.Np)[0])  # bicubic resize once, not every forward
+        self.gf, self.bf_ = f32(bb.norm.weight), f32(bb.norm.bias)
+        self.blocks: List[_BlockState] = []
+        for i, blk in enumerate(bb.blocks):
+            st = _BlockState()
+            W1p, b1p, inds, r = self.blocks_train[i]
+            st.r = r
+            st.inds = inds.to(dev).int().contiguous()
+            st.g1, st.b1 = f32(blk.norm1.weight), f32(blk.norm1.bias)
+            st.g2, st.b2 = f32(blk.norm2.weight), f32(blk.norm2.bias)
+            a = blk.attn
+            st.Wqkv, st.WqkvT = _bf(a.qkv.weight), _bf_t(a.qkv.weight)
+            st.bqkv = f32(a.qkv.bias) if a.qkv.bias is not None else None
+            gam1 = f32(blk.ls1.gamma) if hasattr(blk.ls1, "gamma") else None
+            gam2 = f32(blk.ls2.gamma) if hasattr(blk.ls2, "gamma") else None
+            st.gamma1 = gam1
+            st.row_scale = gam1[st.inds[:r].long()].contiguous() if gam1 is not None else None
+            # natural-order merged projection; frozen rows written here, trainable rows by pack_proj_rows
+            Wn = torch.zeros(D, D, device=dev)
+            bn = torch.zeros(D, device=dev)
+            if isinstance(a, APLA_Attention):
+                fi = st.inds[r:].long()
+                Wn[fi] = a.proj_weight2.detach().float()
+                bn[fi] = a.proj_bias2.detach().float()
+                if gam1 is not None:
+                    Wn[fi] *= gam1[fi, None]
+                    bn[fi] *= gam1[fi]
+            st.Wnat, st.WnatT, st.bnat = Wn.to(_BF), Wn.t().contiguous().to(_BF), bn
+            mlp = blk.mlp
+            if self.swiglu:
+                st.F = mlp.w3.in_features
+                w12 = _interleave_rows(mlp.w12.weight.detach().float())
+                st.W12, st.W12T = w12.to(_BF), w12.t().contiguous().to(_BF)
+                st.b12 = _interleave_rows(mlp.w12.bias.detach().float()).contiguous()
+                w3, b3 = mlp.w3.weight.detach().float(), mlp.w3.bias.detach().float()
+            else:
+                st.F = mlp.fc1.out_features
+                st.Wfc1, st.Wfc1T, st.bfc1 = _bf(mlp.fc1.weight), _bf_t(mlp.fc1.weight), f32(mlp.fc1.bias)
+                w3, b3 = mlp.fc2.weight.detach().float(), mlp.fc2.bias.detach().float()
+            if gam2 is not None:
+                w3, b3 = w3 * gam2[:, None], b3 * gam2
+            st.Wout, st.WoutT, st.bout = w3.to(_BF).contiguous(), w3.t().contiguous().to(_BF), b3.contiguous()
+            st.W1_name, st.b1_name = self.names[2 * i], self.names[2 * i + 1]
+            self.blocks.append(st)
+        self.C = self.model.fc.out_features
+
+    # ------------------------------------------------------------------ activations / workspaces
+    def _alloc_buffers(self):
+        dev, M, D, B, N, H, L = self.device, self.M, self.D, self.B, self.N, self.H, self.L
+        e = lambda *s, dt=_BF: torch.empty(*s, device=dev, dtype=dt)  # noqa: E731
+        self.images = e(B, 3, self.S, self.S, dt=torch.float32)
+        self.labels = torch.zeros(B, device=dev, dtype=torch.int32)
+        self.cols = e(B * self.Np, self.Kp)
+        self.patches = e(B * self.Np, D)
+        self.x = [e(M, D, dt=self.res_dtype) for _ in range(L + 1)]
+        self.xmid = [e(M, D, dt=self.res_dtype) for _ in range(L)]
+        stat = lambda: e(M, dt=torch.float32)  # noqa: E731
+        self.mean1, self.rstd1 = [stat() for _ in range(L)], [stat() for _ in range(L)]
+        self.mean2, self.rstd2 = [stat() for _ in range(L)], [stat() for _ in range(L)]
+        self.qkv = [e(M, 3 * D) for _ in range(L)]
+        self.o = [e(M, D) for _ in range(L)]
+        self.lse = [e(B, H, N, dt=torch.float32) for _ in range(L)]
+        Fsave = (2 * self.blocks[0].F) if self.swiglu else self.blocks[0].F
+        self.act_saved = [e(M, Fsave) for _ in range(L)]       # gelu'(a) or interleaved x12
+        self.ln_out = e(M, D)
+        self.h = e(M, self.blocks[0].F)
+        self.xn = e(B, D, dt=torch.float32)
+        self.meanf, self.rstdf = e(B, dt=torch.float32), e(B, dt=torch.float32)
+        self.logits = e(B, self.C, dt=torch.float32)
+        self.dlogits = e(B, self.C, dt=torch.float32)
+        self.row_loss = e(B, dt=torch.float32)
+        self.loss = e(1, dt=torch.float32)
+        self.dxn = e(B, D, dt=torch.float32)
+        # backward
+        self.G = torch.zeros(M, D, device=dev, dtype=self.grad_dtype)               # residual-gradient stream
+        self.Gb = self.G if self.grad_dtype == _BF else torch.zeros(M, D, device=dev, dtype=_BF)
+        self.dact = e(M, Fsave)
+        self.dln = e(M, D)
+        self.dO = e(M, D)
+        self.dqkv = e(M, 3 * D)
+        self.delta = e(B, H, N, dt=torch.float32)
+        rmax = max(st.r for st in self.blocks)
+        self.dyg = e(M * rmax)
+        self.dw_ws = ops.dw_workspace(M, rmax, D, dev)
+        for st in self.blocks:
+            if ops.lib().apla_dw_workspace_bytes(M, st.r, D) > self.dw_ws.numel() * 4:
+                self.dw_ws = ops.dw_workspace(M, st.r, D, dev)
+
+    # ------------------------------------------------------------------ step pieces
+    def refresh_weights(self):
+        """Re-scatter the trainable projection rows (fp32 masters -> natural-order bf16 weight, its transpose, bias)."""
+        for st in self.blocks:
+            ops.pack_proj_rows(self._param_view(st.W1_name), self._param_view(st.b1_name), st.inds, st.gamma1,
+                               st.Wnat, st.WnatT, st.bnat)
+
+    def _forward(self):
+        B, N, H, D = self.B, self.N, self.H, self.D
+        ops.patchify(self.images, self.patch, self.Kp, out=self.cols)
+        ops.gemm_nt(self.cols, self.Wpe, self.bpe, out=self.patches)
+        ops.assemble_tokens(self.patches, self.cls, self.pos, B, self.Np, out=self.x[0])
+        for i, st in enumerate(self.blocks):
+            ops.layernorm_fwd(self.x[i], st.g1, st.b1, self.eps, out=self.ln_out, mean=self.mean1[i], rstd=self.rstd1[i])
+            ops.gemm_nt(self.ln_out, st.Wqkv, st.bqkv, out=self.qkv[i])
+            ops.attn_fwd(self.qkv[i], B, N, H, self.scale, o=self.o[i], lse=self.lse[i])
+            ops.gemm_nt(self.o[i], st.Wnat, st.bnat, epilogue=ops.EPI_RESIDUAL, aux_in=self.x[i], out=self.xmid[i])
+            ops.layernorm_fwd(self.xmid[i], st.g2, st.b2, self.eps, out=self.ln_out, mean=self.mean2[i], rstd=self.rstd2[i])
+            if self.swiglu:
+                ops.gemm_nt(self.ln_out, st.W12, st.b12, epilogue=ops.EPI_SWIGLU, aux_out=self.act_saved[i], out=self.h)
+            else:
+                ops.gemm_nt(self.ln_out, st.Wfc1, st.bfc1, epilogue=ops.EPI_GELU, aux_out=self.act_saved[i], out=self.h)
+            ops.gemm_nt(self.h, st.Wout, st.bout, epilogue=ops.EPI_RESIDUAL, aux_in=self.xmid[i], out=self.x[i + 1])
+        # final norm on the CLS rows only (vit.py:416-419), fp32 head + mean CE
+        ops.layernorm_fwd(self.x[self.L], self.gf, self.bf_, self.eps, out=self.xn, mean=self.meanf, rstd=self.rstdf,
+                          rows=B, row_stride=N * D)
+        ops.sgemm_small(self.xn, self._param_view("fc.weight"), trans_b=True, bias=self._param_view("fc.bias"),
+                        out=self.logits)
+        ops.cross_entropy(self.logits, self.labels, dlogits=self.dlogits, row_loss=self.row_loss, loss=self.loss)
+
+    def _backward_head(self):
+        B, N, D = self.B, self.N, self.D
+        ops.sgemm_small(self.dlogits, self.xn, trans_a=True, out=self._grad_view("fc.weight"))
+        ops.colsum(self.dlogits, out=self._grad_view("fc.bias"))
+        ops.sgemm_small(self.dlogits, self._param_view("fc.weight"), out=self.dxn)
+        self.G.zero_()
+        if self.Gb is not self.G:
+            self.Gb.zero_()
+        ops.layernorm_bwd(self.dxn, self.x[self.L], self.gf, self.meanf, self.rstdf, out=self.G,
+                          out_bf16=None if self.Gb is self.G else self.Gb, rows=B, row_stride=N * D)
+
+    def _backward_block(self, i):
+        st = self.blocks[i]
+        B, N, H, M, D = self.B, self.N, self.H, self.M, self.D
+        copy = None if self.Gb is self.G else self.Gb
+        if self.swiglu:
+            ops.gemm_nt(self.Gb, st.WoutT, None, epilogue=ops.EPI_SWIGLU_BWD, aux_in=self.act_saved[i], out=self.dact)
+            ops.gemm_nt(self.dact, st.W12T, None, out=self.dln)
+        else:
+            ops.gemm_nt(self.Gb, st.WoutT, None, epilogue=ops.EPI_MUL, aux_in=self.act_saved[i], out=self.dact)
+            ops.gemm_nt(self.dact, st.Wfc1T, None, out=self.dln)
+        dyg = self.dyg[:M * st.r].view(M, st.r)
+        ops.layernorm_bwd(self.dln, self.xmid[i], st.g2, self.mean2[i], self.rstd2[i], dres=self.G, out=self.G,
+                          out_bf16=copy, inds=st.inds, r=st.r, gathered=dyg)
+        ops.proj_dw(dyg, self.o[i], self._grad_view(st.W1_name), self._grad_view(st.b1_name), row_scale=st.row_scale,
+                    workspace=self.dw_ws)
+        if i == 0:
+            return  # nothing upstream of block 0's projection is trainable
+        ops.gemm_nt(self.Gb, st.WnatT, None, out=self.dO)
+        ops.attn_bwd(self.qkv[i], self.o[i], self.dO, self.lse[i], B, N, H, self.scale, dqkv=self.dqkv, delta=self.delta)
+        ops.gemm_nt(self.dqkv, st.WqkvT, None, out=self.dln)
+        ops.layernorm_bwd(self.dln, self.x[i], st.g1, self.mean1[i], self.rstd1[i], dres=self.G, out=self.G, out_bf16=copy)
+
+    def _segment_a(self):
+        self.refresh_weights()
+        self._forward()
+        self._backward_head()
+        for i in range(self.L - 1, self.L // 2 - 1, -1):
+            self._backward_block(i)
+
+    def _segment_b(self):
+        for i in range(self.L // 2 - 1, -1, -1):
+            self._backward_block(i)
+
+    def _capture(self):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):  # warm-up outside capture (lazy module loading, allocator)
+            self._segment_a()
+            self._segment_b()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(ga):
+            self._segment_a()
+        with torch.cuda.graph(gb, pool=ga.pool()):
+            self._segment_b()
+        self._graphs = (ga, gb)
+
+    # ------------------------------------------------------------------ public API
+    def set_batch(self, images: torch.Tensor, labels: torch.Tensor):
+        self.images.copy_(images, non_blocking=True)
+        self.labels.copy_(labels.to(torch.int32), non_blocking=True)
+
+    def forward_backward(self):
+        """Forward + loss + backward of the batch in self.images/self.labels; grads land in the flat buffer.
+        With world > 1 the gradient all-reduce of each chunk is launched on a side stream as soon as its segment of the
+        backward has been enqueued."""
+        if self.use_graphs and self._graphs is None:
+            self._capture()
+        if self.world > 1 and not hasattr(self, "_comm"):
+            self._comm = torch.cuda.Stream()
+        main = torch.cuda.current_stream()
+        segs = ((self._graphs[0].replay, self._graphs[1].replay) if self.use_graphs else (self._segment_a, self._segment_b))
+        for k, run in enumerate(segs):
+            run()
+            if self.world > 1 and k < len(self.chunks):
+                lo, hi = self.chunks[k]
+                if hi > lo:
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                    self._comm.wait_event(ev)
+                    with torch.cuda.stream(self._comm):
+                        torch.distributed.all_reduce(self.flat_grads[lo:hi], group=self.pg)
+        if self.world > 1:
+            main.wait_stream(self._comm)
+
+    def optimizer_step(self, lr: Optional[float] = None):
+        """Fused clip + AdamW on the flat buffer (DDP mean = grad_scale 1/world)."""
+        self.step_count += 1
+        oc = self.optim
+        ops.adamw_step(self.flat_params, self.flat_grads, self.exp_avg, self.exp_avg_sq, self.decay_mask,
+                       lr=oc.lr if lr is None else lr, weight_decay=oc.weight_decay, betas=oc.betas, eps=oc.eps,
+                       step=self.step_count, max_norm=oc.grad_clipping or 0.0, grad_scale=1.0 / self.world,
+                       norm_ws=self.norm_ws)
+
+    def train_step(self, images=None, labels=None, lr: Optional[float] = None):
+        if images is not None:
+            self.set_batch(images, labels)
+        self.forward_backward()
+        self.optimizer_step(lr)
+        return self.loss
+
+    @property
+    def grad_norm(self):
+        return self.norm_ws[1]
+
+    def grads(self):
+        return {n: self._grad_view(n) for n in self.names}
+
+    def peak_memory_bytes(self):
+        return torch.cuda.max_memory_allocated(self.device)

@@ -1,0 +1,313 @@
+"""Autograd Functions that put the HIP kernels behind ordinary nn.Module.forward calls (the drop-in path).
+
+This is what lets ``APLA_Attention`` swap into a timm / dinov2-style ``Attention`` inside somebody else's model and
+train under plain ``loss.backward()``: each Function's forward/backward is a short sequence of C-ABI kernel calls on
+the current HIP stream.  Activations run in bf16 with fp32 accumulation; inputs/outputs keep the caller's dtype.
+Frozen weights are converted to the kernel layout (bf16, plus a transposed bf16 copy for dX) once and cached against
+the parameter's version counter.  No function has a CPU path: CPU tensors raise AplaHipError.
+
+The fused whole-step path (apla_amd/engine.py) does not use autograd at all.
+"""
+import weakref
+from typing import Optional
+
+import torch
+
+from . import ops
+from ._lib import AplaHipError
+
+_BF = torch.bfloat16
+
+
+def require_no_dropout(drop_module, training: bool):
+    """Dropouts are 0 in every shipped APLA config (SURVEY §5 hazard 14); the HIP path asserts that."""
+    p = getattr(drop_module, "p", 0.0)
+    if training and p and p > 0.0:
+        raise NotImplementedError(f"dropout p={p} is not supported on the HIP path (all shipped APLA configs use 0)")
+
+
+def _require_cuda(x: torch.Tensor, what: str):
+    if not x.is_cuda:
+        raise AplaHipError(f"{what}: got a CPU tensor; the APLA path runs on MI355X only (no CPU fallback)")
+
+
+# ------------------------------------------------------------------------------------------------ weight cache
+class _WeightCache:
+    """bf16 (and transposed bf16) copies of parameters keyed by identity + version."""
+
+    def __init__(self):
+        self._store = {}
+
+    def get(self, p: torch.Tensor, kind: str, make):
+        key = (id(p), kind)
+        ent = self._store.get(key)
+        ver = p._version
+        if ent is not None and ent[0] == ver and ent[1]() is p and ent[2].device == p.device:
+            return ent[2]
+        val = make()
+        self._store[key] = (ver, weakref.ref(p), val)
+        return val
+
+    def clear(self):
+        self._store.clear()
+
+
+CACHE = _WeightCache()
+
+
+def w_bf16(p):
+    return CACHE.get(p, "bf16", lambda: p.detach().to(_BF).contiguous())
+
+
+def w_bf16_t(p):
+    return CACHE.get(p, "bf16_t", lambda: p.detach().t().to(_BF).contiguous())
+
+
+def b_f32(p):
+    return None if p is None else CACHE.get(p, "f32", lambda: p.detach().float().contiguous())
+
+
+def _as2d_bf16(x):
+    return x.reshape(-1, x.shape[-1]).to(_BF).contiguous()
+
+
+# ------------------------------------------------------------------------------------------------ LayerNorm
+class _LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        _require_cuda(x, "layer_norm")
+        if weight.requires_grad or bias.requires_grad:
+            raise NotImplementedError("trainable LayerNorm affine is outside the APLA path (all norms are frozen)")
+        x2 = x.reshape(-1, x.shape[-1])
+        x2 = x2 if x2.dtype in (torch.float32, _BF) else x2.float()
+        x2 = x2.contiguous()
+        y, mean, rstd = ops.layernorm_fwd(x2, b_f32(weight), b_f32(bias), eps)
+        ctx.save_for_backward(x2, mean, rstd, weight)
+        ctx.shape, ctx.dtype = x.shape, x.dtype
+        return y.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, mean, rstd, weight = ctx.saved_tensors
+        dx, _ = ops.layernorm_bwd(_as2d_bf16(dy), x2, b_f32(weight), mean, rstd)
+        return dx.reshape(ctx.shape).to(ctx.dtype), None, None, None
+
+
+def layer_norm(x, norm_module):
+    """bf16 output (feeds the next GEMM)."""
+    return _LayerNormFn.apply(x, norm_module.weight, norm_module.bias, norm_module.eps)
+
+
+# ------------------------------------------------------------------------------------------------ Linear
+class _LinearFn(torch.autograd.Function):
+    """y = x W^T + b through apla_gemm_nt.  dX through the transposed copy; dW/db (full-rank, only for the
+    ``partial_size: full`` mode of apla_vit.py:66-75) through the dW kernel with r = out_features."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _require_cuda(x, "linear")
+        x2 = _as2d_bf16(x)
+        y = ops.gemm_nt(x2, w_bf16(weight), b_f32(bias))
+        ctx.save_for_backward(x2, weight, bias if bias is not None else torch.empty(0))
+        ctx.has_bias = bias is not None
+        ctx.shape = x.shape
+        return y.reshape(x.shape[:-1] + (weight.shape[0],))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight, bias = ctx.saved_tensors
+        dy2 = _as2d_bf16(dy)
+        dx = ops.gemm_nt(dy2, w_bf16_t(weight)).reshape(ctx.shape) if ctx.needs_input_grad[0] else None
+        dW = db = None
+        if weight.requires_grad:
+            dW = torch.empty(weight.shape, device=dy.device, dtype=torch.float32)
+            db_ = torch.empty(weight.shape[0], device=dy.device, dtype=torch.float32)
+            ops.proj_dw(dy2, x2, dW, db_)
+            db = db_.to(bias.dtype) if ctx.has_bias and bias.requires_grad else None
+            dW = dW.to(weight.dtype)
+        return dx, dW, db
+
+
+def linear(x, weight, bias=None):
+    return _LinearFn.apply(x, weight, bias)
+
+
+# ------------------------------------------------------------------------------------------------ attention core
+class _AttnCoreFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, B, N, H, scale):
+        qkv2 = qkv.reshape(B * N, -1).contiguous()
+        o, lse = ops.attn_fwd(qkv2, B, N, H, scale)
+        ctx.save_for_backward(qkv2, o, lse)
+        ctx.dims = (B, N, H, scale)
+        ctx.mark_non_differentiable(lse)
+        return o.reshape(B, N, H * 64), lse
+
+    @staticmethod
+    def backward(ctx, do, _dlse):
+        qkv2, o, lse = ctx.saved_tensors
+        B, N, H, scale = ctx.dims
+        dqkv = ops.attn_bwd(qkv2, o, _as2d_bf16(do), lse, B, N, H, scale)
+        return dqkv.reshape(B, N, -1), None, None, None, None
+
+
+def attention_core(qkv, B, N, H, scale):
+    if qkv.shape[-1] != 3 * H * 64:
+        raise NotImplementedError(f"the HIP attention kernel needs head_dim 64 (got {qkv.shape[-1] // (3 * H)})")
+    return _AttnCoreFn.apply(qkv, B, N, H, scale)
+
+
+def attention_module_forward(x, qkv_w, qkv_b, proj_w, proj_b, num_heads, scale, want_attn):
+    """Plain (non-APLA) Attention.forward, vit.py:184-196: returns (x, attn|None)."""
+    B, N, _ = x.shape
+    qkv = linear(x, qkv_w, qkv_b)
+    o, lse = attention_core(qkv, B, N, num_heads, scale)
+    y = linear(o, proj_w, proj_b).to(x.dtype)
+    attn = ops.attn_probs(qkv.detach().reshape(B * N, -1), lse, B, N, num_heads, scale) if want_attn else None
+    return y, attn
+
+
+# ------------------------------------------------------------------------------------------------ APLA projection
+class AplaProjState:
+    """Kernel-layout copies of one APLA projection: natural-order bf16 weight, its transpose, fp32 bias, int32 indices.
+    Frozen rows are written once; the r trainable rows are re-scattered from the fp32 masters before every forward."""
+
+    def __init__(self):
+        self.key = None
+        self.Wnat = self.WnatT = self.bnat = self.inds32 = None
+
+    def refresh(self, W1, b1, W2, b2, inds):
+        D = W1.shape[1]
+        r = W1.shape[0]
+        key = (W2.data_ptr(), W2._version, b2._version, inds._version, str(W1.device), r, D)
+        if key != self.key:
+            idx = inds.to(W1.device).long()
+            Wn = torch.zeros(D, D, device=W1.device, dtype=torch.float32)
+            Wn[idx[r:]] = W2.detach().float()
+            bn = torch.zeros(D, device=W1.device, dtype=torch.float32)
+            bn[idx[r:]] = b2.detach().float()
+            self.Wnat = Wn.to(_BF)
+            self.WnatT = Wn.t().contiguous().to(_BF)
+            self.bnat = bn
+            self.inds32 = idx.int().contiguous()
+            self.key = key
+        ops.pack_proj_rows(W1.detach().float().contiguous(), b1.detach().float().contiguous(), self.inds32, None,
+                           self.Wnat, self.WnatT, self.bnat)
+
+
+class _AplaProjFn(torch.autograd.Function):
+    """APLA output projection (appla_attn.py:62-79).  Forward: one GEMM over the natural-order merged weight (the two
+    scatter_ calls are folded into the weight layout).  Backward: dX over the transposed merged weight; dW1/db1 from
+    the r gathered columns of dY only."""
+
+    @staticmethod
+    def forward(ctx, o, W1, b1, state: AplaProjState):
+        o2 = _as2d_bf16(o)
+        y = ops.gemm_nt(o2, state.Wnat, state.bnat)
+        ctx.save_for_backward(o2, W1, b1)
+        ctx.state, ctx.shape = state, o.shape
+        return y.reshape(o.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        o2, W1, b1 = ctx.saved_tensors
+        st = ctx.state
+        dy2 = _as2d_bf16(dy)
+        do = ops.gemm_nt(dy2, st.WnatT).reshape(ctx.shape) if ctx.needs_input_grad[0] else None
+        r, D = W1.shape
+        dyg = ops.gather_cols(dy2, st.inds32, r)
+        dW1 = torch.empty(r, D, device=dy.device, dtype=torch.float32)
+        db1 = torch.empty(r, device=dy.device, dtype=torch.float32)
+        ops.proj_dw(dyg, o2, dW1, db1)
+        return do, dW1.to(W1.dtype), db1.to(b1.dtype), None
+
+
+def apla_projection(o, W1, b1, W2, b2, inds, state: AplaProjState):
+    if W1.shape[0] % 64 != 0 or W1.shape[1] % 128 != 0:
+        raise NotImplementedError(f"APLA HIP projection needs partial_size % 64 == 0 and dim % 128 == 0 "
+                                  f"(got r={W1.shape[0]}, dim={W1.shape[1]})")
+    with torch.no_grad():
+        state.refresh(W1, b1, W2, b2, inds)
+    return _AplaProjFn.apply(o, W1, b1, state)
+
+
+# ------------------------------------------------------------------------------------------------ MLPs
+class _MlpGeluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        _require_cuda(x, "mlp")
+        x2 = _as2d_bf16(x)
+        gp = torch.empty(x2.shape[0], w1.shape[0], device=x.device, dtype=_BF)
+        h = ops.gemm_nt(x2, w_bf16(w1), b_f32(b1), epilogue=ops.EPI_GELU, aux_out=gp)
+        y = ops.gemm_nt(h, w_bf16(w2), b_f32(b2))
+        ctx.save_for_backward(gp, w1, w2)
+        ctx.shape = x.shape
+        return y.reshape(x.shape[:-1] + (w2.shape[0],))
+
+    @staticmethod
+    def backward(ctx, dy):
+        gp, w1, w2 = ctx.saved_tensors
+        if w1.requires_grad or w2.requires_grad:
+            raise NotImplementedError("trainable MLP weights are outside the APLA path")
+        da = ops.gemm_nt(_as2d_bf16(dy), w_bf16_t(w2), epilogue=ops.EPI_MUL, aux_in=gp)
+        dx = ops.gemm_nt(da, w_bf16_t(w1))
+        return dx.reshape(ctx.shape), None, None, None, None
+
+
+def mlp_gelu(x, w1, b1, w2, b2):
+    return _MlpGeluFn.apply(x, w1, b1, w2, b2).to(x.dtype)
+
+
+def _interleave_rows(w):
+    h = w.shape[0] // 2
+    return torch.stack([w[:h], w[h:]], 1).reshape(w.shape).contiguous()
+
+
+class _MlpSwigluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w12, b12, w3, b3):
+        _require_cuda(x, "mlp")
+        x2 = _as2d_bf16(x)
+        w12i = CACHE.get(w12, "il", lambda: _interleave_rows(w12.detach()).to(_BF))
+        b12i = None if b12 is None else CACHE.get(b12, "il", lambda: _interleave_rows(b12.detach().float()))
+        saved = torch.empty(x2.shape[0], w12.shape[0], device=x.device, dtype=_BF)
+        h = ops.gemm_nt(x2, w12i, b12i, epilogue=ops.EPI_SWIGLU, aux_out=saved)
+        y = ops.gemm_nt(h, w_bf16(w3), b_f32(b3))
+        ctx.save_for_backward(saved, w12, w3)
+        ctx.shape = x.shape
+        return y.reshape(x.shape[:-1] + (w3.shape[0],))
+
+    @staticmethod
+    def backward(ctx, dy):
+        saved, w12, w3 = ctx.saved_tensors
+        if w12.requires_grad or w3.requires_grad:
+            raise NotImplementedError("trainable MLP weights are outside the APLA path")
+        dx12 = ops.gemm_nt(_as2d_bf16(dy), w_bf16_t(w3), epilogue=ops.EPI_SWIGLU_BWD, aux_in=saved)
+        w12it = CACHE.get(w12, "il_t", lambda: _interleave_rows(w12.detach()).t().contiguous().to(_BF))
+        dx = ops.gemm_nt(dx12, w12it)
+        return dx.reshape(ctx.shape), None, None, None, None
+
+
+def mlp_swiglu(x, w12, b12, w3, b3):
+    return _MlpSwigluFn.apply(x, w12, b12, w3, b3).to(x.dtype)
+
+
+# ------------------------------------------------------------------------------------------------ patch embedding
+def patch_embed(images, conv_w, conv_b, patch: int):
+    """Forward-only (frozen, no gradient ever reaches it under APLA).  [B,3,S,S] -> [B,Np,D] bf16."""
+    _require_cuda(images, "patch_embed")
+    if conv_w.requires_grad:
+        raise NotImplementedError("trainable patch embedding is outside the APLA path")
+    B, C, S, _ = images.shape
+    D = conv_w.shape[0]
+    K = C * patch * patch
+    Kp = (K + 63) // 64 * 64
+
+    def make():
+        w = torch.zeros(D, Kp, device=conv_w.device, dtype=torch.float32)
+        w[:, :K] = conv_w.detach().reshape(D, K).float()
+        return w.to(_BF)
+
+    wp = CACHE.get(conv_w, f"pe{Kp}", make)
+    cols = ops.patchify(images.float().contiguous(), patch, Kp)
+    return ops.gemm_nt(cols, wp, b_f32(conv_b)).reshape(B, -1, D)

@@ -90,7 +90,9 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = Non
 
 
 def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-6, *,
-                  out_dtype=torch.bfloat16, rows: Optional[int] = None, row_stride: Optional[int] = None):
+                  out_dtype=torch.bfloat16, rows: Optional[int] = None, row_stride: Optional[int] = None,
+                  out: Optional[torch.Tensor] = None, mean: Optional[torch.Tensor] = None,
+                  rstd: Optional[torch.Tensor] = None):
     """x: [M,D] residual stream (fp32|bf16).  With rows/row_stride given, x is a flat buffer and row m starts at
     m*row_stride (CLS-row selection).  Returns (y [M,D], mean [M], rstd [M])."""
     _req(x, None, "x")
@@ -104,21 +106,30 @@ def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps:
         if (M - 1) * xs + D > x.numel():
             raise ValueError("layernorm_fwd: strided rows exceed the buffer")
     _req(gamma, torch.float32, "gamma", 1), _req(beta, torch.float32, "beta", 1)
-    y = torch.empty(M, D, device=x.device, dtype=out_dtype)
-    mean = torch.empty(M, device=x.device, dtype=torch.float32)
-    rstd = torch.empty_like(mean)
-    rc = lib().apla_layernorm_fwd(x.data_ptr(), _DT[x.dtype], xs, gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
-                                  _DT[out_dtype], D, mean.data_ptr(), rstd.data_ptr(), M, D, float(eps), _stream())
+    if out is None:
+        out = torch.empty(M, D, device=x.device, dtype=out_dtype)
+    if mean is None:
+        mean = torch.empty(M, device=x.device, dtype=torch.float32)
+    if rstd is None:
+        rstd = torch.empty(M, device=x.device, dtype=torch.float32)
+    _req(out, None, "out", 2), _req(mean, torch.float32, "mean", 1), _req(rstd, torch.float32, "rstd", 1)
+    if tuple(out.shape) != (M, D) or mean.numel() != M or rstd.numel() != M:
+        raise ValueError("layernorm_fwd: bad output buffers")
+    rc = lib().apla_layernorm_fwd(x.data_ptr(), _DT[x.dtype], xs, gamma.data_ptr(), beta.data_ptr(), out.data_ptr(),
+                                  _DT[out.dtype], out.stride(0), mean.data_ptr(), rstd.data_ptr(), M, D, float(eps),
+                                  _stream())
     check(rc, "apla_layernorm_fwd")
-    return y, mean, rstd
+    return out, mean, rstd
 
 
 def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor, *,
                   dres: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-                  inds: Optional[torch.Tensor] = None, r: int = 0, rows: Optional[int] = None,
+                  out_bf16: Optional[torch.Tensor] = None, inds: Optional[torch.Tensor] = None, r: int = 0,
+                  gathered: Optional[torch.Tensor] = None, rows: Optional[int] = None,
                   row_stride: Optional[int] = None):
-    """dx = dres + LN_bwd_dx(dy).  Returns (dx, gathered | None).  With rows/row_stride: x and out are flat buffers
-    whose row m starts at m*row_stride (only those rows are read/written)."""
+    """dx = dres + LN_bwd_dx(dy).  Returns (dx, gathered | None).  ``out`` (the gradient stream, fp32|bf16) may alias
+    ``dres``; ``out_bf16`` optionally receives a bf16 copy.  With rows/row_stride: x, out (and out_bf16) are flat
+    buffers whose row m starts at m*row_stride (only those rows are read/written)."""
     _req(dy, None, "dy", 2), _req(x, None, "x")
     M, D, lddy = _rows2d(dy, "dy")
     if rows is None:
@@ -126,25 +137,39 @@ def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mean: 
         if (Mx, Dx) != (M, D):
             raise ValueError("layernorm_bwd: x/dy shape mismatch")
         if out is None:
-            out = torch.empty(M, D, device=x.device, dtype=x.dtype)
+            out = torch.empty(M, D, device=x.device, dtype=dres.dtype if dres is not None else x.dtype)
+        if tuple(out.shape) != (M, D):
+            raise ValueError("layernorm_bwd: out shape")
         dxs = out.stride(0)
+        cbs = out_bf16.stride(0) if out_bf16 is not None else 0
+        if out_bf16 is not None and tuple(out_bf16.shape) != (M, D):
+            raise ValueError("layernorm_bwd: out_bf16 shape")
     else:
         if rows != M or out is None:
             raise ValueError("layernorm_bwd: strided mode needs rows == dy rows and an out buffer")
-        xs = dxs = row_stride
-        if (M - 1) * xs + D > x.numel() or (M - 1) * dxs + D > out.numel():
+        xs = dxs = cbs = row_stride
+        if (M - 1) * xs + D > x.numel() or (M - 1) * dxs + D > out.numel() or \
+                (out_bf16 is not None and (M - 1) * cbs + D > out_bf16.numel()):
             raise ValueError("layernorm_bwd: strided rows exceed the buffer")
-    if out.dtype != x.dtype or (dres is not None and (dres.dtype != x.dtype or dres.shape != out.shape)):
-        raise TypeError("layernorm_bwd: dres/out must match x dtype and out shape")
-    gathered = None
+    _req(out, None, "out")
+    if dres is not None and (dres.dtype != out.dtype or dres.shape != out.shape or dres.stride() != out.stride()):
+        raise TypeError("layernorm_bwd: dres must match out (dtype, shape, strides)")
+    if out_bf16 is not None:
+        _req(out_bf16, torch.bfloat16, "out_bf16")
     if inds is not None:
         _req(inds, torch.int32, "inds", 1)
         if not (0 < r <= D) or inds.numel() < r:
             raise ValueError("layernorm_bwd: bad r")
-        gathered = torch.empty(M, r, device=x.device, dtype=torch.bfloat16)
+        if gathered is None:
+            gathered = torch.empty(M, r, device=x.device, dtype=torch.bfloat16)
+        _req(gathered, torch.bfloat16, "gathered", 2)
+        if tuple(gathered.shape) != (M, r) or not gathered.is_contiguous():
+            raise ValueError("layernorm_bwd: gathered buffer")
+    else:
+        gathered = None
     rc = lib().apla_layernorm_bwd(dy.data_ptr(), _DT[dy.dtype], lddy, x.data_ptr(), _DT[x.dtype], xs, gamma.data_ptr(),
-                                  mean.data_ptr(), rstd.data_ptr(), _ptr(dres), out.data_ptr(), dxs, _ptr(inds), r,
-                                  _ptr(gathered), M, D, _stream())
+                                  mean.data_ptr(), rstd.data_ptr(), _ptr(dres), out.data_ptr(), _DT[out.dtype], dxs,
+                                  _ptr(out_bf16), cbs, _ptr(inds), r, _ptr(gathered), M, D, _stream())
     check(rc, "apla_layernorm_bwd")
     return out, gathered
 
@@ -158,13 +183,19 @@ def gather_cols(src: torch.Tensor, inds: torch.Tensor, r: int) -> torch.Tensor:
     return out
 
 
-def attn_fwd(qkv: torch.Tensor, B: int, N: int, H: int, scale: float):
+def attn_fwd(qkv: torch.Tensor, B: int, N: int, H: int, scale: float, *, o: Optional[torch.Tensor] = None,
+             lse: Optional[torch.Tensor] = None):
     """qkv: [B*N, 3*H*64] bf16 contiguous.  Returns (o [B*N, H*64] bf16, lse [B,H,N] fp32)."""
     _req(qkv, torch.bfloat16, "qkv", 2)
     if tuple(qkv.shape) != (B * N, 3 * H * 64) or not qkv.is_contiguous():
         raise ValueError(f"attn_fwd: qkv must be contiguous [{B * N}, {3 * H * 64}], got {tuple(qkv.shape)}")
-    o = torch.empty(B * N, H * 64, device=qkv.device, dtype=torch.bfloat16)
-    lse = torch.empty(B, H, N, device=qkv.device, dtype=torch.float32)
+    if o is None:
+        o = torch.empty(B * N, H * 64, device=qkv.device, dtype=torch.bfloat16)
+    if lse is None:
+        lse = torch.empty(B, H, N, device=qkv.device, dtype=torch.float32)
+    _req(o, torch.bfloat16, "o", 2), _req(lse, torch.float32, "lse", 3)
+    if tuple(o.shape) != (B * N, H * 64) or tuple(lse.shape) != (B, H, N) or not (o.is_contiguous() and lse.is_contiguous()):
+        raise ValueError("attn_fwd: bad output buffers")
     check(lib().apla_attn_fwd(qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), B, N, H, float(scale), _stream()),
           "apla_attn_fwd")
     return o, lse
@@ -259,13 +290,15 @@ def adamw_step(params, grads, exp_avg, exp_avg_sq, decay_mask, *, lr, weight_dec
                                 norm_ws.data_ptr(), _stream()), "apla_adamw_step")
 
 
-def patchify(images: torch.Tensor, patch: int, Kp: int) -> torch.Tensor:
+def patchify(images: torch.Tensor, patch: int, Kp: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _req(images, torch.float32, "images", 4)
     B, C, S, S2 = images.shape
     if C != 3 or S != S2 or not images.is_contiguous():
         raise ValueError("patchify: expected contiguous [B,3,S,S]")
     Np = (S // patch) ** 2
-    cols = torch.empty(B * Np, Kp, device=images.device, dtype=torch.bfloat16)
+    cols = out if out is not None else torch.empty(B * Np, Kp, device=images.device, dtype=torch.bfloat16)
+    if tuple(cols.shape) != (B * Np, Kp) or cols.dtype != torch.bfloat16 or not cols.is_contiguous():
+        raise ValueError("patchify: bad out buffer")
     check(lib().apla_patchify(images.data_ptr(), cols.data_ptr(), B, S, patch, Kp, _stream()), "apla_patchify")
     return cols
 
@@ -302,15 +335,20 @@ def sgemm_small(A: torch.Tensor, Bm: torch.Tensor, *, trans_a=False, trans_b=Fal
     return out
 
 
-def cross_entropy(logits: torch.Tensor, labels: torch.Tensor):
+def cross_entropy(logits: torch.Tensor, labels: torch.Tensor, *, dlogits=None, row_loss=None, loss=None):
     """Returns (loss [1], dlogits [B,C], row_loss [B]); mean reduction."""
     _req(logits, torch.float32, "logits", 2), _req(labels, torch.int32, "labels", 1)
     B, C = logits.shape
     if labels.numel() != B or not logits.is_contiguous():
         raise ValueError("cross_entropy: labels length / logits must be contiguous")
-    dlogits = torch.empty(B, C, device=logits.device, dtype=torch.float32)
-    row_loss = torch.empty(B, device=logits.device, dtype=torch.float32)
-    loss = torch.empty(1, device=logits.device, dtype=torch.float32)
+    if dlogits is None:
+        dlogits = torch.empty(B, C, device=logits.device, dtype=torch.float32)
+    if row_loss is None:
+        row_loss = torch.empty(B, device=logits.device, dtype=torch.float32)
+    if loss is None:
+        loss = torch.empty(1, device=logits.device, dtype=torch.float32)
+    if tuple(dlogits.shape) != (B, C) or not dlogits.is_contiguous() or row_loss.numel() != B or loss.numel() < 1:
+        raise ValueError("cross_entropy: bad output buffers")
     check(lib().apla_cross_entropy(logits.data_ptr(), logits.stride(0), labels.data_ptr(), dlogits.data_ptr(),
                                    row_loss.data_ptr(), loss.data_ptr(), B, C, _stream()), "apla_cross_entropy")
     return loss, dlogits, row_loss

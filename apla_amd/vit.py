@@ -1,0 +1,237 @@
+"""Host-side ViT module tree for the MI355X APLA path.
+
+This mirrors the *interface* of the reference backbone (utils/transformers/vit.py): same module/parameter names (so
+reference checkpoints and ``state_dict`` layouts interchange: ``blocks.i.{norm1,attn.qkv,attn.proj,ls1.gamma,norm2,
+mlp.fc1,mlp.fc2,ls2.gamma}``, ``patch_embed.proj``, ``cls_token``, ``pos_embed``, ``norm``, ``fc``), same factory
+names and kwargs (``vit_small(pretrained=False, patch_size=…, pretrained_type=…, img_size=[…], block_conf=…)``,
+vit.py:511-596) and the same construction order, so that under the same ``torch.manual_seed`` the synthetic
+initialisation draws bit-identical weights (vit.py:310-350; checked against digests in tests/golden/g5_cfg1_digests.json).
+
+The modules are *state holders plus a drop-in forward*: ``forward`` on HIP tensors runs the hand-written kernels of
+libapla_hip.so through autograd Functions (apla_amd/functional.py).  The fused training step used by the trainer and
+bench does not go through nn.Module.forward at all: apla_amd/engine.py reads the parameters of this tree, lays them
+out for the kernels and runs forward+backward as one explicit launch sequence.  There is no CPU execution path.
+"""
+import math
+from functools import partial
+
+import torch
+import torch.nn as nn
+
+from . import functional as AF
+
+
+def _trunc_normal_(t: torch.Tensor, std: float):
+    # same draw sequence as the reference's helper (vit.py:34-71): uniform -> erfinv -> scale -> clamp to [-2, 2]
+    return nn.init.trunc_normal_(t, mean=0.0, std=std, a=-2.0, b=2.0)
+
+
+class LayerScale(nn.Module):
+    """Per-channel scale, vit.py:232-244 (dinov2).  Frozen under APLA; the engine folds gamma into the weights."""
+
+    def __init__(self, dim, init_values=1e-5, inplace=False):
+        super().__init__()
+        self.inplace = inplace
+        self.gamma = nn.Parameter(init_values * torch.ones(dim))
+
+    def forward(self, x):
+        return x.mul_(self.gamma) if self.inplace else x * self.gamma
+
+
+class Mlp(nn.Module):
+    """fc1 -> GELU(erf) -> fc2, vit.py:152-168."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, drop=0.0):
+        super().__init__()
+        self.fc1 = nn.Linear(in_features, hidden_features or in_features)
+        self.act = nn.GELU()
+        self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features)
+        self.drop = nn.Dropout(drop)
+
+    def forward(self, x):
+        AF.require_no_dropout(self.drop, self.training)
+        return AF.mlp_gelu(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)
+
+
+class SwiGLUFFNFused(nn.Module):
+    """w12 -> silu(x1)*x2 -> w3 with hidden = (int(h*2/3)+7)//8*8, vit.py:108-149 (ViT-g)."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, drop=0.0, bias=True):
+        super().__init__()
+        hidden = hidden_features or in_features
+        hidden = (int(hidden * 2 / 3) + 7) // 8 * 8
+        self.w12 = nn.Linear(in_features, 2 * hidden, bias=bias)
+        self.w3 = nn.Linear(hidden, out_features or in_features, bias=bias)
+
+    def forward(self, x):
+        return AF.mlp_swiglu(x, self.w12.weight, self.w12.bias, self.w3.weight, self.w3.bias)
+
+
+class Attention(nn.Module):
+    """Plain MHSA, vit.py:171-196: the module APLA swaps out (exposes dim/num_heads/scale/qkv/proj/attn_drop/proj_drop,
+    which is the host-model contract of apla_vit.py:17-37)."""
+
+    def __init__(self, dim, num_heads=8, qkv_bias=False, qk_scale=None, attn_drop=0.0, proj_drop=0.0):
+        super().__init__()
+        self.dim = dim
+        self.num_heads = num_heads
+        self.scale = qk_scale or (dim // num_heads) ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = nn.Linear(dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+        self.return_attn_matrix = False
+
+    def forward(self, x):
+        AF.require_no_dropout(self.attn_drop, self.training), AF.require_no_dropout(self.proj_drop, self.training)
+        return AF.attention_module_forward(x, self.qkv.weight, self.qkv.bias, self.proj.weight, self.proj.bias,
+                                           self.num_heads, self.scale, self.return_attn_matrix)
+
+
+class Block(nn.Module):
+    """Pre-LN block, vit.py:247-288.  ``conf`` carries has_layerscale / layerscale_init_values."""
+
+    def __init__(self, dim, num_heads, mlp_ratio=4.0, qkv_bias=False, qk_scale=None, drop=0.0, attn_drop=0.0,
+                 drop_path=0.0, norm_layer=nn.LayerNorm, conf=None, use_swiglu=False):
+        super().__init__()
+        if drop_path > 0.0:
+            raise NotImplementedError("stochastic depth is 0 in every shipped APLA config; not supported on the HIP path")
+        self.norm1 = norm_layer(dim)
+        self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop,
+                              proj_drop=drop)
+        self.drop_path = nn.Identity()
+        self.norm2 = norm_layer(dim)
+        hidden = int(dim * mlp_ratio)
+        self.mlp = SwiGLUFFNFused(dim, hidden, drop=drop) if use_swiglu else Mlp(dim, hidden, drop=drop)
+        has_ls = bool(conf) and bool(_cfg_get(conf, "has_layerscale", False))
+        if has_ls:
+            init = _cfg_get(conf, "layerscale_init_values", 1e-5)
+            self.ls1, self.ls2 = LayerScale(dim, init), LayerScale(dim, init)
+        else:
+            self.ls1, self.ls2 = nn.Identity(), nn.Identity()
+
+    def forward(self, x, return_attention=False, return_intermediate=False):
+        want_attn = return_attention or return_intermediate
+        prev = getattr(self.attn, "return_attn_matrix", False)
+        if want_attn:
+            self.attn.return_attn_matrix = True
+        try:
+            res = self.attn(AF.layer_norm(x, self.norm1))
+        finally:
+            if want_attn:
+                self.attn.return_attn_matrix = prev
+        y, attn = res if isinstance(res, tuple) else (res, None)
+        y = self.ls1(y)
+        if return_attention and not return_intermediate:
+            return attn
+        x = x + y
+        x = x + self.ls2(self.mlp(AF.layer_norm(x, self.norm2)))
+        return (x, attn) if return_intermediate else x
+
+
+def _cfg_get(conf, key, default):
+    if isinstance(conf, dict):
+        return conf.get(key, default)
+    return getattr(conf, key, default)
+
+
+class PatchEmbed(nn.Module):
+    """p x p stride-p conv patchifier, vit.py:291-307 (frozen and forward-only under APLA)."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768):
+        super().__init__()
+        self.img_size, self.patch_size, self.embed_dim = img_size, patch_size, embed_dim
+        self.num_patches = (img_size // patch_size) ** 2
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+
+    def forward(self, x):
+        return AF.patch_embed(x, self.proj.weight, self.proj.bias, self.patch_size)
+
+
+class VisionTransformer(nn.Module):
+    """vit.py:310-508 (forward/forward_features; the visualisation helpers are out of scope)."""
+
+    def __init__(self, img_size=(224,), patch_size=16, in_chans=3, num_classes=0, embed_dim=768, depth=12,
+                 num_heads=12, mlp_ratio=4.0, qkv_bias=False, qk_scale=None, drop_rate=0.0, attn_drop_rate=0.0,
+                 drop_path_rate=0.0, norm_layer=nn.LayerNorm, use_swiglu=False, block_conf=None, **kwargs):
+        super().__init__()
+        self.is_memory_efficient = kwargs.get("is_memory_efficient", False)
+        self.num_features = self.embed_dim = embed_dim
+        self.depth, self.num_heads, self.patch_size, self.use_swiglu = depth, num_heads, patch_size, use_swiglu
+        self.eps = getattr(norm_layer(embed_dim), "eps", 1e-5)
+        self.patch_embed = PatchEmbed(img_size[0], patch_size, in_chans, embed_dim)
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, self.patch_embed.num_patches + 1, embed_dim))
+        self.pos_drop = nn.Dropout(p=drop_rate)
+        dpr = [v.item() for v in torch.linspace(0, drop_path_rate, depth)]
+        self.blocks = nn.ModuleList([
+            Block(embed_dim, num_heads, mlp_ratio, qkv_bias, qk_scale, drop_rate, attn_drop_rate, dpr[i], norm_layer,
+                  block_conf, use_swiglu) for i in range(depth)])
+        self.norm = norm_layer(embed_dim)
+        self.fc = nn.Linear(embed_dim, num_classes) if num_classes > 0 else nn.Identity()
+        _trunc_normal_(self.pos_embed, 0.02)
+        _trunc_normal_(self.cls_token, 0.02)
+        self.apply(self._init_weights)
+
+    @staticmethod
+    def _init_weights(m):
+        if isinstance(m, nn.Linear):
+            _trunc_normal_(m.weight, 0.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    def interpolate_pos_encoding(self, npatch: int) -> torch.Tensor:
+        """Bicubic resize of the patch position grid when the input grid differs from the pretrain grid
+        (vit.py:421-437).  Frozen parameter => computed with torch once per (grid) and cached by the engine."""
+        pe = self.pos_embed
+        N = pe.shape[1] - 1
+        if npatch == N:
+            return pe
+        dim = pe.shape[-1]
+        s = int(math.sqrt(N))
+        grid = nn.functional.interpolate(pe[:, 1:].reshape(1, s, s, dim).permute(0, 3, 1, 2),
+                                         scale_factor=math.sqrt(npatch / N), mode="bicubic", align_corners=False,
+                                         recompute_scale_factor=False)
+        return torch.cat((pe[:, :1], grid.permute(0, 2, 3, 1).reshape(1, -1, dim)), dim=1)
+
+    def forward_features(self, x):
+        x = self.patch_embed(x)
+        B = x.shape[0]
+        x = torch.cat((self.cls_token.expand(B, -1, -1).to(x.dtype), x), dim=1)
+        x = x + self.interpolate_pos_encoding(x.shape[1] - 1).to(x.dtype)
+        AF.require_no_dropout(self.pos_drop, self.training)
+        for blk in self.blocks:
+            x = blk(x)
+        x = AF.layer_norm(x, self.norm)
+        return x[:, 0]
+
+    def forward(self, x):
+        if isinstance(x, (list, tuple)):  # multi-resolution crops: one pass per resolution (vit.py:352-385)
+            return torch.cat([self.fc(self.forward_features(xi)) for xi in x])
+        return self.fc(self.forward_features(x))
+
+
+def _factory(embed_dim, depth, num_heads, **fixed):
+    def make(pretrained=False, **kwargs):
+        if pretrained:
+            raise RuntimeError("pretrained weights need network access (utils/transformers/transformers_utils.py:10-57); "
+                               "load a checkpoint with load_state_dict instead")
+        kwargs = dict(kwargs)
+        ptype = kwargs.get("pretrained_type", "dinov2")
+        kwargs.setdefault("patch_size", 16)
+        qkv_bias = fixed.get("qkv_bias", True) if "qkv_bias_fn" not in fixed else fixed["qkv_bias_fn"](ptype)
+        return VisionTransformer(embed_dim=embed_dim, depth=depth, num_heads=num_heads, mlp_ratio=4, qkv_bias=qkv_bias,
+                                 norm_layer=partial(nn.LayerNorm, eps=1e-6), use_swiglu=fixed.get("use_swiglu", False),
+                                 **kwargs)
+    return make
+
+
+# vit.py:511-596: tiny/small/base/large/giant
+vit_tiny = _factory(192, 12, 3)
+vit_small = _factory(384, 12, 6)
+vit_base = _factory(768, 12, 12, qkv_bias_fn=lambda ptype: ptype != "in21k")
+vit_large = _factory(1024, 24, 16)
+vit_giant = _factory(1536, 40, 24, use_swiglu=True)

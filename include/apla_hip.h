@@ -61,11 +61,14 @@ int apla_layernorm_fwd(const void* x, int res_dtype, long x_row_stride, const fl
                        hipStream_t stream);
 
 /* dx_out = dres_in + LN_backward_dx(dy; x, gamma, mean, rstd)   (gamma/beta frozen: apla/apla_vit.py:80-81).
- * dres_in may be NULL (treated as 0) and may alias dx_out.  If `gather_out` != NULL also writes the APLA-trainable
- * columns of dx_out: gather_out[m, j] = dx_out[m, inds[j]] for j < r (bf16) — the only part of the projection's
- * output gradient that the column-masked dW1 needs (autograd of the scatter at appla_attn.py:70-74). */
-int apla_layernorm_bwd(const void* dy, int dy_dtype, int lddy, const void* x, int res_dtype, long x_row_stride, const float* gamma,
-                       const float* mean, const float* rstd, const void* dres_in, void* dx_out, long dx_row_stride,
+ * x is the saved forward input (x_dtype); dres_in/dx_out are the residual-gradient stream (grad_dtype; dres_in may be
+ * NULL (=0) and may alias dx_out; both use dx_row_stride).  dx_bf16_copy (optional) receives a bf16 copy of dx_out —
+ * the GEMM operand when the gradient stream is fp32.  If `gather_out` != NULL also writes the APLA-trainable columns
+ * of dx_out: gather_out[m, j] = dx_out[m, inds[j]] for j < r (bf16) — the only part of the projection's output
+ * gradient that the column-masked dW1 needs (autograd of the scatter at appla_attn.py:70-74). */
+int apla_layernorm_bwd(const void* dy, int dy_dtype, int lddy, const void* x, int x_dtype, long x_row_stride,
+                       const float* gamma, const float* mean, const float* rstd, const void* dres_in, void* dx_out,
+                       int grad_dtype, long dx_row_stride, void* dx_bf16_copy, long copy_row_stride,
                        const int32_t* inds, int r, void* gather_out, int M, int D, hipStream_t stream);
 
 /* Gather only (used when the projection output gradient is already materialised): out[m,j] = src[m,inds[j]] bf16. */

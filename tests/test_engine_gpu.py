@@ -1,0 +1,153 @@
+"""End-to-end parity of the fused MI355X training step (apla_amd.engine) with the CPU oracle and with the golden
+vectors produced by the actual reference (tests/golden/g5_cfg1_vits.npz: ViT-S/16, r=64, bs=8 — BASELINE config 1).
+
+Tolerances (stated, per SURVEY §7 "hard parts"): the reference CPU path is fp32; the HIP path multiplies in bf16 with
+fp32 accumulation and an fp32 residual stream.  We require  max|logits - ref| / max|ref| <= 1e-2  and
+|loss - ref| <= 5e-3 in that mode, gradients within 3e-2 relative L2.  Index selection is bit-exact (CPU test)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err, t
+from oracle import apla_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_TOL = 1e-2
+GRAD_TOL = 3e-2
+
+
+def rel_l2(a, b):
+    a, b = torch.as_tensor(a).double().flatten(), torch.as_tensor(b).double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def build_classifier(backbone, r, n_classes, tp, seed):
+    from apla_amd.models import Classifier
+    torch.manual_seed(seed)
+    mp = dict(backbone_type=backbone, n_classes=n_classes, pretrained=False, transformers_params=tp,
+              adaptation=dict(mode="apla", params=dict(partial_size=r)))
+    return Classifier(mp, dict(which_GPUs="0"))
+
+
+def oracle_params(model, dtype=torch.float64):
+    p = {}
+    for k, v in model.state_dict().items():
+        k2 = k[len("backbone."):] if k.startswith("backbone.") else k
+        p[k2] = v.detach().cpu().clone().to(dtype) if v.is_floating_point() else v.detach().cpu().clone()
+    return p
+
+
+def small_vit(depth=2, r=64, swiglu=False, ls=True):
+    from apla_amd import vit
+    from apla_amd.apla import build_apla
+    from apla_amd.models import AttrDict
+    import torch.nn as nn
+    from functools import partial
+    torch.manual_seed(3)
+    bb = vit.VisionTransformer(img_size=[32], patch_size=16, embed_dim=128, depth=depth, num_heads=2, qkv_bias=True, mlp_ratio=4.5 if swiglu else 4.0,
+                               norm_layer=partial(nn.LayerNorm, eps=1e-6), use_swiglu=swiglu,
+                               block_conf=dict(has_layerscale=ls, layerscale_init_values=1.0))
+    with torch.no_grad():
+        for n, p_ in bb.named_parameters():
+            if "gamma" in n:
+                p_.uniform_(0.5, 1.5)
+            elif p_.ndim >= 2:
+                p_.normal_(std=0.06)
+            elif "norm" in n and n.endswith("weight"):
+                p_.uniform_(0.8, 1.2)
+            else:
+                p_.normal_(std=0.05)
+    build_apla(AttrDict(partial_size=r), bb, "apla_attn")
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.backbone = bb
+            self.backbone.fc = nn.Identity()
+            self.fc = nn.Linear(128, 10)
+    return Net()
+
+
+@pytest.mark.parametrize("swiglu,res_dtype,grad_dtype", [(False, torch.float32, torch.bfloat16),
+                                                        (False, torch.float32, torch.float32),
+                                                        (False, torch.bfloat16, torch.bfloat16),
+                                                        (True, torch.float32, torch.bfloat16)])
+@pytest.mark.parametrize("use_graphs", [False, True])
+def test_engine_small_vs_oracle(swiglu, res_dtype, grad_dtype, use_graphs):
+    from apla_amd.engine import AplaTrainEngine, OptimConfig
+    model = small_vit(depth=3, swiglu=swiglu)
+    p = oracle_params(model)
+    B = 5
+    g = torch.Generator().manual_seed(1)
+    images = torch.randn(B, 3, 32, 32, generator=g)
+    labels = torch.randint(0, 10, (B,), generator=g)
+    cfg = dict(patch=16, depth=3, heads=2, r=64, swiglu=swiglu)
+    logits_ref, ctx = O.vit_forward(images.double(), p, cfg)
+    loss_ref, dl = O.cross_entropy_fwd_bwd(logits_ref, labels)
+    grads_ref = O.vit_backward(dl, ctx, p, cfg)
+
+    eng = AplaTrainEngine(model, B, 32, res_dtype=res_dtype, grad_dtype=grad_dtype, use_graphs=use_graphs,
+                          optim=OptimConfig(lr=1e-3, weight_decay=1e-2, grad_clipping=1.0))
+    eng.set_batch(images.cuda(), labels.cuda())
+    eng.forward_backward()
+    torch.cuda.synchronize()
+    tol = LOGIT_TOL if res_dtype == torch.float32 else 3 * LOGIT_TOL
+    assert rel_err(eng.logits.cpu(), logits_ref) < tol
+    assert abs(float(eng.loss) - float(loss_ref)) < 5e-3 * (3 if res_dtype == torch.bfloat16 else 1)
+    for n, gr in eng.grads().items():
+        n2 = n[len("backbone."):] if n.startswith("backbone.") else n
+        assert rel_l2(gr.cpu(), grads_ref[n2]) < GRAD_TOL * (2 if res_dtype == torch.bfloat16 else 1), n
+    # optimizer: compare against the oracle applied to the ENGINE's gradients (isolates the fused clip+AdamW)
+    g_eng = {n[len("backbone."):] if n.startswith("backbone.") else n: v.detach().cpu().double().clone()
+             for n, v in eng.grads().items()}
+    gn = O.clip_grad_norm(g_eng, 1.0)
+    O.adamw_step(p, g_eng, {}, lr=1e-3, wd=1e-2)
+    eng.optimizer_step()
+    torch.cuda.synchronize()
+    assert abs(float(eng.grad_norm) - float(gn)) < 1e-4 * float(gn)
+    sd = model.state_dict()
+    for n in eng.names:
+        n2 = n[len("backbone."):] if n.startswith("backbone.") else n
+        assert rel_err(sd[n].cpu(), p[n2]) < 1e-5, n
+    # second step runs (weights re-packed from the updated masters) and the loss changes
+    l0 = float(eng.loss)
+    eng.train_step()
+    torch.cuda.synchronize()
+    assert np.isfinite(float(eng.loss)) and float(eng.loss) != l0
+
+
+def test_engine_cfg1_matches_reference_golden():
+    """BASELINE config 1 (ViT-S/16, r=64, C=10, bs=8): same seed-built weights as the reference (digests checked in the
+    CPU suite), same inputs; logits/loss/grads against what the REFERENCE code produced."""
+    from apla_amd.engine import AplaTrainEngine, OptimConfig
+    g = load_golden("g5_cfg1_vits.npz")
+    tp = dict(img_size=[224], patch_size=16, pretrained_type="dinov2", is_memory_efficient=True,
+              block_conf=dict(has_layerscale=True, layerscale_init_values=1.0))
+    model = build_classifier("vit_small", 64, 10, tp, seed=0)
+    for i in (0, 5, 11):
+        assert torch.equal(model.backbone.blocks[i].attn.inds, t(g[f"inds{i}"]))  # bit-exact column selection
+    gen = torch.Generator().manual_seed(0)
+    images = torch.randn(8, 3, 224, 224, generator=gen)
+    labels = torch.randint(0, 10, (8,), generator=gen)
+    eng = AplaTrainEngine(model, 8, 224, optim=OptimConfig(lr=1e-4, weight_decay=1e-5, grad_clipping=1.0))
+    eng.set_batch(images.cuda(), labels.cuda())
+    eng.forward_backward()
+    torch.cuda.synchronize()
+    e_logits = rel_err(eng.logits.cpu(), g["logits"])
+    print(f"cfg1 logits rel err {e_logits:.3e}; loss {float(eng.loss):.6f} vs ref {float(g['loss']):.6f}")
+    assert e_logits < LOGIT_TOL
+    assert abs(float(eng.loss) - float(g["loss"])) < 5e-3
+    for i in (0, 5, 11):
+        for nm in ("proj_weight1", "proj_bias1"):
+            e = rel_l2(eng.grads()[f"backbone.blocks.{i}.attn.{nm}"].cpu(), g[f"g.blocks.{i}.attn.{nm}"])
+            assert e < GRAD_TOL, (i, nm, e)
+    assert rel_l2(eng.grads()["fc.weight"].cpu(), g["g.fc.weight"]) < GRAD_TOL
+    eng.optimizer_step()
+    torch.cuda.synchronize()
+    assert abs(float(eng.grad_norm) - float(g["gnorm"])) < 2e-2 * float(g["gnorm"])
+    sd = model.state_dict()
+    # after one AdamW step (lr 1e-4) the update is +-lr per element; compare the update direction, not just the value
+    for nm in ("backbone.blocks.5.attn.proj_weight1", "fc.weight"):
+        ref_after = t(g["after." + nm.replace("backbone.", "")])
+        assert float((sd[nm].cpu() - ref_after).abs().max()) < 2.5e-4
