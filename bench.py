@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X-native APLA training step (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one full APLA training step of BASELINE config 2 — ViT-B/16 (dinov2-shaped: qkv bias, LayerScale, eps 1e-6),
+partial_size 192, 1000 classes, 224x224, batch 128 per GPU, bf16 MFMA / fp32 accumulate — forward + cross-entropy +
+backward + gradient all-reduce (world > 1) + global-norm clip + AdamW, on a synthetic batch already resident in HBM.
+Rank 0 prints ONE JSON line.  `value` is whole-job images/s.  See DESIGN.md §Measurement for the roofline accounting.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic work per image for the configs of BASELINE.md §3 (forward + APLA backward, GFLOP)
+STEP_GF_PER_IMG = {"vit_small": 18.76, "vit_base": 70.99}
+PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def build_model(backbone, r, n_classes, img, patch, seed=0):
+    from apla_amd.models import Classifier
+    torch.manual_seed(seed)
+    tp = dict(img_size=[img], patch_size=patch, pretrained_type="dinov2", is_memory_efficient=True,
+              block_conf=dict(has_layerscale=True, layerscale_init_values=1.0))
+    mp = dict(backbone_type=backbone, n_classes=n_classes, pretrained=False, transformers_params=tp,
+              adaptation=dict(mode="apla", params=dict(partial_size=r)))
+    return Classifier(mp, dict(which_GPUs="0"))
+
+
+def time_dominant_kernel(M, D, F, iters=20):
+    """Live HIP-event timing of the dominant kernel: the fc1 GEMM+GELU launch (largest single share of step FLOPs)."""
+    from apla_amd import ops
+    dev = "cuda"
+    a = torch.randn(M, D, device=dev).to(torch.bfloat16)
+    w = (torch.randn(F, D, device=dev) * D ** -0.5).to(torch.bfloat16)
+    b = torch.zeros(F, device=dev)
+    h = torch.empty(M, F, device=dev, dtype=torch.bfloat16)
+    g = torch.empty_like(h)
+    for _ in range(3):
+        ops.gemm_nt(a, w, b, epilogue=ops.EPI_GELU, aux_out=g, out=h)
+    s = torch.cuda.current_stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(s)
+    for _ in range(iters):
+        ops.gemm_nt(a, w, b, epilogue=ops.EPI_GELU, aux_out=g, out=h)
+    e1.record(s)
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    return ms, 2.0 * M * D * F / (ms * 1e-3) / 1e12
+
+
+def cpu_baseline(backbone, r, n_classes, img, patch, sample_bs, threads):
+    """The CPU oracle (a port of the reference step) timed on this box's host cores on a bounded sample."""
+    from oracle import apla_oracle as O
+    torch.set_num_threads(threads)
+    model = build_model(backbone, r, n_classes, img, patch)
+    p = {(k[len("backbone."):] if k.startswith("backbone.") else k): v.detach().clone() for k, v in model.state_dict().items()}
+    bb = model.backbone
+    cfg = dict(patch=patch, depth=bb.depth, heads=bb.num_heads, r=r)
+    g = torch.Generator().manual_seed(0)
+    images = torch.randn(sample_bs, 3, img, img, generator=g)
+    labels = torch.randint(0, n_classes, (sample_bs,), generator=g)
+    state = {}
+    O.train_step(images, labels, p, cfg, state)  # warm-up
+    t0, n = time.perf_counter(), 0
+    while n < 3 or (time.perf_counter() - t0 < 12 and n < 20):
+        O.train_step(images, labels, p, cfg, state)
+        n += 1
+    dt = (time.perf_counter() - t0) / n
+    return sample_bs / dt, n, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--backbone", default="vit_base")
+    ap.add_argument("--batch", type=int, default=128, help="per-GPU batch")
+    ap.add_argument("--partial-size", type=int, default=192)
+    ap.add_argument("--classes", type=int, default=1000)
+    ap.add_argument("--res-dtype", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--grad-dtype", default="bf16", choices=["fp32", "bf16"])
+    ap.add_argument("--no-graphs", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-bs", type=int, default=16)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        sys.exit(f"--gpus {args.gpus} needs a launcher: python -m torch.distributed.run --nproc-per-node {args.gpus} "
+                 f"--master-addr 127.0.0.1 bench.py --gpus {args.gpus} …  (WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        pg = dist.group.WORLD
+
+    from apla_amd.engine import AplaTrainEngine, OptimConfig
+    img, patch = 224, 16
+    dt = {"fp32": torch.float32, "bf16": torch.bfloat16}
+    model = build_model(args.backbone, args.partial_size, args.classes, img, patch, seed=0)  # same seed => same indices on all ranks
+    eng = AplaTrainEngine(model, args.batch, img, res_dtype=dt[args.res_dtype], grad_dtype=dt[args.grad_dtype],
+                          optim=OptimConfig(lr=1e-4, weight_decay=1e-5, grad_clipping=1.0), process_group=pg,
+                          use_graphs=not args.no_graphs)
+    g = torch.Generator(device="cuda").manual_seed(rank)  # each rank owns its shard of the global batch
+    images = torch.randn(args.batch, 3, img, img, device="cuda", generator=g)
+    labels = torch.randint(0, args.classes, (args.batch,), device="cuda", generator=g)
+    eng.set_batch(images, labels)
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.train_step()
+    sync()
+    torch.cuda.reset_peak_memory_stats()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.train_step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    loss = float(eng.loss)
+    if world > 1:
+        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tt)
+    ms_per_step = elapsed / args.steps * 1e3
+    img_s = world * args.batch * args.steps / elapsed
+    peak_mem = torch.cuda.max_memory_allocated() / 2 ** 30
+
+    if rank == 0:
+        bb = model.backbone
+        M = args.batch * eng.N
+        k_ms, k_tf = time_dominant_kernel(M, bb.embed_dim, eng.blocks[0].F)
+        gf = STEP_GF_PER_IMG.get(args.backbone)
+        step_tf = img_s / world * gf / 1e3 if gf else None
+        out = {
+            "metric": "images/sec, ViT-B/16 APLA training step bs=128/GPU (whole job)", "value": round(img_s, 1),
+            "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{args.backbone}/16 dinov2-shaped APLA partial_size={args.partial_size} full training "
+                                   f"step (fwd+CE+bwd+allreduce+clip+AdamW), 224x224, C={args.classes}, "
+                                   f"bs={args.batch}/GPU, residual {args.res_dtype}, grad stream {args.grad_dtype}",
+                       "global_batch": world * args.batch, "parallelism": f"dp{world}",
+                       "hip_graphs": not args.no_graphs},
+            "images_per_sec_per_gpu": round(img_s / world, 1), "peak_mem_gib": round(peak_mem, 2),
+            "final_loss": round(loss, 4),
+            "roofline": {"bound": "mfma", "kernel": f"gemm_nt_kernel<GELU> fc1 M={M} N={eng.blocks[0].F} K={bb.embed_dim}",
+                         "achieved": round(k_tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(k_tf / PEAK_BF16_TFLOPS, 4), "traffic": None, "kernel_ms": round(k_ms, 4),
+                         "step_achieved": round(step_tf, 1) if step_tf else None,
+                         "step_frac": round(step_tf / PEAK_BF16_TFLOPS, 4) if step_tf else None,
+                         "step_gflop_per_image": gf},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            threads = min(64, os.cpu_count() or 1)
+            v, n, dt_s = cpu_baseline(args.backbone, args.partial_size, args.classes, img, patch, args.cpu_sample_bs, threads)
+            out["cpu_baseline"] = {"value": round(v, 2), "unit": "images/s", "cores": threads, "kind": "port",
+                                   "sample": f"{n} full steps of the same model at bs={args.cpu_sample_bs} (fp32 oracle, "
+                                             f"{dt_s:.2f} s/step, os.cpu_count()={os.cpu_count()})"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
