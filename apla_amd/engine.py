@@ -30,6 +30,7 @@ import torch.nn as nn
 from . import ops
 from ._lib import AplaHipError
 from .apla.appla_attn import APLA_Attention
+from .dist import GradExchanger
 
 _BF = torch.bfloat16
 
@@ -134,10 +135,11 @@ class AplaTrainEngine:
             off += k
         self.n_trainable = n_total
         self.names = [n for n, _ in named]
-        # all-reduce chunks in backward order: [second half of blocks + head] first, then the first half
-        half_name = self.names[2 * (self.L // 2)] if self.L > 1 else self.names[0]
-        split = self.slices[half_name][0]
+        # all-reduce chunks in backward order: [second half of blocks + head] first, then the first half; the cut is
+        # exactly where _segment_a / _segment_b split the backward
+        split = self.slices[self.names[2 * (self.L // 2)]][0] if self.L > 1 else 0
         self.chunks = [(split, n_total), (0, split)] if split > 0 else [(0, n_total)]
+        self.exchanger = GradExchanger(self.flat_grads, self.chunks, self.pg)
 
     def _grad_view(self, name):
         off, k, shape = self.slices[name]
@@ -346,22 +348,11 @@ class AplaTrainEngine:
         backward has been enqueued."""
         if self.use_graphs and self._graphs is None:
             self._capture()
-        if self.world > 1 and not hasattr(self, "_comm"):
-            self._comm = torch.cuda.Stream()
-        main = torch.cuda.current_stream()
         segs = ((self._graphs[0].replay, self._graphs[1].replay) if self.use_graphs else (self._segment_a, self._segment_b))
         for k, run in enumerate(segs):
             run()
-            if self.world > 1 and k < len(self.chunks):
-                lo, hi = self.chunks[k]
-                if hi > lo:
-                    ev = torch.cuda.Event()
-                    ev.record(main)
-                    self._comm.wait_event(ev)
-                    with torch.cuda.stream(self._comm):
-                        torch.distributed.all_reduce(self.flat_grads[lo:hi], group=self.pg)
-        if self.world > 1:
-            main.wait_stream(self._comm)
+            self.exchanger.launch_chunk(k)   # RCCL all-reduce of what this segment produced, on the side stream
+        self.exchanger.wait()
 
     def optimizer_step(self, lr: Optional[float] = None):
         """Fused clip + AdamW on the flat buffer (DDP mean = grad_scale 1/world)."""

@@ -1,0 +1,112 @@
+"""Host-side logic on CPU: the plugin surface (build_apla / APLA_Attention) mirrors the reference's behaviour —
+construction order (seed-exact weights and bit-exact column selection), state_dict layout, freeze policy, multi-GPU
+rules, error conventions (apla/apla_vit.py, apla/appla_attn.py) — and the oracle reproduces the reference's BASELINE
+config-1 training step (golden g5_cfg1) from those weights."""
+import hashlib
+import json
+import os
+
+import pytest
+import torch
+
+from conftest import GOLDEN, load_golden, rel_err, t
+from oracle import apla_oracle as O
+
+TP = dict(img_size=[224], patch_size=16, pretrained_type="dinov2", is_memory_efficient=True,
+          block_conf=dict(has_layerscale=True, layerscale_init_values=1.0))
+
+
+def digest(v):
+    return hashlib.sha256(v.detach().contiguous().numpy().tobytes()).hexdigest()[:16]
+
+
+@pytest.fixture(scope="module")
+def cfg1_model():
+    from apla_amd.models import Classifier
+    torch.manual_seed(0)
+    mp = dict(backbone_type="vit_small", n_classes=10, pretrained=False, transformers_params=TP,
+              adaptation=dict(mode="apla", params=dict(partial_size=64)))
+    return Classifier(mp, dict(which_GPUs="0"))
+
+
+def test_seed_exact_construction_matches_reference_digests(cfg1_model):
+    ref = json.load(open(os.path.join(GOLDEN, "g5_cfg1_digests.json")))
+    sd = {(k[len("backbone."):] if k.startswith("backbone.") else k): v for k, v in cfg1_model.state_dict().items()}
+    assert sorted(sd) == sorted(ref["digests"])
+    bad = [k for k, v in sd.items() if digest(v) != ref["digests"][k]]
+    assert not bad, bad[:5]
+    n_train = sum(p.numel() for p in cfg1_model.parameters() if p.requires_grad)
+    assert n_train == ref["n_trainable"] == 299530          # L*(r*D+r) + D*C + C  
+
+
+def test_state_dict_layout_and_trainable_set(cfg1_model):
+    keys = [k for k in cfg1_model.state_dict() if k.startswith("backbone.blocks.0.attn.")]
+    assert sorted(k.split("attn.")[1] for k in keys) == sorted(
+        ["proj_weight1", "proj_weight2", "proj_bias1", "proj_bias2", "inds", "qkv.weight", "qkv.bias"])
+    names = [n for n, p in cfg1_model.named_parameters() if p.requires_grad]
+    assert names == [f"backbone.{n}" for n in O.trainable_names(12)[:-2]] + ["fc.weight", "fc.bias"]
+    a = cfg1_model.backbone.blocks[3].attn
+    assert a.inds.dtype == torch.int64 and a.proj_weight1.shape == (64, 384) and a.proj_weight2.shape == (320, 384)
+    assert torch.equal(a.trainable_inds, a.inds[:64]) and torch.equal(a.freezed_inds, a.inds[64:])
+    from apla_amd.models import get_params_groups
+    groups = get_params_groups(cfg1_model)
+    assert len(groups[0]["params"]) == 13 and len(groups[1]["params"]) == 13 and groups[1]["weight_decay"] == 0.0
+
+
+def test_oracle_reproduces_reference_cfg1_step(cfg1_model):
+    """Oracle on our seed-built weights == what the REFERENCE code produced for config 1 (logits, loss, grads, AdamW)."""
+    g = load_golden("g5_cfg1_vits.npz")
+    p = {(k[len("backbone."):] if k.startswith("backbone.") else k): v.detach().clone()
+         for k, v in cfg1_model.state_dict().items()}
+    gen = torch.Generator().manual_seed(0)
+    images = torch.randn(8, 3, 224, 224, generator=gen)
+    labels = torch.randint(0, 10, (8,), generator=gen)
+    cfg = dict(patch=16, depth=12, heads=6, r=64)
+    logits, ctx = O.vit_forward(images, p, cfg)
+    assert rel_err(logits, g["logits"]) < 2e-5
+    loss, dl = O.cross_entropy_fwd_bwd(logits, labels)
+    assert abs(float(loss) - float(g["loss"])) < 1e-5
+    grads = O.vit_backward(dl, ctx, p, cfg)
+    for i in (0, 5, 11):
+        for nm in ("proj_weight1", "proj_bias1"):
+            assert rel_err(grads[f"blocks.{i}.attn.{nm}"], g[f"g.blocks.{i}.attn.{nm}"]) < 2e-4
+    assert rel_err(grads["fc.weight"], g["g.fc.weight"]) < 2e-4
+    gn = O.clip_grad_norm(grads, 1.0)
+    assert abs(float(gn) - float(g["gnorm"])) < 1e-4 * float(g["gnorm"])
+    O.adamw_step(p, grads, {}, lr=1e-4, wd=1e-5)
+    for nm in ("blocks.5.attn.proj_weight1", "fc.weight", "fc.bias"):
+        assert rel_err(p[nm], g["after." + nm]) < 1e-5
+
+
+def test_build_apla_rules(tmp_path):
+    from apla_amd import vit
+    from apla_amd.apla import APLA_Attention, APLA_MemEffAttention, build_apla
+    from apla_amd.models import AttrDict
+    mk = lambda: vit.VisionTransformer(img_size=[32], patch_size=16, embed_dim=128, depth=2, num_heads=2, qkv_bias=True)  # noqa: E731
+    with pytest.raises(NotImplementedError):
+        build_apla(AttrDict(partial_size=64), mk(), "nope")
+    with pytest.raises(AssertionError):                    # multi-GPU random sampling needs inds_path (apla_vit.py:77)
+        build_apla(AttrDict(partial_size=64), mk(), "apla_attn", is_multi_gpu=True)
+    m = build_apla(AttrDict(partial_size="full"), mk(), "apla_attn", is_multi_gpu=True)   # apla_vit.py:66-75
+    assert not isinstance(m.blocks[0].attn, APLA_Attention)
+    assert sorted(n for n, p in m.named_parameters() if p.requires_grad) == sorted(
+        f"blocks.{i}.attn.proj.{w}" for i in range(2) for w in ("weight", "bias"))
+    with pytest.raises(TypeError):                         # single-GPU 'full' is invalid in the reference too
+        build_apla(AttrDict(partial_size="full"), mk(), "apla_attn")
+    inds = {f"block_{i}": torch.randperm(128)[:64].tolist() for i in range(2)}
+    path = tmp_path / "inds.json"
+    path.write_text(json.dumps(inds))
+    base = mk()
+    w = base.blocks[1].attn.proj.weight.detach().clone()
+    m = build_apla(AttrDict(partial_size=64, inds_path=str(path)), base, "apla_attn_mem_eff", is_multi_gpu=True)
+    a = m.blocks[1].attn
+    assert isinstance(a, APLA_MemEffAttention)
+    assert a.inds[:64].tolist() == inds["block_1"] and a.inds[64:].tolist() == sorted(set(range(128)) - set(inds["block_1"]))
+    assert torch.equal(a.proj_weight1, w[a.inds[:64]]) and torch.equal(a.proj_weight2, w[a.inds[64:]])
+    assert torch.equal(O.indices_from_trainable(inds["block_1"], 128), a.inds)
+
+
+def test_cpu_forward_fails_loudly(cfg1_model):
+    from apla_amd._lib import AplaHipError
+    with pytest.raises(AplaHipError):
+        cfg1_model(torch.zeros(1, 3, 224, 224))
