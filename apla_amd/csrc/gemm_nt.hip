@@ -13,6 +13,8 @@
 //    (bias, GELU, residual, multiplier) a vector op on 8/16-byte global accesses.
 //  * blockIdx -> tile mapping is XCD-aware: each XCD walks a contiguous run of tiles with n fastest, so an A row
 //    panel is fetched into one L2 and reused by all N/128 column tiles.
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -32,11 +34,76 @@ struct GemmParams {
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-__device__ __forceinline__ float gelu_f(float a) { return 0.5f * a * (1.0f + erff(a * 0.70710678118654752f)); }
-__device__ __forceinline__ float gelu_grad_f(float a) {
-  return 0.5f * (1.0f + erff(a * 0.70710678118654752f)) + a * __expf(-0.5f * a * a) * 0.3989422804014327f;
+// GELU (exact erf form) and its derivative from ONE exp2 and ONE rcp per element: Phi(a) via Abramowitz-Stegun 7.1.26
+// (|erf error| < 1.5e-7, far below the bf16 output rounding) sharing E = exp(-a^2/2) with the Gaussian term of gelu'.
+__device__ __forceinline__ void gelu_and_grad(float a, float& h, float& g) {
+  const float x = fabsf(a) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
+  float poly = fmaf(t, 1.061405429f, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  poly *= t;
+  const float E = __builtin_amdgcn_exp2f(a * a * -0.72134752044448170f);  // exp(-a^2/2)
+  const float q = 0.5f * poly * E;                                        // = 1 - Phi(|a|)
+  const float phi = a >= 0.f ? 1.0f - q : q;
+  h = a * phi;
+  g = fmaf(a * E, 0.3989422804014327f, phi);
 }
 __device__ __forceinline__ float sigmoid_f(float a) { return 1.0f / (1.0f + __expf(-a)); }
+
+template <int EPI, typename OutT, int MI = 4>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[MI][4], int m0, int n0, int wm, int wn,
+                                              int lane) {
+  const int frow = lane & 15, fq = lane >> 4;
+  // ---- epilogue: lane owns row m = .. + (lane&15), columns n = .. + 4*(lane>>4) + {0..3} of each 16x16 tile ----
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int m = m0 + wm * (MI * 16) + i * 16 + frow;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + fq * 4;
+      f32x4 v = acc[i][j];
+      if (p.bias != nullptr) v += *(const f32x4*)(p.bias + n);
+      if constexpr (EPI == APLA_EPI_STORE) {
+        Vec4IO<OutT>::store((OutT*)p.C + (size_t)m * p.ldc + n, v);
+      } else if constexpr (EPI == APLA_EPI_GELU) {
+        f32x4 h, g;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { float hh, gg; gelu_and_grad(v[e], hh, gg); h[e] = hh; g[e] = gg; }
+        Vec4IO<bf16>::store((bf16*)p.C + (size_t)m * p.ldc + n, h);
+        Vec4IO<bf16>::store((bf16*)p.aux_out + (size_t)m * p.ld_aux_out + n, g);
+      } else if constexpr (EPI == APLA_EPI_RESIDUAL) {
+        f32x4 r = Vec4IO<OutT>::load((const OutT*)p.aux_in + (size_t)m * p.ld_aux_in + n);
+        Vec4IO<OutT>::store((OutT*)p.C + (size_t)m * p.ldc + n, r + v);
+      } else if constexpr (EPI == APLA_EPI_MUL) {
+        f32x4 g = Vec4IO<bf16>::load((const bf16*)p.aux_in + (size_t)m * p.ld_aux_in + n);
+        Vec4IO<bf16>::store((bf16*)p.C + (size_t)m * p.ldc + n, v * g);
+      } else if constexpr (EPI == APLA_EPI_SWIGLU) {
+        // columns (n, n+1) = (x1_i, x2_i), (n+2, n+3) = (x1_{i+1}, x2_{i+1}); i = n/2
+        Vec4IO<bf16>::store((bf16*)p.aux_out + (size_t)m * p.ld_aux_out + n, v);
+        bf16x2 h;
+        h[0] = (bf16)(v[0] * sigmoid_f(v[0]) * v[1]);
+        h[1] = (bf16)(v[2] * sigmoid_f(v[2]) * v[3]);
+        *(bf16x2*)((bf16*)p.C + (size_t)m * p.ldc + (n >> 1)) = h;
+      } else if constexpr (EPI == APLA_EPI_SWIGLU_BWD) {
+        // v = dh for hidden units n..n+3; saved x12 interleaved at columns 2n..2n+7
+        const bf16* xs = (const bf16*)p.aux_in + (size_t)m * p.ld_aux_in + 2 * n;
+        bf16x8 x12 = *(const bf16x8*)xs;
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float x1 = (float)x12[2 * e], x2 = (float)x12[2 * e + 1];
+          const float s = sigmoid_f(x1);
+          o[2 * e] = (bf16)(v[e] * x2 * s * (1.0f + x1 * (1.0f - s)));
+          o[2 * e + 1] = (bf16)(v[e] * x1 * s);
+        }
+        *(bf16x8*)((bf16*)p.C + (size_t)m * p.ldc + 2 * n) = o;
+      }
+    }
+  }
+}
 
 template <int EPI, typename OutT>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams p) {
@@ -101,65 +168,398 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams p) {
     __syncthreads();
   }
 
-  // ---- epilogue: lane owns row m = .. + (lane&15), columns n = .. + 4*(lane>>4) + {0..3} of each 16x16 tile ----
+  gemm_epilogue<EPI, OutT>(p, acc, m0, n0, wm, wn, lane);
+}
+
+
+// ---- variant: S-stage LDS ring, counted vmcnt + raw s_barrier (LDS-DMA stays in flight across barriers) ----
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int EPI, typename OutT, int S>
+__global__ __launch_bounds__(256) void gemm_ring_kernel(GemmParams p) {
+  __shared__ __attribute__((aligned(16))) char smem[S * STAGE_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int tm = wg / p.tiles_n, tn = wg - tm * p.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const bf16* a_src[4];
+  const bf16* w_src[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wm * 64 + i * 16 + frow;
+  for (int it = 0; it < 4; ++it) {
+    const int piece = wave * 4 + it;
+    const int row = piece * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    int gr = m0 + row;
+    gr = gr < p.M ? gr : p.M - 1;
+    a_src[it] = p.A + (size_t)gr * p.lda + chunk * 8;
+    w_src[it] = p.W + (size_t)(n0 + row) * p.ldw + chunk * 8;
+  }
+  auto stage = [&](int s, int k0) {
+    char* base = smem + s * STAGE_BYTES;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int piece = wave * 4 + it;
+      __builtin_amdgcn_global_load_lds(GLBP(a_src[it] + k0), LDSP(base + piece * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GLBP(w_src[it] + k0), LDSP(base + BM * BK * 2 + piece * 1024), 16, 0, 0);
+    }
+  };
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int frow = lane & 15, fq = lane >> 4;
+  const int nk = p.K / BK;
+#pragma unroll
+  for (int s = 0; s < S - 1; ++s)
+    if (s < nk) stage(s, s * BK);
+  int cur = 0, nxt = S - 1;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + S - 2 < nk) wait_vmcnt<(S - 2) * 8>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (kt + S - 1 < nk) stage(nxt, (kt + S - 1) * BK);
+    const char* As = smem + cur * STAGE_BYTES;
+    const char* Ws = As + BM * BK * 2;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[4], wf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(As + lds_off(wm * 64 + i * 16 + frow, ks * 4 + fq));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wf[j] = *(const bf16x8*)(Ws + lds_off(wn * 64 + j * 16 + frow, ks * 4 + fq));
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    cur = cur + 1 == S ? 0 : cur + 1;
+    nxt = nxt + 1 == S ? 0 : nxt + 1;
+  }
+  gemm_epilogue<EPI, OutT>(p, acc, m0, n0, wm, wn, lane);
+}
+
+// ---- persistent variant -------------------------------------------------------------------------------------------
+// 2 workgroups per CU stay resident and walk the tile list (each XCD owns a contiguous run of tiles, n fastest).  The
+// 2-stage LDS ring runs ACROSS tiles: during the last K-step of a tile the first K-step of the workgroup's next tile is
+// already being DMA'd into the free buffer, so a tile has no load prologue and its epilogue (VALU + global stores)
+// overlaps that DMA; the stores themselves drain under the next main loop.  LDS-DMA completion is tracked with counted
+// s_waitcnt vmcnt + raw s_barrier (vmcnt retires in issue order: the epilogue stores are younger than the prefetch, so
+// the first wait of the next tile leaves exactly those stores outstanding).  The tile's 128 bias values travel with its
+// first K-step as one more LDS-DMA piece and are read back with ds_read in the epilogue: an ordinary global load there
+// would make hipcc drain vmcnt(0) before every store (measured: 16 serialised load->wait->store round trips per tile).
+// Epilogue operands (residual / multiplier) are loaded up front, all at once.  BM = 32*MI (128/160) is picked on the
+// host to minimise tile-count quantisation over the 512 resident workgroups.
+// Output-column ownership in the persistent kernel: the W tile is staged into LDS in "MFMA order" — LDS row
+// wn*64 + j*16 + r holds W row wn*64 + 32*(j>>1) + 8*(r>>2) + 4*(j&1) + (r&3) — so that after the MFMAs a lane owns
+// EIGHT consecutive output columns per n-tile pair (j = 2u, 2u+1): columns 32u + 8*fq + 0..3 from acc[i][2u] and
+// + 4..7 from acc[i][2u+1].  bf16 outputs then leave as one 16-byte store per (row, pair) instead of two 8-byte ones
+// (the epilogue is store-issue bound: half the instructions, 64 contiguous bytes per row per instruction).
+__device__ __forceinline__ int w_row_of_lds_row(int l) {  // l in [0,128)
+  const int r = l & 15, j = (l >> 4) & 3;
+  return (l & 64) + 32 * (j >> 1) + 8 * (r >> 2) + 4 * (j & 1) + (r & 3);
+}
+
+template <int EPI, typename OutT, int MI> struct EpiStores {
+  // store instructions per wave per (full) tile after the prefetch was issued
+  static constexpr int PER_PAIR = (EPI == APLA_EPI_GELU) ? 2 : (EPI == APLA_EPI_SWIGLU) ? 2
+                                  : (EPI == APLA_EPI_SWIGLU_BWD) ? 2 : (sizeof(OutT) == 4 ? 2 : 1);
+  static constexpr int N = MI * 2 * PER_PAIR;
+};
+
+template <typename T> struct Vec8IO;
+template <> struct Vec8IO<float> {
+  static __device__ __forceinline__ void store(float* p, f32x4 lo, f32x4 hi) { *(f32x4*)p = lo; *(f32x4*)(p + 4) = hi; }
+};
+template <> struct Vec8IO<bf16> {
+  static __device__ __forceinline__ void store(bf16* p, f32x4 lo, f32x4 hi) {
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o[e] = (bf16)lo[e]; o[4 + e] = (bf16)hi[e]; }
+    *(bf16x8*)p = o;
+  }
+};
+
+// 2 x (8 consecutive elements) of one row, 32 elements apart, loaded by inline asm (not tracked by hipcc's waitcnt pass)
+template <typename T> struct AuxRegs;
+template <> struct AuxRegs<float> {
+  f32x4 lo, hi;
+  __device__ __forceinline__ f32x4 get_lo() const { return lo; }
+  __device__ __forceinline__ f32x4 get_hi() const { return hi; }
+};
+template <> struct AuxRegs<bf16> {
+  f32x4 lo;  // 8 bf16 in 4 VGPRs
+  __device__ __forceinline__ f32x4 get_lo() const {
+    const bf16x8 t = __builtin_bit_cast(bf16x8, lo);
+    return f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
+  }
+  __device__ __forceinline__ f32x4 get_hi() const {
+    const bf16x8 t = __builtin_bit_cast(bf16x8, lo);
+    return f32x4{(float)t[4], (float)t[5], (float)t[6], (float)t[7]};
+  }
+};
+__device__ __forceinline__ void asm_load_row2(AuxRegs<float>& a0, AuxRegs<float>& a1, const float* p) {
+  asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:16\n\t"
+               "global_load_dwordx4 %2, %4, off offset:128\n\tglobal_load_dwordx4 %3, %4, off offset:144"
+               : "=&v"(a0.lo), "=&v"(a0.hi), "=&v"(a1.lo), "=&v"(a1.hi) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void asm_load_row2(AuxRegs<bf16>& a0, AuxRegs<bf16>& a1, const bf16* p) {
+  asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:64"
+               : "=&v"(a0.lo), "=&v"(a1.lo) : "v"(p) : "memory");
+}
+template <typename T> __device__ __forceinline__ void asm_wait_pin(AuxRegs<T>& a);
+template <> __device__ __forceinline__ void asm_wait_pin<float>(AuxRegs<float>& a) { asm volatile("" : "+v"(a.lo), "+v"(a.hi)); }
+template <> __device__ __forceinline__ void asm_wait_pin<bf16>(AuxRegs<bf16>& a) { asm volatile("" : "+v"(a.lo)); }
+
+template <int EPI, typename OutT, int MI>
+__device__ __forceinline__ void persist_epilogue(const GemmParams& p, f32x4 (&acc)[MI][4], const float* bias_lds,
+                                                 int m0, int n0, int wm, int wn, int lane) {
+  const int frow = lane & 15, fq = lane >> 4;
+  const int ncol = wn * 64 + fq * 8;  // + 32*u : first of the 8 columns this lane owns in pair u (tile-local)
+  int mrow[MI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) mrow[i] = m0 + wm * (MI * 16) + i * 16 + frow;
+  if (p.bias != nullptr) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const f32x4 blo = *(const f32x4*)(bias_lds + ncol + 32 * u), bhi = *(const f32x4*)(bias_lds + ncol + 32 * u + 4);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) { acc[i][2 * u] += blo; acc[i][2 * u + 1] += bhi; }
+    }
+  }
+  if constexpr (EPI == APLA_EPI_RESIDUAL || EPI == APLA_EPI_MUL) {
+    // Epilogue operands through inline-asm loads: an ordinary global load next to in-flight LDS-DMA makes hipcc's waitcnt
+    // pass drain vmcnt(0) inside the K loop (de-pipelining it); asm loads are invisible to that pass, so we wait for them
+    // ourselves: all loads are issued back to back, then ONE s_waitcnt, then every destination is pinned behind it.
+    using AuxT = typename std::conditional<EPI == APLA_EPI_MUL, bf16, OutT>::type;
+    AuxRegs<AuxT> aux[MI][2];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int mr = mrow[i] < p.M ? mrow[i] : p.M - 1;
+      asm_load_row2(aux[i][0], aux[i][1], (const AuxT*)p.aux_in + (size_t)mr * p.ld_aux_in + n0 + ncol);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < MI; ++i) { asm_wait_pin<AuxT>(aux[i][0]); asm_wait_pin<AuxT>(aux[i][1]); }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const f32x4 alo = aux[i][u].get_lo(), ahi = aux[i][u].get_hi();
+        if constexpr (EPI == APLA_EPI_MUL) { acc[i][2 * u] *= alo; acc[i][2 * u + 1] *= ahi; }
+        else { acc[i][2 * u] += alo; acc[i][2 * u + 1] += ahi; }
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int m = mrow[i];
     if (m >= p.M) continue;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wn * 64 + j * 16 + fq * 4;
-      f32x4 v = acc[i][j];
-      if (p.bias != nullptr) v += *(const f32x4*)(p.bias + n);
-      if constexpr (EPI == APLA_EPI_STORE) {
-        Vec4IO<OutT>::store((OutT*)p.C + (size_t)m * p.ldc + n, v);
-      } else if constexpr (EPI == APLA_EPI_GELU) {
-        f32x4 h, g;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { h[e] = gelu_f(v[e]); g[e] = gelu_grad_f(v[e]); }
-        Vec4IO<bf16>::store((bf16*)p.C + (size_t)m * p.ldc + n, h);
-        Vec4IO<bf16>::store((bf16*)p.aux_out + (size_t)m * p.ld_aux_out + n, g);
-      } else if constexpr (EPI == APLA_EPI_RESIDUAL) {
-        f32x4 r = Vec4IO<OutT>::load((const OutT*)p.aux_in + (size_t)m * p.ld_aux_in + n);
-        Vec4IO<OutT>::store((OutT*)p.C + (size_t)m * p.ldc + n, r + v);
+    for (int u = 0; u < 2; ++u) {
+      const int n = n0 + ncol + 32 * u;
+      const f32x4 lo = acc[i][2 * u], hi = acc[i][2 * u + 1];
+      if constexpr (EPI == APLA_EPI_STORE || EPI == APLA_EPI_RESIDUAL) {
+        Vec8IO<OutT>::store((OutT*)p.C + (size_t)m * p.ldc + n, lo, hi);
       } else if constexpr (EPI == APLA_EPI_MUL) {
-        f32x4 g = Vec4IO<bf16>::load((const bf16*)p.aux_in + (size_t)m * p.ld_aux_in + n);
-        Vec4IO<bf16>::store((bf16*)p.C + (size_t)m * p.ldc + n, v * g);
-      } else if constexpr (EPI == APLA_EPI_SWIGLU) {
-        // columns (n, n+1) = (x1_i, x2_i), (n+2, n+3) = (x1_{i+1}, x2_{i+1}); i = n/2
-        Vec4IO<bf16>::store((bf16*)p.aux_out + (size_t)m * p.ld_aux_out + n, v);
-        bf16x2 h;
-        h[0] = (bf16)(v[0] * sigmoid_f(v[0]) * v[1]);
-        h[1] = (bf16)(v[2] * sigmoid_f(v[2]) * v[3]);
-        *(bf16x2*)((bf16*)p.C + (size_t)m * p.ldc + (n >> 1)) = h;
-      } else if constexpr (EPI == APLA_EPI_SWIGLU_BWD) {
-        // v = dh for hidden units n..n+3; saved x12 interleaved at columns 2n..2n+7
-        const bf16* xs = (const bf16*)p.aux_in + (size_t)m * p.ld_aux_in + 2 * n;
-        bf16x8 x12 = *(const bf16x8*)xs;
-        bf16x8 o;
+        Vec8IO<bf16>::store((bf16*)p.C + (size_t)m * p.ldc + n, lo, hi);
+      } else if constexpr (EPI == APLA_EPI_GELU) {
+        f32x4 hl, hh, gl, gh;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float x1 = (float)x12[2 * e], x2 = (float)x12[2 * e + 1];
-          const float s = sigmoid_f(x1);
-          o[2 * e] = (bf16)(v[e] * x2 * s * (1.0f + x1 * (1.0f - s)));
-          o[2 * e + 1] = (bf16)(v[e] * x1 * s);
+          float a, b;
+          gelu_and_grad(lo[e], a, b); hl[e] = a; gl[e] = b;
+          gelu_and_grad(hi[e], a, b); hh[e] = a; gh[e] = b;
         }
-        *(bf16x8*)((bf16*)p.C + (size_t)m * p.ldc + 2 * n) = o;
+        Vec8IO<bf16>::store((bf16*)p.C + (size_t)m * p.ldc + n, hl, hh);
+        Vec8IO<bf16>::store((bf16*)p.aux_out + (size_t)m * p.ld_aux_out + n, gl, gh);
+      } else if constexpr (EPI == APLA_EPI_SWIGLU) {
+        // columns come in (x1_i, x2_i) pairs: 8 columns = 4 hidden units
+        Vec8IO<bf16>::store((bf16*)p.aux_out + (size_t)m * p.ld_aux_out + n, lo, hi);
+        bf16x4 h;
+        h[0] = (bf16)(lo[0] * sigmoid_f(lo[0]) * lo[1]);
+        h[1] = (bf16)(lo[2] * sigmoid_f(lo[2]) * lo[3]);
+        h[2] = (bf16)(hi[0] * sigmoid_f(hi[0]) * hi[1]);
+        h[3] = (bf16)(hi[2] * sigmoid_f(hi[2]) * hi[3]);
+        *(bf16x4*)((bf16*)p.C + (size_t)m * p.ldc + (n >> 1)) = h;
+      } else if constexpr (EPI == APLA_EPI_SWIGLU_BWD) {
+        // dh for hidden units n..n+7; saved x12 interleaved at columns 2n..2n+15
+        const bf16* xs = (const bf16*)p.aux_in + (size_t)m * p.ld_aux_in + 2 * n;
+        const bf16x8 xa = *(const bf16x8*)xs, xb = *(const bf16x8*)(xs + 8);
+        bf16x8 oa, ob;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float x1 = (float)xa[2 * e], x2 = (float)xa[2 * e + 1], sg = sigmoid_f(x1);
+          oa[2 * e] = (bf16)(lo[e] * x2 * sg * (1.0f + x1 * (1.0f - sg)));
+          oa[2 * e + 1] = (bf16)(lo[e] * x1 * sg);
+          x1 = (float)xb[2 * e]; x2 = (float)xb[2 * e + 1]; sg = sigmoid_f(x1);
+          ob[2 * e] = (bf16)(hi[e] * x2 * sg * (1.0f + x1 * (1.0f - sg)));
+          ob[2 * e + 1] = (bf16)(hi[e] * x1 * sg);
+        }
+        *(bf16x8*)((bf16*)p.C + (size_t)m * p.ldc + 2 * n) = oa;
+        *(bf16x8*)((bf16*)p.C + (size_t)m * p.ldc + 2 * n + 8) = ob;
       }
     }
   }
 }
 
+template <int EPI, typename OutT, int MI>
+__global__ __launch_bounds__(256, 2) void gemm_persist_kernel(GemmParams p, int tiles_m) {
+  constexpr int BMv = 32 * MI;
+  constexpr int STG = (BMv + BN) * BK * 2;
+  __shared__ __attribute__((aligned(16))) char smem[2 * STG + 2048];  // + 2 x 1 KB bias pieces
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int frow = lane & 15, fq = lane >> 4;
+  const int nk = p.K / BK;
+  // tile range of this workgroup: XCD x (= blockIdx % 8 under round-robin dispatch; speed only) owns a contiguous run
+  const int total = tiles_m * p.tiles_n;
+  const int G = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int q = total >> 3, rr = total & 7;
+  const int xbeg = xcd * q + (xcd < rr ? xcd : rr), xcnt = q + (xcd < rr ? 1 : 0);
+  const int slots = (G >> 3) + ((G & 7) > xcd ? 1 : 0);
+  const bool has_bias = p.bias != nullptr;
+
+  const bf16* a_src[MI];
+  const bf16* w_src[4];
+  const float* b_src = nullptr;
+  auto setup = [&](int tile) {
+    const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+#pragma unroll
+    for (int it = 0; it < MI; ++it) {
+      const int row = (wave * MI + it) * 8 + (lane >> 3);
+      const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+      int gr = tm * BMv + row;
+      gr = gr < p.M ? gr : p.M - 1;
+      a_src[it] = p.A + (size_t)gr * p.lda + chunk * 8;
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = (wave * 4 + it) * 8 + (lane >> 3);   // LDS row; holds W row w_row_of_lds_row(row)
+      const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+      w_src[it] = p.W + (size_t)(tn * BN + w_row_of_lds_row(row)) * p.ldw + chunk * 8;
+    }
+    if (has_bias) b_src = p.bias + tn * BN + (lane & 31) * 4;  // lanes 32..63 duplicate (keeps EXEC full, stays in bounds)
+  };
+  auto stage = [&](int sbuf, int k0) {
+    char* base = smem + sbuf * STG;
+#pragma unroll
+    for (int it = 0; it < MI; ++it)
+      __builtin_amdgcn_global_load_lds(GLBP(a_src[it] + k0), LDSP(base + (wave * MI + it) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+      __builtin_amdgcn_global_load_lds(GLBP(w_src[it] + k0), LDSP(base + BMv * BK * 2 + (wave * 4 + it) * 1024), 16, 0, 0);
+  };
+  auto stage_bias = [&](int bbuf) {
+    if (has_bias && wave == 0) __builtin_amdgcn_global_load_lds(GLBP(b_src), LDSP(smem + 2 * STG + bbuf * 1024), 16, 0, 0);
+  };
+
+  int idx = slot;
+  if (idx >= xcnt) return;
+  int tile = xbeg + idx;
+  setup(tile);
+  stage(0, 0);
+  stage_bias(0);
+  int cur = 0, bb = 0;
+  bool counted = false;  // may the first wait of this tile leave the previous tile's stores outstanding?
+  while (true) {
+    const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+    const int m0 = tm * BMv, n0 = tn * BN;
+    const int nidx = idx + slots;
+    const bool has_next = nidx < xcnt;
+    f32x4 acc[MI][4];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt == 0 && counted) wait_vmcnt<EpiStores<EPI, OutT, MI>::N>(); else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      if (kt + 1 < nk) {
+        stage(cur ^ 1, (kt + 1) * BK);
+      } else if (has_next) {
+        setup(xbeg + nidx);
+        stage(cur ^ 1, 0);
+        stage_bias(bb ^ 1);
+      }
+      asm volatile("" ::: "memory");
+      const char* As = smem + cur * STG;
+      const char* Ws = As + BMv * BK * 2;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 af[MI], wf[4];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(As + lds_off(wm * (MI * 16) + i * 16 + frow, ks * 4 + fq));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wf[j] = *(const bf16x8*)(Ws + lds_off(wn * 64 + j * 16 + frow, ks * 4 + fq));
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+      }
+      cur ^= 1;
+    }
+    persist_epilogue<EPI, OutT, MI>(p, acc, (const float*)(smem + 2 * STG + bb * 1024), m0, n0, wm, wn, lane);
+    asm volatile("" ::: "memory");
+    if (!has_next) break;
+    // a full (non-tail) tile issues exactly EpiStores::N store instructions per wave after the prefetch (epilogue operand
+    // loads, if any, complete before the stores are issued); a tail tile may skip some, so its successor drains fully
+    counted = (m0 + BMv <= p.M);
+    bb ^= 1;
+    idx = nidx;
+    tile = xbeg + idx;
+  }
+}
+
+int g_variant = 4;  // tuning knob (apla_gemm_set_variant): 4 = persistent (default), 0 = 2-stage __syncthreads, 2/3 = S-stage ring
+constexpr int RESIDENT_WGS = 512;  // 256 CUs x 2 workgroups (64-80 KB LDS, <=256 VGPR)
+
+template <int EPI, typename OutT, int MI>
+int launch_persist(const GemmParams& p, hipStream_t stream) {
+  const int tiles_m = (p.M + 32 * MI - 1) / (32 * MI);
+  const int total = tiles_m * p.tiles_n;
+  int G = total < RESIDENT_WGS ? total : RESIDENT_WGS;
+  hipLaunchKernelGGL((gemm_persist_kernel<EPI, OutT, MI>), dim3(G), dim3(256), 0, stream, p, tiles_m);
+  APLA_CHECK_LAUNCH("apla_gemm_nt");
+  return APLA_OK;
+}
+
+// BM = 32*MI minimising (rounds over the resident workgroups) x (tile height); ties -> larger tile (less W re-reads)
+inline int pick_mi(int M, int tiles_n) {
+  int best = 4;
+  long best_cost = -1;
+  for (int mi = 4; mi <= 5; ++mi) {
+    const long tiles = (long)((M + 32 * mi - 1) / (32 * mi)) * tiles_n;
+    const long rounds = (tiles + RESIDENT_WGS - 1) / RESIDENT_WGS;
+    const long cost = rounds * 32 * mi;
+    if (best_cost < 0 || cost < best_cost || (cost == best_cost && tiles >= RESIDENT_WGS)) { best = mi; best_cost = cost; }
+  }
+  return best;
+}
+
 template <int EPI, typename OutT>
 int launch(const GemmParams& p, hipStream_t stream) {
+  if (g_variant >= 4) {
+    const int mi = g_variant == 4 ? pick_mi(p.M, p.tiles_n) : g_variant;  // 5..6 force; 14 -> MI=4
+    if (mi == 5) return launch_persist<EPI, OutT, 5>(p, stream);
+    return launch_persist<EPI, OutT, 4>(p, stream);
+  }
   const int tiles_m = (p.M + BM - 1) / BM;
   dim3 grid(tiles_m * p.tiles_n), block(256);
-  hipLaunchKernelGGL((gemm_nt_kernel<EPI, OutT>), grid, block, 0, stream, p);
+  if (g_variant == 3) hipLaunchKernelGGL((gemm_ring_kernel<EPI, OutT, 3>), grid, block, 0, stream, p);
+  else if (g_variant == 2) hipLaunchKernelGGL((gemm_ring_kernel<EPI, OutT, 2>), grid, block, 0, stream, p);
+  else hipLaunchKernelGGL((gemm_nt_kernel<EPI, OutT>), grid, block, 0, stream, p);
   APLA_CHECK_LAUNCH("apla_gemm_nt");
   return APLA_OK;
 }
 
 }  // namespace
+
+extern "C" int apla_gemm_set_variant(int v) {
+  const int old = g_variant;
+  g_variant = v;
+  return old;
+}
 
 extern "C" int apla_gemm_nt(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int M,
                             int N, int K, int epilogue, int out_dtype, const void* aux_in, int ld_aux_in,

@@ -53,6 +53,11 @@ int apla_gemm_nt(const void* A, int lda, const void* W, int ldw, const float* bi
                  int K, int epilogue, int out_dtype, const void* aux_in, int ld_aux_in, void* aux_out,
                  int ld_aux_out, hipStream_t stream);
 
+/* Tuning/diagnostic knob: selects the main-loop schedule of apla_gemm_nt for subsequent launches (process-wide):
+ * 0 = 2-stage LDS double buffer with __syncthreads; 2 / 3 = S-stage LDS ring with counted vmcnt + raw s_barrier.
+ * Returns the previous value.  All variants compute identical results. */
+int apla_gemm_set_variant(int variant);
+
 /* y = LayerNorm(x)*gamma+beta (y_dtype bf16, or f32 for the classifier-head input), saving mean/rstd (fp32).  x rows are `x_row_stride` elements apart so
  * the final-norm-on-CLS-rows case (vit.py:416-419) needs no gather.  Replaces nn.LayerNorm(eps=1e-6)
  * (vit.py:251,261,554). */

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Microbenchmark of apla_gemm_nt on the GEMM shapes of the APLA step (ViT-B/16, bs=128 => M=25216), per schedule
+variant, interleaved rounds in one process (cdna guide rule 24), random data (rule 25).  GPU only."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from apla_amd import ops
+from apla_amd._lib import lib
+
+M = int(os.environ.get("GEMM_M", 25216))
+SHAPES = [("qkv", 2304, 768, ops.EPI_STORE), ("proj+res", 768, 768, ops.EPI_RESIDUAL), ("fc1+gelu", 3072, 768, ops.EPI_GELU),
+          ("fc2+res", 768, 3072, ops.EPI_RESIDUAL), ("dfc2*g", 3072, 768, ops.EPI_MUL), ("dfc1", 768, 3072, ops.EPI_STORE),
+          ("dproj", 768, 768, ops.EPI_STORE), ("dqkv", 768, 2304, ops.EPI_STORE)]
+VARIANTS = [int(v) for v in os.environ.get("GEMM_VARIANTS", "0,2,3").split(",")]
+ROUNDS, ITERS = 5, 10
+
+
+def main():
+    dev = "cuda"
+    res = {}
+    for name, N, K, epi in SHAPES:
+        a = torch.randn(M, K, device=dev).to(torch.bfloat16)
+        w = (torch.randn(N, K, device=dev) * K ** -0.5).to(torch.bfloat16)
+        bias = torch.randn(N, device=dev)
+        kw = {}
+        if epi == ops.EPI_RESIDUAL:
+            kw = dict(aux_in=torch.randn(M, N, device=dev), out_dtype=torch.float32)
+        elif epi == ops.EPI_GELU:
+            kw = dict(aux_out=torch.empty(M, N, device=dev, dtype=torch.bfloat16))
+        elif epi == ops.EPI_MUL:
+            kw = dict(aux_in=torch.randn(M, N, device=dev).to(torch.bfloat16))
+        out = torch.empty(M, N, device=dev, dtype=kw.get("out_dtype", torch.bfloat16))
+        ref = None
+        for v in VARIANTS:
+            lib().apla_gemm_set_variant(v)
+            o = ops.gemm_nt(a, w, bias, epilogue=epi, out=out, **{k: x for k, x in kw.items() if k != "out_dtype"}).clone()
+            if ref is None:
+                ref = o
+            else:
+                assert torch.equal(o, ref), f"variant {v} differs on {name}: {(o.float() - ref.float()).abs().max()}"
+        times = {v: [] for v in VARIANTS}
+        for _ in range(ROUNDS):
+            for v in VARIANTS:
+                lib().apla_gemm_set_variant(v)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(ITERS):
+                    ops.gemm_nt(a, w, bias, epilogue=epi, out=out, **{k: x for k, x in kw.items() if k != "out_dtype"})
+                e1.record()
+                torch.cuda.synchronize()
+                times[v].append(e0.elapsed_time(e1) / ITERS)
+        fl = 2.0 * M * N * K
+        line = f"{name:10s} N={N:5d} K={K:5d} "
+        for v in VARIANTS:
+            t = sorted(times[v])[len(times[v]) // 2]
+            res.setdefault(v, 0.0)
+            res[v] += t
+            line += f"| v{v}: {t * 1e3:7.1f} us {fl / t / 1e9:7.1f} TF "
+        print(line, flush=True)
+    print("sum of medians (one of each GEMM): " + "  ".join(f"v{v}: {t:.3f} ms" for v, t in res.items()))
+
+
+if __name__ == "__main__":
+    main()
