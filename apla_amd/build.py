@@ -8,7 +8,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libapla_hip.so")
-SOURCES = ["errors.cpp", "gemm_nt.hip", "layernorm.hip", "attention.hip", "apla_dw.hip", "optim.hip", "misc.hip"]
+SOURCES = ["errors.cpp", "gemm_nt.hip", "gemm_pp2.hip", "layernorm.hip", "attention.hip", "apla_dw.hip", "optim.hip", "misc.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"]
 
@@ -16,7 +16,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-res
 def _stale(obj, src):
     if not os.path.exists(obj):
         return True
-    deps = [src, os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "apla_hip.h")]
+    deps = [src, os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_common.h"), os.path.join(HERE, "..", "include", "apla_hip.h")]
     return any(os.path.getmtime(d) > os.path.getmtime(obj) for d in deps)
 
 

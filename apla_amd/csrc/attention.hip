@@ -102,7 +102,7 @@ __device__ __forceinline__ void store_acc_T(const f32x16 (&acc)[2], bf16* rowptr
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
                                                        float* __restrict__ lse, int N, int H, float scale) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 8192];
   char* Ks = smem;
@@ -116,6 +116,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
 
   int q = q0 + wave * 32 + (lane & 31);
   const bool qvalid = q < N;
+  const bool wave_active = q0 + wave * 32 < N;  // wave-uniform: waves past the sequence end only help staging K/V
   if (!qvalid) q = N - 1;
   bf16x8 qf[4];
   load_row_frags(qf, base + (long)q * ld, lane);
@@ -138,9 +139,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
       tile_load<64>(kr, base + D, ld, (kb + 1) * 64, N, tid);
       tile_load<64>(vr, base + 2 * D, ld, (kb + 1) * 64, N, tid);
     }
+    if (!wave_active) continue;
+    const bool two = kb * 64 + 32 < N;  // second 32-key tile of this block has at least one valid key
     f32x16 s[2];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
+      if (kt == 1 && !two) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[kt][i] = -INFINITY;
+        continue;
+      }
 #pragma unroll
       for (int i = 0; i < 16; ++i) s[kt][i] = 0.f;
 #pragma unroll
@@ -176,7 +184,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc_o[0][i] *= alpha; acc_o[1][i] *= alpha; }
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+    for (int kt = 0; kt < 2; ++kt) {
+      if (kt == 1 && !two) continue;
 #pragma unroll
       for (int sk = 0; sk < 2; ++sk) {
         const bf16x8 pb = acc_to_operand(s[kt], sk);
@@ -184,6 +193,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
         for (int dt = 0; dt < 2; ++dt)
           acc_o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Vs, kt * 32 + 16 * sk, 32 * dt, lane), pb, acc_o[dt], 0, 0, 0);
       }
+    }
   }
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   if (qvalid) {
@@ -193,7 +203,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dQ (+delta)
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
                                                           const bf16* __restrict__ dout, const float* __restrict__ lse,
                                                           float* __restrict__ delta, bf16* __restrict__ dqkv, int N,
                                                           int H, float scale) {
@@ -224,6 +234,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
   }
   dl += __shfl_xor(dl, 32, 64);
   const long statidx = ((long)b * H + h) * N + q;
+  const bool wave_active = q0 + wave * 32 < N;
   if (qvalid && h2 == 0) delta[statidx] = dl;
   const float lse2 = lse[statidx] * LOG2E;
 
@@ -244,8 +255,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
       tile_load<64>(kr, base + D, ld, (kb + 1) * 64, N, tid);
       tile_load<64>(vr, base + 2 * D, ld, (kb + 1) * 64, N, tid);
     }
+    if (!wave_active) continue;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
+      if (kt == 1 && kb * 64 + 32 >= N) continue;  // fully masked key tile
       f32x16 s, dp;
 #pragma unroll
       for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
@@ -274,7 +287,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ dout,
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ dout,
                                                            const float* __restrict__ lse,
                                                            const float* __restrict__ delta, bf16* __restrict__ dqkv,
                                                            int N, int H, float scale) {
@@ -295,6 +308,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
 
   int key = k0 + wave * 32 + (lane & 31);
   const bool kvalid = key < N;
+  const bool wave_active = k0 + wave * 32 < N;
   if (!kvalid) key = N - 1;
   bf16x8 kf[4], vf[4];
   load_row_frags(kf, base + D + (long)key * ld, lane);
@@ -321,8 +335,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
       tile_load<64>(dr, dobase, D, (qb + 1) * 64, N, tid);
       if (tid < 64) { int qq = (qb + 1) * 64 + tid; qq = qq < N ? qq : N - 1; lreg = lsebase[qq] * LOG2E; dreg = dlbase[qq]; }
     }
+    if (!wave_active) continue;
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
+      if (qt == 1 && qb * 64 + 32 >= N) continue;  // fully masked query tile
       f32x16 s, dp;
 #pragma unroll
       for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }

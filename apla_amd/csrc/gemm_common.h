@@ -1,0 +1,294 @@
+// Shared pieces of the bf16 MFMA GEMM kernels (gemm_nt.hip: 128-wide tiles, gemm_wide.hip: 256-wide tiles).
+#pragma once
+#include <type_traits>
+
+#include "common.h"
+
+struct GemmParams {
+  const bf16* A; int lda;
+  const bf16* W; int ldw;
+  const float* bias;
+  void* C; int ldc;
+  const void* aux_in; int ld_aux_in;
+  void* aux_out; int ld_aux_out;
+  int M, N, K, tiles_n;
+};
+
+// 8-wave ping-pong kernel (gemm_pp2.hip); returns APLA_ENOSYS when the shape / (epilogue, dtype) is not covered there
+int apla_gemm_pp2_launch(const GemmParams& p, int epilogue, int out_dtype, hipStream_t stream);
+
+// GELU (exact erf form) and its derivative from ONE exp2 and ONE rcp per element: Phi(a) via Abramowitz-Stegun 7.1.26
+// (|erf error| < 1.5e-7, far below the bf16 output rounding) sharing E = exp(-a^2/2) with the Gaussian term of gelu'.
+__device__ __forceinline__ void gelu_and_grad(float a, float& h, float& g) {
+  const float x = fabsf(a) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
+  float poly = fmaf(t, 1.061405429f, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  poly *= t;
+  const float E = __builtin_amdgcn_exp2f(a * a * -0.72134752044448170f);  // exp(-a^2/2)
+  const float q = 0.5f * poly * E;                                        // = 1 - Phi(|a|)
+  const float phi = a >= 0.f ? 1.0f - q : q;
+  h = a * phi;
+  g = fmaf(a * E, 0.3989422804014327f, phi);
+}
+__device__ __forceinline__ float sigmoid_f(float a) { return 1.0f / (1.0f + __expf(-a)); }
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <typename T> struct Vec8IO;
+template <> struct Vec8IO<float> {
+  static __device__ __forceinline__ void store(float* p, f32x4 lo, f32x4 hi) { *(f32x4*)p = lo; *(f32x4*)(p + 4) = hi; }
+};
+template <> struct Vec8IO<bf16> {
+  static __device__ __forceinline__ void store(bf16* p, f32x4 lo, f32x4 hi) {
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o[e] = (bf16)lo[e]; o[4 + e] = (bf16)hi[e]; }
+    *(bf16x8*)p = o;
+  }
+};
+
+// 8 consecutive elements of an epilogue operand held in registers filled by inline-asm loads (invisible to hipcc's
+// waitcnt pass; see persist_epilogue)
+template <typename T> struct AuxRegs;
+template <> struct AuxRegs<float> {
+  f32x4 lo, hi;
+  __device__ __forceinline__ f32x4 get_lo() const { return lo; }
+  __device__ __forceinline__ f32x4 get_hi() const { return hi; }
+};
+template <> struct AuxRegs<bf16> {
+  f32x4 lo;  // 8 bf16 in 4 VGPRs
+  __device__ __forceinline__ f32x4 get_lo() const {
+    const bf16x8 t = __builtin_bit_cast(bf16x8, lo);
+    return f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
+  }
+  __device__ __forceinline__ f32x4 get_hi() const {
+    const bf16x8 t = __builtin_bit_cast(bf16x8, lo);
+    return f32x4{(float)t[4], (float)t[5], (float)t[6], (float)t[7]};
+  }
+};
+template <typename T> __device__ __forceinline__ void asm_wait_pin(AuxRegs<T>& a);
+template <> __device__ __forceinline__ void asm_wait_pin<float>(AuxRegs<float>& a) { asm volatile("" : "+v"(a.lo), "+v"(a.hi)); }
+template <> __device__ __forceinline__ void asm_wait_pin<bf16>(AuxRegs<bf16>& a) { asm volatile("" : "+v"(a.lo)); }
+
+// Output-column ownership in the persistent kernel: the W tile is staged into LDS in "MFMA order" — LDS row
+// wn*64 + j*16 + r holds W row wn*64 + 32*(j>>1) + 8*(r>>2) + 4*(j&1) + (r&3) — so that after the MFMAs a lane owns
+// EIGHT consecutive output columns per n-tile pair (j = 2u, 2u+1): columns 32u + 8*fq + 0..3 from acc[i][2u] and
+// + 4..7 from acc[i][2u+1].  bf16 outputs then leave as one 16-byte store per (row, pair) instead of two 8-byte ones
+// (the epilogue is store-issue bound: half the instructions, 64 contiguous bytes per row per instruction).
+__device__ __forceinline__ int w_row_of_lds_row(int l) {  // any LDS row index; mapping is per 64-row block
+  const int r = l & 15, j = (l >> 4) & 3;
+  return (l & ~63) + 32 * (j >> 1) + 8 * (r >> 2) + 4 * (j & 1) + (r & 3);
+}
+
+template <int EPI, typename OutT, int MI> struct EpiStores {
+  // store instructions per wave per (full) tile after the prefetch was issued
+  static constexpr int PER_PAIR = (EPI == APLA_EPI_GELU) ? 2 : (EPI == APLA_EPI_SWIGLU) ? 2
+                                  : (EPI == APLA_EPI_SWIGLU_BWD) ? 2 : (sizeof(OutT) == 4 ? 2 : 1);
+  static constexpr int N = MI * 2 * PER_PAIR;
+};
+
+// 2 x (8 consecutive elements) of one row, 32 elements apart, loaded by inline asm (not tracked by hipcc's waitcnt pass)
+__device__ __forceinline__ void asm_load_row2(AuxRegs<float>& a0, AuxRegs<float>& a1, const float* p) {
+  asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:16\n\t"
+               "global_load_dwordx4 %2, %4, off offset:128\n\tglobal_load_dwordx4 %3, %4, off offset:144"
+               : "=&v"(a0.lo), "=&v"(a0.hi), "=&v"(a1.lo), "=&v"(a1.hi) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void asm_load_row2(AuxRegs<bf16>& a0, AuxRegs<bf16>& a1, const bf16* p) {
+  asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:64"
+               : "=&v"(a0.lo), "=&v"(a1.lo) : "v"(p) : "memory");
+}
+template <int EPI, typename OutT, int MI>
+__device__ __forceinline__ void persist_epilogue(const GemmParams& p, f32x4 (&acc)[MI][4], const float* bias_lds,
+                                                 int m0, int n0, int wm, int wn, int lane) {
+  const int frow = lane & 15, fq = lane >> 4;
+  const int ncol = wn * 64 + fq * 8;  // + 32*u : first of the 8 columns this lane owns in pair u (tile-local)
+  int mrow[MI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) mrow[i] = m0 + wm * (MI * 16) + i * 16 + frow;
+  if (p.bias != nullptr) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const f32x4 blo = *(const f32x4*)(bias_lds + ncol + 32 * u), bhi = *(const f32x4*)(bias_lds + ncol + 32 * u + 4);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) { acc[i][2 * u] += blo; acc[i][2 * u + 1] += bhi; }
+    }
+  }
+  if constexpr (EPI == APLA_EPI_RESIDUAL || EPI == APLA_EPI_MUL) {
+    // Epilogue operands through inline-asm loads: an ordinary global load next to in-flight LDS-DMA makes hipcc's waitcnt
+    // pass drain vmcnt(0) inside the K loop (de-pipelining it); asm loads are invisible to that pass, so we wait for them
+    // ourselves: all loads are issued back to back, then ONE s_waitcnt, then every destination is pinned behind it.
+    using AuxT = typename std::conditional<EPI == APLA_EPI_MUL, bf16, OutT>::type;
+    AuxRegs<AuxT> aux[MI][2];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int mr = mrow[i] < p.M ? mrow[i] : p.M - 1;
+      asm_load_row2(aux[i][0], aux[i][1], (const AuxT*)p.aux_in + (size_t)mr * p.ld_aux_in + n0 + ncol);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < MI; ++i) { asm_wait_pin<AuxT>(aux[i][0]); asm_wait_pin<AuxT>(aux[i][1]); }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const f32x4 alo = aux[i][u].get_lo(), ahi = aux[i][u].get_hi();
+        if constexpr (EPI == APLA_EPI_MUL) { acc[i][2 * u] *= alo; acc[i][2 * u + 1] *= ahi; }
+        else { acc[i][2 * u] += alo; acc[i][2 * u + 1] += ahi; }
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int m = mrow[i];
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int n = n0 + ncol + 32 * u;
+      const f32x4 lo = acc[i][2 * u], hi = acc[i][2 * u + 1];
+      if constexpr (EPI == APLA_EPI_STORE || EPI == APLA_EPI_RESIDUAL) {
+        Vec8IO<OutT>::store((OutT*)p.C + (size_t)m * p.ldc + n, lo, hi);
+      } else if constexpr (EPI == APLA_EPI_MUL) {
+        Vec8IO<bf16>::store((bf16*)p.C + (size_t)m * p.ldc + n, lo, hi);
+      } else if constexpr (EPI == APLA_EPI_GELU) {
+        f32x4 hl, hh, gl, gh;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float a, b;
+          gelu_and_grad(lo[e], a, b); hl[e] = a; gl[e] = b;
+          gelu_and_grad(hi[e], a, b); hh[e] = a; gh[e] = b;
+        }
+        Vec8IO<bf16>::store((bf16*)p.C + (size_t)m * p.ldc + n, hl, hh);
+        Vec8IO<bf16>::store((bf16*)p.aux_out + (size_t)m * p.ld_aux_out + n, gl, gh);
+      } else if constexpr (EPI == APLA_EPI_SWIGLU) {
+        // columns come in (x1_i, x2_i) pairs: 8 columns = 4 hidden units
+        Vec8IO<bf16>::store((bf16*)p.aux_out + (size_t)m * p.ld_aux_out + n, lo, hi);
+        bf16x4 h;
+        h[0] = (bf16)(lo[0] * sigmoid_f(lo[0]) * lo[1]);
+        h[1] = (bf16)(lo[2] * sigmoid_f(lo[2]) * lo[3]);
+        h[2] = (bf16)(hi[0] * sigmoid_f(hi[0]) * hi[1]);
+        h[3] = (bf16)(hi[2] * sigmoid_f(hi[2]) * hi[3]);
+        *(bf16x4*)((bf16*)p.C + (size_t)m * p.ldc + (n >> 1)) = h;
+      } else if constexpr (EPI == APLA_EPI_SWIGLU_BWD) {
+        // dh for hidden units n..n+7; saved x12 interleaved at columns 2n..2n+15
+        const bf16* xs = (const bf16*)p.aux_in + (size_t)m * p.ld_aux_in + 2 * n;
+        const bf16x8 xa = *(const bf16x8*)xs, xb = *(const bf16x8*)(xs + 8);
+        bf16x8 oa, ob;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float x1 = (float)xa[2 * e], x2 = (float)xa[2 * e + 1], sg = sigmoid_f(x1);
+          oa[2 * e] = (bf16)(lo[e] * x2 * sg * (1.0f + x1 * (1.0f - sg)));
+          oa[2 * e + 1] = (bf16)(lo[e] * x1 * sg);
+          x1 = (float)xb[2 * e]; x2 = (float)xb[2 * e + 1]; sg = sigmoid_f(x1);
+          ob[2 * e] = (bf16)(hi[e] * x2 * sg * (1.0f + x1 * (1.0f - sg)));
+          ob[2 * e + 1] = (bf16)(hi[e] * x1 * sg);
+        }
+        *(bf16x8*)((bf16*)p.C + (size_t)m * p.ldc + 2 * n) = oa;
+        *(bf16x8*)((bf16*)p.C + (size_t)m * p.ldc + 2 * n + 8) = ob;
+      }
+    }
+  }
+}
+
+
+// ---- 80x128 wave tile (5 x 8 MFMA tiles, 4 column pairs): epilogue of gemm_pp2.hip ----
+template <typename T> __device__ __forceinline__ void asm_load_row4(AuxRegs<T> (&a)[4], const T* p);
+template <> __device__ __forceinline__ void asm_load_row4<float>(AuxRegs<float> (&a)[4], const float* p) {
+  asm volatile(
+      "global_load_dwordx4 %0, %8, off\n\tglobal_load_dwordx4 %1, %8, off offset:16\n\t"
+      "global_load_dwordx4 %2, %8, off offset:128\n\tglobal_load_dwordx4 %3, %8, off offset:144\n\t"
+      "global_load_dwordx4 %4, %8, off offset:256\n\tglobal_load_dwordx4 %5, %8, off offset:272\n\t"
+      "global_load_dwordx4 %6, %8, off offset:384\n\tglobal_load_dwordx4 %7, %8, off offset:400"
+      : "=&v"(a[0].lo), "=&v"(a[0].hi), "=&v"(a[1].lo), "=&v"(a[1].hi), "=&v"(a[2].lo), "=&v"(a[2].hi), "=&v"(a[3].lo), "=&v"(a[3].hi)
+      : "v"(p) : "memory");
+}
+template <> __device__ __forceinline__ void asm_load_row4<bf16>(AuxRegs<bf16> (&a)[4], const bf16* p) {
+  asm volatile(
+      "global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:64\n\t"
+      "global_load_dwordx4 %2, %4, off offset:128\n\tglobal_load_dwordx4 %3, %4, off offset:192"
+      : "=&v"(a[0].lo), "=&v"(a[1].lo), "=&v"(a[2].lo), "=&v"(a[3].lo) : "v"(p) : "memory");
+}
+
+template <int EPI, typename OutT> struct WideEpi {
+  using AuxT = typename std::conditional<EPI == APLA_EPI_MUL, bf16, OutT>::type;
+  static constexpr bool HAS_AUX = (EPI == APLA_EPI_RESIDUAL || EPI == APLA_EPI_MUL);
+  static constexpr int L = HAS_AUX ? (sizeof(AuxT) == 4 ? 8 : 4) : 0;                       // aux loads per row
+  static constexpr int S = (EPI == APLA_EPI_GELU) ? 8 : ((EPI == APLA_EPI_MUL) ? 4 : (sizeof(OutT) == 4 ? 8 : 4));  // stores per row
+  static constexpr int NST = 5 * S;
+};
+
+template <int EPI, typename OutT>
+__device__ __forceinline__ void wide_epilogue(const GemmParams& p, f32x4 (&acc)[5][8], const float* bias_lds, int m0,
+                                              int n0, int wm, int wn, int lane, bool full_tile) {
+  using E = WideEpi<EPI, OutT>;
+  using AuxT = typename E::AuxT;
+  const int frow = lane & 15, fq = lane >> 4;
+  const int ncol = wn * 128 + fq * 8;  // + 32*u
+  if (p.bias != nullptr) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const f32x4 blo = *(const f32x4*)(bias_lds + ncol + 32 * u), bhi = *(const f32x4*)(bias_lds + ncol + 32 * u + 4);
+#pragma unroll
+      for (int i = 0; i < 5; ++i) { acc[i][2 * u] += blo; acc[i][2 * u + 1] += bhi; }
+    }
+  }
+  AuxRegs<AuxT> aux[2][4];  // two rows in flight
+  auto row_ptr = [&](int i) {
+    int mr = m0 + wm * 80 + i * 16 + frow;
+    mr = mr < p.M ? mr : p.M - 1;
+    return (const AuxT*)p.aux_in + (size_t)mr * p.ld_aux_in + n0 + ncol;
+  };
+  if constexpr (E::HAS_AUX) {
+    asm_load_row4<AuxT>(aux[0], row_ptr(0));
+    asm_load_row4<AuxT>(aux[1], row_ptr(1));
+  }
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    if constexpr (E::HAS_AUX) {
+      // operations issued after row i's loads: row i+1's loads (if any) and, from i >= 1, the stores of row i-1
+      constexpr int LN = E::L, SN = E::S;
+      if (i == 0) wait_vmcnt<LN>();
+      else if (i < 4) { if (full_tile) wait_vmcnt<LN + SN>(); else wait_vmcnt<LN>(); }
+      else { if (full_tile) wait_vmcnt<SN>(); else wait_vmcnt<0>(); }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) asm_wait_pin<AuxT>(aux[i & 1][u]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const f32x4 alo = aux[i & 1][u].get_lo(), ahi = aux[i & 1][u].get_hi();
+        if constexpr (EPI == APLA_EPI_MUL) { acc[i][2 * u] *= alo; acc[i][2 * u + 1] *= ahi; }
+        else { acc[i][2 * u] += alo; acc[i][2 * u + 1] += ahi; }
+      }
+    }
+    const int m = m0 + wm * 80 + i * 16 + frow;
+    if (m < p.M) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int n = n0 + ncol + 32 * u;
+        const f32x4 lo = acc[i][2 * u], hi = acc[i][2 * u + 1];
+        if constexpr (EPI == APLA_EPI_STORE || EPI == APLA_EPI_RESIDUAL) {
+          Vec8IO<OutT>::store((OutT*)p.C + (size_t)m * p.ldc + n, lo, hi);
+        } else if constexpr (EPI == APLA_EPI_MUL) {
+          Vec8IO<bf16>::store((bf16*)p.C + (size_t)m * p.ldc + n, lo, hi);
+        } else if constexpr (EPI == APLA_EPI_GELU) {
+          f32x4 hl, hh, gl, gh;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float a, b;
+            gelu_and_grad(lo[e], a, b); hl[e] = a; gl[e] = b;
+            gelu_and_grad(hi[e], a, b); hh[e] = a; gh[e] = b;
+          }
+          Vec8IO<bf16>::store((bf16*)p.C + (size_t)m * p.ldc + n, hl, hh);
+          Vec8IO<bf16>::store((bf16*)p.aux_out + (size_t)m * p.ld_aux_out + n, gl, gh);
+        }
+      }
+    }
+    asm volatile("" ::: "memory");
+    if constexpr (E::HAS_AUX) {
+      if (i + 2 < 5) asm_load_row4<AuxT>(aux[i & 1], row_ptr(i + 2));
+    }
+  }
+}
+

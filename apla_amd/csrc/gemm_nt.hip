@@ -13,44 +13,14 @@
 //    (bias, GELU, residual, multiplier) a vector op on 8/16-byte global accesses.
 //  * blockIdx -> tile mapping is XCD-aware: each XCD walks a contiguous run of tiles with n fastest, so an A row
 //    panel is fetched into one L2 and reused by all N/128 column tiles.
-#include <type_traits>
-
-#include "common.h"
+#include "gemm_common.h"
 
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int STAGE_BYTES = (BM + BN) * BK * 2;  // 32 KB
 
-struct GemmParams {
-  const bf16* A; int lda;
-  const bf16* W; int ldw;
-  const float* bias;
-  void* C; int ldc;
-  const void* aux_in; int ld_aux_in;
-  void* aux_out; int ld_aux_out;
-  int M, N, K, tiles_n;
-};
-
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
-
-// GELU (exact erf form) and its derivative from ONE exp2 and ONE rcp per element: Phi(a) via Abramowitz-Stegun 7.1.26
-// (|erf error| < 1.5e-7, far below the bf16 output rounding) sharing E = exp(-a^2/2) with the Gaussian term of gelu'.
-__device__ __forceinline__ void gelu_and_grad(float a, float& h, float& g) {
-  const float x = fabsf(a) * 0.70710678118654752f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
-  float poly = fmaf(t, 1.061405429f, -1.453152027f);
-  poly = fmaf(poly, t, 1.421413741f);
-  poly = fmaf(poly, t, -0.284496736f);
-  poly = fmaf(poly, t, 0.254829592f);
-  poly *= t;
-  const float E = __builtin_amdgcn_exp2f(a * a * -0.72134752044448170f);  // exp(-a^2/2)
-  const float q = 0.5f * poly * E;                                        // = 1 - Phi(|a|)
-  const float phi = a >= 0.f ? 1.0f - q : q;
-  h = a * phi;
-  g = fmaf(a * E, 0.3989422804014327f, phi);
-}
-__device__ __forceinline__ float sigmoid_f(float a) { return 1.0f / (1.0f + __expf(-a)); }
 
 template <int EPI, typename OutT, int MI = 4>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[MI][4], int m0, int n0, int wm, int wn,
@@ -173,8 +143,6 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams p) {
 
 
 // ---- variant: S-stage LDS ring, counted vmcnt + raw s_barrier (LDS-DMA stays in flight across barriers) ----
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
 template <int EPI, typename OutT, int S>
 __global__ __launch_bounds__(256) void gemm_ring_kernel(GemmParams p) {
   __shared__ __attribute__((aligned(16))) char smem[S * STAGE_BYTES];
@@ -250,159 +218,6 @@ __global__ __launch_bounds__(256) void gemm_ring_kernel(GemmParams p) {
 // would make hipcc drain vmcnt(0) before every store (measured: 16 serialised load->wait->store round trips per tile).
 // Epilogue operands (residual / multiplier) are loaded up front, all at once.  BM = 32*MI (128/160) is picked on the
 // host to minimise tile-count quantisation over the 512 resident workgroups.
-// Output-column ownership in the persistent kernel: the W tile is staged into LDS in "MFMA order" — LDS row
-// wn*64 + j*16 + r holds W row wn*64 + 32*(j>>1) + 8*(r>>2) + 4*(j&1) + (r&3) — so that after the MFMAs a lane owns
-// EIGHT consecutive output columns per n-tile pair (j = 2u, 2u+1): columns 32u + 8*fq + 0..3 from acc[i][2u] and
-// + 4..7 from acc[i][2u+1].  bf16 outputs then leave as one 16-byte store per (row, pair) instead of two 8-byte ones
-// (the epilogue is store-issue bound: half the instructions, 64 contiguous bytes per row per instruction).
-__device__ __forceinline__ int w_row_of_lds_row(int l) {  // l in [0,128)
-  const int r = l & 15, j = (l >> 4) & 3;
-  return (l & 64) + 32 * (j >> 1) + 8 * (r >> 2) + 4 * (j & 1) + (r & 3);
-}
-
-template <int EPI, typename OutT, int MI> struct EpiStores {
-  // store instructions per wave per (full) tile after the prefetch was issued
-  static constexpr int PER_PAIR = (EPI == APLA_EPI_GELU) ? 2 : (EPI == APLA_EPI_SWIGLU) ? 2
-                                  : (EPI == APLA_EPI_SWIGLU_BWD) ? 2 : (sizeof(OutT) == 4 ? 2 : 1);
-  static constexpr int N = MI * 2 * PER_PAIR;
-};
-
-template <typename T> struct Vec8IO;
-template <> struct Vec8IO<float> {
-  static __device__ __forceinline__ void store(float* p, f32x4 lo, f32x4 hi) { *(f32x4*)p = lo; *(f32x4*)(p + 4) = hi; }
-};
-template <> struct Vec8IO<bf16> {
-  static __device__ __forceinline__ void store(bf16* p, f32x4 lo, f32x4 hi) {
-    bf16x8 o;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { o[e] = (bf16)lo[e]; o[4 + e] = (bf16)hi[e]; }
-    *(bf16x8*)p = o;
-  }
-};
-
-// 2 x (8 consecutive elements) of one row, 32 elements apart, loaded by inline asm (not tracked by hipcc's waitcnt pass)
-template <typename T> struct AuxRegs;
-template <> struct AuxRegs<float> {
-  f32x4 lo, hi;
-  __device__ __forceinline__ f32x4 get_lo() const { return lo; }
-  __device__ __forceinline__ f32x4 get_hi() const { return hi; }
-};
-template <> struct AuxRegs<bf16> {
-  f32x4 lo;  // 8 bf16 in 4 VGPRs
-  __device__ __forceinline__ f32x4 get_lo() const {
-    const bf16x8 t = __builtin_bit_cast(bf16x8, lo);
-    return f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
-  }
-  __device__ __forceinline__ f32x4 get_hi() const {
-    const bf16x8 t = __builtin_bit_cast(bf16x8, lo);
-    return f32x4{(float)t[4], (float)t[5], (float)t[6], (float)t[7]};
-  }
-};
-__device__ __forceinline__ void asm_load_row2(AuxRegs<float>& a0, AuxRegs<float>& a1, const float* p) {
-  asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:16\n\t"
-               "global_load_dwordx4 %2, %4, off offset:128\n\tglobal_load_dwordx4 %3, %4, off offset:144"
-               : "=&v"(a0.lo), "=&v"(a0.hi), "=&v"(a1.lo), "=&v"(a1.hi) : "v"(p) : "memory");
-}
-__device__ __forceinline__ void asm_load_row2(AuxRegs<bf16>& a0, AuxRegs<bf16>& a1, const bf16* p) {
-  asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:64"
-               : "=&v"(a0.lo), "=&v"(a1.lo) : "v"(p) : "memory");
-}
-template <typename T> __device__ __forceinline__ void asm_wait_pin(AuxRegs<T>& a);
-template <> __device__ __forceinline__ void asm_wait_pin<float>(AuxRegs<float>& a) { asm volatile("" : "+v"(a.lo), "+v"(a.hi)); }
-template <> __device__ __forceinline__ void asm_wait_pin<bf16>(AuxRegs<bf16>& a) { asm volatile("" : "+v"(a.lo)); }
-
-template <int EPI, typename OutT, int MI>
-__device__ __forceinline__ void persist_epilogue(const GemmParams& p, f32x4 (&acc)[MI][4], const float* bias_lds,
-                                                 int m0, int n0, int wm, int wn, int lane) {
-  const int frow = lane & 15, fq = lane >> 4;
-  const int ncol = wn * 64 + fq * 8;  // + 32*u : first of the 8 columns this lane owns in pair u (tile-local)
-  int mrow[MI];
-#pragma unroll
-  for (int i = 0; i < MI; ++i) mrow[i] = m0 + wm * (MI * 16) + i * 16 + frow;
-  if (p.bias != nullptr) {
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const f32x4 blo = *(const f32x4*)(bias_lds + ncol + 32 * u), bhi = *(const f32x4*)(bias_lds + ncol + 32 * u + 4);
-#pragma unroll
-      for (int i = 0; i < MI; ++i) { acc[i][2 * u] += blo; acc[i][2 * u + 1] += bhi; }
-    }
-  }
-  if constexpr (EPI == APLA_EPI_RESIDUAL || EPI == APLA_EPI_MUL) {
-    // Epilogue operands through inline-asm loads: an ordinary global load next to in-flight LDS-DMA makes hipcc's waitcnt
-    // pass drain vmcnt(0) inside the K loop (de-pipelining it); asm loads are invisible to that pass, so we wait for them
-    // ourselves: all loads are issued back to back, then ONE s_waitcnt, then every destination is pinned behind it.
-    using AuxT = typename std::conditional<EPI == APLA_EPI_MUL, bf16, OutT>::type;
-    AuxRegs<AuxT> aux[MI][2];
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      const int mr = mrow[i] < p.M ? mrow[i] : p.M - 1;
-      asm_load_row2(aux[i][0], aux[i][1], (const AuxT*)p.aux_in + (size_t)mr * p.ld_aux_in + n0 + ncol);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int i = 0; i < MI; ++i) { asm_wait_pin<AuxT>(aux[i][0]); asm_wait_pin<AuxT>(aux[i][1]); }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const f32x4 alo = aux[i][u].get_lo(), ahi = aux[i][u].get_hi();
-        if constexpr (EPI == APLA_EPI_MUL) { acc[i][2 * u] *= alo; acc[i][2 * u + 1] *= ahi; }
-        else { acc[i][2 * u] += alo; acc[i][2 * u + 1] += ahi; }
-      }
-  }
-#pragma unroll
-  for (int i = 0; i < MI; ++i) {
-    const int m = mrow[i];
-    if (m >= p.M) continue;
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int n = n0 + ncol + 32 * u;
-      const f32x4 lo = acc[i][2 * u], hi = acc[i][2 * u + 1];
-      if constexpr (EPI == APLA_EPI_STORE || EPI == APLA_EPI_RESIDUAL) {
-        Vec8IO<OutT>::store((OutT*)p.C + (size_t)m * p.ldc + n, lo, hi);
-      } else if constexpr (EPI == APLA_EPI_MUL) {
-        Vec8IO<bf16>::store((bf16*)p.C + (size_t)m * p.ldc + n, lo, hi);
-      } else if constexpr (EPI == APLA_EPI_GELU) {
-        f32x4 hl, hh, gl, gh;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float a, b;
-          gelu_and_grad(lo[e], a, b); hl[e] = a; gl[e] = b;
-          gelu_and_grad(hi[e], a, b); hh[e] = a; gh[e] = b;
-        }
-        Vec8IO<bf16>::store((bf16*)p.C + (size_t)m * p.ldc + n, hl, hh);
-        Vec8IO<bf16>::store((bf16*)p.aux_out + (size_t)m * p.ld_aux_out + n, gl, gh);
-      } else if constexpr (EPI == APLA_EPI_SWIGLU) {
-        // columns come in (x1_i, x2_i) pairs: 8 columns = 4 hidden units
-        Vec8IO<bf16>::store((bf16*)p.aux_out + (size_t)m * p.ld_aux_out + n, lo, hi);
-        bf16x4 h;
-        h[0] = (bf16)(lo[0] * sigmoid_f(lo[0]) * lo[1]);
-        h[1] = (bf16)(lo[2] * sigmoid_f(lo[2]) * lo[3]);
-        h[2] = (bf16)(hi[0] * sigmoid_f(hi[0]) * hi[1]);
-        h[3] = (bf16)(hi[2] * sigmoid_f(hi[2]) * hi[3]);
-        *(bf16x4*)((bf16*)p.C + (size_t)m * p.ldc + (n >> 1)) = h;
-      } else if constexpr (EPI == APLA_EPI_SWIGLU_BWD) {
-        // dh for hidden units n..n+7; saved x12 interleaved at columns 2n..2n+15
-        const bf16* xs = (const bf16*)p.aux_in + (size_t)m * p.ld_aux_in + 2 * n;
-        const bf16x8 xa = *(const bf16x8*)xs, xb = *(const bf16x8*)(xs + 8);
-        bf16x8 oa, ob;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float x1 = (float)xa[2 * e], x2 = (float)xa[2 * e + 1], sg = sigmoid_f(x1);
-          oa[2 * e] = (bf16)(lo[e] * x2 * sg * (1.0f + x1 * (1.0f - sg)));
-          oa[2 * e + 1] = (bf16)(lo[e] * x1 * sg);
-          x1 = (float)xb[2 * e]; x2 = (float)xb[2 * e + 1]; sg = sigmoid_f(x1);
-          ob[2 * e] = (bf16)(hi[e] * x2 * sg * (1.0f + x1 * (1.0f - sg)));
-          ob[2 * e + 1] = (bf16)(hi[e] * x1 * sg);
-        }
-        *(bf16x8*)((bf16*)p.C + (size_t)m * p.ldc + 2 * n) = oa;
-        *(bf16x8*)((bf16*)p.C + (size_t)m * p.ldc + 2 * n + 8) = ob;
-      }
-    }
-  }
-}
-
 template <int EPI, typename OutT, int MI>
 __global__ __launch_bounds__(256, 2) void gemm_persist_kernel(GemmParams p, int tiles_m) {
   constexpr int BMv = 32 * MI;
@@ -475,6 +290,8 @@ __global__ __launch_bounds__(256, 2) void gemm_persist_kernel(GemmParams p, int 
     for (int kt = 0; kt < nk; ++kt) {
       if (kt == 0 && counted) wait_vmcnt<EpiStores<EPI, OutT, MI>::N>(); else wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();
+      const char* As = smem + cur * STG;
+      const char* Ws = As + BMv * BK * 2;
       if (kt + 1 < nk) {
         stage(cur ^ 1, (kt + 1) * BK);
       } else if (has_next) {
@@ -483,8 +300,6 @@ __global__ __launch_bounds__(256, 2) void gemm_persist_kernel(GemmParams p, int 
         stage_bias(bb ^ 1);
       }
       asm volatile("" ::: "memory");
-      const char* As = smem + cur * STG;
-      const char* Ws = As + BMv * BK * 2;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         bf16x8 af[MI], wf[4];
@@ -511,7 +326,7 @@ __global__ __launch_bounds__(256, 2) void gemm_persist_kernel(GemmParams p, int 
   }
 }
 
-int g_variant = 4;  // tuning knob (apla_gemm_set_variant): 4 = persistent (default), 0 = 2-stage __syncthreads, 2/3 = S-stage ring
+int g_variant = 4;  // tuning knob (apla_gemm_set_variant): 4 = auto, 9 = ping-pong, 14/15 = 128-wide persistent MI 4/5, 0 = 2-stage __syncthreads, 2/3 = S-stage ring
 constexpr int RESIDENT_WGS = 512;  // 256 CUs x 2 workgroups (64-80 KB LDS, <=256 VGPR)
 
 template <int EPI, typename OutT, int MI>
@@ -539,8 +354,14 @@ inline int pick_mi(int M, int tiles_n) {
 
 template <int EPI, typename OutT>
 int launch(const GemmParams& p, hipStream_t stream) {
+  // auto (4): the 8-wave ping-pong kernel for large problems whose epilogue it handles well, else the 128-wide persistent
+  // kernel; 9 forces ping-pong wherever it is instantiated; 14/15 force the 128-wide persistent kernel with MI 4/5.
+  if (g_variant == 9 || (g_variant == 4 && p.M >= 2048)) {
+    const int rc = apla_gemm_pp2_launch(p, EPI, std::is_same<OutT, float>::value ? APLA_F32 : APLA_BF16, stream);
+    if (rc != APLA_ENOSYS) return rc;
+  }
   if (g_variant >= 4) {
-    const int mi = g_variant == 4 ? pick_mi(p.M, p.tiles_n) : g_variant;  // 5..6 force; 14 -> MI=4
+    const int mi = (g_variant == 4 || g_variant == 9) ? pick_mi(p.M, p.tiles_n) : g_variant - 10;
     if (mi == 5) return launch_persist<EPI, OutT, 5>(p, stream);
     return launch_persist<EPI, OutT, 4>(p, stream);
   }

@@ -1,0 +1,223 @@
+// Ping-pong persistent bf16 MFMA GEMM, second generation: tile 320(M) x 256(N) x 32(K), 8 waves, one workgroup per CU.
+//
+// Same role alternation as gemm_pp.hip (two groups of four waves, one wave of each group on every SIMD; while one group
+// issues its 40 MFMAs the other issues LDS-DMA and reads fragments; one s_barrier per phase), with the tile reshaped so
+// that the NON-compute phase gets cheaper than the compute phase (measured on gemm_pp: 7 LDS-DMA pieces + 18
+// ds_read_b128 per prepare phase took ~1100 cycles against 640 cycles of MFMA):
+//   * the groups split the tile along M (rows g*160 .. g*160+159) and every wave owns 80 x 128 outputs (5 x 8 MFMA tiles,
+//     160 accumulator registers): per 40 MFMAs a wave now reads 13 fragments (was 18) and issues 5 LDS-DMA pieces (was 7);
+//     the tile does 142 FLOP per staged byte (was 101).
+//   * K-step 32 -> a stage is 36 KB and FOUR stages fit (144 KB): LDS-DMA runs three K-steps ahead (up to 108 KB in
+//     flight per CU), which covers the 2-3 us loaded L2 latency.
+// M = 25216 gives 79 row tiles: N = 768 -> 237 tiles = one round over 256 CUs at 92.6 %.
+// Only the operand-free epilogues (STORE, GELU) are instantiated: with 160 accumulator registers per wave there is no
+// room for residual / multiplier operands (tried: two-row asm pipeline -> spills and in-order vmcnt stalls; residual as
+// accumulator init -> hipcc spills or drains vmcnt(0) inside the MFMA loop).  Those epilogues stay on gemm_nt.hip's 4-wave
+// persistent kernel, whose two co-resident workgroups overlap one workgroup's epilogue with the other's main loop.
+#include "gemm_common.h"
+
+namespace {
+
+constexpr int QBM = 320, QBN = 256, QBK = 32;
+constexpr int QA_BYTES = QBM * QBK * 2;  // 20 KB
+constexpr int QW_BYTES = QBN * QBK * 2;  // 16 KB
+constexpr int QSTG = QA_BYTES + QW_BYTES;
+constexpr int QNS = 4;
+constexpr int QGRP = 5;  // LDS-DMA pieces per wave per K-step: 36 real (20 A + 16 W) + 4 duplicates over 8 waves
+constexpr int QAHEAD = 3;
+
+template <int EPI, typename OutT>
+__global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmParams p, int tiles_m) {
+  using E = WideEpi<EPI, OutT>;
+  __shared__ __attribute__((aligned(16))) char smem[QNS * QSTG + 2048];  // + two bias pieces (256 floats each)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, lw = wave & 3, wm = lw >> 1, wn = lw & 1;
+  const int frow = lane & 15, fq = lane >> 4;
+  const int nk = p.K / QBK;
+  const int tiles_n = p.N / QBN;
+  const int total = tiles_m * tiles_n;
+  const int G = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int q = total >> 3, rr = total & 7;
+  const int xbeg = xcd * q + (xcd < rr ? xcd : rr), xcnt = q + (xcd < rr ? 1 : 0);
+  const int slots = (G >> 3) + ((G & 7) > xcd ? 1 : 0);
+  if (slot >= xcnt) return;
+  const int my_tiles = (xcnt - slot + slots - 1) / slots;
+  const int s_total = my_tiles * nk;
+  const bool has_bias = p.bias != nullptr;
+
+  // ------------------------------------------------------------------ LDS-DMA stream
+  // piece c = 5*wave + it of the combined list [A0..A19 | W0..W15 | 4 x W15 again]; a piece is 16 LDS rows x 64 B; lane i
+  // fills row 16*piece + (i>>2), physical chunk i&3, from logical chunk (i&3) ^ ((-(i>>4)) & 3)
+  const int srow = lane >> 2;
+  const int koff = ((lane & 3) ^ ((-(srow >> 2)) & 3)) * 8;
+  const bf16* src[QGRP];
+  int d_step = 0, d_k = 0, d_tile = 0;
+  auto dma_setup = [&](int ordinal) {
+    const int tile = xbeg + slot + ordinal * slots;
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+#pragma unroll
+    for (int it = 0; it < QGRP; ++it) {
+      int c = wave * QGRP + it;
+      c = c < 36 ? c : 35;
+      if (c < 20) {
+        int gr = tm * QBM + c * 16 + srow;
+        gr = gr < p.M ? gr : p.M - 1;
+        src[it] = p.A + (size_t)gr * p.lda + koff;
+      } else {
+        // W piece pw = c-20 fills LDS rows 16*pw + srow = (wn'=pw>>3)*128 + (j=pw&7)*16 + srow, which hold W row
+        //   wn'*128 + 32*(j>>1) + 8*(srow>>2) + 4*(j&1) + (srow&3)     (MFMA order, see gemm_common.h)
+        const int pw = c - 20, j = pw & 7;
+        const int wrow = tn * QBN + (pw >> 3) * 128 + 32 * (j >> 1) + 8 * (srow >> 2) + 4 * (j & 1) + (srow & 3);
+        src[it] = p.W + (size_t)wrow * p.ldw + koff;
+      }
+    }
+  };
+  auto dma_issue = [&]() {
+    if (d_step >= s_total) return;
+    if (d_k == 0) dma_setup(d_tile);
+    char* base = smem + __builtin_amdgcn_readfirstlane((d_step % QNS) * QSTG);
+    const int k0 = d_k * QBK;
+#pragma unroll
+    for (int it = 0; it < QGRP; ++it) {
+      int c = wave * QGRP + it;
+      c = c < 36 ? c : 35;
+      __builtin_amdgcn_global_load_lds(GLBP(src[it] + k0), LDSP(base + c * 1024), 16, 0, 0);  // W pieces follow A: c*1024
+    }
+    if (d_k == 0 && has_bias && wave == 0) {
+      const int tile = xbeg + slot + d_tile * slots;
+      const int tn = tile % tiles_n;
+      __builtin_amdgcn_global_load_lds(GLBP(p.bias + tn * QBN + lane * 4), LDSP(smem + QNS * QSTG + (d_tile & 1) * 1024), 16, 0, 0);
+    }
+    ++d_step;
+    if (++d_k == nk) { d_k = 0; ++d_tile; }
+  };
+
+  // ------------------------------------------------------------------ fragments / accumulators
+  bf16x8 af[5], wf[8];
+  f32x4 acc[5][8];
+  const int foff = frow * 64 + ((fq ^ ((-(frow >> 2)) & 3)) << 4);
+  const int a_off = (grp * 160 + wm * 80) * 64 + foff;
+  const int w_off = QA_BYTES + (wn * 128) * 64 + foff;
+  auto read_frags = [&](int s) {
+    const char* st = smem + __builtin_amdgcn_readfirstlane((s % QNS) * QSTG);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) af[i] = *(const bf16x8*)(st + a_off + i * 1024);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wf[j] = *(const bf16x8*)(st + w_off + j * 1024);
+  };
+  auto frags_landed = [&]() {  // fragment reads complete BEFORE the barrier: their stage is re-filled from the next phase on
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 5; ++i) asm volatile("" : "+v"(af[i]));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(wf[j]));
+  };
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  zero_acc();  // accumulators are cleared here and at the end of every epilogue: the MFMAs always update in place
+  auto compute = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  bool relaxed = false;
+  auto epilogue = [&](int ordinal) {
+    const int tile = xbeg + slot + ordinal * slots;
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * QBM + grp * 160, n0 = tn * QBN;
+    const bool full = m0 + 160 <= p.M;
+    wide_epilogue<EPI, OutT>(p, acc, (const float*)(smem + QNS * QSTG + (ordinal & 1) * 1024), m0, n0, wm, wn, lane, full);
+    asm volatile("" ::: "memory");
+    zero_acc();
+    relaxed = full;
+  };
+  // end of even phase 2s: K-step s+1 must have landed everywhere (group 0 reads it in phase 2s+1).  Every wave has issued
+  // its shares up to K-step s+3 by now, so two younger groups may stay in flight (fewer at the very end), plus — once
+  // after a full tile's epilogue — that tile's stores.
+  auto end_even_phase = [&](int s) {
+    if (s + 3 < s_total) {
+      if (relaxed) wait_vmcnt<2 * QGRP + E::NST>(); else wait_vmcnt<2 * QGRP>();
+    } else if (s + 2 < s_total) {
+      wait_vmcnt<QGRP>();
+    } else {
+      wait_vmcnt<0>();
+    }
+    relaxed = false;
+  };
+
+  // ------------------------------------------------------------------ prologue: K-steps 0..2 issued by everyone
+  dma_issue();
+  dma_issue();
+  dma_issue();
+  if (s_total > 2) wait_vmcnt<2 * QGRP>(); else wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  if (grp == 0) {
+    dma_issue();  // share of K-step 3 (phase -1)
+    read_frags(0);
+    frags_landed();
+    __builtin_amdgcn_s_barrier();
+    for (int s = 0; s < s_total; ++s) {
+      compute();  // phase 2s
+      end_even_phase(s);
+      __builtin_amdgcn_s_barrier();
+      if (((s + 1) % nk) == 0) epilogue((s + 1) / nk - 1);  // phase 2s+1: prepare K-step s+1
+      if (s + 1 < s_total) {
+        dma_issue();  // share of K-step s+4
+        read_frags(s + 1);
+        frags_landed();
+      }
+      __builtin_amdgcn_s_barrier();
+    }
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+  } else {
+    __builtin_amdgcn_s_barrier();
+    for (int s = 0; s < s_total; ++s) {
+      if (s > 0 && (s % nk) == 0) epilogue(s / nk - 1);  // phase 2s: prepare K-step s
+      dma_issue();  // share of K-step s+3
+      read_frags(s);
+      frags_landed();
+      end_even_phase(s);
+      __builtin_amdgcn_s_barrier();
+      compute();  // phase 2s+1
+      __builtin_amdgcn_s_barrier();
+    }
+    epilogue(my_tiles - 1);
+    __builtin_amdgcn_s_barrier();
+  }
+}
+
+}  // namespace
+
+int apla_gemm_pp2_launch(const GemmParams& p, int epilogue, int out_dtype, hipStream_t stream) {
+  if (p.N % QBN != 0 || p.K % QBK != 0 || p.K < 4 * QBK) return APLA_ENOSYS;
+  const int tiles_m = (p.M + QBM - 1) / QBM;
+  const int total = tiles_m * (p.N / QBN);
+  const int G = total < 256 ? total : 256;
+#define PP2_LAUNCH(E, T)                                                                                 \
+  do {                                                                                                   \
+    hipLaunchKernelGGL((gemm_pp2_kernel<E, T>), dim3(G), dim3(512), 0, stream, p, tiles_m);              \
+    hipError_t e__ = hipGetLastError();                                                                  \
+    if (e__ != hipSuccess) { apla_set_error("apla_gemm_nt[pp2]: launch failed: %s", hipGetErrorString(e__)); return APLA_EIO; } \
+    return APLA_OK;                                                                                      \
+  } while (0)
+  switch (epilogue) {
+    case APLA_EPI_STORE:
+      if (out_dtype == APLA_F32) PP2_LAUNCH(APLA_EPI_STORE, float); else PP2_LAUNCH(APLA_EPI_STORE, bf16);
+    case APLA_EPI_GELU:
+      PP2_LAUNCH(APLA_EPI_GELU, bf16);
+    default:
+      return APLA_ENOSYS;
+  }
+#undef PP2_LAUNCH
+}

@@ -7,10 +7,10 @@
 
 namespace {
 
-constexpr int MAXC = 8;  // row chunks of 4 elements per lane: D <= 64*4*MAXC = 2048
+constexpr int MAXC = 8;  // row chunks of 4 elements per lane: D <= 64*4*MAXC = 2048 (kernels are instantiated per chunk count)
 constexpr int ROWS_PER_BLOCK = 4;
 
-template <typename ResT, typename YT>
+template <typename ResT, typename YT, int NC>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const ResT* __restrict__ x, long xs, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, YT* __restrict__ y, int ldy,
                                                      float* __restrict__ mean_o, float* __restrict__ rstd_o, int M,
@@ -19,10 +19,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const ResT* __restrict__ x,
   const int nchunk = D >> 2;
   for (int m = blockIdx.x * ROWS_PER_BLOCK + wave; m < M; m += gridDim.x * ROWS_PER_BLOCK) {
     const ResT* xr = x + (size_t)m * xs;
-    f32x4 v[MAXC];
+    f32x4 v[NC];
     float s = 0.f;
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
+    for (int c = 0; c < NC; ++c) {
       const int ch = lane + c * 64;
       if (ch < nchunk) {
         v[c] = Vec4IO<ResT>::load(xr + ch * 4);
@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const ResT* __restrict__ x,
     const float mean = wave_sum(s) / (float)D;
     float q = 0.f;
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
+    for (int c = 0; c < NC; ++c) {
       const int ch = lane + c * 64;
       if (ch < nchunk) {
 #pragma unroll
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const ResT* __restrict__ x,
     if (lane == 0) { mean_o[m] = mean; rstd_o[m] = rstd; }
     YT* yr = y + (size_t)m * ldy;
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
+    for (int c = 0; c < NC; ++c) {
       const int ch = lane + c * 64;
       if (ch < nchunk) {
         const f32x4 g = *(const f32x4*)(gamma + ch * 4), b = *(const f32x4*)(beta + ch * 4);
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const ResT* __restrict__ x,
 
 // dx_out = dres_in + ((dy*g) - mean(dy*g) - xhat*mean(dy*g*xhat)) * rstd ; optional bf16 copy of dx_out (GEMM operand
 // when the gradient stream is fp32) and optional gather of the APLA-trainable columns.
-template <typename XT, typename DYT, typename GT, bool GATHER>
+template <typename XT, typename DYT, typename GT, bool GATHER, int NC>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const DYT* __restrict__ dy, int lddy, const XT* __restrict__ x,
                                                      long xs, const float* __restrict__ gamma,
                                                      const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
@@ -75,10 +75,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const DYT* __restrict__ dy,
       const XT* xr = x + (size_t)m * xs;
       const DYT* dyr = dy + (size_t)m * lddy;
       const float mean = mean_i[m], rstd = rstd_i[m];
-      f32x4 xh[MAXC], w[MAXC];
+      f32x4 xh[NC], w[NC];
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-      for (int c = 0; c < MAXC; ++c) {
+      for (int c = 0; c < NC; ++c) {
         const int ch = lane + c * 64;
         if (ch < nchunk) {
           const f32x4 xv = Vec4IO<XT>::load(xr + ch * 4);
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const DYT* __restrict__ dy,
       const float c1 = wave_sum(s1) / (float)D, c2 = wave_sum(s2) / (float)D;
       GT* dxr = dx + (size_t)m * dxs;
 #pragma unroll
-      for (int c = 0; c < MAXC; ++c) {
+      for (int c = 0; c < NC; ++c) {
         const int ch = lane + c * 64;
         if (ch < nchunk) {
           f32x4 o;
@@ -142,7 +142,17 @@ extern "C" int apla_layernorm_fwd(const void* x, int res_dtype, long x_row_strid
   APLA_REQUIRE(x && y && gamma && beta && mean && rstd, "apla_layernorm_fwd: null pointer");
   APLA_REQUIRE(x_row_stride % 4 == 0 && ldy % 4 == 0 && x_row_stride >= D && ldy >= D, "apla_layernorm_fwd: strides must be >= D and multiples of 4");
   APLA_REQUIRE(apla_aligned16(x) && apla_aligned16(gamma) && apla_aligned16(beta) && (((uintptr_t)y) & 7) == 0, "apla_layernorm_fwd: alignment");
-#define LN_FWD(T, Y) hipLaunchKernelGGL((ln_fwd_kernel<T, Y>), dim3(ln_grid(M)), dim3(256), 0, stream, (const T*)x, x_row_stride, gamma, beta, (Y*)y, ldy, mean, rstd, M, D, eps)
+#define LN_FWD_NC(T, Y, NCV) hipLaunchKernelGGL((ln_fwd_kernel<T, Y, NCV>), dim3(ln_grid(M)), dim3(256), 0, stream, (const T*)x, x_row_stride, gamma, beta, (Y*)y, ldy, mean, rstd, M, D, eps)
+#define LN_FWD(T, Y)                                    \
+  do {                                                  \
+    const int nc_ = (D + 255) / 256;                    \
+    if (nc_ <= 1) LN_FWD_NC(T, Y, 1);                   \
+    else if (nc_ == 2) LN_FWD_NC(T, Y, 2);              \
+    else if (nc_ == 3) LN_FWD_NC(T, Y, 3);              \
+    else if (nc_ == 4) LN_FWD_NC(T, Y, 4);              \
+    else if (nc_ <= 6) LN_FWD_NC(T, Y, 6);              \
+    else LN_FWD_NC(T, Y, 8);                            \
+  } while (0)
   if (res_dtype == APLA_F32 && y_dtype == APLA_BF16) LN_FWD(float, bf16);
   else if (res_dtype == APLA_F32 && y_dtype == APLA_F32) LN_FWD(float, float);
   else if (res_dtype == APLA_BF16 && y_dtype == APLA_BF16) LN_FWD(bf16, bf16);
@@ -152,6 +162,7 @@ extern "C" int apla_layernorm_fwd(const void* x, int res_dtype, long x_row_strid
     return APLA_ENOSYS;
   }
 #undef LN_FWD
+#undef LN_FWD_NC
   APLA_CHECK_LAUNCH("apla_layernorm_fwd");
   return APLA_OK;
 }
@@ -168,10 +179,20 @@ extern "C" int apla_layernorm_bwd(const void* dy, int dy_dtype, int lddy, const 
   APLA_REQUIRE(gather_out == nullptr || (inds != nullptr && r > 0 && r <= D), "apla_layernorm_bwd: gather needs inds and 0<r<=D");
   const bool gather = gather_out != nullptr;
   const size_t lds = gather ? (size_t)ROWS_PER_BLOCK * D * sizeof(float) : 0;
-#define LN_BWD(X, Y, G, GA)                                                                                            \
-  hipLaunchKernelGGL((ln_bwd_kernel<X, Y, G, GA>), dim3(ln_grid(M)), dim3(256), lds, stream, (const Y*)dy, lddy,       \
+#define LN_BWD_NC(X, Y, G, GA, NCV)                                                                                    \
+  hipLaunchKernelGGL((ln_bwd_kernel<X, Y, G, GA, NCV>), dim3(ln_grid(M)), dim3(256), lds, stream, (const Y*)dy, lddy,  \
                      (const X*)x, x_row_stride, gamma, mean, rstd, (const G*)dres_in, (G*)dx_out, dx_row_stride,       \
                      (bf16*)dx_bf16_copy, copy_row_stride, inds, r, (bf16*)gather_out, M, D)
+#define LN_BWD(X, Y, G, GA)                             \
+  do {                                                  \
+    const int nc_ = (D + 255) / 256;                    \
+    if (nc_ <= 1) LN_BWD_NC(X, Y, G, GA, 1);            \
+    else if (nc_ == 2) LN_BWD_NC(X, Y, G, GA, 2);       \
+    else if (nc_ == 3) LN_BWD_NC(X, Y, G, GA, 3);       \
+    else if (nc_ == 4) LN_BWD_NC(X, Y, G, GA, 4);       \
+    else if (nc_ <= 6) LN_BWD_NC(X, Y, G, GA, 6);       \
+    else LN_BWD_NC(X, Y, G, GA, 8);                     \
+  } while (0)
 #define LN_BWD_G(X, Y, G) do { if (gather) LN_BWD(X, Y, G, true); else LN_BWD(X, Y, G, false); } while (0)
 #define LN_BWD_Y(X, G)                                           \
   do {                                                           \
@@ -191,6 +212,7 @@ extern "C" int apla_layernorm_bwd(const void* dy, int dy_dtype, int lddy, const 
 #undef LN_BWD_Y
 #undef LN_BWD_G
 #undef LN_BWD
+#undef LN_BWD_NC
   APLA_CHECK_LAUNCH("apla_layernorm_bwd");
   return APLA_OK;
 }

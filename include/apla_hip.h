@@ -53,9 +53,12 @@ int apla_gemm_nt(const void* A, int lda, const void* W, int ldw, const float* bi
                  int K, int epilogue, int out_dtype, const void* aux_in, int ld_aux_in, void* aux_out,
                  int ld_aux_out, hipStream_t stream);
 
-/* Tuning/diagnostic knob: selects the main-loop schedule of apla_gemm_nt for subsequent launches (process-wide):
- * 0 = 2-stage LDS double buffer with __syncthreads; 2 / 3 = S-stage LDS ring with counted vmcnt + raw s_barrier.
- * Returns the previous value.  All variants compute identical results. */
+/* Tuning/diagnostic knob: selects the kernel schedule of apla_gemm_nt for subsequent launches (process-wide):
+ *   4  = auto (default): 8-wave ping-pong kernel (320x256x32 tile, gemm_pp2.hip) for M >= 2048, N % 256 == 0 and the
+ *        STORE / GELU epilogues; otherwise the 4-wave persistent kernel (128/160 x 128 x 64 tile, gemm_nt.hip)
+ *   9  = ping-pong wherever instantiated; 14 / 15 = 4-wave persistent kernel with BM 128 / 160
+ *   0  = non-persistent 2-stage kernel; 2 / 3 = non-persistent S-stage LDS ring
+ * Returns the previous value.  All variants compute the same results (tests/test_kernels_gpu.py). */
 int apla_gemm_set_variant(int variant);
 
 /* y = LayerNorm(x)*gamma+beta (y_dtype bf16, or f32 for the classifier-head input), saving mean/rstd (fp32).  x rows are `x_row_stride` elements apart so

@@ -325,3 +325,34 @@ def test_head_and_cross_entropy(ops):
     assert rel_err(dW.cpu(), rdl.t() @ xn.double()) < 1e-5
     assert rel_err(dxn.cpu(), rdl @ W.double()) < 1e-5
     assert rel_err(db.cpu(), rdl.sum(0)) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------- GEMM schedule variants
+@pytest.mark.parametrize("variant", [4, 9, 14, 15, 0, 3])
+@pytest.mark.parametrize("M,N,K", [(25216, 768, 768), (1000, 512, 256), (333, 256, 128), (161, 256, 192)])
+def test_gemm_variants_all_epilogues(ops, variant, M, N, K):
+    """Every main-loop schedule (apla_gemm_set_variant) must give the same results for every epilogue, including the
+    persistent multi-tile-per-workgroup case (M = 25216) and row tails."""
+    from apla_amd._lib import lib
+    a, ad = bf(rnd(M, K, seed=81))
+    w, wd = bf(rnd(N, K, scale=K ** -0.5, seed=82))
+    bias = rnd(N, seed=83)
+    base = ad @ wd.t() + bias.double()
+    res32 = rnd(M, N, seed=84)
+    g, gd = bf(rnd(M, N, seed=85))
+    old = lib().apla_gemm_set_variant(variant)
+    try:
+        A, W, Bv = dev(a), dev(w), dev(bias)
+        assert rel_err(ops.gemm_nt(A, W, Bv).cpu(), base) < BF16_OUT
+        assert rel_err(ops.gemm_nt(A, W, Bv, out_dtype=torch.float32).cpu(), base) < F32_OUT
+        gp = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        h = ops.gemm_nt(A, W, Bv, epilogue=ops.EPI_GELU, aux_out=gp)
+        assert rel_err(h.cpu(), O.gelu_fwd(base)) < BF16_OUT and rel_err(gp.cpu(), O.gelu_grad(base)) < BF16_OUT
+        r = ops.gemm_nt(A, W, Bv, epilogue=ops.EPI_RESIDUAL, aux_in=dev(res32), out_dtype=torch.float32)
+        assert rel_err(r.cpu(), base + res32.double()) < F32_OUT
+        rb = ops.gemm_nt(A, W, Bv, epilogue=ops.EPI_RESIDUAL, aux_in=dev(res32, torch.bfloat16), out_dtype=torch.bfloat16)
+        assert rel_err(rb.cpu(), base + res32.to(torch.bfloat16).double()) < BF16_OUT
+        mlt = ops.gemm_nt(A, W, None, epilogue=ops.EPI_MUL, aux_in=dev(g))
+        assert rel_err(mlt.cpu(), (ad @ wd.t()) * gd) < BF16_OUT
+    finally:
+        lib().apla_gemm_set_variant(old)
