@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void proj_dw_reduce_kernel(const float* __rest
 
 inline int dw_slabs(int M, int r, int D) {
   const int tiles = (r / TJ) * (D / TK);
-  int S = (768 + tiles - 1) / tiles;  // aim at ~3 workgroups per CU
+  int S = (448 + tiles - 1) / tiles;  // ~1.75 workgroups per CU: enough parallelism, fewer partial slabs to write and re-read
   const int max_s = (M + TM - 1) / TM;
   if (S > max_s) S = max_s;
   if (S < 1) S = 1;

@@ -405,6 +405,43 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(const bf16* __restrict_
   }
 }
 
+// ------------------------------------------------------------------------------------------------ backward, CLS-only dO
+// Last block of the ViT: only the CLS query (row 0 of every sequence) carries gradient into the attention output (final
+// norm + x[:,0], vit.py:416-419).  Then dV[k] = P[0,k] dO[0], dK[k] = scale dS[0,k] q[0], dQ[0] = scale sum_k dS[0,k] K[k]
+// and dQ[q>0] = 0: a rank-1, HBM-bound pass over K and V instead of the 7-product flash backward.
+// One workgroup per (b,h); lane = head-dim element; each wave walks keys wave, wave+4, ...
+__global__ __launch_bounds__(256) void attn_bwd_cls_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
+                                                           const bf16* __restrict__ do_cls, const float* __restrict__ lse,
+                                                           bf16* __restrict__ dqkv, int N, int H, float scale) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y, h = blockIdx.x;
+  const int D = H * 64;
+  const long ld = 3L * D;
+  const bf16* base = qkv + (long)b * N * ld + h * 64;
+  bf16* dbase = dqkv + (long)b * N * ld + h * 64;
+  const float q0 = (float)base[lane];
+  const float do0 = (float)do_cls[(long)b * D + h * 64 + lane];
+  const float o0 = (float)o[(long)b * N * D + h * 64 + lane];
+  const float delta = wave_sum(do0 * o0);
+  const float l0 = lse[((long)b * H + h) * N];
+  float dq = 0.f;
+  for (int k = wave; k < N; k += 4) {
+    const float kv = (float)base[(long)k * ld + D + lane], vv = (float)base[(long)k * ld + 2 * D + lane];
+    const float s = wave_sum(q0 * kv), dp = wave_sum(do0 * vv);
+    const float pr = __expf(s * scale - l0);
+    const float ds = pr * (dp - delta) * scale;
+    dq += ds * kv;
+    bf16* orow = dbase + (long)k * ld;
+    orow[D + lane] = (bf16)(ds * q0);
+    orow[2 * D + lane] = (bf16)(pr * do0);
+    if (k > 0) orow[lane] = (bf16)0.f;
+  }
+  red[wave][lane] = dq;
+  __syncthreads();
+  if (wave == 0) dbase[lane] = (bf16)(red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
+}
+
 }  // namespace
 
 extern "C" int apla_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, float scale,
@@ -435,5 +472,13 @@ extern "C" int apla_attn_probs(const void* qkv, const float* lse, float* attn, i
   APLA_REQUIRE(qkv && lse && attn && B > 0 && N > 0 && H > 0 && B <= 65535 && H <= 65535, "apla_attn_probs: bad arguments");
   hipLaunchKernelGGL(attn_probs_kernel, dim3(N, H, B), dim3(256), 0, stream, (const bf16*)qkv, lse, attn, N, H, scale);
   APLA_CHECK_LAUNCH("apla_attn_probs");
+  return APLA_OK;
+}
+
+extern "C" int apla_attn_bwd_cls(const void* qkv, const void* o, const void* do_cls, const float* lse, void* dqkv, int B,
+                                 int N, int H, float scale, hipStream_t stream) {
+  APLA_REQUIRE(qkv && o && do_cls && lse && dqkv && B > 0 && N > 0 && H > 0 && B <= 65535, "apla_attn_bwd_cls: bad arguments");
+  hipLaunchKernelGGL(attn_bwd_cls_kernel, dim3(H, B), dim3(256), 0, stream, (const bf16*)qkv, (const bf16*)o, (const bf16*)do_cls, lse, (bf16*)dqkv, N, H, scale);
+  APLA_CHECK_LAUNCH("apla_attn_bwd_cls");
   return APLA_OK;
 }

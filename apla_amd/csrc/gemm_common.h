@@ -12,10 +12,42 @@ struct GemmParams {
   const void* aux_in; int ld_aux_in;
   void* aux_out; int ld_aux_out;
   int M, N, K, tiles_n;
+  int ngrp;  // n-tiles per column group of the tile walk (0 = plain row-major walk); see tile_coords
 };
 
 // 8-wave ping-pong kernel (gemm_pp2.hip); returns APLA_ENOSYS when the shape / (epilogue, dtype) is not covered there
 int apla_gemm_pp2_launch(const GemmParams& p, int epilogue, int out_dtype, hipStream_t stream);
+
+// Tile walk.  Linear tile ids are dealt to XCDs in contiguous runs (each XCD has its own 4 MB L2).  With n fastest, a run
+// touches ALL column tiles, i.e. the whole weight matrix: fine while W fits next to the streaming A panels (N = 768:
+// 1.2 MB), but for N = 2304 / 3072 (3.5 / 4.7 MB of W) the L2 thrashes and W is re-fetched from beyond L2 all the time
+// (PMC: FETCH_SIZE 5x the algorithmic bytes).  So wide problems are walked in column groups of `ngrp` n-tiles (<= ~2 MB of
+// W per group): inside a group m-major with n fastest, group after group.  Placement affects speed only.
+__device__ __forceinline__ void tile_coords(int t, int tiles_m, int tiles_n, int ngrp, int& tm, int& tn) {
+  if (ngrp <= 0 || ngrp >= tiles_n) { tm = t / tiles_n; tn = t - tm * tiles_n; return; }
+  const int per = tiles_m * ngrp;
+  const int nfull = tiles_n / ngrp;  // full groups; a smaller last group may follow
+  const int g = t / per;
+  if (g < nfull) {
+    const int r = t - g * per;
+    tm = r / ngrp;
+    tn = g * ngrp + (r - tm * ngrp);
+  } else {
+    const int last = tiles_n - nfull * ngrp;
+    const int r = t - nfull * per;
+    tm = r / last;
+    tn = nfull * ngrp + (r - tm * last);
+  }
+}
+// host: n-tiles per group so that a group's weight slice (bn x K bf16 per tile) stays around 2 MB, groups equalised
+static inline int pick_ngrp(int tiles_n, int bn, int K) {
+  const long tile_bytes = (long)bn * K * 2;
+  if ((long)tiles_n * tile_bytes <= (5L << 19)) return 0;  // <= 2.5 MB: plain walk
+  long per = (2L << 20) / tile_bytes;
+  if (per < 1) per = 1;
+  const int groups = (int)((tiles_n + per - 1) / per);
+  return (tiles_n + groups - 1) / groups;
+}
 
 // GELU (exact erf form) and its derivative from ONE exp2 and ONE rcp per element: Phi(a) via Abramowitz-Stegun 7.1.26
 // (|erf error| < 1.5e-7, far below the bf16 output rounding) sharing E = exp(-a^2/2) with the Gaussian term of gelu'.

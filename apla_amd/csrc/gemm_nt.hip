@@ -239,7 +239,8 @@ __global__ __launch_bounds__(256, 2) void gemm_persist_kernel(GemmParams p, int 
   const bf16* w_src[4];
   const float* b_src = nullptr;
   auto setup = [&](int tile) {
-    const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+    int tm, tn;
+    tile_coords(tile, tiles_m, p.tiles_n, p.ngrp, tm, tn);
 #pragma unroll
     for (int it = 0; it < MI; ++it) {
       const int row = (wave * MI + it) * 8 + (lane >> 3);
@@ -278,7 +279,8 @@ __global__ __launch_bounds__(256, 2) void gemm_persist_kernel(GemmParams p, int 
   int cur = 0, bb = 0;
   bool counted = false;  // may the first wait of this tile leave the previous tile's stores outstanding?
   while (true) {
-    const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+    int tm, tn;
+    tile_coords(tile, tiles_m, p.tiles_n, p.ngrp, tm, tn);
     const int m0 = tm * BMv, n0 = tn * BN;
     const int nidx = idx + slots;
     const bool has_next = nidx < xcnt;
@@ -330,7 +332,9 @@ int g_variant = 4;  // tuning knob (apla_gemm_set_variant): 4 = auto, 9 = ping-p
 constexpr int RESIDENT_WGS = 512;  // 256 CUs x 2 workgroups (64-80 KB LDS, <=256 VGPR)
 
 template <int EPI, typename OutT, int MI>
-int launch_persist(const GemmParams& p, hipStream_t stream) {
+int launch_persist(const GemmParams& p_in, hipStream_t stream) {
+  GemmParams p = p_in;
+  p.ngrp = pick_ngrp(p.tiles_n, BN, p.K);
   const int tiles_m = (p.M + 32 * MI - 1) / (32 * MI);
   const int total = tiles_m * p.tiles_n;
   int G = total < RESIDENT_WGS ? total : RESIDENT_WGS;
@@ -391,7 +395,7 @@ extern "C" int apla_gemm_nt(const void* A, int lda, const void* W, int ldw, cons
   APLA_REQUIRE(apla_aligned16(A) && apla_aligned16(W) && apla_aligned16(C) && A && W && C, "apla_gemm_nt: pointers must be 16-byte aligned");
   APLA_REQUIRE(bias == nullptr || apla_aligned16(bias), "apla_gemm_nt: bias must be 16-byte aligned");
   APLA_REQUIRE(ldc % 4 == 0, "apla_gemm_nt: ldc %% 4 != 0");
-  GemmParams p{(const bf16*)A, lda, (const bf16*)W, ldw, bias, C, ldc, aux_in, ld_aux_in, aux_out, ld_aux_out, M, N, K, N / BN};
+  GemmParams p{(const bf16*)A, lda, (const bf16*)W, ldw, bias, C, ldc, aux_in, ld_aux_in, aux_out, ld_aux_out, M, N, K, N / BN, 0};
   switch (epilogue) {
     case APLA_EPI_STORE:
       APLA_REQUIRE(ldc >= N, "apla_gemm_nt: ldc < N");

@@ -55,7 +55,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmParams p, int tile
   int d_step = 0, d_k = 0, d_tile = 0;
   auto dma_setup = [&](int ordinal) {
     const int tile = xbeg + slot + ordinal * slots;
-    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    int tm, tn;
+    tile_coords(tile, tiles_m, tiles_n, p.ngrp, tm, tn);
 #pragma unroll
     for (int it = 0; it < QGRP; ++it) {
       int c = wave * QGRP + it;
@@ -86,7 +87,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmParams p, int tile
     }
     if (d_k == 0 && has_bias && wave == 0) {
       const int tile = xbeg + slot + d_tile * slots;
-      const int tn = tile % tiles_n;
+      int tm_, tn;
+      tile_coords(tile, tiles_m, tiles_n, p.ngrp, tm_, tn);
       __builtin_amdgcn_global_load_lds(GLBP(p.bias + tn * QBN + lane * 4), LDSP(smem + QNS * QSTG + (d_tile & 1) * 1024), 16, 0, 0);
     }
     ++d_step;
@@ -133,7 +135,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmParams p, int tile
   bool relaxed = false;
   auto epilogue = [&](int ordinal) {
     const int tile = xbeg + slot + ordinal * slots;
-    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    int tm, tn;
+    tile_coords(tile, tiles_m, tiles_n, p.ngrp, tm, tn);
     const int m0 = tm * QBM + grp * 160, n0 = tn * QBN;
     const bool full = m0 + 160 <= p.M;
     wide_epilogue<EPI, OutT>(p, acc, (const float*)(smem + QNS * QSTG + (ordinal & 1) * 1024), m0, n0, wm, wn, lane, full);
@@ -199,8 +202,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmParams p, int tile
 
 }  // namespace
 
-int apla_gemm_pp2_launch(const GemmParams& p, int epilogue, int out_dtype, hipStream_t stream) {
-  if (p.N % QBN != 0 || p.K % QBK != 0 || p.K < 4 * QBK) return APLA_ENOSYS;
+int apla_gemm_pp2_launch(const GemmParams& p_in, int epilogue, int out_dtype, hipStream_t stream) {
+  if (p_in.N % QBN != 0 || p_in.K % QBK != 0 || p_in.K < 4 * QBK) return APLA_ENOSYS;
+  GemmParams p = p_in;
+  p.ngrp = pick_ngrp(p.N / QBN, QBN, p.K);
   const int tiles_m = (p.M + QBM - 1) / QBM;
   const int total = tiles_m * (p.N / QBN);
   const int G = total < 256 ? total : 256;

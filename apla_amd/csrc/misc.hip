@@ -37,31 +37,31 @@ __global__ __launch_bounds__(256) void assemble_tokens_kernel(const bf16* __rest
   }
 }
 
-// C[i,j] (+)= sum_k A[i*sai + k*sak] * B[k*sbk + j*sbj] (+ bias[j]); 32x32 tile per workgroup, fp32 FMA.
+// C[i,j] (+)= sum_k A[i*sai + k*sak] * B[k*sbk + j*sbj] (+ bias[j]); 32x32 tile per workgroup, 128-deep K chunks (the
+// head GEMMs are latency-bound: few, long dependent load->barrier->FMA rounds), fp32 FMA.
+constexpr int SG_BK = 128;
 __global__ __launch_bounds__(256) void sgemm_small_kernel(const float* __restrict__ A, long sai, long sak,
                                                           const float* __restrict__ Bm, long sbk, long sbj,
                                                           const float* __restrict__ bias, float* __restrict__ C,
                                                           long ldc, int M, int N, int K, int accumulate) {
-  __shared__ float As[32][33], Bs[32][33];
+  __shared__ float As[32][SG_BK + 1], Bs[SG_BK][33];
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;  // 16 x 16 threads, 2x2 outputs each
   const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
   float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-  for (int k0 = 0; k0 < K; k0 += 32) {
-    for (int e = threadIdx.x; e < 1024; e += 256) {
-      const int a = e >> 5, c = e & 31;
-      // A tile: As[i][k]; pick the faster-varying global index for the inner thread index
-      {
-        const int i = sak <= sai ? a : c, k = sak <= sai ? c : a;
+  for (int k0 = 0; k0 < K; k0 += SG_BK) {
+    for (int e = threadIdx.x; e < 32 * SG_BK; e += 256) {
+      {  // A tile As[i][k]: let the faster-varying global index follow the thread index
+        const int i = sak <= sai ? e / SG_BK : e % 32, k = sak <= sai ? e % SG_BK : e / 32;
         As[i][k] = (i0 + i < M && k0 + k < K) ? A[(long)(i0 + i) * sai + (long)(k0 + k) * sak] : 0.f;
       }
       {
-        const int k = sbj <= sbk ? a : c, j = sbj <= sbk ? c : a;
+        const int k = sbj <= sbk ? e / 32 : e % SG_BK, j = sbj <= sbk ? e % 32 : e / SG_BK;
         Bs[k][j] = (j0 + j < N && k0 + k < K) ? Bm[(long)(k0 + k) * sbk + (long)(j0 + j) * sbj] : 0.f;
       }
     }
     __syncthreads();
-#pragma unroll 8
-    for (int k = 0; k < 32; ++k) {
+#pragma unroll 16
+    for (int k = 0; k < SG_BK; ++k) {
       const float a0 = As[ty][k], a1 = As[ty + 16][k], b0 = Bs[k][tx], b1 = Bs[k][tx + 16];
       acc[0][0] += a0 * b0; acc[0][1] += a0 * b1; acc[1][0] += a1 * b0; acc[1][1] += a1 * b1;
     }

@@ -242,6 +242,9 @@ class AplaTrainEngine:
         self.dqkv = e(M, 3 * D)
         self.delta = e(B, H, N, dt=torch.float32)
         rmax = max(st.r for st in self.blocks)
+        # CLS-only backward of the last block (compact [B, .] operands)
+        self.dact_cls, self.dln_cls, self.dO_cls = e(B, Fsave), e(B, D), e(B, D)
+        self.dyg_cls = e(B * rmax)
         self.dyg = e(M * rmax)
         self.dw_ws = ops.dw_workspace(M, rmax, D, dev)
         for st in self.blocks:
@@ -311,11 +314,40 @@ class AplaTrainEngine:
         ops.gemm_nt(self.dqkv, st.WqkvT, None, out=self.dln)
         ops.layernorm_bwd(self.dln, self.x[i], st.g1, self.mean1[i], self.rstd1[i], dres=self.G, out=self.G, out_bf16=copy)
 
+    def _backward_last_block(self):
+        """Backward of block L-1 exploiting that only the CLS rows (token 0 of every sequence) of the incoming residual
+        gradient are non-zero (final norm + x[:,0], vit.py:416-419): the MLP backward, LN2 backward, dW1 and the projection
+        dX run on B rows instead of B*N, and the attention backward is rank-1 per head (apla_attn_bwd_cls).  From dqkv on
+        the gradient is dense again."""
+        i = self.L - 1
+        st = self.blocks[i]
+        B, N, H, D = self.B, self.N, self.H, self.D
+        cls = lambda t: t.view(B, -1)[:, :t.shape[1]]          # rows b*N of a [B*N, C] buffer as a strided [B, C] view
+        copy = None if self.Gb is self.G else self.Gb
+        if self.swiglu:
+            ops.gemm_nt(cls(self.Gb), st.WoutT, None, epilogue=ops.EPI_SWIGLU_BWD, aux_in=cls(self.act_saved[i]), out=self.dact_cls)
+            ops.gemm_nt(self.dact_cls, st.W12T, None, out=self.dln_cls)
+        else:
+            ops.gemm_nt(cls(self.Gb), st.WoutT, None, epilogue=ops.EPI_MUL, aux_in=cls(self.act_saved[i]), out=self.dact_cls)
+            ops.gemm_nt(self.dact_cls, st.Wfc1T, None, out=self.dln_cls)
+        dyg = self.dyg_cls[:B * st.r].view(B, st.r)
+        ops.layernorm_bwd(self.dln_cls, self.xmid[i], st.g2, self.mean2[i][::N].contiguous(), self.rstd2[i][::N].contiguous(),
+                          dres=self.G, out=self.G, out_bf16=copy, inds=st.inds, r=st.r, gathered=dyg, rows=B, row_stride=N * D)
+        ops.proj_dw(dyg, cls(self.o[i]), self._grad_view(st.W1_name), self._grad_view(st.b1_name), row_scale=st.row_scale,
+                    workspace=self.dw_ws)
+        if i == 0:
+            return
+        ops.gemm_nt(cls(self.Gb), st.WnatT, None, out=self.dO_cls)
+        ops.attn_bwd_cls(self.qkv[i], self.o[i], self.dO_cls, self.lse[i], B, N, H, self.scale, dqkv=self.dqkv)
+        ops.gemm_nt(self.dqkv, st.WqkvT, None, out=self.dln)
+        ops.layernorm_bwd(self.dln, self.x[i], st.g1, self.mean1[i], self.rstd1[i], dres=self.G, out=self.G, out_bf16=copy)
+
     def _segment_a(self):
         self.refresh_weights()
         self._forward()
         self._backward_head()
-        for i in range(self.L - 1, self.L // 2 - 1, -1):
+        self._backward_last_block()
+        for i in range(self.L - 2, self.L // 2 - 1, -1):
             self._backward_block(i)
 
     def _segment_b(self):

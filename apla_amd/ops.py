@@ -221,6 +221,23 @@ def attn_bwd(qkv: torch.Tensor, o: torch.Tensor, do: torch.Tensor, lse: torch.Te
     return dqkv
 
 
+def attn_bwd_cls(qkv: torch.Tensor, o: torch.Tensor, do_cls: torch.Tensor, lse: torch.Tensor, B: int, N: int, H: int,
+                 scale: float, *, dqkv: Optional[torch.Tensor] = None):
+    """Attention backward for dO that is non-zero only at token 0 of every sequence; do_cls: [B, H*64] bf16."""
+    _req(qkv, torch.bfloat16, "qkv", 2), _req(o, torch.bfloat16, "o", 2), _req(do_cls, torch.bfloat16, "do_cls", 2)
+    _req(lse, torch.float32, "lse", 3)
+    if tuple(qkv.shape) != (B * N, 3 * H * 64) or tuple(o.shape) != (B * N, H * 64) or tuple(do_cls.shape) != (B, H * 64) \
+            or tuple(lse.shape) != (B, H, N) or not (qkv.is_contiguous() and o.is_contiguous() and do_cls.is_contiguous() and lse.is_contiguous()):
+        raise ValueError("attn_bwd_cls: shape mismatch / non-contiguous operand")
+    if dqkv is None:
+        dqkv = torch.empty_like(qkv)
+    if dqkv.shape != qkv.shape or not dqkv.is_contiguous() or dqkv.dtype != torch.bfloat16:
+        raise ValueError("attn_bwd_cls: bad dqkv buffer")
+    check(lib().apla_attn_bwd_cls(qkv.data_ptr(), o.data_ptr(), do_cls.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), B, N, H,
+                                  float(scale), _stream()), "apla_attn_bwd_cls")
+    return dqkv
+
+
 def attn_probs(qkv: torch.Tensor, lse: torch.Tensor, B: int, N: int, H: int, scale: float) -> torch.Tensor:
     _req(qkv, torch.bfloat16, "qkv", 2), _req(lse, torch.float32, "lse", 3)
     if tuple(qkv.shape) != (B * N, 3 * H * 64) or not qkv.is_contiguous() or tuple(lse.shape) != (B, H, N):

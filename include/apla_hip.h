@@ -93,6 +93,12 @@ int apla_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, flo
 int apla_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv, int B,
                   int N, int H, float scale, hipStream_t stream);
 
+/* Attention backward when only the CLS query (token 0 of every sequence) has a non-zero output gradient — the last ViT
+ * block under `x[:,0]` pooling (utils/transformers/vit.py:416-419).  do_cls is compact [B, H*64] (the CLS rows of dO);
+ * writes the full dqkv [B*N, 3*H*64] (dq is zero except token 0).  Same math as apla_attn_bwd, rank-1 per head. */
+int apla_attn_bwd_cls(const void* qkv, const void* o, const void* do_cls, const float* lse, void* dqkv, int B, int N,
+                      int H, float scale, hipStream_t stream);
+
 /* Materialise attn[B,H,N,N] (fp32) on demand — the second return value of APLA_Attention.forward (appla_attn.py:83),
  * used only by Block.forward(return_attention=True) (vit.py:279-287). */
 int apla_attn_probs(const void* qkv, const float* lse, float* attn, int B, int N, int H, float scale,

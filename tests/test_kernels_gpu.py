@@ -356,3 +356,20 @@ def test_gemm_variants_all_epilogues(ops, variant, M, N, K):
         assert rel_err(mlt.cpu(), (ad @ wd.t()) * gd) < BF16_OUT
     finally:
         lib().apla_gemm_set_variant(old)
+
+
+@pytest.mark.parametrize("B,N,H", [(3, 197, 2), (2, 5, 1), (1, 300, 3)])
+def test_attention_bwd_cls_only(ops, B, N, H):
+    """dO non-zero only at token 0 (last ViT block): the rank-1 kernel equals the general backward."""
+    D = 64 * H
+    scale = 64 ** -0.5
+    qkv, qkvd = bf(rnd(B, N, 3 * D, seed=91))
+    o, lse = ops.attn_fwd(dev(qkv).reshape(B * N, 3 * D), B, N, H, scale)
+    do_cls, dod = bf(rnd(B, D, seed=92))
+    do_full = torch.zeros(B, N, D, dtype=torch.float64)
+    do_full[:, 0] = dod
+    ref = O.attention_bwd(do_full, qkvd, o.cpu().double().reshape(B, N, D), lse.cpu().double(), H, scale)
+    got = ops.attn_bwd_cls(dev(qkv).reshape(B * N, 3 * D), o, dev(do_cls), lse, B, N, H, scale).cpu().reshape(B, N, 3 * D)
+    for i, nm in enumerate(("dq", "dk", "dv")):
+        assert rel_err(got[..., i * D:(i + 1) * D], ref[..., i * D:(i + 1) * D]) < 1e-2, nm
+    assert float(got[:, 1:, :D].abs().max()) == 0.0 if N > 1 else True
