@@ -21,7 +21,7 @@ SIGNATURES = {
                              c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "apla_gemm_set_variant": (c_int, [c_int]),
     "apla_layernorm_fwd": (c_int, [c_void_p, c_int, c_long, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
-                                   c_void_p, c_int, c_int, c_float, c_void_p]),
+                                   c_void_p, c_int, c_int, c_float, c_void_p, c_long, c_void_p, c_long, c_void_p]),
     "apla_layernorm_bwd": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_long, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_int, c_long, c_void_p, c_long, c_void_p, c_int, c_void_p,
                                    c_int, c_int, c_void_p]),

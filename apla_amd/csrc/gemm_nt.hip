@@ -1,18 +1,20 @@
-// bf16 MFMA GEMM  C[M,N] = A[M,K] · W[N,K]^T  with fused epilogues, for gfx950.
+// bf16 MFMA GEMM  C[M,N] = A[M,K] · W[N,K]^T  with fused epilogues, for gfx950: dispatcher + the 4-wave kernels.
 //
 // Every dense contraction on the APLA step is expressed in this "NT" form (both operands K-contiguous): forward
 // linears use the frozen weight as stored by nn.Linear ([out,in]); the dX backward uses a transposed bf16 copy of the
 // same frozen weight that the engine prepares once (288 GB of HBM makes the duplicate free), so no "NN" kernel exists.
 //
-// Tile 128x128x64, 256 threads = 4 waves (2x2), each wave 64x64 = 4x4 tiles of v_mfma_f32_16x16x32_bf16.
-//  * staging: __builtin_amdgcn_global_load_lds, 16 B per lane, straight into a double-buffered LDS image
-//    (2 x (16 KB A + 16 KB W)).  The LDS destination of an LDS-DMA is lane-linear, so the bank-conflict swizzle
-//    (16-byte chunk index XOR ((row>>1)&7)) is applied to the per-lane SOURCE address and again on the ds_read.
-//  * the MFMA is issued with the WEIGHT fragment as the A operand and the ACTIVATION fragment as the B operand, i.e.
-//    it computes C^T tiles: a lane then owns 4 consecutive output columns of one output row, which makes the epilogue
-//    (bias, GELU, residual, multiplier) a vector op on 8/16-byte global accesses.
-//  * blockIdx -> tile mapping is XCD-aware: each XCD walks a contiguous run of tiles with n fastest, so an A row
-//    panel is fetched into one L2 and reused by all N/128 column tiles.
+// Three schedules share the data layout, swizzles and epilogue code (gemm_common.h); apla_gemm_set_variant picks one:
+//   * gemm_pp2.hip — 8-wave ping-pong kernel, 320x256x32 tile, one workgroup per CU (STORE / GELU epilogues, large M);
+//   * gemm_persist_kernel (here) — 4 waves, (128|160)x128x64 tile, 2 persistent workgroups per CU whose LDS ring runs
+//     across tiles (no load prologue, epilogue overlapped with the next tile's LDS-DMA and with the co-resident
+//     workgroup's main loop); carries the operand epilogues (RESIDUAL, MUL, SwiGLU) and all small problems;
+//   * gemm_nt_kernel (here) — the simple non-persistent 128x128x64 kernel this work started from (A/B baseline).
+// Common to all: staging by __builtin_amdgcn_global_load_lds (16 B per lane) into an LDS image whose bank-conflict
+// swizzle is applied to the per-lane SOURCE address (an LDS-DMA destination is lane-linear) and again on the
+// ds_read_b128; v_mfma_f32_16x16x32_bf16 with the WEIGHT fragment as the A operand, i.e. C^T tiles, so that a lane owns
+// consecutive output columns of one output row and the epilogue is a vector op on 16-byte global accesses; XCD-aware
+// tile walk (gemm_common.h:tile_coords).
 #include "gemm_common.h"
 
 namespace {
@@ -142,71 +144,6 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams p) {
 }
 
 
-// ---- variant: S-stage LDS ring, counted vmcnt + raw s_barrier (LDS-DMA stays in flight across barriers) ----
-template <int EPI, typename OutT, int S>
-__global__ __launch_bounds__(256) void gemm_ring_kernel(GemmParams p) {
-  __shared__ __attribute__((aligned(16))) char smem[S * STAGE_BYTES];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int tm = wg / p.tiles_n, tn = wg - tm * p.tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
-  const bf16* a_src[4];
-  const bf16* w_src[4];
-#pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int piece = wave * 4 + it;
-    const int row = piece * 8 + (lane >> 3);
-    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-    int gr = m0 + row;
-    gr = gr < p.M ? gr : p.M - 1;
-    a_src[it] = p.A + (size_t)gr * p.lda + chunk * 8;
-    w_src[it] = p.W + (size_t)(n0 + row) * p.ldw + chunk * 8;
-  }
-  auto stage = [&](int s, int k0) {
-    char* base = smem + s * STAGE_BYTES;
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int piece = wave * 4 + it;
-      __builtin_amdgcn_global_load_lds(GLBP(a_src[it] + k0), LDSP(base + piece * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(GLBP(w_src[it] + k0), LDSP(base + BM * BK * 2 + piece * 1024), 16, 0, 0);
-    }
-  };
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int frow = lane & 15, fq = lane >> 4;
-  const int nk = p.K / BK;
-#pragma unroll
-  for (int s = 0; s < S - 1; ++s)
-    if (s < nk) stage(s, s * BK);
-  int cur = 0, nxt = S - 1;
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + S - 2 < nk) wait_vmcnt<(S - 2) * 8>(); else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    if (kt + S - 1 < nk) stage(nxt, (kt + S - 1) * BK);
-    const char* As = smem + cur * STAGE_BYTES;
-    const char* Ws = As + BM * BK * 2;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 af[4], wf[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(As + lds_off(wm * 64 + i * 16 + frow, ks * 4 + fq));
-#pragma unroll
-      for (int j = 0; j < 4; ++j) wf[j] = *(const bf16x8*)(Ws + lds_off(wn * 64 + j * 16 + frow, ks * 4 + fq));
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
-    }
-    cur = cur + 1 == S ? 0 : cur + 1;
-    nxt = nxt + 1 == S ? 0 : nxt + 1;
-  }
-  gemm_epilogue<EPI, OutT>(p, acc, m0, n0, wm, wn, lane);
-}
-
 // ---- persistent variant -------------------------------------------------------------------------------------------
 // 2 workgroups per CU stay resident and walk the tile list (each XCD owns a contiguous run of tiles, n fastest).  The
 // 2-stage LDS ring runs ACROSS tiles: during the last K-step of a tile the first K-step of the workgroup's next tile is
@@ -328,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void gemm_persist_kernel(GemmParams p, int 
   }
 }
 
-int g_variant = 4;  // tuning knob (apla_gemm_set_variant): 4 = auto, 9 = ping-pong, 14/15 = 128-wide persistent MI 4/5, 0 = 2-stage __syncthreads, 2/3 = S-stage ring
+int g_variant = 4;  // tuning knob (apla_gemm_set_variant): 4 = auto, 9 = ping-pong, 14/15 = 128-wide persistent MI 4/5, 0 = simple non-persistent kernel
 constexpr int RESIDENT_WGS = 512;  // 256 CUs x 2 workgroups (64-80 KB LDS, <=256 VGPR)
 
 template <int EPI, typename OutT, int MI>
@@ -371,9 +308,7 @@ int launch(const GemmParams& p, hipStream_t stream) {
   }
   const int tiles_m = (p.M + BM - 1) / BM;
   dim3 grid(tiles_m * p.tiles_n), block(256);
-  if (g_variant == 3) hipLaunchKernelGGL((gemm_ring_kernel<EPI, OutT, 3>), grid, block, 0, stream, p);
-  else if (g_variant == 2) hipLaunchKernelGGL((gemm_ring_kernel<EPI, OutT, 2>), grid, block, 0, stream, p);
-  else hipLaunchKernelGGL((gemm_nt_kernel<EPI, OutT>), grid, block, 0, stream, p);
+  hipLaunchKernelGGL((gemm_nt_kernel<EPI, OutT>), grid, block, 0, stream, p);
   APLA_CHECK_LAUNCH("apla_gemm_nt");
   return APLA_OK;
 }

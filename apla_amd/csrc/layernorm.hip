@@ -10,11 +10,15 @@ namespace {
 constexpr int MAXC = 8;  // row chunks of 4 elements per lane: D <= 64*4*MAXC = 2048 (kernels are instantiated per chunk count)
 constexpr int ROWS_PER_BLOCK = 4;
 
+// Optional fused residual add: x_new = x + add (add = bf16 branch output of the previous GEMM) is formed in registers,
+// written to xout and normalised in the same pass — the "x = x + branch" of vit.py:284-285 costs no kernel of its own and
+// no fp32 read-modify-write in a GEMM epilogue.
 template <typename ResT, typename YT, int NC>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const ResT* __restrict__ x, long xs, const float* __restrict__ gamma,
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const ResT* x, long xs, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, YT* __restrict__ y, int ldy,
                                                      float* __restrict__ mean_o, float* __restrict__ rstd_o, int M,
-                                                     int D, float eps) {
+                                                     int D, float eps, const bf16* __restrict__ add, long adds,
+                                                     ResT* xout, long xouts) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nchunk = D >> 2;
   for (int m = blockIdx.x * ROWS_PER_BLOCK + wave; m < M; m += gridDim.x * ROWS_PER_BLOCK) {
@@ -26,6 +30,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const ResT* __restrict__ x,
       const int ch = lane + c * 64;
       if (ch < nchunk) {
         v[c] = Vec4IO<ResT>::load(xr + ch * 4);
+        if (add != nullptr) {
+          v[c] += Vec4IO<bf16>::load(add + (size_t)m * adds + ch * 4);
+          Vec4IO<ResT>::store(xout + (size_t)m * xouts + ch * 4, v[c]);
+          if constexpr (sizeof(ResT) == 2) {  // statistics of the value as stored (bf16-rounded), like a separate LN pass would see
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[c][e] = (float)(bf16)v[c][e];
+          }
+        }
         s += v[c][0] + v[c][1] + v[c][2] + v[c][3];
       }
     }
@@ -137,12 +149,15 @@ inline int ln_grid(int M) {
 
 extern "C" int apla_layernorm_fwd(const void* x, int res_dtype, long x_row_stride, const float* gamma,
                                   const float* beta, void* y, int y_dtype, int ldy, float* mean, float* rstd, int M,
-                                  int D, float eps, hipStream_t stream) {
+                                  int D, float eps, const void* add_in, long add_row_stride, void* x_out,
+                                  long x_out_row_stride, hipStream_t stream) {
   APLA_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 256 * MAXC, "apla_layernorm_fwd: need D%%4==0 and D<=2048 (D=%d)", D);
   APLA_REQUIRE(x && y && gamma && beta && mean && rstd, "apla_layernorm_fwd: null pointer");
   APLA_REQUIRE(x_row_stride % 4 == 0 && ldy % 4 == 0 && x_row_stride >= D && ldy >= D, "apla_layernorm_fwd: strides must be >= D and multiples of 4");
   APLA_REQUIRE(apla_aligned16(x) && apla_aligned16(gamma) && apla_aligned16(beta) && (((uintptr_t)y) & 7) == 0, "apla_layernorm_fwd: alignment");
-#define LN_FWD_NC(T, Y, NCV) hipLaunchKernelGGL((ln_fwd_kernel<T, Y, NCV>), dim3(ln_grid(M)), dim3(256), 0, stream, (const T*)x, x_row_stride, gamma, beta, (Y*)y, ldy, mean, rstd, M, D, eps)
+  APLA_REQUIRE(add_in == nullptr || (x_out != nullptr && add_row_stride % 4 == 0 && add_row_stride >= D && x_out_row_stride % 4 == 0 && x_out_row_stride >= D),
+               "apla_layernorm_fwd: fused residual add needs x_out and valid strides");
+#define LN_FWD_NC(T, Y, NCV) hipLaunchKernelGGL((ln_fwd_kernel<T, Y, NCV>), dim3(ln_grid(M)), dim3(256), 0, stream, (const T*)x, x_row_stride, gamma, beta, (Y*)y, ldy, mean, rstd, M, D, eps, (const bf16*)add_in, add_row_stride, (T*)x_out, x_out_row_stride)
 #define LN_FWD(T, Y)                                    \
   do {                                                  \
     const int nc_ = (D + 255) / 256;                    \

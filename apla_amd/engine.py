@@ -225,6 +225,7 @@ class AplaTrainEngine:
         Fsave = (2 * self.blocks[0].F) if self.swiglu else self.blocks[0].F
         self.act_saved = [e(M, Fsave) for _ in range(L)]       # gelu'(a) or interleaved x12
         self.ln_out = e(M, D)
+        self.branch = e(M, D)  # bf16 branch output (projection / fc2) awaiting the fused residual add
         self.h = e(M, self.blocks[0].F)
         self.xn = e(B, D, dt=torch.float32)
         self.meanf, self.rstdf = e(B, dt=torch.float32), e(B, dt=torch.float32)
@@ -263,20 +264,29 @@ class AplaTrainEngine:
         ops.patchify(self.images, self.patch, self.Kp, out=self.cols)
         ops.gemm_nt(self.cols, self.Wpe, self.bpe, out=self.patches)
         ops.assemble_tokens(self.patches, self.cls, self.pos, B, self.Np, out=self.x[0])
+        # The residual updates x += branch (vit.py:284-285) are fused into the NEXT LayerNorm: the projection / fc2 GEMMs store
+        # their (LayerScale-folded) branch output in bf16 — as the reference's fp16-autocast Linear does before the fp32
+        # residual add — and the LN kernel forms x_new = x + branch in registers, writes it and normalises it in one pass.
+        # The GEMM epilogues stay operand-free (eligible for the ping-pong kernel), the adds cost no kernel of their own.
         for i, st in enumerate(self.blocks):
-            ops.layernorm_fwd(self.x[i], st.g1, st.b1, self.eps, out=self.ln_out, mean=self.mean1[i], rstd=self.rstd1[i])
+            if i == 0:
+                ops.layernorm_fwd(self.x[0], st.g1, st.b1, self.eps, out=self.ln_out, mean=self.mean1[0], rstd=self.rstd1[0])
+            else:
+                ops.layernorm_fwd(self.xmid[i - 1], st.g1, st.b1, self.eps, out=self.ln_out, mean=self.mean1[i],
+                                  rstd=self.rstd1[i], add=self.branch, x_out=self.x[i])
             ops.gemm_nt(self.ln_out, st.Wqkv, st.bqkv, out=self.qkv[i])
             ops.attn_fwd(self.qkv[i], B, N, H, self.scale, o=self.o[i], lse=self.lse[i])
-            ops.gemm_nt(self.o[i], st.Wnat, st.bnat, epilogue=ops.EPI_RESIDUAL, aux_in=self.x[i], out=self.xmid[i])
-            ops.layernorm_fwd(self.xmid[i], st.g2, st.b2, self.eps, out=self.ln_out, mean=self.mean2[i], rstd=self.rstd2[i])
+            ops.gemm_nt(self.o[i], st.Wnat, st.bnat, out=self.branch)
+            ops.layernorm_fwd(self.x[i], st.g2, st.b2, self.eps, out=self.ln_out, mean=self.mean2[i], rstd=self.rstd2[i],
+                              add=self.branch, x_out=self.xmid[i])
             if self.swiglu:
                 ops.gemm_nt(self.ln_out, st.W12, st.b12, epilogue=ops.EPI_SWIGLU, aux_out=self.act_saved[i], out=self.h)
             else:
                 ops.gemm_nt(self.ln_out, st.Wfc1, st.bfc1, epilogue=ops.EPI_GELU, aux_out=self.act_saved[i], out=self.h)
-            ops.gemm_nt(self.h, st.Wout, st.bout, epilogue=ops.EPI_RESIDUAL, aux_in=self.xmid[i], out=self.x[i + 1])
-        # final norm on the CLS rows only (vit.py:416-419), fp32 head + mean CE
-        ops.layernorm_fwd(self.x[self.L], self.gf, self.bf_, self.eps, out=self.xn, mean=self.meanf, rstd=self.rstdf,
-                          rows=B, row_stride=N * D)
+            ops.gemm_nt(self.h, st.Wout, st.bout, out=self.branch)
+        # final norm on the CLS rows only (vit.py:416-419) with the last residual add fused, fp32 head + mean CE
+        ops.layernorm_fwd(self.xmid[self.L - 1], self.gf, self.bf_, self.eps, out=self.xn, mean=self.meanf, rstd=self.rstdf,
+                          rows=B, row_stride=N * D, add=self.branch, x_out=self.x[self.L])
         ops.sgemm_small(self.xn, self._param_view("fc.weight"), trans_b=True, bias=self._param_view("fc.bias"),
                         out=self.logits)
         ops.cross_entropy(self.logits, self.labels, dlogits=self.dlogits, row_loss=self.row_loss, loss=self.loss)

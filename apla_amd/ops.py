@@ -92,9 +92,11 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = Non
 def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-6, *,
                   out_dtype=torch.bfloat16, rows: Optional[int] = None, row_stride: Optional[int] = None,
                   out: Optional[torch.Tensor] = None, mean: Optional[torch.Tensor] = None,
-                  rstd: Optional[torch.Tensor] = None):
-    """x: [M,D] residual stream (fp32|bf16).  With rows/row_stride given, x is a flat buffer and row m starts at
-    m*row_stride (CLS-row selection).  Returns (y [M,D], mean [M], rstd [M])."""
+                  rstd: Optional[torch.Tensor] = None, add: Optional[torch.Tensor] = None,
+                  x_out: Optional[torch.Tensor] = None):
+    """x: [M,D] residual stream (fp32|bf16).  With rows/row_stride given, x (and add / x_out) are flat buffers and row m
+    starts at m*row_stride (CLS-row selection).  With ``add`` (bf16 branch output) the residual update x_out = x + add is
+    fused (x_out may alias x).  Returns (y [M,D], mean [M], rstd [M])."""
     _req(x, None, "x")
     D = gamma.numel()
     if rows is None:
@@ -115,9 +117,20 @@ def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps:
     _req(out, None, "out", 2), _req(mean, torch.float32, "mean", 1), _req(rstd, torch.float32, "rstd", 1)
     if tuple(out.shape) != (M, D) or mean.numel() != M or rstd.numel() != M:
         raise ValueError("layernorm_fwd: bad output buffers")
+    adds = xouts = 0
+    if add is not None:
+        _req(add, torch.bfloat16, "add"), _req(x_out, x.dtype, "x_out")
+        if rows is None:
+            if tuple(add.shape) != (M, D) or tuple(x_out.shape) != (M, D):
+                raise ValueError("layernorm_fwd: add / x_out shape")
+            adds, xouts = add.stride(0), x_out.stride(0)
+        else:
+            adds = xouts = row_stride
+            if (M - 1) * row_stride + D > add.numel() or (M - 1) * row_stride + D > x_out.numel():
+                raise ValueError("layernorm_fwd: strided add / x_out exceed their buffers")
     rc = lib().apla_layernorm_fwd(x.data_ptr(), _DT[x.dtype], xs, gamma.data_ptr(), beta.data_ptr(), out.data_ptr(),
                                   _DT[out.dtype], out.stride(0), mean.data_ptr(), rstd.data_ptr(), M, D, float(eps),
-                                  _stream())
+                                  _ptr(add), adds, _ptr(x_out), xouts, _stream())
     check(rc, "apla_layernorm_fwd")
     return out, mean, rstd
 

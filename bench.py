@@ -24,6 +24,19 @@ sys.path.insert(0, ROOT)
 # algorithmic work per image for the configs of BASELINE.md §3 (forward + APLA backward, GFLOP)
 STEP_GF_PER_IMG = {"vit_small": 18.76, "vit_base": 70.99}
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
+PMC_FILE = os.path.join(ROOT, "profiles", "pmc_dominant_kernel.json")  # written by tools/measure_round.sh (separate --pmc passes)
+
+
+def dominant_kernel_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes: FETCH_SIZE and WRITE_SIZE are
+    in KiB; on gfx950 FETCH_SIZE reports half of the bytes of a wide coalesced read stream (MI355X_MICROARCH.md §HBM), so
+    it is doubled; WRITE_SIZE is exact for 16-byte-per-lane stores.  None when no PMC summary has been committed."""
+    try:
+        with open(PMC_FILE) as f:
+            d = json.load(f)
+        return (2.0 * d["FETCH_SIZE_KiB"] + d["WRITE_SIZE_KiB"]) * 1024.0
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def build_model(backbone, r, n_classes, img, patch, seed=0):
@@ -164,9 +177,11 @@ def main():
                        "hip_graphs": not args.no_graphs},
             "images_per_sec_per_gpu": round(img_s / world, 1), "peak_mem_gib": round(peak_mem, 2),
             "final_loss": round(loss, 4),
-            "roofline": {"bound": "mfma", "kernel": f"gemm_nt_kernel<GELU> fc1 M={M} N={eng.blocks[0].F} K={bb.embed_dim}",
+            "roofline": {"bound": "mfma", "kernel": f"gemm_pp2_kernel<GELU> (apla_gemm_nt, fc1+GELU launch) M={M} N={eng.blocks[0].F} K={bb.embed_dim}",
                          "achieved": round(k_tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(k_tf / PEAK_BF16_TFLOPS, 4), "traffic": None, "kernel_ms": round(k_ms, 4),
+                         "frac": round(k_tf / PEAK_BF16_TFLOPS, 4), "traffic": dominant_kernel_traffic(),
+                         "algorithmic_bytes": 2.0 * (M * bb.embed_dim + eng.blocks[0].F * bb.embed_dim + 2 * M * eng.blocks[0].F),
+                         "kernel_ms": round(k_ms, 4),
                          "step_achieved": round(step_tf, 1) if step_tf else None,
                          "step_frac": round(step_tf / PEAK_BF16_TFLOPS, 4) if step_tf else None,
                          "step_gflop_per_image": gf},

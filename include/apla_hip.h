@@ -57,15 +57,18 @@ int apla_gemm_nt(const void* A, int lda, const void* W, int ldw, const float* bi
  *   4  = auto (default): 8-wave ping-pong kernel (320x256x32 tile, gemm_pp2.hip) for M >= 2048, N % 256 == 0 and the
  *        STORE / GELU epilogues; otherwise the 4-wave persistent kernel (128/160 x 128 x 64 tile, gemm_nt.hip)
  *   9  = ping-pong wherever instantiated; 14 / 15 = 4-wave persistent kernel with BM 128 / 160
- *   0  = non-persistent 2-stage kernel; 2 / 3 = non-persistent S-stage LDS ring
+ *   0  = simple non-persistent 2-stage kernel (the round-1 starting point; kept as an in-tree A/B baseline)
  * Returns the previous value.  All variants compute the same results (tests/test_kernels_gpu.py). */
 int apla_gemm_set_variant(int variant);
 
-/* y = LayerNorm(x)*gamma+beta (y_dtype bf16, or f32 for the classifier-head input), saving mean/rstd (fp32).  x rows are `x_row_stride` elements apart so
- * the final-norm-on-CLS-rows case (vit.py:416-419) needs no gather.  Replaces nn.LayerNorm(eps=1e-6)
- * (vit.py:251,261,554). */
+/* y = LayerNorm(x [+ add_in])*gamma+beta (y_dtype bf16, or f32 for the classifier-head input), saving mean/rstd (fp32).
+ * x rows are `x_row_stride` elements apart so the final-norm-on-CLS-rows case (vit.py:416-419) needs no gather.
+ * If add_in != NULL (bf16 [M,D], the branch output of the preceding projection / fc2 GEMM) the residual update
+ * x_new = x + add_in of Block.forward (vit.py:284-285) is fused: x_new is written to x_out (residual dtype; may alias x)
+ * and normalised in the same pass.  Replaces nn.LayerNorm(eps=1e-6) (vit.py:251,261,554). */
 int apla_layernorm_fwd(const void* x, int res_dtype, long x_row_stride, const float* gamma, const float* beta,
                        void* y, int y_dtype, int ldy, float* mean, float* rstd, int M, int D, float eps,
+                       const void* add_in, long add_row_stride, void* x_out, long x_out_row_stride,
                        hipStream_t stream);
 
 /* dx_out = dres_in + LN_backward_dx(dy; x, gamma, mean, rstd)   (gamma/beta frozen: apla/apla_vit.py:80-81).

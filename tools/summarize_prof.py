@@ -19,13 +19,41 @@ def demangle(name):
     return name
 
 
+def manual_demangle(name):
+    """llvm-cxxfilt of this ROCm does not know DF16b (__bf16): decode `_ZN12_GLOBAL__N_1<len><ident>I<targs>E...` by hand."""
+    m = re.match(r"_ZN12_GLOBAL__N_1(\d+)", name)
+    if not m:
+        return name
+    n = int(m.group(1))
+    ident = name[m.end():m.end() + n]
+    rest = name[m.end() + n:]
+    targs = []
+    if rest.startswith("I"):
+        body = rest[1:]
+        while body and not body.startswith("E"):
+            if body.startswith("Li"):
+                v = re.match(r"Li(\d+)E", body); targs.append(v.group(1)); body = body[v.end():]
+            elif body.startswith("Lb"):
+                targs.append("true" if body[2] == "1" else "false"); body = body[4:]
+            elif body.startswith("DF16b"):
+                targs.append("bf16"); body = body[5:]
+            elif body[0] == "f":
+                targs.append("float"); body = body[1:]
+            else:
+                break
+    return f"{ident}<{', '.join(targs)}>" if targs else ident
+
+
 def short(name):
-    name = demangle(name)
+    if name.startswith("_ZN12_GLOBAL__N_1") and "DF16b" in name:
+        name = manual_demangle(name)
+    else:
+        name = demangle(name)
     name = re.sub(r"\(anonymous namespace\)::", "", name)
     name = name.replace("__bf16", "bf16")
-    m = re.match(r"(?:void )?gemm_nt_kernel<(\d), (\w+)>", name)
+    m = re.match(r"(?:void )?(gemm_\w+_kernel|gemm_nt_kernel)<(\d), (\w+)(.*)>", name)
     if m:
-        return f"gemm_nt_kernel<{EPI.get(m.group(1), m.group(1))},{m.group(2)}>"
+        return f"{m.group(1)}<{EPI.get(m.group(2), m.group(2))},{m.group(3)}{m.group(4)}>"
     name = re.sub(r"^void ", "", name)
     name = re.sub(r"\(.*$", "", name)
     if name.startswith("at::native"):
