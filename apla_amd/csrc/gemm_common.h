@@ -71,9 +71,16 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 
 template <typename T> struct Vec8IO;
 template <> struct Vec8IO<float> {
+  static __device__ __forceinline__ f32x4 pack(f32x4 lo, f32x4 hi) { return lo + hi; }
   static __device__ __forceinline__ void store(float* p, f32x4 lo, f32x4 hi) { *(f32x4*)p = lo; *(f32x4*)(p + 4) = hi; }
 };
 template <> struct Vec8IO<bf16> {
+  static __device__ __forceinline__ bf16x8 pack(f32x4 lo, f32x4 hi) {
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o[e] = (bf16)lo[e]; o[4 + e] = (bf16)hi[e]; }
+    return o;
+  }
   static __device__ __forceinline__ void store(bf16* p, f32x4 lo, f32x4 hi) {
     bf16x8 o;
 #pragma unroll
@@ -249,13 +256,48 @@ template <int EPI, typename OutT> struct WideEpi {
   static constexpr int L = HAS_AUX ? (sizeof(AuxT) == 4 ? 8 : 4) : 0;                       // aux loads per row
   static constexpr int S = (EPI == APLA_EPI_GELU) ? 8 : ((EPI == APLA_EPI_MUL) ? 4 : (sizeof(OutT) == 4 ? 8 : 4));  // stores per row
   static constexpr int NST = 5 * S;
+  static constexpr bool LINES = !HAS_AUX && sizeof(OutT) == 2 && (EPI == APLA_EPI_STORE || EPI == APLA_EPI_GELU);  // whole-line stores via LDS
 };
 
+// GELU and GELU' of 8 accumulator values, packed to bf16.  Four values at a time, each group's packed results pinned by an
+// (empty) volatile asm: left alone hipcc computes all h first and keeps phi and E of every element for the g pass, and
+// the epilogue — which starts with all 160 accumulators live — then spills lane constants that the K loop reloads with
+// vmcnt(0) in front of every LDS-DMA.
+__device__ __forceinline__ void gelu8(f32x4 lo, f32x4 hi, bf16x8& h, bf16x8& g) {
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  unsigned hp[4], gp[4];
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const f32x4 a = half ? hi : lo;
+    float x[4], y[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) gelu_and_grad(a[e], x[e], y[e]);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      bf16x2_t hh, gg;
+      hh[0] = (bf16)x[2 * e]; hh[1] = (bf16)x[2 * e + 1]; gg[0] = (bf16)y[2 * e]; gg[1] = (bf16)y[2 * e + 1];
+      hp[2 * half + e] = __builtin_bit_cast(unsigned, hh);
+      gp[2 * half + e] = __builtin_bit_cast(unsigned, gg);
+    }
+  }
+  asm volatile("" : "+v"(hp[0]), "+v"(gp[0]), "+v"(hp[1]), "+v"(gp[1]), "+v"(hp[2]), "+v"(gp[2]), "+v"(hp[3]), "+v"(gp[3]));
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  h = __builtin_bit_cast(bf16x8, u32x4_t{hp[0], hp[1], hp[2], hp[3]});
+  g = __builtin_bit_cast(bf16x8, u32x4_t{gp[0], gp[1], gp[2], gp[3]});
+}
+
+// bf16 outputs without a second operand go through a per-wave 2 KB LDS buffer `tbuf` (16 rows x 128 B, 16-B chunk c of row
+// r at chunk c ^ (r >> 1): conflict-free both ways) so that a store instruction writes 8 rows x 128 B = whole cache lines.
+// In the MFMA layout a wave instruction covers 16 rows x 64 B, and a CU then stores at ~23 GB/s whatever the rest of the
+// chip does; with whole lines one CU reaches ~80 GB/s and only the chip-wide HBM rate bounds it (tools/store_probe.hip).
 template <int EPI, typename OutT>
-__device__ __forceinline__ void wide_epilogue(const GemmParams& p, f32x4 (&acc)[5][8], const float* bias_lds, int m0,
-                                              int n0, int wm, int wn, int lane, bool full_tile) {
+__device__ __forceinline__ void wide_epilogue(const GemmParams& p, f32x4 (&acc)[5][8], const float* bias_lds, char* tbuf,
+                                              int m0, int n0, int wm, int wn, int lane, bool full_tile) {
   using E = WideEpi<EPI, OutT>;
   using AuxT = typename E::AuxT;
+  // every address below derives from this opaque copy of the lane id, so hipcc cannot hoist the (loop-invariant) address
+  // arithmetic out of the persistent loop, where it would stay live across the MFMA phases and push other values to scratch
+  asm volatile("" : "+v"(lane));
   const int frow = lane & 15, fq = lane >> 4;
   const int ncol = wn * 128 + fq * 8;  // + 32*u
   if (p.bias != nullptr) {
@@ -265,6 +307,45 @@ __device__ __forceinline__ void wide_epilogue(const GemmParams& p, f32x4 (&acc)[
 #pragma unroll
       for (int i = 0; i < 5; ++i) { acc[i][2 * u] += blo; acc[i][2 * u + 1] += bhi; }
     }
+  }
+  if constexpr (E::LINES) {
+    char* wr0 = tbuf + frow * 128 + ((fq ^ (frow >> 1)) << 4);         // logical chunk fq
+    char* wr1 = tbuf + frow * 128 + (((4 + fq) ^ (frow >> 1)) << 4);   // logical chunk 4 + fq
+    const int rrow = lane >> 3, rc = lane & 7;
+    const char* rd0 = tbuf + rrow * 128 + ((rc ^ (rrow >> 1)) << 4);
+    const char* rd1 = tbuf + (rrow + 8) * 128 + ((rc ^ ((rrow + 8) >> 1)) << 4);
+    const int mbase = m0 + wm * 80 + rrow;
+    const size_t cbase = (size_t)n0 + wn * 128 + rc * 8;
+    auto flush = [&](bf16* dst, int ld, int i, int h, bf16x8 c0, bf16x8 c1) {
+      *(bf16x8*)wr0 = c0;
+      *(bf16x8*)wr1 = c1;
+      const bf16x8 r0 = *(const bf16x8*)rd0, r1 = *(const bf16x8*)rd1;
+      const int ma = mbase + i * 16, mb = ma + 8;
+#if defined(APLA_ABL_NOSTORE)
+      asm volatile("" :: "v"(r0), "v"(r1));
+#else
+      if (ma < p.M) *(bf16x8*)(dst + (size_t)ma * ld + cbase + h * 64) = r0;
+      if (mb < p.M) *(bf16x8*)(dst + (size_t)mb * ld + cbase + h * 64) = r1;
+#endif
+    };
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const f32x4 a0 = acc[i][4 * h], a1 = acc[i][4 * h + 1], b0 = acc[i][4 * h + 2], b1 = acc[i][4 * h + 3];
+        if constexpr (EPI == APLA_EPI_STORE) {
+          flush((bf16*)p.C, p.ldc, i, h, Vec8IO<bf16>::pack(a0, a1), Vec8IO<bf16>::pack(b0, b1));
+        } else {
+          bf16x8 hc0, gc0, hc1, gc1;
+          gelu8(a0, a1, hc0, gc0);
+          gelu8(b0, b1, hc1, gc1);
+          flush((bf16*)p.C, p.ldc, i, h, hc0, hc1);
+          flush((bf16*)p.aux_out, p.ld_aux_out, i, h, gc0, gc1);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the (i, h) groups apart: interleaving them costs registers, not time
+      }
+    }
+    return;
   }
   AuxRegs<AuxT> aux[2][4];  // two rows in flight
   auto row_ptr = [&](int i) {
@@ -295,11 +376,31 @@ __device__ __forceinline__ void wide_epilogue(const GemmParams& p, f32x4 (&acc)[
       }
     }
     const int m = m0 + wm * 80 + i * 16 + frow;
+#if defined(APLA_ABL_NOEPI)
+    if (m < -p.M) {  // diagnostic build: keep the code, never execute it
+#else
     if (m < p.M) {
+#endif
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int n = n0 + ncol + 32 * u;
         const f32x4 lo = acc[i][2 * u], hi = acc[i][2 * u + 1];
+#if defined(APLA_ABL_NOSTORE)
+        if constexpr (EPI == APLA_EPI_STORE) {
+          auto r = Vec8IO<OutT>::pack(lo, hi);
+          asm volatile("" :: "v"(r));
+        } else if constexpr (EPI == APLA_EPI_GELU) {
+          f32x4 hl, hh, gl, gh;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float a, b;
+            gelu_and_grad(lo[e], a, b); hl[e] = a; gl[e] = b;
+            gelu_and_grad(hi[e], a, b); hh[e] = a; gh[e] = b;
+          }
+          auto r0 = Vec8IO<bf16>::pack(hl, hh), r1 = Vec8IO<bf16>::pack(gl, gh);
+          asm volatile("" :: "v"(r0), "v"(r1));
+        } else
+#endif
         if constexpr (EPI == APLA_EPI_STORE || EPI == APLA_EPI_RESIDUAL) {
           Vec8IO<OutT>::store((OutT*)p.C + (size_t)m * p.ldc + n, lo, hi);
         } else if constexpr (EPI == APLA_EPI_MUL) {

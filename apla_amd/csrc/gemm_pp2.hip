@@ -29,7 +29,7 @@ constexpr int QAHEAD = 3;
 template <int EPI, typename OutT>
 __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmParams p, int tiles_m) {
   using E = WideEpi<EPI, OutT>;
-  __shared__ __attribute__((aligned(16))) char smem[QNS * QSTG + 2048];  // + two bias pieces (256 floats each)
+  __shared__ __attribute__((aligned(16))) char smem[QNS * QSTG + 2048 + 4 * 2048];  // + two bias pieces (256 floats each) + four 2 KB epilogue line buffers
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave >> 2, lw = wave & 3, wm = lw >> 1, wn = lw & 1;
@@ -48,50 +48,61 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmParams p, int tile
 
   // ------------------------------------------------------------------ LDS-DMA stream
   // piece c = 5*wave + it of the combined list [A0..A19 | W0..W15 | 4 x W15 again]; a piece is 16 LDS rows x 64 B; lane i
-  // fills row 16*piece + (i>>2), physical chunk i&3, from logical chunk (i&3) ^ ((-(i>>4)) & 3)
+  // fills row 16*piece + (i>>2), physical chunk i&3, from logical chunk (i&3) ^ ((-(i>>4)) & 3).
+  // Addresses are (wave-uniform base in SGPRs) + (32-bit lane offset): two lane constants cover every piece of every
+  // tile; only a tile that hangs over the M edge recomputes clamped row offsets (keeps VGPRs for the accumulators).
   const int srow = lane >> 2;
   const int koff = ((lane & 3) ^ ((-(srow >> 2)) & 3)) * 8;
-  const bf16* src[QGRP];
-  int d_step = 0, d_k = 0, d_tile = 0;
-  auto dma_setup = [&](int ordinal) {
-    const int tile = xbeg + slot + ordinal * slots;
-    int tm, tn;
-    tile_coords(tile, tiles_m, tiles_n, p.ngrp, tm, tn);
+  // waves 0-3 stream the 20 A pieces (c = 5*wave + it), waves 4-7 the 16 W pieces (+ 4 duplicates of the last one)
+  const bool a_wave = wave < 4;
+  const unsigned lane_off = a_wave ? ((unsigned)srow * (unsigned)p.lda + koff) * 2u
+                                   : ((unsigned)(8 * (srow >> 2) + (srow & 3)) * (unsigned)p.ldw + koff) * 2u;
+  int d_step = 0, d_k = 0, d_tile = 0, d_tm = 0, d_tn = 0, d_slot = 0;
+  bool d_edge = false;
+  // wave-uniform addressing: one operand base per tile (SGPR pair) + this wave's five piece offsets (fixed for the kernel)
+  unsigned poff[QGRP];
 #pragma unroll
-    for (int it = 0; it < QGRP; ++it) {
-      int c = wave * QGRP + it;
-      c = c < 36 ? c : 35;
-      if (c < 20) {
-        int gr = tm * QBM + c * 16 + srow;
-        gr = gr < p.M ? gr : p.M - 1;
-        src[it] = p.A + (size_t)gr * p.lda + koff;
-      } else {
-        // W piece pw = c-20 fills LDS rows 16*pw + srow = (wn'=pw>>3)*128 + (j=pw&7)*16 + srow, which hold W row
-        //   wn'*128 + 32*(j>>1) + 8*(srow>>2) + 4*(j&1) + (srow&3)     (MFMA order, see gemm_common.h)
-        const int pw = c - 20, j = pw & 7;
-        const int wrow = tn * QBN + (pw >> 3) * 128 + 32 * (j >> 1) + 8 * (srow >> 2) + 4 * (j & 1) + (srow & 3);
-        src[it] = p.W + (size_t)wrow * p.ldw + koff;
-      }
-    }
-  };
+  for (int it = 0; it < QGRP; ++it) {
+    int c = wave * QGRP + it;
+    c = c < 36 ? c : 35;
+    // W piece pw = c-20 fills LDS rows 16*pw + srow = (wn'=pw>>3)*128 + (j=pw&7)*16 + srow, which hold W row
+    //   wn'*128 + 32*(j>>1) + 8*(srow>>2) + 4*(j&1) + (srow&3)     (MFMA order, see gemm_common.h)
+    const int pw = c - 20, j = pw & 7;
+    poff[it] = a_wave ? (unsigned)(c * 16) * (unsigned)p.lda * 2u
+                      : (unsigned)((pw >> 3) * 128 + 32 * (j >> 1) + 4 * (j & 1)) * (unsigned)p.ldw * 2u;
+  }
+  const char* tbase = nullptr;
   auto dma_issue = [&]() {
     if (d_step >= s_total) return;
-    if (d_k == 0) dma_setup(d_tile);
-    char* base = smem + __builtin_amdgcn_readfirstlane((d_step % QNS) * QSTG);
-    const int k0 = d_k * QBK;
+    if (d_k == 0) {
+      tile_coords(xbeg + slot + d_tile * slots, tiles_m, tiles_n, p.ngrp, d_tm, d_tn);
+      d_edge = a_wave && d_tm * QBM + QBM > p.M;
+      tbase = a_wave ? (const char*)(p.A + (size_t)(d_tm * QBM) * p.lda) : (const char*)(p.W + (size_t)(d_tn * QBN) * p.ldw);
+    }
+    char* base = smem + d_slot * QSTG + (a_wave ? wave * QGRP * 1024 : 0);
+    const int kb = d_k * QBK * 2;  // byte offset of this K-step inside a row
+    if (!d_edge) {
 #pragma unroll
-    for (int it = 0; it < QGRP; ++it) {
-      int c = wave * QGRP + it;
-      c = c < 36 ? c : 35;
-      __builtin_amdgcn_global_load_lds(GLBP(src[it] + k0), LDSP(base + c * 1024), 16, 0, 0);  // W pieces follow A: c*1024
+      for (int it = 0; it < QGRP; ++it) {
+        int c = wave * QGRP + it;
+        c = c < 36 ? c : 35;
+        char* dst = a_wave ? base + it * 1024 : base + c * 1024;
+        __builtin_amdgcn_global_load_lds(GLBP(tbase + kb + poff[it] + lane_off), LDSP(dst), 16, 0, 0);
+      }
+    } else {  // A rows hang over the M edge: clamp them (reads stay inside A; those rows are never stored)
+#pragma unroll
+      for (int it = 0; it < QGRP; ++it) {
+        const int c = wave * QGRP + it;
+        int gr = d_tm * QBM + c * 16 + srow;
+        gr = gr < p.M ? gr : p.M - 1;
+        const unsigned off = ((unsigned)gr * (unsigned)p.lda + koff) * 2u;
+        __builtin_amdgcn_global_load_lds(GLBP((const char*)p.A + kb + off), LDSP(base + it * 1024), 16, 0, 0);
+      }
     }
-    if (d_k == 0 && has_bias && wave == 0) {
-      const int tile = xbeg + slot + d_tile * slots;
-      int tm_, tn;
-      tile_coords(tile, tiles_m, tiles_n, p.ngrp, tm_, tn);
-      __builtin_amdgcn_global_load_lds(GLBP(p.bias + tn * QBN + lane * 4), LDSP(smem + QNS * QSTG + (d_tile & 1) * 1024), 16, 0, 0);
-    }
+    if (d_k == 0 && has_bias && wave == 0)
+      __builtin_amdgcn_global_load_lds(GLBP(p.bias + d_tn * QBN + lane * 4), LDSP(smem + QNS * QSTG + (d_tile & 1) * 1024), 16, 0, 0);
     ++d_step;
+    d_slot = (d_slot + 1) & (QNS - 1);
     if (++d_k == nk) { d_k = 0; ++d_tile; }
   };
 
@@ -101,8 +112,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmParams p, int tile
   const int foff = frow * 64 + ((fq ^ ((-(frow >> 2)) & 3)) << 4);
   const int a_off = (grp * 160 + wm * 80) * 64 + foff;
   const int w_off = QA_BYTES + (wn * 128) * 64 + foff;
-  auto read_frags = [&](int s) {
-    const char* st = smem + __builtin_amdgcn_readfirstlane((s % QNS) * QSTG);
+  int r_slot = 0;  // ring slot of the next K-step to read
+  auto read_frags = [&]() {
+    const char* st = smem + r_slot * QSTG;
+    r_slot = (r_slot + 1) & (QNS - 1);
 #pragma unroll
     for (int i = 0; i < 5; ++i) af[i] = *(const bf16x8*)(st + a_off + i * 1024);
 #pragma unroll
@@ -132,30 +145,32 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmParams p, int tile
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
   };
-  bool relaxed = false;
+  int relaxed = 0;
   auto epilogue = [&](int ordinal) {
     const int tile = xbeg + slot + ordinal * slots;
     int tm, tn;
     tile_coords(tile, tiles_m, tiles_n, p.ngrp, tm, tn);
     const int m0 = tm * QBM + grp * 160, n0 = tn * QBN;
     const bool full = m0 + 160 <= p.M;
-    wide_epilogue<EPI, OutT>(p, acc, (const float*)(smem + QNS * QSTG + (ordinal & 1) * 1024), m0, n0, wm, wn, lane, full);
+    wide_epilogue<EPI, OutT>(p, acc, (const float*)(smem + QNS * QSTG + (ordinal & 1) * 1024), smem + QNS * QSTG + 2048 + lw * 2048,
+                              m0, n0, wm, wn, lane, full);
     asm volatile("" ::: "memory");
     zero_acc();
-    relaxed = full;
+    relaxed = full ? 3 : 0;
   };
   // end of even phase 2s: K-step s+1 must have landed everywhere (group 0 reads it in phase 2s+1).  Every wave has issued
-  // its shares up to K-step s+3 by now, so two younger groups may stay in flight (fewer at the very end), plus — once
-  // after a full tile's epilogue — that tile's stores.
+  // its shares up to K-step s+3 by now, so two younger groups may stay in flight (fewer at the very end).  A full tile's
+  // epilogue issues its stores right AFTER the share of K-step s+3, so for the next three waits the stores sit behind the
+  // K-step being waited for in the (in-order) vmcnt queue and may stay in flight too.
   auto end_even_phase = [&](int s) {
     if (s + 3 < s_total) {
-      if (relaxed) wait_vmcnt<2 * QGRP + E::NST>(); else wait_vmcnt<2 * QGRP>();
+      if (relaxed > 0) wait_vmcnt<2 * QGRP + E::NST>(); else wait_vmcnt<2 * QGRP>();
     } else if (s + 2 < s_total) {
       wait_vmcnt<QGRP>();
     } else {
       wait_vmcnt<0>();
     }
-    relaxed = false;
+    --relaxed;
   };
 
   // ------------------------------------------------------------------ prologue: K-steps 0..2 issued by everyone
@@ -164,21 +179,29 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmParams p, int tile
   dma_issue();
   if (s_total > 2) wait_vmcnt<2 * QGRP>(); else wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
+  // A phase that prepares a K-step reads its fragments FIRST and does the LDS-DMA issue and the bookkeeping while those
+  // reads are in flight; only at a tile boundary the order is DMA, epilogue, reads (the epilogue needs the fragment
+  // registers, and its stores must queue behind the DMA share: see end_even_phase).
+  int kk = 0, ord = 0;
   if (grp == 0) {
-    dma_issue();  // share of K-step 3 (phase -1)
-    read_frags(0);
+    read_frags();  // K-step 0
+    dma_issue();   // share of K-step 3 (phase -1)
     frags_landed();
     __builtin_amdgcn_s_barrier();
     for (int s = 0; s < s_total; ++s) {
       compute();  // phase 2s
       end_even_phase(s);
       __builtin_amdgcn_s_barrier();
-      if (((s + 1) % nk) == 0) epilogue((s + 1) / nk - 1);  // phase 2s+1: prepare K-step s+1
-      if (s + 1 < s_total) {
-        dma_issue();  // share of K-step s+4
-        read_frags(s + 1);
-        frags_landed();
+      const bool more = s + 1 < s_total;  // phase 2s+1: prepare K-step s+1, issue the share of K-step s+4
+      const bool tile_end = ++kk == nk;
+      if (tile_end) {
+        kk = 0;
+        dma_issue();
+        epilogue(ord++);
       }
+      if (more) read_frags();  // one call site: two would merge 52 fragment registers through PHI copies
+      if (!tile_end) dma_issue();
+      if (more) frags_landed();
       __builtin_amdgcn_s_barrier();
     }
     wait_vmcnt<0>();
@@ -186,16 +209,22 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmParams p, int tile
   } else {
     __builtin_amdgcn_s_barrier();
     for (int s = 0; s < s_total; ++s) {
-      if (s > 0 && (s % nk) == 0) epilogue(s / nk - 1);  // phase 2s: prepare K-step s
-      dma_issue();  // share of K-step s+3
-      read_frags(s);
+      const bool tile_end = kk == nk;  // phase 2s: prepare K-step s, issue the share of K-step s+3
+      if (tile_end) {
+        kk = 0;
+        dma_issue();
+        epilogue(ord++);
+      }
+      read_frags();
+      if (!tile_end) dma_issue();
+      ++kk;
       frags_landed();
       end_even_phase(s);
       __builtin_amdgcn_s_barrier();
       compute();  // phase 2s+1
       __builtin_amdgcn_s_barrier();
     }
-    epilogue(my_tiles - 1);
+    epilogue(ord);
     __builtin_amdgcn_s_barrier();
   }
 }
@@ -204,6 +233,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmParams p, int tile
 
 int apla_gemm_pp2_launch(const GemmParams& p_in, int epilogue, int out_dtype, hipStream_t stream) {
   if (p_in.N % QBN != 0 || p_in.K % QBK != 0 || p_in.K < 4 * QBK) return APLA_ENOSYS;
+  if ((size_t)p_in.M * p_in.lda >= (1ull << 30) || (size_t)p_in.N * p_in.ldw >= (1ull << 30)) return APLA_ENOSYS;  // 32-bit operand offsets
   GemmParams p = p_in;
   p.ngrp = pick_ngrp(p.N / QBN, QBN, p.K);
   const int tiles_m = (p.M + QBM - 1) / QBM;

@@ -4,6 +4,9 @@ variant, interleaved rounds in one process (cdna guide rule 24), random data (ru
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from apla_amd import _lib
+if os.environ.get("APLA_LIB"):  # A/B experiments against another build of the library (tool only)
+    _lib.LIB_PATH = os.environ["APLA_LIB"]
 from apla_amd import ops
 from apla_amd._lib import lib
 
