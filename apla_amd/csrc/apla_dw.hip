@@ -9,6 +9,8 @@
 // (2) apla_pack_proj_rows: scatter the r trainable rows (scaled by gamma) into the natural-order bf16 weight, its
 //     transposed copy and the natural-order bias.  This replaces the two activation-side scatter_ calls of the
 //     reference forward (appla_attn.py:70-79) by a weight-side scatter of r*D elements per step.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -32,122 +34,243 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* lds, int rbase, int c0, in
   return out;
 }
 
-constexpr int TJ = 64, TK = 128, TM = 64;  // output tile 64 (j) x 128 (k); 64 token rows per step
+// Transposed fragments by inline asm with base + immediate addressing.  (a) Next to in-flight LDS-DMA hipcc puts
+// s_waitcnt vmcnt(0) in front of every ds_read_b64_tr_b16 it can see (draining the ring each step); the asm form is waited
+// for by hand (lgkmcnt).  (b) The swizzle term of tile_off does not depend on the 16-row step ks (rows move by 16) nor on
+// the sub-tile, so a lane needs one address per (column half, row half) and everything else is an immediate: left to the
+// compiler, the ~110 fragment addresses of a step were recomputed every step (~1000 VALU ops, 2 us per step).
+__device__ __forceinline__ unsigned tr_base(const char* tile, int c0, int half, int lane) {
+  const int g = lane >> 4, i = lane & 15;
+  const int col = c0 + 16 * (g & 1) + 4 * (i & 3);
+  const int r = 4 * (g >> 1) + (i >> 2) + 8 * half;
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(tile + tile_off(r, col >> 3) + ((col & 4) << 1));
+}
+template <int OFF> __device__ __forceinline__ bf16x4 tr_read(unsigned addr) {
+  bf16x4 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+__device__ __forceinline__ bf16x8 join8(bf16x4 lo, bf16x4 hi) {
+  bf16x8 o;
+  o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
+  o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
+  return o;
+}
 
-// grid = (tiles_k * tiles_j, S).  partial layout: [S][r][D] fp32, then [S][r] fp32 for the bias sums.
+template <int I> struct IntC { static constexpr int value = I; };
+template <int B, int E, typename F> __device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < E) { f(IntC<B>{}); static_for<B + 1, E>(f); }
+}
+
+constexpr int TJ = 64, TK = 128, TM = 64;  // j granule 64; output tile (64*NJ) x 128 (k); 64 token rows per step
+
+// One workgroup: NJ*64 trainable rows (j) x 128 input features (k) over one slab of tokens.  The four waves split k
+// (32 columns each) and keep all NJ*64 rows: with r = 192 = 3*64 the activation x is then read ONCE in total and dyg
+// D/128 times (L2 hits), instead of r/64 and D/128 times.
+// Operands stream global -> LDS by LDS-DMA (16 B per lane, 1 KB pieces of 8 rows x 128 B; the XOR swizzle of tile_off is
+// applied on the SOURCE column because the LDS side of a DMA is lane-linear) through a 3-stage ring: two 64-token steps
+// are in flight while one is multiplied, one s_barrier per step, counted vmcnt (never 0 inside the loop).
+// grid = 8 * ceil(S/8) * tiles_k * j_groups (1-D).  partial layout: [S][r][D] fp32, then [S][r] fp32 for the bias sums.
+#define DW_LDSP(p) ((__attribute__((address_space(3))) void*)(p))
+#define DW_GLBP(p) ((const __attribute__((address_space(1))) void*)(p))
+template <int N> __device__ __forceinline__ void dw_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int NJ>
 __global__ __launch_bounds__(256) void proj_dw_partial_kernel(const bf16* __restrict__ dyg, const bf16* __restrict__ x,
                                                               int ldx, float* __restrict__ partial, int M, int r,
-                                                              int D, int rows_per_slab) {
-  __shared__ __attribute__((aligned(16))) char smem[3 * 8192];
-  char* Ys = smem;          // [64 m][64 j]
-  char* Xs = smem + 8192;   // 2 x [64 m][64 k]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h2 = lane >> 5;
-  const int tiles_k = D / TK;
-  const int tj = blockIdx.x / tiles_k, tk = blockIdx.x - tj * tiles_k;
-  const int j0 = tj * TJ, k0 = tk * TK;
-  const int slab = blockIdx.y;
+                                                              int D, int rows_per_slab, int S) {
+  constexpr int STG = (NJ + 2) * 8192, NS = 3, PW = (NJ + 2) * 2;  // stage bytes; ring depth; pieces per wave per step
+  __shared__ __attribute__((aligned(16))) char smem[NS * STG];
+  const int tid = threadIdx.x, lane = tid & 63, h2 = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // Workgroup ids are dealt round-robin to the 8 XCDs: all (tj, tk) tiles of one token slab get ids of the same residue
+  // mod 8, so the slab's dyg and x rows are fetched from HBM once and shared through that XCD's L2.
+  const int tiles_k = D / TK, tiles = tiles_k * (r / (TJ * NJ));
+  const int xcd = blockIdx.x & 7, n = blockIdx.x >> 3;
+  const int tile = n % tiles, slab = (n / tiles) * 8 + xcd;
+  if (slab >= S) return;
+  const int tj = tile / tiles_k, tk = tile - tj * tiles_k;
+  const int j0 = tj * (TJ * NJ), k0 = tk * TK;
   const int m_begin = slab * rows_per_slab;
   int m_end = m_begin + rows_per_slab;
   m_end = m_end < M ? m_end : M;
+  const int nsteps = m_end > m_begin ? (m_end - m_begin + TM - 1) / TM : 0;
 
-  const int wj = (wave & 1) * 32;   // this wave's 32 output rows (j) inside the tile
-  const int wk = (wave >> 1) * 64;  // and its 64 output columns (k): two 32-wide MFMA tiles
-  f32x16 acc[2];
+  // piece p = wave*PW + it: sub-tile p>>3 (Y sub-tiles first), rows 8*(p&7) + (lane>>3), physical chunk lane&7
+  auto issue = [&](int step) {
+    char* st = smem + (step % NS) * STG;
+    const int mb = m_begin + step * TM;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
-  float bsum = 0.f;  // threads 0..63 of the tk==0 workgroups: column sum of dyg for j = j0 + tid
+    for (int it = 0; it < PW; ++it) {
+      const int pc = wave * PW + it, sub = pc >> 3;
+      const int row = 8 * (pc & 7) + (lane >> 3);
+      const int f = (((row >> 1) & 1) << 2) | ((row >> 2) & 3);
+      const int c = (lane & 7) ^ f;  // logical 16-byte chunk that lands at physical chunk lane&7 of this row
+      int m = mb + row;
+      m = m < M ? m : M - 1;  // tail rows are zeroed in LDS after they land (below)
+      const bf16* src = sub < NJ ? dyg + (size_t)m * r + j0 + sub * 64 + c * 8
+                                 : x + (size_t)m * ldx + k0 + (sub - NJ) * 64 + c * 8;
+      __builtin_amdgcn_global_load_lds(DW_GLBP(src), DW_LDSP(st + pc * 1024), 16, 0, 0);
+    }
+  };
 
-  for (int mb = m_begin; mb < m_end; mb += TM) {
-    // stage: dyg tile 64x64 (2 chunks/thread), x tile 64x128 (4 chunks/thread); rows >= m_end are zero-filled
-    bf16x8 yv[2], xv[4];
+  const int wk = wave * 32;  // this wave's 32 output columns (k)
+  f32x16 acc[2 * NJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int e = tid + i * 256, row = e >> 3, chunk = e & 7;
-      const int m = mb + row;
-      if (m < m_end) yv[i] = *(const bf16x8*)(dyg + (size_t)m * r + j0 + chunk * 8);
-      else {
+  for (int t = 0; t < 2 * NJ; ++t)
 #pragma unroll
-        for (int q = 0; q < 8; ++q) yv[i][q] = (bf16)0.f;
-      }
-    }
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  float bsum[2 * NJ];  // tk==0 workgroups: column sums of dyg (the bias gradient), wave w sums the token rows of ks == w
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int e = tid + i * 256, row = (e >> 3) & 63, chunk = e & 7, sub = e >> 9;
-      const int m = mb + row;
-      if (m < m_end) xv[i] = *(const bf16x8*)(x + (size_t)m * ldx + k0 + sub * 64 + chunk * 8);
-      else {
+  for (int t = 0; t < 2 * NJ; ++t) bsum[t] = 0.f;
+
+  // fragment base addresses (stage 0, ks = 0, sub-tile 0): [column half of the 64-wide sub-tile][row half]
+  unsigned yb[2][2], xb[2];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) xv[i][q] = (bf16)0.f;
-      }
-    }
-    __syncthreads();  // previous step's fragment reads are done
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int e = tid + i * 256, row = e >> 3, chunk = e & 7;
-      *(bf16x8*)(Ys + tile_off(row, chunk)) = yv[i];
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int e = tid + i * 256, row = (e >> 3) & 63, chunk = e & 7, sub = e >> 9;
-      *(bf16x8*)(Xs + sub * 8192 + tile_off(row, chunk)) = xv[i];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const bf16x8 a = tr_frag(Ys, 16 * ks, wj, lane);  // A[row = j][k' = m]
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int kc = wk + 32 * t;
-        const bf16x8 b = tr_frag(Xs + (kc >> 6) * 8192, 16 * ks, kc & 63, lane);  // B[k' = m][col = k]
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
-      }
-    }
-    if (tk == 0 && tid < 64) {
-      const int chunk = tid >> 3, within = (tid & 7) * 2;
-#pragma unroll 8
-      for (int row = 0; row < 64; ++row) bsum += (float)*(const bf16*)(Ys + tile_off(row, chunk) + within);
-    }
+  for (int hh = 0; hh < 2; ++hh) {
+    yb[0][hh] = tr_base(smem, 0, hh, lane);
+    yb[1][hh] = tr_base(smem, 32, hh, lane);
+    xb[hh] = tr_base(smem + NJ * 8192 + (wk >> 6) * 8192, wk & 63, hh, lane);
   }
-  // D[j][k]: lane col = k (lane&31), rows j = acc_row(reg, h2)
-  float* P = partial + (size_t)slab * r * D;
+  if (nsteps > 0) issue(0);
+  if (nsteps > 1) issue(1);
+  for (int s = 0; s < nsteps; ++s) {
+    if (s + 1 < nsteps) dw_wait_vmcnt<PW>(); else dw_wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();  // stage s has landed for every wave; everyone is done reading stage s-1
+#if !defined(APLA_ABL_DWNODMA)
+    if (s + 2 < nsteps) issue(s + 2);
+#endif
+    char* Ys = smem + (s % NS) * STG;  // NJ x [64 m][64 j]
+    char* Xs = Ys + NJ * 8192;         // 2 x [64 m][64 k]
+    const int valid = m_end - (m_begin + s * TM);  // token rows of this step that exist (< 64 only at the very end of M)
+    // Rows past the end were fetched from a clamped address: their dyg fragment elements are forced to zero (element e
+    // of a transposed fragment is token row 16*ks + 8*(e>>2) + 4*(lane>>5) + (e&3)).  No LDS writes here: a plain LDS
+    // store next to in-flight LDS-DMA makes hipcc drain vmcnt(0) in front of the fragment reads of every step.
+    const unsigned so = (unsigned)((s % NS) * STG);
+    const unsigned xa0 = xb[0] + so, xa1 = xb[1] + so;
+    const unsigned ya00 = yb[0][0] + so, ya01 = yb[0][1] + so, ya10 = yb[1][0] + so, ya11 = yb[1][1] + so;
+    static_for<0, 4>([&](auto KS) {
+      constexpr int ks = KS.value;
+      bf16x4 blo, bhi, alo[2 * NJ], ahi[2 * NJ];
+      blo = tr_read<2048 * ks>(xa0);  // B[k' = m][col = k]
+      bhi = tr_read<2048 * ks>(xa1);
+      static_for<0, 2 * NJ>([&](auto T) {  // A[row = j][k' = m]
+        constexpr int t = T.value;
+        alo[t] = tr_read<2048 * ks + 8192 * (t >> 1)>((t & 1) ? ya10 : ya00);
+        ahi[t] = tr_read<2048 * ks + 8192 * (t >> 1)>((t & 1) ? ya11 : ya01);
+      });
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      const bf16x8 b = join8(blo, bhi);
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < 2 * NJ; ++t) {
+        bf16x8 a = join8(alo[t], ahi[t]);
+        if (valid < TM) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (16 * ks + 8 * (e >> 2) + 4 * h2 + (e & 3) >= valid) a[e] = (bf16)0.f;
+        }
+#if defined(APLA_ABL_DWNOMFMA)
+        asm volatile("" :: "v"(a), "v"(b));
+#else
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
+#endif
+        if (tk == 0 && ks == wave) {  // lane holds dyg[8 token rows][j = 32t + (lane&31)]
+          float sm = 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) sm += (float)a[e];
+          bsum[t] += sm;
+        }
+      }
+    });
+  }
+  // D[j][k]: lane col = k (lane&31), rows j = acc_row(reg, h2).  The tile goes through LDS (the ring is idle now) so that
+  // the partial slab is written with 16-byte stores of whole 512-byte rows instead of 32*NJ dword stores per wave.
+  __syncthreads();
+  float* Ts = (float*)smem;  // [64*NJ][128] fp32, row pitch 132 floats (bank spread for the column-wise writes)
+#pragma unroll
+  for (int t = 0; t < 2 * NJ; ++t)
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
-      const int j = j0 + wj + (reg & 3) + 8 * (reg >> 2) + 4 * h2;
-      const int k = k0 + wk + 32 * t + (lane & 31);
-      P[(size_t)j * D + k] = acc[t][reg];
+      const int j = 32 * t + (reg & 3) + 8 * (reg >> 2) + 4 * h2;
+      Ts[j * 132 + wk + (lane & 31)] = acc[t][reg];
     }
-  if (tk == 0 && tid < 64) partial[(size_t)gridDim.y * r * D + (size_t)slab * r + j0 + tid] = bsum;
+  __syncthreads();
+  float* P = partial + (size_t)slab * r * D;
+  for (int e = tid; e < 64 * NJ * 32; e += 256) {
+    const int j = e >> 5, c4 = (e & 31) * 4;
+    *(f32x4*)(P + (size_t)(j0 + j) * D + k0 + c4) = *(const f32x4*)(Ts + j * 132 + c4);
+  }
+  if (tk == 0) {  // fold the two lane halves, then the four waves (fixed order), through LDS
+    __syncthreads();
+    float* Bs = (float*)smem;  // [4 waves][64*NJ]
+#pragma unroll
+    for (int t = 0; t < 2 * NJ; ++t) {
+      const float v = bsum[t] + __shfl_xor(bsum[t], 32, 64);
+      if (h2 == 0) Bs[wave * 64 * NJ + 32 * t + (lane & 31)] = v;
+    }
+    __syncthreads();
+    if (tid < 64 * NJ)
+      partial[(size_t)S * r * D + (size_t)slab * r + j0 + tid] =
+          (Bs[tid] + Bs[64 * NJ + tid]) + (Bs[2 * 64 * NJ + tid] + Bs[3 * 64 * NJ + tid]);
+  }
 }
 
+// Slab sum in a fixed order (bitwise reproducible).  Four lanes share one float4 of the output: lane q of the quad sums
+// slabs q, q+4, q+8, ... (eight loads in flight), then the quad is folded 0+2, 1+3, (0+2)+(1+3).
 __global__ __launch_bounds__(256) void proj_dw_reduce_kernel(const float* __restrict__ partial,
                                                              const float* __restrict__ row_scale,
                                                              float* __restrict__ dW1, float* __restrict__ db1, int r,
                                                              int D, int S, int accumulate) {
   const long n4 = (long)r * D / 4;
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const long i = t >> 2;
+  const int q = (int)(t & 3);
+  const size_t stride = (size_t)r * D;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
   if (i < n4) {
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int sl = 0; sl < S; ++sl) s += *(const f32x4*)(partial + (size_t)sl * r * D + i * 4);
+    const float* src = partial + i * 4;
+    for (int sl = q; sl < S; sl += 64) {  // sixteen loads in flight; slabs past S contribute zero
+      f32x4 v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (sl + 4 * u < S) v[u] = *(const f32x4*)(src + (size_t)(sl + 4 * u) * stride);
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) s += v[u];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    s[e] += __shfl_xor(s[e], 2, 64);
+    s[e] += __shfl_xor(s[e], 1, 64);
+  }
+  if (i < n4 && q == 0) {
     const int j = (int)(i * 4 / D);
     if (row_scale != nullptr) s *= row_scale[j];
     if (accumulate) s += *(const f32x4*)(dW1 + i * 4);
     *(f32x4*)(dW1 + i * 4) = s;
   }
-  if (i < r) {
-    const float* pb = partial + (size_t)S * r * D;
-    float s = 0.f;
-    for (int sl = 0; sl < S; ++sl) s += pb[(size_t)sl * r + i];
-    if (row_scale != nullptr) s *= row_scale[i];
-    if (accumulate) s += db1[i];
-    db1[i] = s;
+  if (t < r) {
+    const float* pb = partial + (size_t)S * stride;
+    float b = 0.f;
+    for (int sl = 0; sl < S; ++sl) b += pb[(size_t)sl * r + t];
+    if (row_scale != nullptr) b *= row_scale[t];
+    if (accumulate) b += db1[t];
+    db1[t] = b;
   }
 }
 
+inline int dw_group(int r) { return r % 192 == 0 ? 3 : (r % 128 == 0 ? 2 : 1); }  // 64-row granules per workgroup
+
 inline int dw_slabs(int M, int r, int D) {
-  const int tiles = (r / TJ) * (D / TK);
-  int S = (448 + tiles - 1) / tiles;  // ~1.75 workgroups per CU: enough parallelism, fewer partial slabs to write and re-read
+  const int tiles = (r / (TJ * dw_group(r))) * (D / TK);
+  int S = 256 / tiles / 8 * 8;  // a multiple of 8 (one slab set per XCD), at most one workgroup per CU
+#if defined(APLA_ABL_DWSLABS)  // diagnostic build: slab count from the environment
+  if (const char* e = getenv("APLA_DW_SLABS")) S = atoi(e);
+#endif
+  if (S < 8) S = 8;             // every slab costs an r x D fp32 partial to write and re-read
   const int max_s = (M + TM - 1) / TM;
   if (S > max_s) S = max_s;
   if (S < 1) S = 1;
@@ -185,10 +308,14 @@ extern "C" int apla_proj_dw(const void* dyg, const void* x, int ldx, const float
   APLA_REQUIRE(ldx % 8 == 0 && ldx >= D && apla_aligned16(dyg) && apla_aligned16(x) && apla_aligned16(dW1) && apla_aligned16(partial), "apla_proj_dw: alignment");
   const int S = dw_slabs(M, r, D);
   int rows_per_slab = ((M + S - 1) / S + TM - 1) / TM * TM;
-  hipLaunchKernelGGL(proj_dw_partial_kernel, dim3((r / TJ) * (D / TK), S), dim3(256), 0, stream, (const bf16*)dyg, (const bf16*)x, ldx, (float*)partial, M, r, D, rows_per_slab);
+  const int nj = dw_group(r);
+  const dim3 grid(8 * ((S + 7) / 8) * (r / (TJ * nj)) * (D / TK));
+  if (nj == 3) hipLaunchKernelGGL(proj_dw_partial_kernel<3>, grid, dim3(256), 0, stream, (const bf16*)dyg, (const bf16*)x, ldx, (float*)partial, M, r, D, rows_per_slab, S);
+  else if (nj == 2) hipLaunchKernelGGL(proj_dw_partial_kernel<2>, grid, dim3(256), 0, stream, (const bf16*)dyg, (const bf16*)x, ldx, (float*)partial, M, r, D, rows_per_slab, S);
+  else hipLaunchKernelGGL(proj_dw_partial_kernel<1>, grid, dim3(256), 0, stream, (const bf16*)dyg, (const bf16*)x, ldx, (float*)partial, M, r, D, rows_per_slab, S);
   APLA_CHECK_LAUNCH("apla_proj_dw[partial]");
   const long n4 = (long)r * D / 4;
-  hipLaunchKernelGGL(proj_dw_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, (const float*)partial, row_scale, dW1, db1, r, D, S, accumulate);
+  hipLaunchKernelGGL(proj_dw_reduce_kernel, dim3((unsigned)((4 * n4 + 255) / 256)), dim3(256), 0, stream, (const float*)partial, row_scale, dW1, db1, r, D, S, accumulate);
   APLA_CHECK_LAUNCH("apla_proj_dw[reduce]");
   return APLA_OK;
 }

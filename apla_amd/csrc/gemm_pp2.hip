@@ -74,13 +74,20 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmParams p, int tile
   const char* tbase = nullptr;
   auto dma_issue = [&]() {
     if (d_step >= s_total) return;
+#if defined(APLA_ABL_NODMA)  // diagnostic build: only the first stages are streamed
+    if (d_step > 8) { ++d_step; d_slot = (d_slot + 1) & (QNS - 1); if (++d_k == nk) { d_k = 0; ++d_tile; } return; }
+#endif
     if (d_k == 0) {
       tile_coords(xbeg + slot + d_tile * slots, tiles_m, tiles_n, p.ngrp, d_tm, d_tn);
       d_edge = a_wave && d_tm * QBM + QBM > p.M;
       tbase = a_wave ? (const char*)(p.A + (size_t)(d_tm * QBM) * p.lda) : (const char*)(p.W + (size_t)(d_tn * QBN) * p.ldw);
     }
     char* base = smem + d_slot * QSTG + (a_wave ? wave * QGRP * 1024 : 0);
+#if defined(APLA_ABL_SAMEK)  // diagnostic build: every K-step streams the k = 0 slice again (cache-resident source)
+    const int kb = 0;
+#else
     const int kb = d_k * QBK * 2;  // byte offset of this K-step inside a row
+#endif
     if (!d_edge) {
 #pragma unroll
       for (int it = 0; it < QGRP; ++it) {
@@ -116,6 +123,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmParams p, int tile
   auto read_frags = [&]() {
     const char* st = smem + r_slot * QSTG;
     r_slot = (r_slot + 1) & (QNS - 1);
+#if defined(APLA_ABL_NOREAD)  // diagnostic build: fragments are read once
+    if (r_slot != 1 || d_step > 8) return;
+#endif
 #pragma unroll
     for (int i = 0; i < 5; ++i) af[i] = *(const bf16x8*)(st + a_off + i * 1024);
 #pragma unroll
