@@ -20,6 +20,7 @@ SIGNATURES = {
     "apla_gemm_nt": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                              c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "apla_gemm_set_variant": (c_int, [c_int]),
+    "apla_attn_set_variant": (c_int, [c_int]),
     "apla_layernorm_fwd": (c_int, [c_void_p, c_int, c_long, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                    c_void_p, c_int, c_int, c_float, c_void_p, c_long, c_void_p, c_long, c_void_p]),
     "apla_layernorm_bwd": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_long, c_void_p, c_void_p, c_void_p,

@@ -91,6 +91,11 @@ int apla_gather_cols(const void* src, int res_dtype, long src_row_stride, const 
  * Replaces appla_attn.py:53-60 without materialising attn[B,H,N,N].  head_dim must be 64. */
 int apla_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, float scale, hipStream_t stream);
 
+/* Tuning/diagnostic knob for apla_attn_fwd / apla_attn_bwd (process-wide): 0 = auto (default): sequences of up to 256 tokens
+ * use the one-workgroup-per-head kernels that keep the whole K/V (Q/dO) of a head in LDS; 1 = always the key-blocked
+ * kernels.  Returns the previous value.  Both compute the same results (tests/test_kernels_gpu.py). */
+int apla_attn_set_variant(int variant);
+
 /* Attention backward from (qkv, o, do, lse): dqkv[B*N, 3*H*64].  `delta` is a caller workspace of B*H*N floats.
  * Deterministic (no atomics).  Autograd of appla_attn.py:53-60. */
 int apla_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv, int B,

@@ -181,8 +181,19 @@ def test_layernorm_cls_rows_strided(ops):
 
 
 # ------------------------------------------------------------------------------------------- attention
-@pytest.mark.parametrize("B,N,H", [(2, 197, 2), (1, 64, 1), (3, 300, 3), (1, 1, 1), (2, 129, 2), (1, 1370, 1)])
-def test_attention_fwd_bwd(ops, B, N, H):
+@pytest.fixture
+def attn_variant(request):
+    """0 = auto (one-workgroup-per-head kernels for N <= 256), 1 = always the key-blocked kernels."""
+    from apla_amd._lib import lib
+    old = lib().apla_attn_set_variant(request.param)
+    yield request.param
+    lib().apla_attn_set_variant(old)
+
+
+@pytest.mark.parametrize("attn_variant", [0, 1], indirect=True)
+@pytest.mark.parametrize("B,N,H", [(2, 197, 2), (1, 64, 1), (3, 300, 3), (1, 1, 1), (2, 129, 2), (1, 1370, 1), (2, 256, 3),
+                                   (1, 33, 2), (2, 224, 1)])
+def test_attention_fwd_bwd(ops, attn_variant, B, N, H):
     D = 64 * H
     scale = 64 ** -0.5
     qkv, qkvd = bf(rnd(B, N, 3 * D, seed=31))
@@ -203,7 +214,8 @@ def test_attention_fwd_bwd(ops, B, N, H):
     assert rel_err(attn.cpu(), aref) < 1e-4
 
 
-def test_attention_online_softmax_rescale_branch(ops):
+@pytest.mark.parametrize("attn_variant", [0, 1], indirect=True)
+def test_attention_online_softmax_rescale_branch(ops, attn_variant):
     """Force the running max to jump at a later key block (guide rule 26): one key spikes against every query."""
     B, N, H = 1, 200, 1
     scale = 64 ** -0.5
