@@ -101,17 +101,32 @@ __device__ __forceinline__ void store_acc_T(const f32x16 (&acc)[2], bf16* rowptr
     }
 }
 
+// Sequence geometry.  Uniform batch (cu == nullptr): sequence b holds tokens [b*N, (b+1)*N) and lse/delta are [B, H, N].
+// Packed variable-length batch (block-diagonal attention, appla_attn_mem_eff.py:40-42 with a BlockDiagonalMask): sequence b
+// holds tokens [cu[b], cu[b+1]) of one [total, ...] activation and lse/delta are [H, total].
+struct Seq { int start, n; long stat; int stat_h; };  // stat index of (h, q) = stat + h*stat_h + q
+__device__ __forceinline__ Seq seq_of(const int32_t* __restrict__ cu, int b, int N, int H, int total) {
+  Seq s;
+  if (cu != nullptr) { s.start = cu[b]; s.n = cu[b + 1] - s.start; s.stat = s.start; s.stat_h = total; }
+  else { s.start = b * N; s.n = N; s.stat = (long)b * H * N; s.stat_h = N; }
+  return s;
+}
+
 // ------------------------------------------------------------------------------------------------ forward
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
-                                                       float* __restrict__ lse, int N, int H, float scale) {
+                                                       float* __restrict__ lse, int Nmax, int H, float scale,
+    const int32_t* __restrict__ cu, int total) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 8192];
   char* Ks = smem;
   char* Vs = smem + 8192;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h2 = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128;
+  const Seq sq = seq_of(cu, b, Nmax, H, total);
+  const int N = sq.n;
+  if (q0 >= N) return;  // packed batches: this sequence is shorter than the grid's longest
   const int D = H * 64;
   const long ld = 3L * D;
-  const bf16* base = qkv + (long)b * N * ld + h * 64;
+  const bf16* base = qkv + (long)sq.start * ld + h * 64;
   const float c = scale * LOG2E;
 
   int q = q0 + wave * 32 + (lane & 31);
@@ -197,8 +212,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
   }
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   if (qvalid) {
-    store_acc_T(acc_o, o + ((long)b * N + q) * D + h * 64, h2, 1.0f / l_tot);
-    if (h2 == 0) lse[((long)b * H + h) * N + q] = m_run * scale + __logf(l_tot);
+    store_acc_T(acc_o, o + ((long)sq.start + q) * D + h * 64, h2, 1.0f / l_tot);
+    if (h2 == 0) lse[sq.stat + (long)h * sq.stat_h + q] = m_run * scale + __logf(l_tot);
   }
 }
 
@@ -213,15 +228,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
 constexpr int SMALL_MAX_ROWS = 256;
 
 __global__ __launch_bounds__(512, 4) void attn_fwd_small_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
-                                                                float* __restrict__ lse, int N, int H, float scale) {
+                                                                float* __restrict__ lse, int Nmax, int H, float scale,
+    const int32_t* __restrict__ cu, int total) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // K rows [NP][64] then V rows [NP][64], NP = 32 * waves
   const int tid = threadIdx.x, lane = tid & 63, h2 = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nw = blockDim.x >> 6, NP = nw * 32;
   const int b = blockIdx.y, h = blockIdx.x;
+  const Seq sq = seq_of(cu, b, Nmax, H, total);
+  const int N = sq.n;
+  if (N <= 0) return;
   const int D = H * 64;
   const long ld = 3L * D;
-  const bf16* base = qkv + (long)b * N * ld + h * 64;
+  const bf16* base = qkv + (long)sq.start * ld + h * 64;
   const float c = scale * LOG2E;
   char* Ks = smem;
   char* Vs = smem + NP * 128;
@@ -253,6 +272,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_small_kernel(const bf16* __re
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  if (wave * 32 >= N) return;  // packed batches: waves past this sequence's end only helped loading
 
   const int nkb = (N + 63) / 64;
   for (int kb = 0; kb < nkb; ++kb) {
@@ -313,24 +333,27 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_small_kernel(const bf16* __re
   }
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   if (qvalid) {
-    store_acc_T(acc_o, o + ((long)b * N + q) * D + h * 64, h2, 1.0f / l_tot);
-    if (h2 == 0) lse[((long)b * H + h) * N + q] = m_run * scale + __logf(l_tot);
+    store_acc_T(acc_o, o + ((long)sq.start + q) * D + h * 64, h2, 1.0f / l_tot);
+    if (h2 == 0) lse[sq.stat + (long)h * sq.stat_h + q] = m_run * scale + __logf(l_tot);
   }
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dQ (+delta)
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
                                                           const bf16* __restrict__ dout, const float* __restrict__ lse,
-                                                          float* __restrict__ delta, bf16* __restrict__ dqkv, int N,
-                                                          int H, float scale) {
+                                                          float* __restrict__ delta, bf16* __restrict__ dqkv, int Nmax, int H, float scale,
+    const int32_t* __restrict__ cu, int total) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 8192];
   char* Ks = smem;
   char* Vs = smem + 8192;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h2 = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128;
+  const Seq sq = seq_of(cu, b, Nmax, H, total);
+  const int N = sq.n;
+  if (q0 >= N) return;  // packed batches: this sequence is shorter than the grid's longest
   const int D = H * 64;
   const long ld = 3L * D;
-  const bf16* base = qkv + (long)b * N * ld + h * 64;
+  const bf16* base = qkv + (long)sq.start * ld + h * 64;
   const float c = scale * LOG2E;
 
   int q = q0 + wave * 32 + (lane & 31);
@@ -338,18 +361,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restr
   if (!qvalid) q = N - 1;
   bf16x8 qf[4], dof[4];
   load_row_frags(qf, base + (long)q * ld, lane);
-  load_row_frags(dof, dout + ((long)b * N + q) * D + h * 64, lane);
+  load_row_frags(dof, dout + ((long)sq.start + q) * D + h * 64, lane);
   float dl = 0.f;
   {
     bf16x8 of[4];
-    load_row_frags(of, o + ((long)b * N + q) * D + h * 64, lane);
+    load_row_frags(of, o + ((long)sq.start + q) * D + h * 64, lane);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
       for (int j = 0; j < 8; ++j) dl += (float)dof[ks][j] * (float)of[ks][j];
   }
   dl += __shfl_xor(dl, 32, 64);
-  const long statidx = ((long)b * H + h) * N + q;
+  const long statidx = sq.stat + (long)h * sq.stat_h + q;
   const bool wave_active = q0 + wave * 32 < N;
   if (qvalid && h2 == 0) delta[statidx] = dl;
   const float lse2 = lse[statidx] * LOG2E;
@@ -399,7 +422,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restr
       }
     }
   }
-  if (qvalid) store_acc_T(acc_dq, dqkv + ((long)b * N + q) * ld + h * 64, h2, scale);
+  if (qvalid) store_acc_T(acc_dq, dqkv + ((long)sq.start + q) * ld + h * 64, h2, scale);
 }
 
 // ------------------------------------------------------------------------------------------------ backward dQ, short sequences
@@ -409,15 +432,19 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_dq_small_kernel(const bf16* _
                                                                    const bf16* __restrict__ dout,
                                                                    const float* __restrict__ lse,
                                                                    float* __restrict__ delta, bf16* __restrict__ dqkv,
-                                                                   int N, int H, float scale) {
+                                                                   int Nmax, int H, float scale,
+    const int32_t* __restrict__ cu, int total) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // K rows [NP][64] then V rows [NP][64], NP = 32 * waves
   const int tid = threadIdx.x, lane = tid & 63, h2 = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nw = blockDim.x >> 6, NP = nw * 32;
   const int b = blockIdx.y, h = blockIdx.x;
+  const Seq sq = seq_of(cu, b, Nmax, H, total);
+  const int N = sq.n;
+  if (N <= 0) return;
   const int D = H * 64;
   const long ld = 3L * D;
-  const bf16* base = qkv + (long)b * N * ld + h * 64;
+  const bf16* base = qkv + (long)sq.start * ld + h * 64;
   const float c = scale * LOG2E;
   char* Ks = smem;
   char* Vs = smem + NP * 128;
@@ -439,18 +466,18 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_dq_small_kernel(const bf16* _
   if (!qvalid) q = N - 1;
   bf16x8 qf[4], dof[4];
   load_row_frags(qf, base + (long)q * ld, lane);
-  load_row_frags(dof, dout + ((long)b * N + q) * D + h * 64, lane);
+  load_row_frags(dof, dout + ((long)sq.start + q) * D + h * 64, lane);
   float dl = 0.f;
   {
     bf16x8 of[4];
-    load_row_frags(of, o + ((long)b * N + q) * D + h * 64, lane);
+    load_row_frags(of, o + ((long)sq.start + q) * D + h * 64, lane);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
       for (int j = 0; j < 8; ++j) dl += (float)dof[ks][j] * (float)of[ks][j];
   }
   dl += __shfl_xor(dl, 32, 64);
-  const long statidx = ((long)b * H + h) * N + q;
+  const long statidx = sq.stat + (long)h * sq.stat_h + q;
   if (qvalid && h2 == 0) delta[statidx] = dl;
   const float lse2 = lse[statidx] * LOG2E;
 
@@ -460,6 +487,7 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_dq_small_kernel(const bf16* _
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  if (wave * 32 >= N) return;  // packed batches: waves past this sequence's end only helped loading
 
   const int nkt = (N + 31) / 32;
   for (int kt = 0; kt < nkt; ++kt) {
@@ -486,14 +514,15 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_dq_small_kernel(const bf16* _
         acc_dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Ks, kt * 32 + 16 * sk, 32 * dt, lane), dsb, acc_dq[dt], 0, 0, 0);
     }
   }
-  if (qvalid) store_acc_T(acc_dq, dqkv + ((long)b * N + q) * ld + h * 64, h2, scale);
+  if (qvalid) store_acc_T(acc_dq, dqkv + ((long)sq.start + q) * ld + h * 64, h2, scale);
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ dout,
                                                            const float* __restrict__ lse,
                                                            const float* __restrict__ delta, bf16* __restrict__ dqkv,
-                                                           int N, int H, float scale) {
+                                                           int Nmax, int H, float scale,
+    const int32_t* __restrict__ cu, int total) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 8192 + 2 * 64 * 4];
   char* Qs = smem;
   char* dOs = smem + 8192;
@@ -501,12 +530,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __rest
   float* dls = lses + 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h2 = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * 128;
+  const Seq sq = seq_of(cu, b, Nmax, H, total);
+  const int N = sq.n;
+  if (k0 >= N) return;  // packed batches: this sequence is shorter than the grid's longest
   const int D = H * 64;
   const long ld = 3L * D;
-  const bf16* base = qkv + (long)b * N * ld + h * 64;
-  const bf16* dobase = dout + (long)b * N * D + h * 64;
-  const float* lsebase = lse + ((long)b * H + h) * N;
-  const float* dlbase = delta + ((long)b * H + h) * N;
+  const bf16* base = qkv + (long)sq.start * ld + h * 64;
+  const bf16* dobase = dout + (long)sq.start * D + h * 64;
+  const float* lsebase = lse + sq.stat + (long)h * sq.stat_h;
+  const float* dlbase = delta + sq.stat + (long)h * sq.stat_h;
   const float c = scale * LOG2E;
 
   int key = k0 + wave * 32 + (lane & 31);
@@ -577,7 +609,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __rest
     }
   }
   if (kvalid) {
-    bf16* orow = dqkv + ((long)b * N + key) * ld + h * 64;
+    bf16* orow = dqkv + ((long)sq.start + key) * ld + h * 64;
     store_acc_T(acc_dk, orow + D, h2, scale);
     store_acc_T(acc_dv, orow + 2 * D, h2, 1.0f);
   }
@@ -650,19 +682,43 @@ __global__ __launch_bounds__(256) void attn_bwd_cls_kernel(const bf16* __restric
 static int g_attn_variant = 0;  // 0 = auto (short-sequence kernels when N <= 256), 1 = always the blocked kernels (tests)
 extern "C" int apla_attn_set_variant(int v) { const int old = g_attn_variant; g_attn_variant = v; return old; }
 
+// B sequences of (at most) N tokens; cu == nullptr: uniform batch, else packed with cu[B+1] token offsets and `total` tokens
+static int launch_attn_fwd(const void* qkv, void* o, float* lse, const int32_t* cu, int total, int B, int N, int H,
+                           float scale, hipStream_t stream, const char* who) {
+  if (N <= SMALL_MAX_ROWS && g_attn_variant != 1) {
+    const int nw = (N + 31) / 32;
+    hipLaunchKernelGGL(attn_fwd_small_kernel, dim3(H, B), dim3(64 * nw), (size_t)nw * 32 * 256, stream, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, cu, total);
+  } else {
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3((N + 127) / 128, H, B), dim3(256), 0, stream, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, cu, total);
+  }
+  APLA_CHECK_LAUNCH(who);
+  return APLA_OK;
+}
+
+static int launch_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv,
+                           const int32_t* cu, int total, int B, int N, int H, float scale, hipStream_t stream,
+                           const char* who) {
+  dim3 grid((N + 127) / 128, H, B);
+  if (N <= SMALL_MAX_ROWS && g_attn_variant != 1) {
+    const int nw = (N + 31) / 32;
+    hipLaunchKernelGGL(attn_bwd_dq_small_kernel, dim3(H, B), dim3(64 * nw), (size_t)nw * 32 * 256, stream, (const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse, delta, (bf16*)dqkv, N, H, scale, cu, total);
+  } else {
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, stream, (const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse, delta, (bf16*)dqkv, N, H, scale, cu, total);
+  }
+  APLA_CHECK_LAUNCH(who);
+  // dK/dV stay on the key-blocked kernel: a one-pass variant with Q/dO of the head in LDS measured 7 % slower (it needs
+  // ~200 VGPRs either way, so it gains no occupancy)
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, stream, (const bf16*)qkv, (const bf16*)d_o, lse, delta, (bf16*)dqkv, N, H, scale, cu, total);
+  APLA_CHECK_LAUNCH(who);
+  return APLA_OK;
+}
+
 extern "C" int apla_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, float scale,
                              hipStream_t stream) {
   APLA_REQUIRE(qkv && o && lse && B > 0 && N > 0 && H > 0, "apla_attn_fwd: bad arguments");
   APLA_REQUIRE(apla_aligned16(qkv) && apla_aligned16(o), "apla_attn_fwd: pointers must be 16-byte aligned");
   APLA_REQUIRE(B <= 65535 && H <= 65535, "apla_attn_fwd: B/H exceed grid limits");
-  if (N <= SMALL_MAX_ROWS && g_attn_variant != 1) {
-    const int nw = (N + 31) / 32;
-    hipLaunchKernelGGL(attn_fwd_small_kernel, dim3(H, B), dim3(64 * nw), (size_t)nw * 32 * 256, stream, (const bf16*)qkv, (bf16*)o, lse, N, H, scale);
-  } else {
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3((N + 127) / 128, H, B), dim3(256), 0, stream, (const bf16*)qkv, (bf16*)o, lse, N, H, scale);
-  }
-  APLA_CHECK_LAUNCH("apla_attn_fwd");
-  return APLA_OK;
+  return launch_attn_fwd(qkv, o, lse, nullptr, B * N, B, N, H, scale, stream, "apla_attn_fwd");
 }
 
 extern "C" int apla_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta,
@@ -670,19 +726,24 @@ extern "C" int apla_attn_bwd(const void* qkv, const void* o, const void* d_o, co
   APLA_REQUIRE(qkv && o && d_o && lse && delta && dqkv && B > 0 && N > 0 && H > 0, "apla_attn_bwd: bad arguments");
   APLA_REQUIRE(apla_aligned16(qkv) && apla_aligned16(o) && apla_aligned16(d_o) && apla_aligned16(dqkv), "apla_attn_bwd: pointers must be 16-byte aligned");
   APLA_REQUIRE(B <= 65535 && H <= 65535, "apla_attn_bwd: B/H exceed grid limits");
-  dim3 grid((N + 127) / 128, H, B);
-  if (N <= SMALL_MAX_ROWS && g_attn_variant != 1) {
-    const int nw = (N + 31) / 32;
-    hipLaunchKernelGGL(attn_bwd_dq_small_kernel, dim3(H, B), dim3(64 * nw), (size_t)nw * 32 * 256, stream, (const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse, delta, (bf16*)dqkv, N, H, scale);
-  } else {
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, stream, (const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse, delta, (bf16*)dqkv, N, H, scale);
-  }
-  APLA_CHECK_LAUNCH("apla_attn_bwd[dq]");
-  // dK/dV stay on the key-blocked kernel: a one-pass variant with Q/dO of the head in LDS measured 7 % slower (it needs
-  // ~200 VGPRs either way, so it gains no occupancy)
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, stream, (const bf16*)qkv, (const bf16*)d_o, lse, delta, (bf16*)dqkv, N, H, scale);
-  APLA_CHECK_LAUNCH("apla_attn_bwd[dkv]");
-  return APLA_OK;
+  return launch_attn_bwd(qkv, o, d_o, lse, delta, dqkv, nullptr, B * N, B, N, H, scale, stream, "apla_attn_bwd");
+}
+
+extern "C" int apla_attn_varlen_fwd(const void* qkv, void* o, float* lse, const int32_t* cu_seqlens, int S, int total,
+                                    int max_n, int H, float scale, hipStream_t stream) {
+  APLA_REQUIRE(qkv && o && lse && cu_seqlens && S > 0 && total > 0 && max_n > 0 && H > 0, "apla_attn_varlen_fwd: bad arguments");
+  APLA_REQUIRE(apla_aligned16(qkv) && apla_aligned16(o), "apla_attn_varlen_fwd: pointers must be 16-byte aligned");
+  APLA_REQUIRE(S <= 65535 && H <= 65535, "apla_attn_varlen_fwd: S/H exceed grid limits");
+  return launch_attn_fwd(qkv, o, lse, cu_seqlens, total, S, max_n, H, scale, stream, "apla_attn_varlen_fwd");
+}
+
+extern "C" int apla_attn_varlen_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta,
+                                    void* dqkv, const int32_t* cu_seqlens, int S, int total, int max_n, int H,
+                                    float scale, hipStream_t stream) {
+  APLA_REQUIRE(qkv && o && d_o && lse && delta && dqkv && cu_seqlens && S > 0 && total > 0 && max_n > 0 && H > 0, "apla_attn_varlen_bwd: bad arguments");
+  APLA_REQUIRE(apla_aligned16(qkv) && apla_aligned16(o) && apla_aligned16(d_o) && apla_aligned16(dqkv), "apla_attn_varlen_bwd: pointers must be 16-byte aligned");
+  APLA_REQUIRE(S <= 65535 && H <= 65535, "apla_attn_varlen_bwd: S/H exceed grid limits");
+  return launch_attn_bwd(qkv, o, d_o, lse, delta, dqkv, cu_seqlens, total, S, max_n, H, scale, stream, "apla_attn_varlen_bwd");
 }
 
 extern "C" int apla_attn_probs(const void* qkv, const float* lse, float* attn, int B, int N, int H, float scale,

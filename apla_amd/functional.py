@@ -151,6 +151,36 @@ class _AttnCoreFn(torch.autograd.Function):
         return dqkv.reshape(B, N, -1), None, None, None, None
 
 
+class _AttnVarlenFn(torch.autograd.Function):
+    """Block-diagonal attention over a packed batch (xformers memory_efficient_attention with a BlockDiagonalMask in the
+    reference, appla_attn_mem_eff.py:40-42)."""
+
+    @staticmethod
+    def forward(ctx, qkv, cu_seqlens, max_n, H, scale):
+        shape = qkv.shape
+        qkv2 = qkv.reshape(-1, shape[-1]).contiguous()
+        o, lse = ops.attn_varlen_fwd(qkv2, cu_seqlens, max_n, H, scale)
+        ctx.save_for_backward(qkv2, o, lse, cu_seqlens)
+        ctx.dims = (shape, max_n, H, scale)
+        return o.reshape(*shape[:-1], H * 64)
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv2, o, lse, cu = ctx.saved_tensors
+        shape, max_n, H, scale = ctx.dims
+        dqkv = ops.attn_varlen_bwd(qkv2, o, _as2d_bf16(do), lse, cu, max_n, H, scale)
+        return dqkv.reshape(shape), None, None, None, None
+
+
+def attention_core_varlen(qkv, cu_seqlens, max_n, H, scale):
+    """qkv [..., total, 3*H*64] with all leading dims of size 1 (a packed batch); cu_seqlens int32[S+1] on qkv's device."""
+    if qkv.shape[-1] != 3 * H * 64:
+        raise NotImplementedError(f"the HIP attention kernel needs head_dim 64 (got {qkv.shape[-1] // (3 * H)})")
+    if qkv.numel() != qkv.shape[-2] * qkv.shape[-1]:
+        raise ValueError("a packed (block-diagonal) batch must have batch size 1: [1, total, 3*dim]")
+    return _AttnVarlenFn.apply(qkv, cu_seqlens, max_n, H, scale)
+
+
 def attention_core(qkv, B, N, H, scale):
     if qkv.shape[-1] != 3 * H * 64:
         raise NotImplementedError(f"the HIP attention kernel needs head_dim 64 (got {qkv.shape[-1] // (3 * H)})")

@@ -234,6 +234,59 @@ def attn_bwd(qkv: torch.Tensor, o: torch.Tensor, do: torch.Tensor, lse: torch.Te
     return dqkv
 
 
+def _check_cu(cu: torch.Tensor, total: int, who: str):
+    _req(cu, torch.int32, "cu_seqlens", 1)
+    if cu.numel() < 2 or not cu.is_contiguous():
+        raise ValueError(f"{who}: cu_seqlens must be a contiguous int32 vector of S+1 offsets")
+    return cu.numel() - 1
+
+
+def attn_varlen_fwd(qkv: torch.Tensor, cu_seqlens: torch.Tensor, max_n: int, H: int, scale: float, *,
+                    o: Optional[torch.Tensor] = None, lse: Optional[torch.Tensor] = None):
+    """Block-diagonal attention over packed sequences.  qkv: [total, 3*H*64] bf16; cu_seqlens: int32[S+1] on the device
+    (cu[0] = 0, cu[S] = total; the caller guarantees it, the kernels trust it); max_n = longest sequence.
+    Returns (o [total, H*64] bf16, lse [H, total] fp32)."""
+    _req(qkv, torch.bfloat16, "qkv", 2)
+    total = qkv.shape[0]
+    S = _check_cu(cu_seqlens, total, "attn_varlen_fwd")
+    if qkv.shape[1] != 3 * H * 64 or not qkv.is_contiguous() or max_n <= 0 or max_n > total:
+        raise ValueError(f"attn_varlen_fwd: qkv must be contiguous [total, {3 * H * 64}] and 0 < max_n <= total")
+    if o is None:
+        o = torch.empty(total, H * 64, device=qkv.device, dtype=torch.bfloat16)
+    if lse is None:
+        lse = torch.empty(H, total, device=qkv.device, dtype=torch.float32)
+    _req(o, torch.bfloat16, "o", 2), _req(lse, torch.float32, "lse", 2)
+    if tuple(o.shape) != (total, H * 64) or tuple(lse.shape) != (H, total) or not (o.is_contiguous() and lse.is_contiguous()):
+        raise ValueError("attn_varlen_fwd: bad output buffers")
+    check(lib().apla_attn_varlen_fwd(qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), cu_seqlens.data_ptr(), S, total,
+                                     int(max_n), H, float(scale), _stream()), "apla_attn_varlen_fwd")
+    return o, lse
+
+
+def attn_varlen_bwd(qkv: torch.Tensor, o: torch.Tensor, do: torch.Tensor, lse: torch.Tensor, cu_seqlens: torch.Tensor,
+                    max_n: int, H: int, scale: float, *, dqkv: Optional[torch.Tensor] = None,
+                    delta: Optional[torch.Tensor] = None):
+    _req(qkv, torch.bfloat16, "qkv", 2), _req(o, torch.bfloat16, "o", 2), _req(do, torch.bfloat16, "do", 2)
+    _req(lse, torch.float32, "lse", 2)
+    total = qkv.shape[0]
+    S = _check_cu(cu_seqlens, total, "attn_varlen_bwd")
+    if qkv.shape[1] != 3 * H * 64 or tuple(o.shape) != (total, H * 64) or o.shape != do.shape \
+            or tuple(lse.shape) != (H, total) or max_n <= 0 or max_n > total:
+        raise ValueError("attn_varlen_bwd: shape mismatch")
+    if not (qkv.is_contiguous() and o.is_contiguous() and do.is_contiguous() and lse.is_contiguous()):
+        raise ValueError("attn_varlen_bwd: operands must be contiguous")
+    if dqkv is None:
+        dqkv = torch.empty_like(qkv)
+    if delta is None:
+        delta = torch.empty(H, total, device=qkv.device, dtype=torch.float32)
+    if dqkv.shape != qkv.shape or not dqkv.is_contiguous() or delta.numel() < H * total:
+        raise ValueError("attn_varlen_bwd: bad dqkv/delta buffers")
+    check(lib().apla_attn_varlen_bwd(qkv.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(), delta.data_ptr(),
+                                     dqkv.data_ptr(), cu_seqlens.data_ptr(), S, total, int(max_n), H, float(scale),
+                                     _stream()), "apla_attn_varlen_bwd")
+    return dqkv
+
+
 def attn_bwd_cls(qkv: torch.Tensor, o: torch.Tensor, do_cls: torch.Tensor, lse: torch.Tensor, B: int, N: int, H: int,
                  scale: float, *, dqkv: Optional[torch.Tensor] = None):
     """Attention backward for dO that is non-zero only at token 0 of every sequence; do_cls: [B, H*64] bf16."""

@@ -91,6 +91,16 @@ int apla_gather_cols(const void* src, int res_dtype, long src_row_stride, const 
  * Replaces appla_attn.py:53-60 without materialising attn[B,H,N,N].  head_dim must be 64. */
 int apla_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, float scale, hipStream_t stream);
 
+/* Block-diagonal attention over a PACKED batch of S variable-length sequences (the dinov2 nested-tensor path:
+ * appla_attn_mem_eff.py:40-42 calls xformers memory_efficient_attention with a BlockDiagonalMask over the concatenated
+ * crops, dinov2/layers/block.py:254-288).  qkv [total, 3*H*64], o / d_o [total, H*64], dqkv like qkv; cu_seqlens int32[S+1]
+ * on the device (cu[0] = 0, cu[S] = total); lse / delta are [H, total] fp32; max_n = longest sequence (sizes the grid).
+ * Token t of sequence s attends to the tokens of sequence s only.  Same kernels as the uniform-batch entry points. */
+int apla_attn_varlen_fwd(const void* qkv, void* o, float* lse, const int32_t* cu_seqlens, int S, int total, int max_n,
+                         int H, float scale, hipStream_t stream);
+int apla_attn_varlen_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv,
+                         const int32_t* cu_seqlens, int S, int total, int max_n, int H, float scale, hipStream_t stream);
+
 /* Tuning/diagnostic knob for apla_attn_fwd / apla_attn_bwd (process-wide): 0 = auto (default): sequences of up to 256 tokens
  * use the one-workgroup-per-head kernels that keep the whole K/V (Q/dO) of a head in LDS; 1 = always the key-blocked
  * kernels.  Returns the previous value.  Both compute the same results (tests/test_kernels_gpu.py). */

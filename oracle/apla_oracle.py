@@ -145,6 +145,31 @@ def attention_fwd(qkv: Tensor, num_heads: int, scale: float, return_attn: bool =
     return (o, lse, attn) if return_attn else (o, lse)
 
 
+def attention_varlen_fwd(qkv: Tensor, seqlens, num_heads: int, scale: float):
+    """Block-diagonal attention over a packed batch: qkv [total, 3*D]; sequence s owns tokens
+    [sum(seqlens[:s]), sum(seqlens[:s+1])) and attends to itself only — what
+    xformers.memory_efficient_attention(q, k, v, attn_bias=BlockDiagonalMask.from_seqlens(seqlens)) computes at
+    appla_attn_mem_eff.py:40-42 (xformers 0.0.18 is not installed: pinned through this per-sequence equivalence with
+    the dense softmax attention that the goldens do pin).  Returns o [total, D], lse [H, total]."""
+    outs, lses, a = [], [], 0
+    for n in seqlens:
+        o, l = attention_fwd(qkv[a:a + n][None], num_heads, scale)
+        outs.append(o[0])
+        lses.append(l[0])  # [H, n]
+        a += n
+    return torch.cat(outs, 0), torch.cat(lses, 1)
+
+
+def attention_varlen_bwd(do: Tensor, qkv: Tensor, o: Tensor, lse: Tensor, seqlens, num_heads: int, scale: float) -> Tensor:
+    """Backward of attention_varlen_fwd, sequence by sequence.  lse is [H, total]."""
+    outs, a = [], 0
+    for n in seqlens:
+        outs.append(attention_bwd(do[a:a + n][None], qkv[a:a + n][None], o[a:a + n][None], lse[:, a:a + n][None],
+                                  num_heads, scale)[0])
+        a += n
+    return torch.cat(outs, 0)
+
+
 def attention_bwd(do: Tensor, qkv: Tensor, o: Tensor, lse: Tensor, num_heads: int, scale: float) -> Tensor:
     """Flash-style backward from saved (qkv, o, lse): recompute P = exp(S*scale - lse);
     delta = rowsum(dO*O); dS = P*(dP - delta); dQ = dS K scale; dK = dS^T Q scale; dV = P^T dO."""

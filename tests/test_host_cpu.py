@@ -110,3 +110,51 @@ def test_cpu_forward_fails_loudly(cfg1_model):
     from apla_amd._lib import AplaHipError
     with pytest.raises(AplaHipError):
         cfg1_model(torch.zeros(1, 3, 224, 224))
+
+
+# ----------------------------------------------------------------------------------------------- packed batches (a4)
+def test_block_diagonal_mask_api():
+    """The subset of xformers' BlockDiagonalMask that the reference touches (dinov2/layers/block.py:188-217)."""
+    from apla_amd.nested import BlockDiagonalMask
+    xs = [torch.arange(2 * 5 * 3, dtype=torch.float32).reshape(2, 5, 3), torch.ones(3, 2, 3)]
+    mask, packed = BlockDiagonalMask.from_tensor_list(xs)
+    assert mask.seqlens == [5, 5, 2, 2, 2] and mask.total == 16 and mask.max_seqlen == 5
+    assert mask.seqstart_py == [0, 5, 10, 12, 14, 16]
+    assert packed.shape == (1, 16, 3)
+    back = mask.split(packed)
+    assert all(torch.equal(a, b) for a, b in zip(xs, back))
+    m2 = BlockDiagonalMask.from_seqlens([5, 5, 2, 2, 2])
+    assert [t.shape for t in m2.split(packed)] == [(2, 5, 3), (3, 2, 3)]   # grouping by equal consecutive lengths
+    assert mask.cu_seqlens("cpu").dtype == torch.int32 and mask.cu_seqlens("cpu").tolist() == mask.seqstart_py
+    dense = mask.materialize()
+    assert dense.shape == (16, 16) and dense[0, 4] == 0 and dense[4, 5] == float("-inf") and dense[15, 14] == 0
+    with pytest.raises(ValueError):
+        BlockDiagonalMask([])
+    with pytest.raises(NotImplementedError):
+        BlockDiagonalMask.from_seqlens([3], kv_seqlen=[4])
+
+
+def test_oracle_block_diagonal_equals_masked_dense():
+    """The oracle's per-sequence restatement of block-diagonal attention equals dense softmax attention with the
+    materialised -inf mask (what the reference's xformers call computes)."""
+    from apla_amd.nested import BlockDiagonalMask
+    from oracle import apla_oracle as O
+    H, seqlens = 2, [7, 3, 12]
+    total, D = sum(seqlens), 2 * 16
+    g = torch.Generator().manual_seed(3)
+    qkv = torch.randn(total, 3 * D, generator=g, dtype=torch.float64)
+    o, lse = O.attention_varlen_fwd(qkv, seqlens, H, 0.25)
+    t = qkv.reshape(total, 3, H, 16).permute(1, 2, 0, 3)
+    s = (t[0] @ t[1].transpose(-2, -1)) * 0.25 + BlockDiagonalMask(seqlens).materialize(torch.float64)
+    ref = (torch.softmax(s, -1) @ t[2]).permute(1, 0, 2).reshape(total, D)
+    assert torch.allclose(o, ref, atol=1e-12)
+    assert torch.allclose(lse, torch.logsumexp(s, -1), atol=1e-12)
+    # backward against autograd of the masked dense form
+    qkv_a = qkv.clone().requires_grad_(True)
+    ta = qkv_a.reshape(total, 3, H, 16).permute(1, 2, 0, 3)
+    sa = (ta[0] @ ta[1].transpose(-2, -1)) * 0.25 + BlockDiagonalMask(seqlens).materialize(torch.float64)
+    oa = (torch.softmax(sa, -1) @ ta[2]).permute(1, 0, 2).reshape(total, D)
+    do = torch.randn(total, D, generator=g, dtype=torch.float64)
+    oa.backward(do)
+    dqkv = O.attention_varlen_bwd(do, qkv, o, lse, seqlens, H, 0.25)
+    assert torch.allclose(dqkv, qkv_a.grad, atol=1e-10)

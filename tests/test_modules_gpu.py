@@ -1,0 +1,99 @@
+"""Drop-in module path on the GPU: the reference's plugin surface — APLA_Attention(...).forward(x) ->
+(x, attn) and APLA_MemEffAttention.forward(x, attn_bias) -> x — running the HIP kernels through torch.autograd, checked
+against the fp64 CPU oracle (which the reference goldens pin, tests/test_oracle_golden.py).
+
+Tolerances: activations / input gradients are products of bf16 MFMA GEMMs with fp32 accumulation -> relative L2 error
+<= 1e-2 against fp64; dW1/db1 contract bf16-rounded operands over ~400 tokens -> <= 2e-2.
+"""
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import apla_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+ACT_TOL, GRAD_TOL = 1e-2, 2e-2
+
+
+def make_module(cls, dim, heads, r, seed):
+    from apla_amd.models import AttrDict
+    torch.manual_seed(seed)
+    m = cls(AttrDict(partial_size=r), dim, num_heads=heads, qkv_bias=True)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.copy_(torch.randn(p.shape) * (0.05 if p.ndim > 1 else 0.1))
+    return m
+
+
+def oracle_params(m):
+    return {"a." + k: (v.detach().cpu() if k == "inds" else v.detach().double().cpu()) for k, v in m.state_dict().items()}
+
+
+@pytest.mark.parametrize("B,N,dim,heads,r", [(2, 197, 256, 4, 64), (3, 50, 128, 2, 128), (1, 257, 384, 6, 192)])
+def test_apla_attention_module_fwd_bwd(B, N, dim, heads, r):
+    from apla_amd.apla import APLA_Attention
+    m = make_module(APLA_Attention, dim, heads, r, seed=5)
+    p = oracle_params(m)
+    x = torch.randn(B, N, dim, generator=torch.Generator().manual_seed(6))
+    m = m.cuda()
+    m.return_attn_matrix = True
+    xg = x.cuda().requires_grad_(True)
+    y, attn = m(xg)
+    loss = y.float().square().mean()
+    loss.backward()
+
+    yref, aref, ctx = O.apla_attention_fwd(x.double(), p, "a.", heads, r, return_attn=True)
+    dyref = 2.0 * yref / yref.numel()
+    dxref, dW1ref, db1ref = O.apla_attention_bwd(dyref, ctx, p, "a.", heads)
+    assert rel_err(y.detach().cpu(), yref) < ACT_TOL
+    assert rel_err(attn.cpu(), aref) < ACT_TOL
+    assert rel_err(xg.grad.cpu(), dxref) < GRAD_TOL
+    assert rel_err(m.proj_weight1.grad.cpu(), dW1ref) < GRAD_TOL
+    assert rel_err(m.proj_bias1.grad.cpu(), db1ref) < GRAD_TOL
+    # frozen parameters get no gradient (apla_vit.py freeze policy; appla_attn.py:37-45)
+    assert m.proj_weight2.grad is None and m.qkv.weight.grad is None
+
+
+@pytest.mark.parametrize("crops", [[(2, 257), (8, 50)], [(1, 197)], [(3, 33), (2, 129), (1, 64)]])
+def test_mem_eff_attention_block_diagonal(crops):
+    """dinov2 nested-tensor path: crops of different sizes packed into [1, total, C] with a BlockDiagonalMask must give,
+    crop by crop, what the dense module gives on each crop batch — forward and backward (appla_attn_mem_eff.py:27-67)."""
+    from apla_amd.apla import APLA_MemEffAttention
+    from apla_amd.nested import BlockDiagonalMask
+    dim, heads, r = 256, 4, 64
+    m = make_module(APLA_MemEffAttention, dim, heads, r, seed=7)
+    p = oracle_params(m)
+    m = m.cuda()
+    g = torch.Generator().manual_seed(8)
+    xs = [torch.randn(b, n, dim, generator=g) for b, n in crops]
+    xs_dev = [x.cuda().requires_grad_(True) for x in xs]
+    mask, packed = BlockDiagonalMask.from_tensor_list(xs_dev)
+    out = m(packed, attn_bias=mask)
+    assert out.shape == packed.shape
+    outs = mask.split(out)
+    loss = sum(o.float().square().mean() for o in outs)
+    loss.backward()
+    gW = m.proj_weight1.grad.clone()
+
+    dW_ref = torch.zeros_like(p["a.proj_weight1"])
+    for x, xd, o in zip(xs, xs_dev, outs):
+        yref, _, ctx = O.apla_attention_fwd(x.double(), p, "a.", heads, r)
+        dxref, dW1ref, _ = O.apla_attention_bwd(2.0 * yref / yref.numel(), ctx, p, "a.", heads)
+        dW_ref += dW1ref
+        assert rel_err(o.detach().cpu(), yref) < ACT_TOL
+        assert rel_err(xd.grad.cpu(), dxref) < GRAD_TOL
+    assert rel_err(gW.cpu(), dW_ref) < GRAD_TOL
+
+    # and the packed path equals the module's own dense path on each crop batch to bf16 rounding of the same kernels
+    m.zero_grad()
+    dense = [m(x.detach().cuda()) for x in xs]
+    for a, b in zip(dense, outs):
+        assert rel_err(a.detach().cpu(), b.detach().cpu().double()) < 2e-3
+
+
+def test_mem_eff_attention_rejects_foreign_bias():
+    from apla_amd.apla import APLA_MemEffAttention
+    m = make_module(APLA_MemEffAttention, 128, 2, 64, seed=9).cuda()
+    with pytest.raises(TypeError):
+        m(torch.zeros(1, 10, 128, device="cuda"), attn_bias=torch.zeros(10, 10))
