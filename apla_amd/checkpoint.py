@@ -1,0 +1,107 @@
+"""Checkpoint interchange with the reference.
+
+* Backbone weights: the module tree uses the reference's / timm's parameter names (``blocks.i.{norm1,attn.qkv,attn.proj,
+  ls1.gamma,norm2,mlp.fc1,mlp.fc2,ls2.gamma}``, utils/transformers/vit.py), so a dinov2 checkpoint loads with
+  ``load_state_dict`` once the keys the reference drops are dropped too (``mask_token``; transformers_utils.py:45-47).
+  Load it BEFORE ``build_apla`` — exactly like the reference, which splits ``attn.proj`` afterwards (apla_vit.py:31-49).
+* Session files: ``Trainer.save_session`` writes ``{'iters','state_dict','original_state','optimizer','epoch','parameters',
+  'best_val_target'[, 'scaler']}`` (defaults/bases.py:447-467) where ``optimizer`` is a ``torch.optim.AdamW.state_dict()``
+  over the two parameter groups of ``get_params_groups`` (defaults/wrappers.py:205-221: decayed = 2-D weights, then
+  non-decayed = biases, each in ``named_parameters`` order).  ``session_dict`` / ``load_session`` translate between that
+  layout and the engine's flat fp32 buffers (params, exp_avg, exp_avg_sq), so a run can move between the two stacks.
+"""
+from typing import Dict, Optional
+
+import torch
+
+DINOV2_DROPPED_KEYS = ("mask_token",)  # transformers_utils.py:45-47
+
+
+def clean_pretrained_state_dict(sd: Dict[str, torch.Tensor], pretrained_type: str = "dinov2") -> Dict[str, torch.Tensor]:
+    if pretrained_type == "dinov2":
+        return {k: v for k, v in sd.items() if not any(sub in k for sub in DINOV2_DROPPED_KEYS)}
+    return dict(sd)
+
+
+def load_pretrained_backbone(backbone: torch.nn.Module, sd: Dict[str, torch.Tensor], pretrained_type: str = "dinov2",
+                             strict: bool = True):
+    """Load a (dinov2 / timm-named) checkpoint into a freshly built ViT — before ``build_apla``."""
+    if any(hasattr(b.attn, "proj_weight1") for b in getattr(backbone, "blocks", [])):
+        raise RuntimeError("load the pretrained backbone before build_apla(): the checkpoint holds the unsplit attn.proj")
+    return backbone.load_state_dict(clean_pretrained_state_dict(sd, pretrained_type), strict=strict)
+
+
+def _group_order(model: torch.nn.Module):
+    """Names of the trainable parameters in torch-optimizer index order: group 0 (decayed) then group 1."""
+    reg, no_reg = [], []
+    for name, p in model.named_parameters():
+        if p.requires_grad:
+            (no_reg if name.endswith(".bias") or p.ndim == 1 else reg).append(name)
+    return reg, no_reg
+
+
+def optimizer_state_dict(engine) -> dict:
+    """The engine's AdamW state as a ``torch.optim.AdamW(get_params_groups(model)).state_dict()`` (CPU tensors)."""
+    reg, no_reg = _group_order(engine.model)
+    oc, state, idx = engine.optim, {}, 0
+    for name in reg + no_reg:
+        off, k, shape = engine.slices[name]
+        state[idx] = {"step": torch.tensor(float(engine.step_count)),
+                      "exp_avg": engine.exp_avg[off:off + k].view(shape).detach().cpu().clone(),
+                      "exp_avg_sq": engine.exp_avg_sq[off:off + k].view(shape).detach().cpu().clone()}
+        idx += 1
+    common = dict(lr=oc.lr, betas=tuple(oc.betas), eps=oc.eps, amsgrad=False, maximize=False, foreach=None, capturable=False,
+                  differentiable=False, fused=None)
+    groups = [dict(common, weight_decay=oc.weight_decay, params=list(range(len(reg)))),
+              dict(common, weight_decay=0.0, params=list(range(len(reg), len(reg) + len(no_reg))))]
+    return {"state": state, "param_groups": groups}
+
+
+def load_optimizer_state_dict(engine, osd: dict):
+    reg, no_reg = _group_order(engine.model)
+    names = reg + no_reg
+    if sorted(osd["state"].keys()) not in ([], list(range(len(names)))):
+        raise ValueError(f"optimizer state has {len(osd['state'])} entries, the model has {len(names)} trainable tensors")
+    steps = set()
+    for idx, name in enumerate(names):
+        if idx not in osd["state"]:
+            continue
+        st = osd["state"][idx]
+        off, k, shape = engine.slices[name]
+        if tuple(st["exp_avg"].shape) != tuple(shape):
+            raise ValueError(f"optimizer state {idx} ({name}): shape {tuple(st['exp_avg'].shape)} != {tuple(shape)}")
+        engine.exp_avg[off:off + k].copy_(st["exp_avg"].reshape(-1).float())
+        engine.exp_avg_sq[off:off + k].copy_(st["exp_avg_sq"].reshape(-1).float())
+        steps.add(int(float(st["step"])))
+    if len(steps) > 1:
+        raise ValueError(f"per-tensor step counts differ ({sorted(steps)}): the fused optimizer keeps one step count")
+    engine.step_count = steps.pop() if steps else 0
+
+
+def session_dict(engine, *, iters: int = 0, epoch: int = 0, parameters: Optional[dict] = None,
+                 best_val_target: float = 0.0, original_state: Optional[dict] = None) -> dict:
+    """What ``Trainer.save_session`` stores (defaults/bases.py:456-464); ``torch.save`` it to interchange."""
+    return {"iters": iters,
+            "state_dict": {k: v.detach().cpu().clone() for k, v in engine.model.state_dict().items()},
+            "original_state": original_state,
+            "optimizer": optimizer_state_dict(engine),
+            "epoch": epoch,
+            "parameters": parameters,
+            "best_val_target": best_val_target}
+
+
+def load_session(engine, session: dict, load_optimizer: bool = True):
+    """Restore model (trainable rows live in the flat buffer: copied in place) and optimizer state from a session dict."""
+    sd = session["state_dict"]
+    sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in sd.items()}  # DDP-wrapped saves
+    own = engine.model.state_dict()
+    missing = [k for k in own if k not in sd]
+    if missing:
+        raise KeyError(f"session state_dict lacks {missing[:4]}…")
+    with torch.no_grad():
+        for k, v in own.items():
+            v.copy_(sd[k].to(v.dtype))  # parameters are views of engine.flat_params: in-place copy keeps the aliasing
+    engine.refresh_frozen_copies()
+    if load_optimizer and session.get("optimizer") is not None:
+        load_optimizer_state_dict(engine, session["optimizer"])
+    return session.get("iters", 0), session.get("epoch", 0)

@@ -252,6 +252,14 @@ class AplaTrainEngine:
             if ops.lib().apla_dw_workspace_bytes(M, st.r, D) > self.dw_ws.numel() * 4:
                 self.dw_ws = ops.dw_workspace(M, st.r, D, dev)
 
+    def refresh_frozen_copies(self):
+        """Rebuild the kernel-layout copies of the frozen weights (bf16, transposed, LayerScale folded) after the module's
+        frozen parameters were overwritten, e.g. by checkpoint.load_session.  Only before the step graphs are captured:
+        the captured launches hold the old buffers' addresses."""
+        if self._graphs is not None:
+            raise RuntimeError("frozen weights cannot be replaced after hipGraph capture; load the checkpoint before the first step")
+        self._build_frozen_layout()
+
     # ------------------------------------------------------------------ step pieces
     def refresh_weights(self):
         """Re-scatter the trainable projection rows (fp32 masters -> natural-order bf16 weight, its transpose, bias)."""

@@ -18,7 +18,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
-from _ref_shim import Cfg, load_reference  # noqa: E402
+from _ref_shim import Cfg, REF_SRC, load_reference  # noqa: E402
 
 vit, attn_mod, avit, mem_mod = load_reference()
 torch.set_num_threads(8)
@@ -174,6 +174,64 @@ def g4():
 
 
 # ---------------------------------------------------------------- G5: whole-model training step
+def g9_lr_schedule():
+    """Per-iteration learning rates produced by the reference's own scheduler classes (utils/_utils.py LinearWarmup and
+    MixedLRScheduler, wired as in defaults/wrappers.py:255-303).  utils/_utils.py cannot be imported as a module here
+    (torchvision / timm are absent), so the two class definitions are taken from its AST and executed in this process;
+    only the resulting number sequences are stored."""
+    import ast, json, warnings
+    from torch.optim.lr_scheduler import _LRScheduler, CosineAnnealingLR
+    src = open(os.path.join(REF_SRC, "utils", "_utils.py")).read()
+    tree = ast.parse(src)
+    class _LRSchedulerCompat(_LRScheduler):  # torch >= 2.7 dropped the `verbose` positional the reference still passes
+        def __init__(self, optimizer, last_epoch=-1, verbose=False):
+            super().__init__(optimizer, last_epoch)
+
+    ns = {"_LRScheduler": _LRSchedulerCompat, "warnings": warnings, "print_ddp": lambda *a, **k: None, "torch": torch}
+    for node in tree.body:
+        if isinstance(node, ast.ClassDef) and node.name in ("LinearWarmup", "MixedLRScheduler"):
+            exec(compile(ast.Module(body=[node], type_ignores=[]), "ref_utils", "exec"), ns)
+    LinearWarmup, Mixed = ns["LinearWarmup"], ns["MixedLRScheduler"]
+
+    def run(max_lr, types, steps_per_epoch, epochs, n, warm=None, cos_eta=1e-6):
+        prm = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.AdamW([prm], lr=max_lr)
+        scheds, warmup_iters = [], 0
+        for t in types:  # same order and parameter rules as defaults/wrappers.py:255-303
+            if t == "LinearWarmup":
+                sc = LinearWarmup(opt, max_lr=max_lr, steps_per_epoch=steps_per_epoch, **warm)
+                warmup_iters = sc.warmup_iters
+            else:
+                T_max = steps_per_epoch * epochs - (warmup_iters if "LinearWarmup" in types else 0)
+                sc = CosineAnnealingLR(opt, T_max=T_max, eta_min=cos_eta)
+            scheds.append(sc)
+        mixed = Mixed(scheds, list(types), steps_per_epoch)
+        lrs = []
+        for _ in range(n):
+            lrs.append(opt.param_groups[0]["lr"])
+            opt.step()
+            mixed.step(None, None)
+        return lrs
+
+    cases = {
+        "shipped_warmup500": dict(max_lr=5e-4, types=["LinearWarmup"], steps_per_epoch=100, epochs=3, n=700,
+                                  warm=dict(warmup_iters=500, warmup_epochs=0)),
+        "warmup_epochs2": dict(max_lr=1e-3, types=["LinearWarmup"], steps_per_epoch=7, epochs=5, n=40,
+                               warm=dict(warmup_iters=0, warmup_epochs=2)),
+        "warmup_then_cosine": dict(max_lr=1e-3, types=["LinearWarmup", "CosineAnnealingLR"], steps_per_epoch=10, epochs=6,
+                                   n=60, warm=dict(warmup_iters=12, warmup_epochs=0)),
+        "cosine_only": dict(max_lr=2e-3, types=["CosineAnnealingLR"], steps_per_epoch=8, epochs=4, n=32, warm=None),
+    }
+    out = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for name, c in cases.items():
+            out[name] = dict(config={k: v for k, v in c.items()}, lr=run(**c))
+    with open(os.path.join(HERE, "g9_lr_schedule.json"), "w") as f:
+        json.dump(out, f)
+    print("g9_lr_schedule.json", {k: len(v["lr"]) for k, v in out.items()})
+
+
 def classifier_step(model, fc, images, labels, lr=1e-4, wd=1e-5, clip=1.0):
     """defaults/trainer.py:106-151 (no AMP) with the param groups of defaults/wrappers.py:205-221."""
     named = [(n, p_) for n, p_ in list(model.named_parameters()) + [("fc." + n, p_) for n, p_ in fc.named_parameters()]
@@ -272,3 +330,4 @@ if __name__ == "__main__":
     g4()
     g5_tiny()
     g5_cfg1()
+    g9_lr_schedule()

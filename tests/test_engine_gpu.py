@@ -151,3 +151,49 @@ def test_engine_cfg1_matches_reference_golden():
     for nm in ("backbone.blocks.5.attn.proj_weight1", "fc.weight"):
         ref_after = t(g["after." + nm.replace("backbone.", "")])
         assert float((sd[nm].cpu() - ref_after).abs().max()) < 2.5e-4
+
+
+def test_session_checkpoint_interchange_with_torch_adamw():
+    """a session dict exported from the engine has the reference layout (defaults/bases.py:456-464) and its
+    'optimizer' entry loads into a real torch.optim.AdamW over get_params_groups(model) (defaults/wrappers.py:186-221);
+    continuing from it with torch's own optimizer and continuing in the engine give the same parameters (fp32 rounding)."""
+    import copy
+    from apla_amd.engine import AplaTrainEngine, OptimConfig
+    from apla_amd import checkpoint as ckpt
+    from apla_amd.models import get_params_groups
+    net = small_vit(depth=2, r=64)
+    ref_net = copy.deepcopy(net)          # CPU twin holding the same initial weights
+    eng = AplaTrainEngine(net.cuda(), 4, 32, optim=OptimConfig(lr=1e-3, weight_decay=1e-2, grad_clipping=0.0), use_graphs=False)
+    g = torch.Generator().manual_seed(0)
+    images, labels = torch.randn(4, 3, 32, 32, generator=g), torch.randint(0, 10, (4,), generator=g)
+    for _ in range(2):
+        eng.train_step(images.cuda(), labels.cuda())
+    sess = ckpt.session_dict(eng, iters=2, epoch=0, parameters={"note": "test"})
+    assert set(sess) == {"iters", "state_dict", "original_state", "optimizer", "epoch", "parameters", "best_val_target"}
+    assert set(sess["state_dict"]) == set(ref_net.state_dict())
+
+    # (1) the reference stack can pick the run up: plain torch modules + torch AdamW
+    ref_net.load_state_dict(sess["state_dict"])
+    opt = torch.optim.AdamW(get_params_groups(ref_net), lr=1e-3, weight_decay=1e-2)
+    opt.load_state_dict(sess["optimizer"])
+    assert opt.state_dict()["param_groups"][1]["weight_decay"] == 0.0
+    eng.forward_backward()
+    grads = {n: t.detach().cpu().clone() for n, t in eng.grads().items()}
+    for n, p in ref_net.named_parameters():
+        if p.requires_grad:
+            p.grad = grads[n].reshape(p.shape)
+    opt.step()
+    eng.optimizer_step()
+    for n, p in ref_net.named_parameters():
+        if p.requires_grad:
+            mine = dict(eng.model.named_parameters())[n].detach().cpu()
+            assert torch.allclose(mine, p.detach(), rtol=2e-6, atol=1e-8), n
+
+    # (2) and back: a fresh engine restored from the session continues bit-identically to the engine that wrote it
+    sess3 = ckpt.session_dict(eng, iters=3)
+    eng2 = AplaTrainEngine(small_vit(depth=2, r=64).cuda(), 4, 32, optim=OptimConfig(lr=1e-3, weight_decay=1e-2, grad_clipping=0.0),
+                           use_graphs=False)
+    assert ckpt.load_session(eng2, sess3) == (3, 0)
+    a = eng.train_step(images.cuda(), labels.cuda()).clone()
+    b = eng2.train_step(images.cuda(), labels.cuda()).clone()
+    assert torch.equal(a, b) and torch.equal(eng.flat_params, eng2.flat_params)

@@ -158,3 +158,47 @@ def test_oracle_block_diagonal_equals_masked_dense():
     oa.backward(do)
     dqkv = O.attention_varlen_bwd(do, qkv, o, lse, seqlens, H, 0.25)
     assert torch.allclose(dqkv, qkv_a.grad, atol=1e-10)
+
+
+# ----------------------------------------------------------------------------------------------- LR schedule (f2)
+@pytest.mark.parametrize("case", ["shipped_warmup500", "warmup_epochs2", "warmup_then_cosine", "cosine_only"])
+def test_lr_schedule_matches_reference_sequences(case):
+    """G9: per-iteration learning rates produced by the reference's LinearWarmup / MixedLRScheduler (+ torch's
+    CosineAnnealingLR) — apla_amd.schedule.LRSchedule must give the same floats (1e-12 relative), quirks included."""
+    import json
+    import os
+    from apla_amd.schedule import LRSchedule
+    with open(os.path.join(os.path.dirname(__file__), "golden", "g9_lr_schedule.json")) as f:
+        c = json.load(f)[case]
+    cfg, warm = c["config"], c["config"].get("warm") or {}
+    sch = LRSchedule(cfg["max_lr"], use_warmup="LinearWarmup" in cfg["types"], cosine="CosineAnnealingLR" in cfg["types"],
+                     steps_per_epoch=cfg["steps_per_epoch"], epochs=cfg["epochs"], cosine_eta_min=1e-6, **warm)
+    seq = sch.sequence(cfg["n"])
+    assert len(seq) == len(c["lr"])
+    assert max(abs(a - b) / abs(b) for a, b in zip(seq, c["lr"])) < 1e-12
+    # stepping API == sequence API
+    sch.reset()
+    assert sch.lr == seq[0] and sch.step() == seq[1]
+
+
+# ----------------------------------------------------------------------------------------------- checkpoints (f3)
+def test_pretrained_backbone_loading_rules():
+    """transformers_utils.py:45-47 drops dinov2's mask_token; weights load BEFORE build_apla (apla_vit.py:31-49 splits
+    attn.proj afterwards), and the split module then carries exactly the checkpoint's rows."""
+    from apla_amd import vit, checkpoint as ckpt
+    from apla_amd.apla import build_apla
+    from apla_amd.models import AttrDict
+    torch.manual_seed(1)
+    src = vit.vit_tiny(pretrained=False, img_size=[32], patch_size=16)
+    sd = {k: v.clone() for k, v in src.state_dict().items()}
+    sd["mask_token"] = torch.zeros(1, 192)
+    assert "mask_token" not in ckpt.clean_pretrained_state_dict(sd)
+    dst = vit.vit_tiny(pretrained=False, img_size=[32], patch_size=16)
+    res = ckpt.load_pretrained_backbone(dst, sd)
+    assert not res.missing_keys and not res.unexpected_keys
+    assert torch.equal(dst.blocks[0].attn.proj.weight, src.blocks[0].attn.proj.weight)
+    build_apla(AttrDict(partial_size=64), dst, "apla_attn")
+    a = dst.blocks[0].attn
+    assert torch.equal(a.proj_weight1, src.blocks[0].attn.proj.weight[a.inds[:64]])
+    with pytest.raises(RuntimeError):
+        ckpt.load_pretrained_backbone(dst, sd)
