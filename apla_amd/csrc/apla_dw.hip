@@ -137,9 +137,7 @@ __global__ __launch_bounds__(256) void proj_dw_partial_kernel(const bf16* __rest
   for (int s = 0; s < nsteps; ++s) {
     if (s + 1 < nsteps) dw_wait_vmcnt<PW>(); else dw_wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();  // stage s has landed for every wave; everyone is done reading stage s-1
-#if !defined(APLA_ABL_DWNODMA)
     if (s + 2 < nsteps) issue(s + 2);
-#endif
     char* Ys = smem + (s % NS) * STG;  // NJ x [64 m][64 j]
     char* Xs = Ys + NJ * 8192;         // 2 x [64 m][64 k]
     const int valid = m_end - (m_begin + s * TM);  // token rows of this step that exist (< 64 only at the very end of M)
@@ -170,11 +168,7 @@ __global__ __launch_bounds__(256) void proj_dw_partial_kernel(const bf16* __rest
           for (int e = 0; e < 8; ++e)
             if (16 * ks + 8 * (e >> 2) + 4 * h2 + (e & 3) >= valid) a[e] = (bf16)0.f;
         }
-#if defined(APLA_ABL_DWNOMFMA)
-        asm volatile("" :: "v"(a), "v"(b));
-#else
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
-#endif
         if (tk == 0 && ks == wave) {  // lane holds dyg[8 token rows][j = 32t + (lane&31)]
           float sm = 0.f;
 #pragma unroll

@@ -523,11 +523,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __rest
                                                            const float* __restrict__ delta, bf16* __restrict__ dqkv,
                                                            int Nmax, int H, float scale,
     const int32_t* __restrict__ cu, int total) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * 8192 + 2 * 64 * 4];
-  char* Qs = smem;
-  char* dOs = smem + 8192;
-  float* lses = (float*)(smem + 16384);
-  float* dls = lses + 64;
+  // two (Q tile, dO tile) buffers filled by LDS-DMA (no staging registers: the kernel then fits three waves per SIMD),
+  // then two (lse, delta) buffers
+  __shared__ __attribute__((aligned(16))) char smem[2 * 16384 + 2 * 2 * 64 * 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h2 = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * 128;
   const Seq sq = seq_of(cu, b, Nmax, H, total);
@@ -554,22 +552,51 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __rest
   for (int i = 0; i < 16; ++i) { acc_dk[0][i] = 0.f; acc_dk[1][i] = 0.f; acc_dv[0][i] = 0.f; acc_dv[1][i] = 0.f; }
 
   const int nqb = (N + 63) / 64;
-  TileRegs<64> qr, dr;
-  float lreg = 0.f, dreg = 0.f;
-  tile_load<64>(qr, base, ld, 0, N, tid);
-  tile_load<64>(dr, dobase, D, 0, N, tid);
-  if (tid < 64) { const int qq = tid < N ? tid : N - 1; lreg = lsebase[qq] * LOG2E; dreg = dlbase[qq]; }
-  for (int qb = 0; qb < nqb; ++qb) {
-    __syncthreads();
-    tile_store<64>(qr, Qs, tid);
-    tile_store<64>(dr, dOs, tid);
-    if (tid < 64) { lses[tid] = lreg; dls[tid] = dreg; }
-    __syncthreads();
-    if (qb + 1 < nqb) {
-      tile_load<64>(qr, base, ld, (qb + 1) * 64, N, tid);
-      tile_load<64>(dr, dobase, D, (qb + 1) * 64, N, tid);
-      if (tid < 64) { int qq = (qb + 1) * 64 + tid; qq = qq < N ? qq : N - 1; lreg = lsebase[qq] * LOG2E; dreg = dlbase[qq]; }
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  auto issue = [&](int qb) {  // 16 pieces of 8 rows x 128 B (8 of Q, 8 of dO), four per wave; swizzle on the source column
+    char* buf = smem + (qb & 1) * 16384;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int pc = wave_u * 4 + it;
+      const bool isd = pc >= 8;
+      const int pr = pc & 7;
+      const int row = pr * 8 + (lane >> 3);
+      const int f = (((row >> 1) & 1) << 2) | ((row >> 2) & 3);
+      const int ch = (lane & 7) ^ f;
+      int gr = qb * 64 + row;
+      gr = gr < N ? gr : N - 1;
+      const bf16* src = isd ? dobase + (long)gr * D + ch * 8 : base + (long)gr * ld + ch * 8;
+      __builtin_amdgcn_global_load_lds(ATT_GLBP(src), ATT_LDSP(buf + (isd ? 8192 : 0) + pr * 1024), 16, 0, 0);
     }
+  };
+  auto stat = [&](int qb, float& l, float& d) {
+    int qq = qb * 64 + tid;
+    qq = qq < N ? qq : N - 1;
+    l = lsebase[qq] * LOG2E;
+    d = dlbase[qq];
+  };
+  float* stats = (float*)(smem + 2 * 16384);  // [2 buffers][lse 64 | delta 64]
+  float lreg = 0.f, dreg = 0.f;
+  issue(0);
+  if (tid < 64) {
+    stat(0, lreg, dreg);
+    stats[tid] = lreg; stats[64 + tid] = dreg;
+    if (nqb > 1) stat(1, lreg, dreg);
+  }
+  for (int qb = 0; qb < nqb; ++qb) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // tile qb (and its lse/delta) is in LDS; every wave is done with tile qb-1
+    if (qb + 1 < nqb) {
+      issue(qb + 1);
+      if (tid < 64) {
+        stats[((qb + 1) & 1) * 128 + tid] = lreg; stats[((qb + 1) & 1) * 128 + 64 + tid] = dreg;
+        if (qb + 2 < nqb) stat(qb + 2, lreg, dreg);
+      }
+    }
+    const char* Qs = smem + (qb & 1) * 16384;
+    const char* dOs = Qs + 8192;
+    const float* lses = stats + (qb & 1) * 128;
+    const float* dls = lses + 64;
     if (!wave_active) continue;
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
@@ -583,7 +610,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __rest
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(dOs, qt * 32, ks, lane), vf[ks], dp, 0, 0, 0);
       }
       const bool tail = qb * 64 + qt * 32 + 32 > N;
-      f32x16 ds;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int r0 = qt * 32 + 8 * g + 4 * h2;
@@ -594,12 +620,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __rest
           float p = __builtin_amdgcn_exp2f(fmaf(s[i], c, -l4[e]));
           if (tail && qb * 64 + r0 + e >= N) p = 0.f;
           s[i] = p;
-          ds[i] = p * (dp[i] - d4[e]);
+          dp[i] = p * (dp[i] - d4[e]);  // dS, in place
         }
       }
 #pragma unroll
       for (int sk = 0; sk < 2; ++sk) {
-        const bf16x8 pb = acc_to_operand(s, sk), dsb = acc_to_operand(ds, sk);
+        const bf16x8 pb = acc_to_operand(s, sk), dsb = acc_to_operand(dp, sk);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
           acc_dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(dOs, qt * 32 + 16 * sk, 32 * dt, lane), pb, acc_dv[dt], 0, 0, 0);

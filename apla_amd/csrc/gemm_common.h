@@ -376,31 +376,11 @@ __device__ __forceinline__ void wide_epilogue(const GemmParams& p, f32x4 (&acc)[
       }
     }
     const int m = m0 + wm * 80 + i * 16 + frow;
-#if defined(APLA_ABL_NOEPI)
-    if (m < -p.M) {  // diagnostic build: keep the code, never execute it
-#else
     if (m < p.M) {
-#endif
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int n = n0 + ncol + 32 * u;
         const f32x4 lo = acc[i][2 * u], hi = acc[i][2 * u + 1];
-#if defined(APLA_ABL_NOSTORE)
-        if constexpr (EPI == APLA_EPI_STORE) {
-          auto r = Vec8IO<OutT>::pack(lo, hi);
-          asm volatile("" :: "v"(r));
-        } else if constexpr (EPI == APLA_EPI_GELU) {
-          f32x4 hl, hh, gl, gh;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float a, b;
-            gelu_and_grad(lo[e], a, b); hl[e] = a; gl[e] = b;
-            gelu_and_grad(hi[e], a, b); hh[e] = a; gh[e] = b;
-          }
-          auto r0 = Vec8IO<bf16>::pack(hl, hh), r1 = Vec8IO<bf16>::pack(gl, gh);
-          asm volatile("" :: "v"(r0), "v"(r1));
-        } else
-#endif
         if constexpr (EPI == APLA_EPI_STORE || EPI == APLA_EPI_RESIDUAL) {
           Vec8IO<OutT>::store((OutT*)p.C + (size_t)m * p.ldc + n, lo, hi);
         } else if constexpr (EPI == APLA_EPI_MUL) {

@@ -1,0 +1,24 @@
+#!/bin/bash
+# Diagnostic builds of the library for ablation timing (see DESIGN.md §4 "Where the time goes"): each variant compiles ONE
+# source with a -DAPLA_ABL_* switch and links it with the product objects into apla_amd/build/exp/libapla_<variant>.so.
+# Results of these builds are WRONG by construction; they exist to be timed (tools/gemm_bench.py / tools/dw_bench.py with
+# APLA_LIB=<path>).  Run after `python -m apla_amd.build`.
+set -e
+cd "$(dirname "$0")/../apla_amd/build"
+mkdir -p exp
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result"
+OBJS="errors gemm_nt gemm_pp2 layernorm attention apla_dw optim misc"
+build() {  # name source "defines"
+  $HIPCC $FLAGS $3 -c ../csrc/$2.hip -o exp/$2_$1.o
+  local objs=""
+  for o in $OBJS; do if [ $o = $2 ]; then objs="$objs exp/$2_$1.o"; else objs="$objs $o.o"; fi; done
+  $HIPCC --offload-arch=gfx950 -shared -fPIC -o exp/libapla_$1.so $objs
+  echo "built exp/libapla_$1.so"
+}
+build NOSTORE gemm_pp2 "-DAPLA_ABL_NOSTORE"          # ping-pong GEMM epilogue computes but does not store
+build NOREAD gemm_pp2 "-DAPLA_ABL_NOREAD"            # K loop without LDS fragment reads
+build NODMA gemm_pp2 "-DAPLA_ABL_NODMA"              # K loop without LDS-DMA
+build NOREADNODMA gemm_pp2 "-DAPLA_ABL_NOREAD -DAPLA_ABL_NODMA"   # MFMA + barriers only: the structure's floor
+build SAMEK gemm_pp2 "-DAPLA_ABL_SAMEK"              # LDS-DMA always from the k = 0 slice (cache-resident source)
+build DWSLABS apla_dw "-DAPLA_ABL_DWSLABS"           # dW slab count from APLA_DW_SLABS
