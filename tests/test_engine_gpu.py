@@ -38,14 +38,16 @@ def oracle_params(model, dtype=torch.float64):
     return p
 
 
-def small_vit(depth=2, r=64, swiglu=False, ls=True):
+def small_vit(depth=2, r=64, swiglu=False, ls=True, dim=128, heads=2, img=32, patch=16, mlp_ratio=None, classes=10):
     from apla_amd import vit
     from apla_amd.apla import build_apla
     from apla_amd.models import AttrDict
     import torch.nn as nn
     from functools import partial
     torch.manual_seed(3)
-    bb = vit.VisionTransformer(img_size=[32], patch_size=16, embed_dim=128, depth=depth, num_heads=2, qkv_bias=True, mlp_ratio=4.5 if swiglu else 4.0,
+    if mlp_ratio is None:
+        mlp_ratio = 4.5 if swiglu else 4.0
+    bb = vit.VisionTransformer(img_size=[img], patch_size=patch, embed_dim=dim, depth=depth, num_heads=heads, qkv_bias=True, mlp_ratio=mlp_ratio,
                                norm_layer=partial(nn.LayerNorm, eps=1e-6), use_swiglu=swiglu,
                                block_conf=dict(has_layerscale=ls, layerscale_init_values=1.0))
     with torch.no_grad():
@@ -53,7 +55,7 @@ def small_vit(depth=2, r=64, swiglu=False, ls=True):
             if "gamma" in n:
                 p_.uniform_(0.5, 1.5)
             elif p_.ndim >= 2:
-                p_.normal_(std=0.06)
+                p_.normal_(std=0.06 * (128 / dim) ** 0.5)  # keeps the per-layer gain of the dim-128 case at any width
             elif "norm" in n and n.endswith("weight"):
                 p_.uniform_(0.8, 1.2)
             else:
@@ -65,7 +67,7 @@ def small_vit(depth=2, r=64, swiglu=False, ls=True):
             super().__init__()
             self.backbone = bb
             self.backbone.fc = nn.Identity()
-            self.fc = nn.Linear(128, 10)
+            self.fc = nn.Linear(dim, classes)
     return Net()
 
 
@@ -115,6 +117,36 @@ def test_engine_small_vs_oracle(swiglu, res_dtype, grad_dtype, use_graphs):
     eng.train_step()
     torch.cuda.synchronize()
     assert np.isfinite(float(eng.loss)) and float(eng.loss) != l0
+
+
+@pytest.mark.parametrize("name,kw,B", [
+    # BASELINE config 3 geometry (ViT-L/14: D=1024, H=16, F=4096, r=256, N=257 @ 224/14), two blocks
+    ("vit_l14", dict(depth=2, r=256, dim=1024, heads=16, img=224, patch=14), 3),
+    # BASELINE config 5 geometry (ViT-g/14: D=1536, H=24, SwiGLU hidden 4096, r=512, N=1370 @ 518/14), one block
+    ("vit_g14", dict(depth=1, r=512, dim=1536, heads=24, img=518, patch=14, swiglu=True, mlp_ratio=4.0), 2),
+])
+def test_engine_large_geometries_vs_oracle(name, kw, B):
+    """The other BASELINE configurations' shapes (token counts 257 / 1370, widths 1024 / 1536, partial sizes 256 / 512,
+    SwiGLU) at reduced depth and batch: logits, loss and every trainable gradient against the fp64 oracle."""
+    from apla_amd.engine import AplaTrainEngine, OptimConfig
+    model = small_vit(**kw)
+    p = oracle_params(model)
+    g = torch.Generator().manual_seed(2)
+    images = torch.randn(B, 3, kw["img"], kw["img"], generator=g)
+    labels = torch.randint(0, 10, (B,), generator=g)
+    cfg = dict(patch=kw["patch"], depth=kw["depth"], heads=kw["heads"], r=kw["r"], swiglu=kw.get("swiglu", False))
+    logits_ref, ctx = O.vit_forward(images.double(), p, cfg)
+    loss_ref, dl = O.cross_entropy_fwd_bwd(logits_ref, labels)
+    grads_ref = O.vit_backward(dl, ctx, p, cfg)
+    eng = AplaTrainEngine(model, B, kw["img"], use_graphs=False, optim=OptimConfig(lr=1e-3, weight_decay=1e-2, grad_clipping=1.0))
+    eng.set_batch(images.cuda(), labels.cuda())
+    eng.forward_backward()
+    torch.cuda.synchronize()
+    assert rel_err(eng.logits.cpu(), logits_ref) < LOGIT_TOL
+    assert abs(float(eng.loss) - float(loss_ref)) < 5e-3
+    for n, gr in eng.grads().items():
+        n2 = n[len("backbone."):] if n.startswith("backbone.") else n
+        assert rel_l2(gr.cpu(), grads_ref[n2]) < GRAD_TOL, n
 
 
 def test_engine_cfg1_matches_reference_golden():
