@@ -316,34 +316,55 @@ __device__ __forceinline__ void wide_epilogue(const GemmParams& p, f32x4 (&acc)[
     const char* rd1 = tbuf + (rrow + 8) * 128 + ((rc ^ ((rrow + 8) >> 1)) << 4);
     const int mbase = m0 + wm * 80 + rrow;
     const size_t cbase = (size_t)n0 + wn * 128 + rc * 8;
-    auto flush = [&](bf16* dst, int ld, int i, int h, bf16x8 c0, bf16x8 c1) {
+    // One buffer, software-pipelined: LDS serves a wave's operations in order, so the writes of step k+1 may be issued
+    // right behind the reads of step k; the global stores of step k go out while step k+1's round trip is in flight.
+    // Full tiles take a branch-free path (per-row predication splits the stream into basic blocks hipcc cannot overlap).
+    auto stage = [&](bf16x8 c0, bf16x8 c1, bf16x8& r0, bf16x8& r1) {
       *(bf16x8*)wr0 = c0;
       *(bf16x8*)wr1 = c1;
-      const bf16x8 r0 = *(const bf16x8*)rd0, r1 = *(const bf16x8*)rd1;
+      r0 = *(const bf16x8*)rd0;
+      r1 = *(const bf16x8*)rd1;
+    };
+    auto commit = [&](auto FULL, bf16* dst, int ld, int i, int h, bf16x8 r0, bf16x8 r1) {
       const int ma = mbase + i * 16, mb = ma + 8;
 #if defined(APLA_ABL_NOSTORE)
       asm volatile("" :: "v"(r0), "v"(r1));
 #else
-      if (ma < p.M) *(bf16x8*)(dst + (size_t)ma * ld + cbase + h * 64) = r0;
-      if (mb < p.M) *(bf16x8*)(dst + (size_t)mb * ld + cbase + h * 64) = r1;
+      if (FULL.value || ma < p.M) *(bf16x8*)(dst + (size_t)ma * ld + cbase + h * 64) = r0;
+      if (FULL.value || mb < p.M) *(bf16x8*)(dst + (size_t)mb * ld + cbase + h * 64) = r1;
 #endif
     };
+    auto run = [&](auto FULL) {
+      if constexpr (EPI == APLA_EPI_STORE) {
+        bf16x8 p0, p1;  // step k-1, read back and waiting to be stored
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const f32x4 a0 = acc[i][4 * h], a1 = acc[i][4 * h + 1], b0 = acc[i][4 * h + 2], b1 = acc[i][4 * h + 3];
-        if constexpr (EPI == APLA_EPI_STORE) {
-          flush((bf16*)p.C, p.ldc, i, h, Vec8IO<bf16>::pack(a0, a1), Vec8IO<bf16>::pack(b0, b1));
-        } else {
-          bf16x8 hc0, gc0, hc1, gc1;
-          gelu8(a0, a1, hc0, gc0);
-          gelu8(b0, b1, hc1, gc1);
-          flush((bf16*)p.C, p.ldc, i, h, hc0, hc1);
-          flush((bf16*)p.aux_out, p.ld_aux_out, i, h, gc0, gc1);
+        for (int k = 0; k <= 10; ++k) {
+          const int i = k >> 1, h = k & 1;
+          bf16x8 n0_, n1_;
+          if (k < 10)
+            stage(Vec8IO<bf16>::pack(acc[i][4 * h], acc[i][4 * h + 1]), Vec8IO<bf16>::pack(acc[i][4 * h + 2], acc[i][4 * h + 3]), n0_, n1_);
+          if (k > 0) commit(FULL, (bf16*)p.C, p.ldc, (k - 1) >> 1, (k - 1) & 1, p0, p1);
+          p0 = n0_; p1 = n1_;
         }
-        __builtin_amdgcn_sched_barrier(0);  // keep the (i, h) groups apart: interleaving them costs registers, not time
+      } else {  // GELU: the two outputs of a step overlap each other; no cross-step registers (the kernel has none to spare)
+#pragma unroll
+        for (int k = 0; k < 10; ++k) {
+          const int i = k >> 1, h = k & 1;
+          bf16x8 hc0, gc0, hc1, gc1, n0_, n1_, m0_, m1_;
+          gelu8(acc[i][4 * h], acc[i][4 * h + 1], hc0, gc0);
+          gelu8(acc[i][4 * h + 2], acc[i][4 * h + 3], hc1, gc1);
+          stage(hc0, hc1, n0_, n1_);
+          stage(gc0, gc1, m0_, m1_);
+          commit(FULL, (bf16*)p.C, p.ldc, i, h, n0_, n1_);
+          commit(FULL, (bf16*)p.aux_out, p.ld_aux_out, i, h, m0_, m1_);
+          __builtin_amdgcn_sched_barrier(0);  // keep the steps apart: interleaving them costs registers, not time
+        }
       }
+    };
+    if constexpr (EPI == APLA_EPI_STORE) {
+      if (full_tile) run(std::true_type{}); else run(std::false_type{});
+    } else {
+      run(std::false_type{});  // one copy only: a second unrolled GELU epilogue costs registers the kernel does not have
     }
     return;
   }
