@@ -425,98 +425,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restr
   if (qvalid) store_acc_T(acc_dq, dqkv + ((long)sq.start + q) * ld + h * 64, h2, scale);
 }
 
-// ------------------------------------------------------------------------------------------------ backward dQ, short sequences
-// Same organisation as attn_fwd_small_kernel: one workgroup per (b, h), K and V of the head in LDS (one LDS-DMA pass, one
-// barrier), wave w owns query rows 32w .. 32w+31 and walks all keys on its own.
-__global__ __launch_bounds__(512, 4) void attn_bwd_dq_small_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
-                                                                   const bf16* __restrict__ dout,
-                                                                   const float* __restrict__ lse,
-                                                                   float* __restrict__ delta, bf16* __restrict__ dqkv,
-                                                                   int Nmax, int H, float scale,
-    const int32_t* __restrict__ cu, int total) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // K rows [NP][64] then V rows [NP][64], NP = 32 * waves
-  const int tid = threadIdx.x, lane = tid & 63, h2 = lane >> 5;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nw = blockDim.x >> 6, NP = nw * 32;
-  const int b = blockIdx.y, h = blockIdx.x;
-  const Seq sq = seq_of(cu, b, Nmax, H, total);
-  const int N = sq.n;
-  if (N <= 0) return;
-  const int D = H * 64;
-  const long ld = 3L * D;
-  const bf16* base = qkv + (long)sq.start * ld + h * 64;
-  const float c = scale * LOG2E;
-  char* Ks = smem;
-  char* Vs = smem + NP * 128;
-#pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    const int pc = wave * 8 + it;
-    const bool isv = pc >= NP / 8;
-    const int pr = isv ? pc - NP / 8 : pc;
-    const int row = pr * 8 + (lane >> 3);
-    const int f = (((row >> 1) & 1) << 2) | ((row >> 2) & 3);
-    const int ch = (lane & 7) ^ f;
-    const int gr = row < N ? row : N - 1;
-    const bf16* src = base + (isv ? 2 * D : D) + (long)gr * ld + ch * 8;
-    __builtin_amdgcn_global_load_lds(ATT_GLBP(src), ATT_LDSP((isv ? Vs : Ks) + pr * 1024), 16, 0, 0);
-  }
-
-  int q = wave * 32 + (lane & 31);
-  const bool qvalid = q < N;
-  if (!qvalid) q = N - 1;
-  bf16x8 qf[4], dof[4];
-  load_row_frags(qf, base + (long)q * ld, lane);
-  load_row_frags(dof, dout + ((long)sq.start + q) * D + h * 64, lane);
-  float dl = 0.f;
-  {
-    bf16x8 of[4];
-    load_row_frags(of, o + ((long)sq.start + q) * D + h * 64, lane);
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) dl += (float)dof[ks][j] * (float)of[ks][j];
-  }
-  dl += __shfl_xor(dl, 32, 64);
-  const long statidx = sq.stat + (long)h * sq.stat_h + q;
-  if (qvalid && h2 == 0) delta[statidx] = dl;
-  const float lse2 = lse[statidx] * LOG2E;
-
-  f32x16 acc_dq[2];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) { acc_dq[0][i] = 0.f; acc_dq[1][i] = 0.f; }
-
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (wave * 32 >= N) return;  // packed batches: waves past this sequence's end only helped loading
-
-  const int nkt = (N + 31) / 32;
-  for (int kt = 0; kt < nkt; ++kt) {
-    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    f32x16 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Ks, kt * 32, 0, lane), qf[0], zero, 0, 0, 0);
-    f32x16 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Vs, kt * 32, 0, lane), dof[0], zero, 0, 0, 0);
-#pragma unroll
-    for (int ks = 1; ks < 4; ++ks) {
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Ks, kt * 32, ks, lane), qf[ks], s, 0, 0, 0);
-      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Vs, kt * 32, ks, lane), dof[ks], dp, 0, 0, 0);
-    }
-    const bool tail = kt * 32 + 32 > N;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      float p = __builtin_amdgcn_exp2f(fmaf(s[i], c, -lse2));
-      if (tail && kt * 32 + acc_row(i, h2) >= N) p = 0.f;
-      s[i] = p * (dp[i] - dl);  // dS^T (unscaled)
-    }
-#pragma unroll
-    for (int sk = 0; sk < 2; ++sk) {
-      const bf16x8 dsb = acc_to_operand(s, sk);
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
-        acc_dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Ks, kt * 32 + 16 * sk, 32 * dt, lane), dsb, acc_dq[dt], 0, 0, 0);
-    }
-  }
-  if (qvalid) store_acc_T(acc_dq, dqkv + ((long)sq.start + q) * ld + h * 64, h2, scale);
-}
-
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ dout,
                                                            const float* __restrict__ lse,
@@ -725,15 +633,10 @@ static int launch_attn_bwd(const void* qkv, const void* o, const void* d_o, cons
                            const int32_t* cu, int total, int B, int N, int H, float scale, hipStream_t stream,
                            const char* who) {
   dim3 grid((N + 127) / 128, H, B);
-  if (N <= SMALL_MAX_ROWS && g_attn_variant != 1) {
-    const int nw = (N + 31) / 32;
-    hipLaunchKernelGGL(attn_bwd_dq_small_kernel, dim3(H, B), dim3(64 * nw), (size_t)nw * 32 * 256, stream, (const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse, delta, (bf16*)dqkv, N, H, scale, cu, total);
-  } else {
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, stream, (const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse, delta, (bf16*)dqkv, N, H, scale, cu, total);
-  }
+  // The backward stays key-blocked at every length: one-workgroup-per-head variants of dQ (K/V of the head in LDS) and of
+  // dK/dV (Q/dO in LDS) were built and measured 4 % and 7 % slower than these kernels.
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, stream, (const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse, delta, (bf16*)dqkv, N, H, scale, cu, total);
   APLA_CHECK_LAUNCH(who);
-  // dK/dV stay on the key-blocked kernel: a one-pass variant with Q/dO of the head in LDS measured 7 % slower (it needs
-  // ~200 VGPRs either way, so it gains no occupancy)
   hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, stream, (const bf16*)qkv, (const bf16*)d_o, lse, delta, (bf16*)dqkv, N, H, scale, cu, total);
   APLA_CHECK_LAUNCH(who);
   return APLA_OK;

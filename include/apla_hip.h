@@ -101,9 +101,9 @@ int apla_attn_varlen_fwd(const void* qkv, void* o, float* lse, const int32_t* cu
 int apla_attn_varlen_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv,
                          const int32_t* cu_seqlens, int S, int total, int max_n, int H, float scale, hipStream_t stream);
 
-/* Tuning/diagnostic knob for apla_attn_fwd / apla_attn_bwd (process-wide): 0 = auto (default): sequences of up to 256 tokens
- * use the one-workgroup-per-head kernels that keep the whole K/V (Q/dO) of a head in LDS; 1 = always the key-blocked
- * kernels.  Returns the previous value.  Both compute the same results (tests/test_kernels_gpu.py). */
+/* Tuning/diagnostic knob for apla_attn_fwd (process-wide): 0 = auto (default): sequences of up to 256 tokens use the
+ * one-workgroup-per-head forward kernel that keeps the whole K/V of a head in LDS; 1 = always the key-blocked kernel.
+ * Returns the previous value.  Both compute the same results (tests/test_kernels_gpu.py). */
 int apla_attn_set_variant(int variant);
 
 /* Attention backward from (qkv, o, do, lse): dqkv[B*N, 3*H*64].  `delta` is a caller workspace of B*H*N floats.
