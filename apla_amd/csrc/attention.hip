@@ -15,6 +15,9 @@
 // bitwise reproducible.  delta = rowsum(dO*O) is produced by the dQ kernel and consumed by the dKdV kernel.
 #include "common.h"
 
+#define ATT_LDSP(p) ((__attribute__((address_space(3))) void*)(p))
+#define ATT_GLBP(p) ((const __attribute__((address_space(1))) void*)(p))
+
 namespace {
 
 constexpr float LOG2E = 1.4426950408889634f;
@@ -223,8 +226,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
 // swizzle of tile_off is applied on the source column since the LDS side of a DMA is lane-linear), one barrier, and then
 // every wave walks the keys on its own — no per-block staging through registers, no further barriers.  Two workgroups
 // per CU (56 KB of LDS each at N = 197).
-#define ATT_LDSP(p) ((__attribute__((address_space(3))) void*)(p))
-#define ATT_GLBP(p) ((const __attribute__((address_space(1))) void*)(p))
 constexpr int SMALL_MAX_ROWS = 256;
 
 __global__ __launch_bounds__(512, 4) void attn_fwd_small_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
@@ -343,9 +344,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restr
                                                           const bf16* __restrict__ dout, const float* __restrict__ lse,
                                                           float* __restrict__ delta, bf16* __restrict__ dqkv, int Nmax, int H, float scale,
     const int32_t* __restrict__ cu, int total) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * 8192];
-  char* Ks = smem;
-  char* Vs = smem + 8192;
+  __shared__ __attribute__((aligned(16))) char smem[2 * 16384];  // two (K tile, V tile) buffers filled by LDS-DMA
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h2 = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128;
   const Seq sq = seq_of(cu, b, Nmax, H, total);
@@ -382,36 +381,54 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restr
   for (int i = 0; i < 16; ++i) { acc_dq[0][i] = 0.f; acc_dq[1][i] = 0.f; }
 
   const int nkb = (N + 63) / 64;
-  TileRegs<64> kr, vr;
-  tile_load<64>(kr, base + D, ld, 0, N, tid);
-  tile_load<64>(vr, base + 2 * D, ld, 0, N, tid);
-  for (int kb = 0; kb < nkb; ++kb) {
-    __syncthreads();
-    tile_store<64>(kr, Ks, tid);
-    tile_store<64>(vr, Vs, tid);
-    __syncthreads();
-    if (kb + 1 < nkb) {
-      tile_load<64>(kr, base + D, ld, (kb + 1) * 64, N, tid);
-      tile_load<64>(vr, base + 2 * D, ld, (kb + 1) * 64, N, tid);
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  auto issue = [&](int kb) {  // 16 pieces of 8 rows x 128 B (8 of K, 8 of V), four per wave; swizzle on the source column
+    char* buf = smem + (kb & 1) * 16384;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int pc = wave_u * 4 + it;
+      const bool isv = pc >= 8;
+      const int pr = pc & 7;
+      const int row = pr * 8 + (lane >> 3);
+      const int f = (((row >> 1) & 1) << 2) | ((row >> 2) & 3);
+      const int ch = (lane & 7) ^ f;
+      int gr = kb * 64 + row;
+      gr = gr < N ? gr : N - 1;
+      const bf16* src = base + (isv ? 2 * D : D) + (long)gr * ld + ch * 8;
+      __builtin_amdgcn_global_load_lds(ATT_GLBP(src), ATT_LDSP(buf + (isv ? 8192 : 0) + pr * 1024), 16, 0, 0);
     }
+  };
+  issue(0);
+  for (int kb = 0; kb < nkb; ++kb) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // tile kb is in LDS; every wave is done with tile kb-1
+    if (kb + 1 < nkb) issue(kb + 1);
+    const char* Ks = smem + (kb & 1) * 16384;
+    const char* Vs = Ks + 8192;
     if (!wave_active) continue;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
       if (kt == 1 && kb * 64 + 32 >= N) continue;  // fully masked key tile
-      f32x16 s, dp;
+      const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      f32x16 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Ks, kt * 32, 0, lane), qf[0], zero, 0, 0, 0);
+      f32x16 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Vs, kt * 32, 0, lane), dof[0], zero, 0, 0, 0);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
+      for (int ks = 1; ks < 4; ++ks) {
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Ks, kt * 32, ks, lane), qf[ks], s, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Vs, kt * 32, ks, lane), dof[ks], dp, 0, 0, 0);
       }
-      const bool tail = kb * 64 + kt * 32 + 32 > N;
+      // dS^T (unscaled).  Only the sequence's last key tile needs the per-key mask: as one predicated loop hipcc emits the
+      // compare/select pair for every element of every tile (45 % of this kernel's VALU instructions).
+      if (kb * 64 + kt * 32 + 32 <= N) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        float p = __builtin_amdgcn_exp2f(fmaf(s[i], c, -lse2));
-        if (tail && kb * 64 + kt * 32 + acc_row(i, h2) >= N) p = 0.f;
-        s[i] = p * (dp[i] - dl);  // dS^T (unscaled)
+        for (int i = 0; i < 16; ++i) s[i] = __builtin_amdgcn_exp2f(fmaf(s[i], c, -lse2)) * (dp[i] - dl);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          float p = __builtin_amdgcn_exp2f(fmaf(s[i], c, -lse2));
+          if (kb * 64 + kt * 32 + acc_row(i, h2) >= N) p = 0.f;
+          s[i] = p * (dp[i] - dl);
+        }
       }
 #pragma unroll
       for (int sk = 0; sk < 2; ++sk) {
@@ -517,18 +534,33 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __rest
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Qs, qt * 32, ks, lane), kf[ks], s, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(dOs, qt * 32, ks, lane), vf[ks], dp, 0, 0, 0);
       }
-      const bool tail = qb * 64 + qt * 32 + 32 > N;
+      // P and dS (in place of dP).  Only the sequence's last query tile needs the per-row mask (see the dQ kernel).
+      if (qb * 64 + qt * 32 + 32 <= N) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int r0 = qt * 32 + 8 * g + 4 * h2;
-        const f32x4 l4 = *(const f32x4*)(lses + r0), d4 = *(const f32x4*)(dls + r0);
+        for (int g = 0; g < 4; ++g) {
+          const int r0 = qt * 32 + 8 * g + 4 * h2;
+          const f32x4 l4 = *(const f32x4*)(lses + r0), d4 = *(const f32x4*)(dls + r0);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int i = 4 * g + e;
-          float p = __builtin_amdgcn_exp2f(fmaf(s[i], c, -l4[e]));
-          if (tail && qb * 64 + r0 + e >= N) p = 0.f;
-          s[i] = p;
-          dp[i] = p * (dp[i] - d4[e]);  // dS, in place
+          for (int e = 0; e < 4; ++e) {
+            const int i = 4 * g + e;
+            const float p = __builtin_amdgcn_exp2f(fmaf(s[i], c, -l4[e]));
+            s[i] = p;
+            dp[i] = p * (dp[i] - d4[e]);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int r0 = qt * 32 + 8 * g + 4 * h2;
+          const f32x4 l4 = *(const f32x4*)(lses + r0), d4 = *(const f32x4*)(dls + r0);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int i = 4 * g + e;
+            float p = __builtin_amdgcn_exp2f(fmaf(s[i], c, -l4[e]));
+            if (qb * 64 + r0 + e >= N) p = 0.f;
+            s[i] = p;
+            dp[i] = p * (dp[i] - d4[e]);
+          }
         }
       }
 #pragma unroll
