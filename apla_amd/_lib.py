@@ -8,15 +8,17 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_long, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libapla_hip.so")
+LIB_PATH = os.path.join(HERE, "libapla_hip.so")          # bf16 operands (default)
+LIB_PATH_F16 = os.path.join(HERE, "libapla_hip_f16.so")  # fp16 operands (same sources, -DAPLA_FP16)
 
-APLA_BF16, APLA_F32 = 0, 2
+APLA_BF16, APLA_F16, APLA_F32 = 0, 1, 2
 EPI_STORE, EPI_GELU, EPI_RESIDUAL, EPI_MUL, EPI_SWIGLU, EPI_SWIGLU_BWD = 0, 1, 2, 3, 4, 5
 
 # name -> (restype, argtypes); must list every symbol of include/apla_hip.h (tests/test_cabi.py checks this)
 SIGNATURES = {
     "apla_last_error": (c_char_p, []),
     "apla_version": (c_int, []),
+    "apla_operand_dtype": (c_int, []),
     "apla_gemm_nt": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                              c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "apla_gemm_set_variant": (c_int, [c_int]),
@@ -51,28 +53,39 @@ SIGNATURES = {
     "apla_colsum": (c_int, [c_void_p, c_long, c_void_p, c_int, c_int, c_void_p]),
 }
 
-_lib = None
+_libs = {}      # operand code (APLA_BF16 / APLA_F16) -> ctypes handle
+_current = APLA_BF16  # which library lib() returns: switched by ops.use_half
 
 
 class AplaHipError(RuntimeError):
     pass
 
 
-def lib():
-    """Load (once) and return the ctypes handle; raises if the HIP library is missing."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
+def lib(operand=None):
+    """Load (once) and return the ctypes handle of the library built for `operand` (default: the current one, bf16 unless
+    inside ops.use_half(torch.float16)); raises if that library is missing."""
+    code = _current if operand is None else operand
+    if code not in _libs:
+        path = LIB_PATH if code == APLA_BF16 else LIB_PATH_F16
+        if not os.path.exists(path):
             raise AplaHipError(
-                f"{LIB_PATH} not found: the APLA HIP kernels are not built. Run `python -m apla_amd.build` "
+                f"{path} not found: the APLA HIP kernels are not built. Run `python -m apla_amd.build` "
                 "(needs hipcc, targets gfx950). There is no CPU fallback.")
-        handle = ctypes.CDLL(LIB_PATH)
+        handle = ctypes.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the .so does not export a declared symbol
             fn.restype = res
             fn.argtypes = args
-        _lib = handle
-    return _lib
+        if handle.apla_operand_dtype() != code:
+            raise AplaHipError(f"{path} was built for operand dtype {handle.apla_operand_dtype()}, expected {code}")
+        _libs[code] = handle
+    return _libs[code]
+
+
+def set_current(code):
+    global _current
+    old, _current = _current, code
+    return old
 
 
 def check(rc, what):

@@ -7,7 +7,8 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OUT = os.path.join(HERE, "libapla_hip.so")
+OUT = os.path.join(HERE, "libapla_hip.so")          # bf16 operands (default, benchmarked)
+OUT_F16 = os.path.join(HERE, "libapla_hip_f16.so")  # same sources with -DAPLA_FP16: IEEE fp16 operands
 SOURCES = ["errors.cpp", "gemm_nt.hip", "gemm_pp2.hip", "layernorm.hip", "attention.hip", "apla_dw.hip", "optim.hip", "misc.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"]
@@ -20,15 +21,23 @@ def _stale(obj, src):
     return any(os.path.getmtime(d) > os.path.getmtime(obj) for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
-    objdir = os.path.join(HERE, "build")
+def build(force: bool = False, verbose: bool = True, fp16: bool = True) -> str:
+    """Compile libapla_hip.so and (fp16=True) libapla_hip_f16.so."""
+    _build_one(OUT, "build", [], force, verbose)
+    if fp16:
+        _build_one(OUT_F16, os.path.join("build", "f16"), ["-DAPLA_FP16"], force, verbose)
+    return OUT
+
+
+def _build_one(out, objsub, defines, force, verbose):
+    objdir = os.path.join(HERE, objsub)
     os.makedirs(objdir, exist_ok=True)
     jobs = []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(objdir, s.rsplit(".", 1)[0] + ".o")
         if force or _stale(obj, src):
-            cmd = [HIPCC] + FLAGS + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", src, "-o", obj]
+            cmd = [HIPCC] + FLAGS + defines + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", src, "-o", obj]
             jobs.append(cmd)
     def run(cmd):
         if verbose:
@@ -39,9 +48,9 @@ def build(force: bool = False, verbose: bool = True) -> str:
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
     objs = [os.path.join(objdir, s.rsplit(".", 1)[0] + ".o") for s in SOURCES]
-    if jobs or not os.path.exists(OUT):
-        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs)
-    return OUT
+    if jobs or not os.path.exists(out):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+    return out
 
 
 if __name__ == "__main__":

@@ -26,8 +26,8 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* lds, int rbase, int c0, in
   const int r = rbase + 4 * (g >> 1) + (i >> 2);
   const int a0 = tile_off(r, col >> 3) + ((col & 4) << 1);
   const int a1 = tile_off(r + 8, col >> 3) + ((col & 4) << 1);
-  bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(lds + a0));
-  bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(lds + a1));
+  bf16x4 lo = DS_READ_TR16_B64_H16(lds + a0);
+  bf16x4 hi = DS_READ_TR16_B64_H16(lds + a1);
   bf16x8 out;
   out[0] = lo[0]; out[1] = lo[1]; out[2] = lo[2]; out[3] = lo[3];
   out[4] = hi[0]; out[5] = hi[1]; out[6] = hi[2]; out[7] = hi[3];
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void proj_dw_partial_kernel(const bf16* __rest
           for (int e = 0; e < 8; ++e)
             if (16 * ks + 8 * (e >> 2) + 4 * h2 + (e & 3) >= valid) a[e] = (bf16)0.f;
         }
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
+        acc[t] = MFMA_F32_32x32x16_H16(a, b, acc[t]);
         if (tk == 0 && ks == wave) {  // lane holds dyg[8 token rows][j = 32t + (lane&31)]
           float sm = 0.f;
 #pragma unroll

@@ -67,8 +67,8 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* lds, int rbase, int c0, in
   const int r = rbase + 4 * (g >> 1) + (i >> 2);
   const int a0 = tile_off(r, col >> 3) + ((col & 4) << 1);
   const int a1 = tile_off(r + 8, col >> 3) + ((col & 4) << 1);
-  bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(lds + a0));
-  bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(lds + a1));
+  bf16x4 lo = DS_READ_TR16_B64_H16(lds + a0);
+  bf16x4 hi = DS_READ_TR16_B64_H16(lds + a1);
   bf16x8 out;
   out[0] = lo[0]; out[1] = lo[1]; out[2] = lo[2]; out[3] = lo[3];
   out[4] = hi[0]; out[5] = hi[1]; out[6] = hi[2]; out[7] = hi[3];
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
       for (int i = 0; i < 16; ++i) s[kt][i] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
-        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Ks, kt * 32, ks, lane), qf[ks], s[kt], 0, 0, 0);
+        s[kt] = MFMA_F32_32x32x16_H16(row_frag(Ks, kt * 32, ks, lane), qf[ks], s[kt]);
     }
     if (kb * 64 + 64 > N) {
 #pragma unroll
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
         const bf16x8 pb = acc_to_operand(s[kt], sk);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
-          acc_o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Vs, kt * 32 + 16 * sk, 32 * dt, lane), pb, acc_o[dt], 0, 0, 0);
+          acc_o[dt] = MFMA_F32_32x32x16_H16(tr_frag(Vs, kt * 32 + 16 * sk, 32 * dt, lane), pb, acc_o[dt]);
       }
     }
   }
@@ -287,10 +287,10 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_small_kernel(const bf16* __re
         continue;
       }
       const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Ks, kb * 64 + kt * 32, 0, lane), qf[0], zero, 0, 0, 0);
+      s[kt] = MFMA_F32_32x32x16_H16(row_frag(Ks, kb * 64 + kt * 32, 0, lane), qf[0], zero);
 #pragma unroll
       for (int ks = 1; ks < 4; ++ks)
-        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Ks, kb * 64 + kt * 32, ks, lane), qf[ks], s[kt], 0, 0, 0);
+        s[kt] = MFMA_F32_32x32x16_H16(row_frag(Ks, kb * 64 + kt * 32, ks, lane), qf[ks], s[kt]);
     }
     if (kb * 64 + 64 > N) {
 #pragma unroll
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_small_kernel(const bf16* __re
         const bf16x8 pb = acc_to_operand(s[kt], sk);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
-          acc_o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Vs, kb * 64 + kt * 32 + 16 * sk, 32 * dt, lane), pb, acc_o[dt], 0, 0, 0);
+          acc_o[dt] = MFMA_F32_32x32x16_H16(tr_frag(Vs, kb * 64 + kt * 32 + 16 * sk, 32 * dt, lane), pb, acc_o[dt]);
       }
     }
   }
@@ -410,12 +410,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restr
     for (int kt = 0; kt < 2; ++kt) {
       if (kt == 1 && kb * 64 + 32 >= N) continue;  // fully masked key tile
       const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      f32x16 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Ks, kt * 32, 0, lane), qf[0], zero, 0, 0, 0);
-      f32x16 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Vs, kt * 32, 0, lane), dof[0], zero, 0, 0, 0);
+      f32x16 s = MFMA_F32_32x32x16_H16(row_frag(Ks, kt * 32, 0, lane), qf[0], zero);
+      f32x16 dp = MFMA_F32_32x32x16_H16(row_frag(Vs, kt * 32, 0, lane), dof[0], zero);
 #pragma unroll
       for (int ks = 1; ks < 4; ++ks) {
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Ks, kt * 32, ks, lane), qf[ks], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Vs, kt * 32, ks, lane), dof[ks], dp, 0, 0, 0);
+        s = MFMA_F32_32x32x16_H16(row_frag(Ks, kt * 32, ks, lane), qf[ks], s);
+        dp = MFMA_F32_32x32x16_H16(row_frag(Vs, kt * 32, ks, lane), dof[ks], dp);
       }
       // dS^T (unscaled).  Only the sequence's last key tile needs the per-key mask: as one predicated loop hipcc emits the
       // compare/select pair for every element of every tile (45 % of this kernel's VALU instructions).
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restr
         const bf16x8 dsb = acc_to_operand(s, sk);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
-          acc_dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Ks, kt * 32 + 16 * sk, 32 * dt, lane), dsb, acc_dq[dt], 0, 0, 0);
+          acc_dq[dt] = MFMA_F32_32x32x16_H16(tr_frag(Ks, kt * 32 + 16 * sk, 32 * dt, lane), dsb, acc_dq[dt]);
       }
     }
   }
@@ -531,8 +531,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __rest
       for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Qs, qt * 32, ks, lane), kf[ks], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(dOs, qt * 32, ks, lane), vf[ks], dp, 0, 0, 0);
+        s = MFMA_F32_32x32x16_H16(row_frag(Qs, qt * 32, ks, lane), kf[ks], s);
+        dp = MFMA_F32_32x32x16_H16(row_frag(dOs, qt * 32, ks, lane), vf[ks], dp);
       }
       // P and dS (in place of dP).  Only the sequence's last query tile needs the per-row mask (see the dQ kernel).
       if (qb * 64 + qt * 32 + 32 <= N) {
@@ -568,8 +568,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __rest
         const bf16x8 pb = acc_to_operand(s, sk), dsb = acc_to_operand(dp, sk);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
-          acc_dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(dOs, qt * 32 + 16 * sk, 32 * dt, lane), pb, acc_dv[dt], 0, 0, 0);
-          acc_dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Qs, qt * 32 + 16 * sk, 32 * dt, lane), dsb, acc_dk[dt], 0, 0, 0);
+          acc_dv[dt] = MFMA_F32_32x32x16_H16(tr_frag(dOs, qt * 32 + 16 * sk, 32 * dt, lane), pb, acc_dv[dt]);
+          acc_dk[dt] = MFMA_F32_32x32x16_H16(tr_frag(Qs, qt * 32 + 16 * sk, 32 * dt, lane), dsb, acc_dk[dt]);
         }
       }
     }

@@ -6,7 +6,23 @@
 
 #include "../../include/apla_hip.h"
 
+// `bf16` is this build's 16-bit operand type: __bf16 by default, IEEE half with -DAPLA_FP16 (libapla_hip_f16.so).  The
+// kernels are written once against the name; the three type-specific builtins are behind the macros below.
+#if defined(APLA_FP16)
+typedef _Float16 bf16;
+#define APLA_H16 APLA_F16
+#define MFMA_F32_16x16x32_H16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+#define MFMA_F32_32x32x16_H16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+typedef __fp16 apla_v4fp16 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+#define DS_READ_TR16_B64_H16(p) \
+  __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) apla_v4fp16*)(p)))
+#else
 typedef __bf16 bf16;
+#define APLA_H16 APLA_BF16
+#define MFMA_F32_16x16x32_H16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#define MFMA_F32_32x32x16_H16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#define DS_READ_TR16_B64_H16(p) __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p))
+#endif
 typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef bf16 bf16x2 __attribute__((ext_vector_type(2)));

@@ -15,3 +15,11 @@ void apla_set_error(const char* fmt, ...) {
 
 extern "C" const char* apla_last_error(void) { return g_err; }
 extern "C" int apla_version(void) { return 100; }
+
+extern "C" int apla_operand_dtype(void) {
+#if defined(APLA_FP16)
+  return APLA_F16;
+#else
+  return APLA_BF16;
+#endif
+}

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[i][j] = MFMA_F32_16x16x32_H16(wf[j], af[i], acc[i][j]);
     }
     __syncthreads();
   }
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void gemm_persist_kernel(GemmParams p, int 
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < 4; ++j) acc[i][j] = MFMA_F32_16x16x32_H16(wf[j], af[i], acc[i][j]);
       }
       cur ^= 1;
     }
@@ -298,7 +298,7 @@ int launch(const GemmParams& p, hipStream_t stream) {
   // auto (4): the 8-wave ping-pong kernel for large problems whose epilogue it handles well, else the 128-wide persistent
   // kernel; 9 forces ping-pong wherever it is instantiated; 14/15 force the 128-wide persistent kernel with MI 4/5.
   if (g_variant == 9 || (g_variant == 4 && p.M >= 2048)) {
-    const int rc = apla_gemm_pp2_launch(p, EPI, std::is_same<OutT, float>::value ? APLA_F32 : APLA_BF16, stream);
+    const int rc = apla_gemm_pp2_launch(p, EPI, std::is_same<OutT, float>::value ? APLA_F32 : APLA_H16, stream);
     if (rc != APLA_ENOSYS) return rc;
   }
   if (g_variant >= 4) {
@@ -334,7 +334,7 @@ extern "C" int apla_gemm_nt(const void* A, int lda, const void* W, int ldw, cons
   switch (epilogue) {
     case APLA_EPI_STORE:
       APLA_REQUIRE(ldc >= N, "apla_gemm_nt: ldc < N");
-      if (out_dtype == APLA_BF16) return launch<APLA_EPI_STORE, bf16>(p, stream);
+      if (out_dtype == APLA_H16) return launch<APLA_EPI_STORE, bf16>(p, stream);
       if (out_dtype == APLA_F32) return launch<APLA_EPI_STORE, float>(p, stream);
       break;
     case APLA_EPI_GELU:
@@ -342,7 +342,7 @@ extern "C" int apla_gemm_nt(const void* A, int lda, const void* W, int ldw, cons
       return launch<APLA_EPI_GELU, bf16>(p, stream);
     case APLA_EPI_RESIDUAL:
       APLA_REQUIRE(aux_in && apla_aligned16(aux_in) && ld_aux_in % 4 == 0 && ld_aux_in >= N && ldc >= N, "apla_gemm_nt[residual]: aux_in [M,N] required");
-      if (out_dtype == APLA_BF16) return launch<APLA_EPI_RESIDUAL, bf16>(p, stream);
+      if (out_dtype == APLA_H16) return launch<APLA_EPI_RESIDUAL, bf16>(p, stream);
       if (out_dtype == APLA_F32) return launch<APLA_EPI_RESIDUAL, float>(p, stream);
       break;
     case APLA_EPI_MUL:

@@ -168,10 +168,10 @@ extern "C" int apla_layernorm_fwd(const void* x, int res_dtype, long x_row_strid
     else if (nc_ <= 6) LN_FWD_NC(T, Y, 6);              \
     else LN_FWD_NC(T, Y, 8);                            \
   } while (0)
-  if (res_dtype == APLA_F32 && y_dtype == APLA_BF16) LN_FWD(float, bf16);
+  if (res_dtype == APLA_F32 && y_dtype == APLA_H16) LN_FWD(float, bf16);
   else if (res_dtype == APLA_F32 && y_dtype == APLA_F32) LN_FWD(float, float);
-  else if (res_dtype == APLA_BF16 && y_dtype == APLA_BF16) LN_FWD(bf16, bf16);
-  else if (res_dtype == APLA_BF16 && y_dtype == APLA_F32) LN_FWD(bf16, float);
+  else if (res_dtype == APLA_H16 && y_dtype == APLA_H16) LN_FWD(bf16, bf16);
+  else if (res_dtype == APLA_H16 && y_dtype == APLA_F32) LN_FWD(bf16, float);
   else {
     apla_set_error("apla_layernorm_fwd: bad res_dtype %d / y_dtype %d", res_dtype, y_dtype);
     return APLA_ENOSYS;
@@ -211,18 +211,18 @@ extern "C" int apla_layernorm_bwd(const void* dy, int dy_dtype, int lddy, const 
 #define LN_BWD_G(X, Y, G) do { if (gather) LN_BWD(X, Y, G, true); else LN_BWD(X, Y, G, false); } while (0)
 #define LN_BWD_Y(X, G)                                           \
   do {                                                           \
-    if (dy_dtype == APLA_BF16) LN_BWD_G(X, bf16, G);             \
+    if (dy_dtype == APLA_H16) LN_BWD_G(X, bf16, G);             \
     else LN_BWD_G(X, float, G);                                  \
   } while (0)
-  const bool ok = (x_dtype == APLA_F32 || x_dtype == APLA_BF16) && (dy_dtype == APLA_F32 || dy_dtype == APLA_BF16) &&
-                  (grad_dtype == APLA_F32 || grad_dtype == APLA_BF16);
+  const bool ok = (x_dtype == APLA_F32 || x_dtype == APLA_H16) && (dy_dtype == APLA_F32 || dy_dtype == APLA_H16) &&
+                  (grad_dtype == APLA_F32 || grad_dtype == APLA_H16);
   if (!ok) {
     apla_set_error("apla_layernorm_bwd: bad dtypes x=%d dy=%d grad=%d", x_dtype, dy_dtype, grad_dtype);
     return APLA_ENOSYS;
   }
   if (x_dtype == APLA_F32 && grad_dtype == APLA_F32) LN_BWD_Y(float, float);
-  else if (x_dtype == APLA_F32 && grad_dtype == APLA_BF16) LN_BWD_Y(float, bf16);
-  else if (x_dtype == APLA_BF16 && grad_dtype == APLA_F32) LN_BWD_Y(bf16, float);
+  else if (x_dtype == APLA_F32 && grad_dtype == APLA_H16) LN_BWD_Y(float, bf16);
+  else if (x_dtype == APLA_H16 && grad_dtype == APLA_F32) LN_BWD_Y(bf16, float);
   else LN_BWD_Y(bf16, bf16);
 #undef LN_BWD_Y
 #undef LN_BWD_G
@@ -237,7 +237,7 @@ extern "C" int apla_gather_cols(const void* src, int res_dtype, long src_row_str
   APLA_REQUIRE(src && inds && out && M > 0 && r > 0 && r <= D, "apla_gather_cols: bad arguments");
   if (res_dtype == APLA_F32)
     hipLaunchKernelGGL(gather_cols_kernel<float>, dim3(ln_grid(M)), dim3(256), 0, stream, (const float*)src, src_row_stride, inds, r, (bf16*)out, M);
-  else if (res_dtype == APLA_BF16)
+  else if (res_dtype == APLA_H16)
     hipLaunchKernelGGL(gather_cols_kernel<bf16>, dim3(ln_grid(M)), dim3(256), 0, stream, (const bf16*)src, src_row_stride, inds, r, (bf16*)out, M);
   else {
     apla_set_error("apla_gather_cols: bad res_dtype %d", res_dtype);

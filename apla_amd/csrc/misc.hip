@@ -151,7 +151,7 @@ extern "C" int apla_assemble_tokens(const void* patches, int ldp, const float* c
   APLA_REQUIRE(patches && cls_token && pos_embed && tokens && B > 0 && Np > 0 && D % 4 == 0 && ldp % 4 == 0, "apla_assemble_tokens: bad arguments");
   if (res_dtype == APLA_F32)
     hipLaunchKernelGGL(assemble_tokens_kernel<float>, dim3(B * (Np + 1)), dim3(256), 0, stream, (const bf16*)patches, ldp, cls_token, pos_embed, (float*)tokens, Np, D);
-  else if (res_dtype == APLA_BF16)
+  else if (res_dtype == APLA_H16)
     hipLaunchKernelGGL(assemble_tokens_kernel<bf16>, dim3(B * (Np + 1)), dim3(256), 0, stream, (const bf16*)patches, ldp, cls_token, pos_embed, (bf16*)tokens, Np, D);
   else {
     apla_set_error("apla_assemble_tokens: bad res_dtype %d", res_dtype);

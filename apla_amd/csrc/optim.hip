@@ -35,12 +35,14 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
       const float norm = sqrtf(s);
       float coef = 1.0f;
       if (max_norm > 0.f) { coef = max_norm / (norm + 1e-6f); coef = coef < 1.0f ? coef : 1.0f; }
-      coef_s = coef * grad_scale;
+      // a non-finite norm (fp16 gradients that overflowed under the loss scale) skips the update, like GradScaler.step
+      coef_s = isfinite(norm) ? coef * grad_scale : __builtin_nanf("");
       if (blockIdx.x == 0) { ws[0] = s; ws[1] = norm; }
     }
   }
   __syncthreads();
   const float coef = coef_s;
+  if (coef != coef) return;
   const float step_size = lr / bc1;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     const float gi = g[i] * coef;

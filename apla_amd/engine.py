@@ -32,7 +32,6 @@ from ._lib import AplaHipError
 from .apla.appla_attn import APLA_Attention
 from .dist import GradExchanger
 
-_BF = torch.bfloat16
 
 
 @dataclass
@@ -49,11 +48,11 @@ class _BlockState:
 
 
 def _bf(t):
-    return t.detach().to(_BF).contiguous()
+    return t.detach().to(ops.half()).contiguous()
 
 
 def _bf_t(t):
-    return t.detach().t().contiguous().to(_BF)
+    return t.detach().t().contiguous().to(ops.half())
 
 
 def _interleave_rows(w):
@@ -61,9 +60,21 @@ def _interleave_rows(w):
     return torch.stack([w[:h], w[h:]], 1).reshape(w.shape).contiguous()
 
 
+def _half_mode(fn):
+    """Run a public engine method against the library built for the engine's operand dtype."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *a, **k):
+        with ops.use_half(self.hdt):
+            return fn(self, *a, **k)
+    return wrapped
+
+
 class AplaTrainEngine:
     def __init__(self, model: nn.Module, batch_size: int, img_size: int, device="cuda", res_dtype=torch.float32,
-                 grad_dtype=_BF, optim: Optional[OptimConfig] = None, process_group=None, use_graphs: bool = True):
+                 grad_dtype=None, optim: Optional[OptimConfig] = None, process_group=None, use_graphs: bool = True,
+                 compute_dtype=torch.bfloat16, loss_scale: float = 1.0):
         if not torch.cuda.is_available():
             raise AplaHipError("AplaTrainEngine needs an MI355X (no CPU fallback)")
         self.device = torch.device(device)
@@ -79,7 +90,11 @@ class AplaTrainEngine:
         self.M = self.B * self.N
         self.eps = bb.eps
         self.swiglu = bb.use_swiglu
-        self.res_dtype, self.grad_dtype = res_dtype, grad_dtype
+        if compute_dtype not in (torch.bfloat16, torch.float16):
+            raise TypeError("compute_dtype must be torch.bfloat16 (default) or torch.float16")
+        self.hdt = compute_dtype                  # 16-bit operand type: selects libapla_hip.so / libapla_hip_f16.so
+        self.loss_scale = float(loss_scale)       # static loss scale for fp16 gradients (the reference's GradScaler role)
+        self.res_dtype, self.grad_dtype = res_dtype, (grad_dtype or compute_dtype)
         self.optim = optim or OptimConfig()
         self.pg = process_group
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
@@ -87,10 +102,11 @@ class AplaTrainEngine:
         self.scale = bb.blocks[0].attn.scale
         self.step_count = 0
         self._graphs = None
-        self._build_flat_params()
-        self._build_frozen_layout()
-        self._alloc_buffers()
-        self.refresh_weights()
+        with ops.use_half(self.hdt):
+            self._build_flat_params()
+            self._build_frozen_layout()
+            self._alloc_buffers()
+            self.refresh_weights()
 
     # ------------------------------------------------------------------ trainable state
     def _build_flat_params(self):
@@ -157,7 +173,7 @@ class AplaTrainEngine:
         self.Kp = (K + 63) // 64 * 64
         wpe = torch.zeros(D, self.Kp, device=dev)
         wpe[:, :K] = bb.patch_embed.proj.weight.detach().reshape(D, K).float()
-        self.Wpe, self.bpe = wpe.to(_BF), f32(bb.patch_embed.proj.bias)
+        self.Wpe, self.bpe = wpe.to(ops.half()), f32(bb.patch_embed.proj.bias)
         self.cls = f32(bb.cls_token).reshape(D)
         with torch.no_grad():
             self.pos = f32(bb.interpolate_pos_encoding(self.Np)[0])  # bicubic resize once, not every forward
@@ -187,12 +203,12 @@ class AplaTrainEngine:
                 if gam1 is not None:
                     Wn[fi] *= gam1[fi, None]
                     bn[fi] *= gam1[fi]
-            st.Wnat, st.WnatT, st.bnat = Wn.to(_BF), Wn.t().contiguous().to(_BF), bn
+            st.Wnat, st.WnatT, st.bnat = Wn.to(ops.half()), Wn.t().contiguous().to(ops.half()), bn
             mlp = blk.mlp
             if self.swiglu:
                 st.F = mlp.w3.in_features
                 w12 = _interleave_rows(mlp.w12.weight.detach().float())
-                st.W12, st.W12T = w12.to(_BF), w12.t().contiguous().to(_BF)
+                st.W12, st.W12T = w12.to(ops.half()), w12.t().contiguous().to(ops.half())
                 st.b12 = _interleave_rows(mlp.w12.bias.detach().float()).contiguous()
                 w3, b3 = mlp.w3.weight.detach().float(), mlp.w3.bias.detach().float()
             else:
@@ -201,7 +217,7 @@ class AplaTrainEngine:
                 w3, b3 = mlp.fc2.weight.detach().float(), mlp.fc2.bias.detach().float()
             if gam2 is not None:
                 w3, b3 = w3 * gam2[:, None], b3 * gam2
-            st.Wout, st.WoutT, st.bout = w3.to(_BF).contiguous(), w3.t().contiguous().to(_BF), b3.contiguous()
+            st.Wout, st.WoutT, st.bout = w3.to(ops.half()).contiguous(), w3.t().contiguous().to(ops.half()), b3.contiguous()
             st.W1_name, st.b1_name = self.names[2 * i], self.names[2 * i + 1]
             self.blocks.append(st)
         self.C = self.model.fc.out_features
@@ -209,7 +225,7 @@ class AplaTrainEngine:
     # ------------------------------------------------------------------ activations / workspaces
     def _alloc_buffers(self):
         dev, M, D, B, N, H, L = self.device, self.M, self.D, self.B, self.N, self.H, self.L
-        e = lambda *s, dt=_BF: torch.empty(*s, device=dev, dtype=dt)  # noqa: E731
+        e = lambda *s, dt=ops.half(): torch.empty(*s, device=dev, dtype=dt)  # noqa: E731
         self.images = e(B, 3, self.S, self.S, dt=torch.float32)
         self.labels = torch.zeros(B, device=dev, dtype=torch.int32)
         self.cols = e(B * self.Np, self.Kp)
@@ -236,7 +252,7 @@ class AplaTrainEngine:
         self.dxn = e(B, D, dt=torch.float32)
         # backward
         self.G = torch.zeros(M, D, device=dev, dtype=self.grad_dtype)               # residual-gradient stream
-        self.Gb = self.G if self.grad_dtype == _BF else torch.zeros(M, D, device=dev, dtype=_BF)
+        self.Gb = self.G if self.grad_dtype == ops.half() else torch.zeros(M, D, device=dev, dtype=ops.half())
         self.dact = e(M, Fsave)
         self.dln = e(M, D)
         self.dO = e(M, D)
@@ -252,6 +268,7 @@ class AplaTrainEngine:
             if ops.lib().apla_dw_workspace_bytes(M, st.r, D) > self.dw_ws.numel() * 4:
                 self.dw_ws = ops.dw_workspace(M, st.r, D, dev)
 
+    @_half_mode
     def refresh_frozen_copies(self):
         """Rebuild the kernel-layout copies of the frozen weights (bf16, transposed, LayerScale folded) after the module's
         frozen parameters were overwritten, e.g. by checkpoint.load_session.  Only before the step graphs are captured:
@@ -261,6 +278,7 @@ class AplaTrainEngine:
         self._build_frozen_layout()
 
     # ------------------------------------------------------------------ step pieces
+    @_half_mode
     def refresh_weights(self):
         """Re-scatter the trainable projection rows (fp32 masters -> natural-order bf16 weight, its transpose, bias)."""
         for st in self.blocks:
@@ -298,6 +316,8 @@ class AplaTrainEngine:
         ops.sgemm_small(self.xn, self._param_view("fc.weight"), trans_b=True, bias=self._param_view("fc.bias"),
                         out=self.logits)
         ops.cross_entropy(self.logits, self.labels, dlogits=self.dlogits, row_loss=self.row_loss, loss=self.loss)
+        if self.loss_scale != 1.0:
+            self.dlogits.mul_(self.loss_scale)  # every gradient carries the scale until the optimizer divides it out
 
     def _backward_head(self):
         B, N, D = self.B, self.N, self.D
@@ -392,6 +412,7 @@ class AplaTrainEngine:
         self.images.copy_(images, non_blocking=True)
         self.labels.copy_(labels.to(torch.int32), non_blocking=True)
 
+    @_half_mode
     def forward_backward(self):
         """Forward + loss + backward of the batch in self.images/self.labels; grads land in the flat buffer.
         With world > 1 the gradient all-reduce of each chunk is launched on a side stream as soon as its segment of the
@@ -404,15 +425,17 @@ class AplaTrainEngine:
             self.exchanger.launch_chunk(k)   # RCCL all-reduce of what this segment produced, on the side stream
         self.exchanger.wait()
 
+    @_half_mode
     def optimizer_step(self, lr: Optional[float] = None):
         """Fused clip + AdamW on the flat buffer (DDP mean = grad_scale 1/world)."""
         self.step_count += 1
         oc = self.optim
         ops.adamw_step(self.flat_params, self.flat_grads, self.exp_avg, self.exp_avg_sq, self.decay_mask,
                        lr=oc.lr if lr is None else lr, weight_decay=oc.weight_decay, betas=oc.betas, eps=oc.eps,
-                       step=self.step_count, max_norm=oc.grad_clipping or 0.0, grad_scale=1.0 / self.world,
+                       step=self.step_count, max_norm=oc.grad_clipping or 0.0, grad_scale=1.0 / (self.world * self.loss_scale),
                        norm_ws=self.norm_ws)
 
+    @_half_mode
     def train_step(self, images=None, labels=None, lr: Optional[float] = None):
         if images is not None:
             self.set_batch(images, labels)

@@ -9,10 +9,40 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import (APLA_BF16, APLA_F32, EPI_GELU, EPI_MUL, EPI_RESIDUAL, EPI_STORE, EPI_SWIGLU,  # noqa: F401
+from ._lib import (APLA_BF16, APLA_F16, APLA_F32, EPI_GELU, EPI_MUL, EPI_RESIDUAL, EPI_STORE, EPI_SWIGLU,  # noqa: F401
                    EPI_SWIGLU_BWD, check, lib)
 
-_DT = {torch.bfloat16: APLA_BF16, torch.float32: APLA_F32}
+_DT = {torch.bfloat16: APLA_BF16, torch.float16: APLA_F16, torch.float32: APLA_F32}
+_HALF = torch.bfloat16  # the 16-bit operand type the wrappers currently accept (and the library lib() returns)
+
+
+def half():
+    """The current 16-bit operand dtype: torch.bfloat16 unless inside ``use_half(torch.float16)``."""
+    return _HALF
+
+
+class use_half:
+    """Context manager: run the wrappers against the fp16 build of the library (libapla_hip_f16.so; every "bf16" operand is
+    then torch.float16).  The kernels, layouts and entry points are identical; only the operand rounding differs (8x
+    smaller), and fp16 gradients need a loss scale (AplaTrainEngine(loss_scale=...))."""
+
+    def __init__(self, dtype):
+        if dtype not in (torch.bfloat16, torch.float16):
+            raise TypeError("operand dtype must be torch.bfloat16 or torch.float16")
+        self.dtype = dtype
+
+    def __enter__(self):
+        global _HALF
+        self._old = (_HALF, _lib.set_current(_DT[self.dtype]))
+        _HALF = self.dtype
+        lib()  # fail here, loudly, if that build is missing
+        return self
+
+    def __exit__(self, *exc):
+        global _HALF
+        _HALF = self._old[0]
+        _lib.set_current(self._old[1])
+        return False
 
 
 def _stream():
@@ -43,10 +73,10 @@ def _rows2d(t: torch.Tensor, name: str):
 
 
 def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, epilogue: int = EPI_STORE,
-            out: Optional[torch.Tensor] = None, out_dtype=torch.bfloat16, aux_in: Optional[torch.Tensor] = None,
+            out: Optional[torch.Tensor] = None, out_dtype=None, aux_in: Optional[torch.Tensor] = None,
             aux_out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[M,Nout] = epilogue(a[M,K] @ w[N,K]^T + bias).  See include/apla_hip.h:apla_gemm_nt."""
-    _req(a, torch.bfloat16, "a", 2), _req(w, torch.bfloat16, "w", 2)
+    _req(a, half(), "a", 2), _req(w, half(), "w", 2)
     M, K, lda = _rows2d(a, "a")
     N, Kw, ldw = _rows2d(w, "w")
     if K != Kw:
@@ -57,7 +87,7 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = Non
             raise ValueError("gemm_nt: bias length != N")
     n_out = {EPI_SWIGLU: N // 2, EPI_SWIGLU_BWD: 2 * N}.get(epilogue, N)
     if out is None:
-        out = torch.empty(M, n_out, device=a.device, dtype=out_dtype)
+        out = torch.empty(M, n_out, device=a.device, dtype=out_dtype or half())
     _req(out, None, "out", 2)
     if out.shape != (M, n_out):
         raise ValueError(f"gemm_nt: out shape {tuple(out.shape)} != {(M, n_out)}")
@@ -69,11 +99,11 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = Non
             raise ValueError(f"gemm_nt: aux_in shape {tuple(aux_in.shape)} invalid for epilogue {epilogue}")
         if epilogue == EPI_RESIDUAL and aux_in.dtype != out.dtype:
             raise TypeError("gemm_nt: residual and output dtypes differ")
-        if epilogue in (EPI_MUL, EPI_SWIGLU_BWD) and aux_in.dtype != torch.bfloat16:
+        if epilogue in (EPI_MUL, EPI_SWIGLU_BWD) and aux_in.dtype != half():
             raise TypeError("gemm_nt: aux_in must be bf16")
         ld_in = aux_in.stride(0)
     if aux_out is not None:
-        _req(aux_out, torch.bfloat16, "aux_out", 2)
+        _req(aux_out, half(), "aux_out", 2)
         if tuple(aux_out.shape) != (M, N):
             raise ValueError("gemm_nt: aux_out shape")
         ld_out = aux_out.stride(0)
@@ -81,7 +111,7 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = Non
         raise ValueError("gemm_nt: epilogue needs aux_out")
     if epilogue in (EPI_RESIDUAL, EPI_MUL, EPI_SWIGLU_BWD) and aux_in is None:
         raise ValueError("gemm_nt: epilogue needs aux_in")
-    if epilogue not in (EPI_STORE, EPI_RESIDUAL) and out.dtype != torch.bfloat16:
+    if epilogue not in (EPI_STORE, EPI_RESIDUAL) and out.dtype != half():
         raise TypeError("gemm_nt: this epilogue writes bf16")
     rc = lib().apla_gemm_nt(a.data_ptr(), lda, w.data_ptr(), ldw, _ptr(bias), out.data_ptr(), out.stride(0), M, N, K,
                             epilogue, _DT[out.dtype], _ptr(aux_in), ld_in, _ptr(aux_out), ld_out, _stream())
@@ -90,7 +120,7 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = Non
 
 
 def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-6, *,
-                  out_dtype=torch.bfloat16, rows: Optional[int] = None, row_stride: Optional[int] = None,
+                  out_dtype=None, rows: Optional[int] = None, row_stride: Optional[int] = None,
                   out: Optional[torch.Tensor] = None, mean: Optional[torch.Tensor] = None,
                   rstd: Optional[torch.Tensor] = None, add: Optional[torch.Tensor] = None,
                   x_out: Optional[torch.Tensor] = None):
@@ -109,7 +139,7 @@ def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps:
             raise ValueError("layernorm_fwd: strided rows exceed the buffer")
     _req(gamma, torch.float32, "gamma", 1), _req(beta, torch.float32, "beta", 1)
     if out is None:
-        out = torch.empty(M, D, device=x.device, dtype=out_dtype)
+        out = torch.empty(M, D, device=x.device, dtype=out_dtype or half())
     if mean is None:
         mean = torch.empty(M, device=x.device, dtype=torch.float32)
     if rstd is None:
@@ -119,7 +149,7 @@ def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps:
         raise ValueError("layernorm_fwd: bad output buffers")
     adds = xouts = 0
     if add is not None:
-        _req(add, torch.bfloat16, "add"), _req(x_out, x.dtype, "x_out")
+        _req(add, half(), "add"), _req(x_out, x.dtype, "x_out")
         if rows is None:
             if tuple(add.shape) != (M, D) or tuple(x_out.shape) != (M, D):
                 raise ValueError("layernorm_fwd: add / x_out shape")
@@ -168,14 +198,14 @@ def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mean: 
     if dres is not None and (dres.dtype != out.dtype or dres.shape != out.shape or dres.stride() != out.stride()):
         raise TypeError("layernorm_bwd: dres must match out (dtype, shape, strides)")
     if out_bf16 is not None:
-        _req(out_bf16, torch.bfloat16, "out_bf16")
+        _req(out_bf16, half(), "out_bf16")
     if inds is not None:
         _req(inds, torch.int32, "inds", 1)
         if not (0 < r <= D) or inds.numel() < r:
             raise ValueError("layernorm_bwd: bad r")
         if gathered is None:
-            gathered = torch.empty(M, r, device=x.device, dtype=torch.bfloat16)
-        _req(gathered, torch.bfloat16, "gathered", 2)
+            gathered = torch.empty(M, r, device=x.device, dtype=half())
+        _req(gathered, half(), "gathered", 2)
         if tuple(gathered.shape) != (M, r) or not gathered.is_contiguous():
             raise ValueError("layernorm_bwd: gathered buffer")
     else:
@@ -190,7 +220,7 @@ def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mean: 
 def gather_cols(src: torch.Tensor, inds: torch.Tensor, r: int) -> torch.Tensor:
     _req(src, None, "src", 2), _req(inds, torch.int32, "inds", 1)
     M, D, ss = _rows2d(src, "src")
-    out = torch.empty(M, r, device=src.device, dtype=torch.bfloat16)
+    out = torch.empty(M, r, device=src.device, dtype=half())
     check(lib().apla_gather_cols(src.data_ptr(), _DT[src.dtype], ss, inds.data_ptr(), r, out.data_ptr(), M, D,
                                  _stream()), "apla_gather_cols")
     return out
@@ -199,14 +229,14 @@ def gather_cols(src: torch.Tensor, inds: torch.Tensor, r: int) -> torch.Tensor:
 def attn_fwd(qkv: torch.Tensor, B: int, N: int, H: int, scale: float, *, o: Optional[torch.Tensor] = None,
              lse: Optional[torch.Tensor] = None):
     """qkv: [B*N, 3*H*64] bf16 contiguous.  Returns (o [B*N, H*64] bf16, lse [B,H,N] fp32)."""
-    _req(qkv, torch.bfloat16, "qkv", 2)
+    _req(qkv, half(), "qkv", 2)
     if tuple(qkv.shape) != (B * N, 3 * H * 64) or not qkv.is_contiguous():
         raise ValueError(f"attn_fwd: qkv must be contiguous [{B * N}, {3 * H * 64}], got {tuple(qkv.shape)}")
     if o is None:
-        o = torch.empty(B * N, H * 64, device=qkv.device, dtype=torch.bfloat16)
+        o = torch.empty(B * N, H * 64, device=qkv.device, dtype=half())
     if lse is None:
         lse = torch.empty(B, H, N, device=qkv.device, dtype=torch.float32)
-    _req(o, torch.bfloat16, "o", 2), _req(lse, torch.float32, "lse", 3)
+    _req(o, half(), "o", 2), _req(lse, torch.float32, "lse", 3)
     if tuple(o.shape) != (B * N, H * 64) or tuple(lse.shape) != (B, H, N) or not (o.is_contiguous() and lse.is_contiguous()):
         raise ValueError("attn_fwd: bad output buffers")
     check(lib().apla_attn_fwd(qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), B, N, H, float(scale), _stream()),
@@ -216,7 +246,7 @@ def attn_fwd(qkv: torch.Tensor, B: int, N: int, H: int, scale: float, *, o: Opti
 
 def attn_bwd(qkv: torch.Tensor, o: torch.Tensor, do: torch.Tensor, lse: torch.Tensor, B: int, N: int, H: int,
              scale: float, *, dqkv: Optional[torch.Tensor] = None, delta: Optional[torch.Tensor] = None):
-    _req(qkv, torch.bfloat16, "qkv", 2), _req(o, torch.bfloat16, "o", 2), _req(do, torch.bfloat16, "do", 2)
+    _req(qkv, half(), "qkv", 2), _req(o, half(), "o", 2), _req(do, half(), "do", 2)
     _req(lse, torch.float32, "lse", 3)
     if tuple(qkv.shape) != (B * N, 3 * H * 64) or tuple(o.shape) != (B * N, H * 64) or o.shape != do.shape \
             or tuple(lse.shape) != (B, H, N):
@@ -246,16 +276,16 @@ def attn_varlen_fwd(qkv: torch.Tensor, cu_seqlens: torch.Tensor, max_n: int, H: 
     """Block-diagonal attention over packed sequences.  qkv: [total, 3*H*64] bf16; cu_seqlens: int32[S+1] on the device
     (cu[0] = 0, cu[S] = total; the caller guarantees it, the kernels trust it); max_n = longest sequence.
     Returns (o [total, H*64] bf16, lse [H, total] fp32)."""
-    _req(qkv, torch.bfloat16, "qkv", 2)
+    _req(qkv, half(), "qkv", 2)
     total = qkv.shape[0]
     S = _check_cu(cu_seqlens, total, "attn_varlen_fwd")
     if qkv.shape[1] != 3 * H * 64 or not qkv.is_contiguous() or max_n <= 0 or max_n > total:
         raise ValueError(f"attn_varlen_fwd: qkv must be contiguous [total, {3 * H * 64}] and 0 < max_n <= total")
     if o is None:
-        o = torch.empty(total, H * 64, device=qkv.device, dtype=torch.bfloat16)
+        o = torch.empty(total, H * 64, device=qkv.device, dtype=half())
     if lse is None:
         lse = torch.empty(H, total, device=qkv.device, dtype=torch.float32)
-    _req(o, torch.bfloat16, "o", 2), _req(lse, torch.float32, "lse", 2)
+    _req(o, half(), "o", 2), _req(lse, torch.float32, "lse", 2)
     if tuple(o.shape) != (total, H * 64) or tuple(lse.shape) != (H, total) or not (o.is_contiguous() and lse.is_contiguous()):
         raise ValueError("attn_varlen_fwd: bad output buffers")
     check(lib().apla_attn_varlen_fwd(qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), cu_seqlens.data_ptr(), S, total,
@@ -266,7 +296,7 @@ def attn_varlen_fwd(qkv: torch.Tensor, cu_seqlens: torch.Tensor, max_n: int, H: 
 def attn_varlen_bwd(qkv: torch.Tensor, o: torch.Tensor, do: torch.Tensor, lse: torch.Tensor, cu_seqlens: torch.Tensor,
                     max_n: int, H: int, scale: float, *, dqkv: Optional[torch.Tensor] = None,
                     delta: Optional[torch.Tensor] = None):
-    _req(qkv, torch.bfloat16, "qkv", 2), _req(o, torch.bfloat16, "o", 2), _req(do, torch.bfloat16, "do", 2)
+    _req(qkv, half(), "qkv", 2), _req(o, half(), "o", 2), _req(do, half(), "do", 2)
     _req(lse, torch.float32, "lse", 2)
     total = qkv.shape[0]
     S = _check_cu(cu_seqlens, total, "attn_varlen_bwd")
@@ -290,14 +320,14 @@ def attn_varlen_bwd(qkv: torch.Tensor, o: torch.Tensor, do: torch.Tensor, lse: t
 def attn_bwd_cls(qkv: torch.Tensor, o: torch.Tensor, do_cls: torch.Tensor, lse: torch.Tensor, B: int, N: int, H: int,
                  scale: float, *, dqkv: Optional[torch.Tensor] = None):
     """Attention backward for dO that is non-zero only at token 0 of every sequence; do_cls: [B, H*64] bf16."""
-    _req(qkv, torch.bfloat16, "qkv", 2), _req(o, torch.bfloat16, "o", 2), _req(do_cls, torch.bfloat16, "do_cls", 2)
+    _req(qkv, half(), "qkv", 2), _req(o, half(), "o", 2), _req(do_cls, half(), "do_cls", 2)
     _req(lse, torch.float32, "lse", 3)
     if tuple(qkv.shape) != (B * N, 3 * H * 64) or tuple(o.shape) != (B * N, H * 64) or tuple(do_cls.shape) != (B, H * 64) \
             or tuple(lse.shape) != (B, H, N) or not (qkv.is_contiguous() and o.is_contiguous() and do_cls.is_contiguous() and lse.is_contiguous()):
         raise ValueError("attn_bwd_cls: shape mismatch / non-contiguous operand")
     if dqkv is None:
         dqkv = torch.empty_like(qkv)
-    if dqkv.shape != qkv.shape or not dqkv.is_contiguous() or dqkv.dtype != torch.bfloat16:
+    if dqkv.shape != qkv.shape or not dqkv.is_contiguous() or dqkv.dtype != half():
         raise ValueError("attn_bwd_cls: bad dqkv buffer")
     check(lib().apla_attn_bwd_cls(qkv.data_ptr(), o.data_ptr(), do_cls.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), B, N, H,
                                   float(scale), _stream()), "apla_attn_bwd_cls")
@@ -305,7 +335,7 @@ def attn_bwd_cls(qkv: torch.Tensor, o: torch.Tensor, do_cls: torch.Tensor, lse: 
 
 
 def attn_probs(qkv: torch.Tensor, lse: torch.Tensor, B: int, N: int, H: int, scale: float) -> torch.Tensor:
-    _req(qkv, torch.bfloat16, "qkv", 2), _req(lse, torch.float32, "lse", 3)
+    _req(qkv, half(), "qkv", 2), _req(lse, torch.float32, "lse", 3)
     if tuple(qkv.shape) != (B * N, 3 * H * 64) or not qkv.is_contiguous() or tuple(lse.shape) != (B, H, N):
         raise ValueError("attn_probs: shape mismatch")
     attn = torch.empty(B, H, N, N, device=qkv.device, dtype=torch.float32)
@@ -325,7 +355,7 @@ def proj_dw(dyg: torch.Tensor, x: torch.Tensor, dW1: torch.Tensor, db1: torch.Te
             row_scale: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None,
             accumulate: bool = False):
     """dW1[r,D] (+)= row_scale * dyg[M,r]^T @ x[M,D]; db1[r] (+)= row_scale * colsum(dyg)."""
-    _req(dyg, torch.bfloat16, "dyg", 2), _req(x, torch.bfloat16, "x", 2)
+    _req(dyg, half(), "dyg", 2), _req(x, half(), "x", 2)
     _req(dW1, torch.float32, "dW1", 2), _req(db1, torch.float32, "db1", 1)
     M, r = dyg.shape
     Mx, D, ldx = _rows2d(x, "x")
@@ -346,7 +376,7 @@ def proj_dw(dyg: torch.Tensor, x: torch.Tensor, dW1: torch.Tensor, db1: torch.Te
 def pack_proj_rows(W1: torch.Tensor, b1: Optional[torch.Tensor], inds: torch.Tensor, gamma: Optional[torch.Tensor],
                    Wnat: torch.Tensor, WnatT: torch.Tensor, bnat: Optional[torch.Tensor]):
     _req(W1, torch.float32, "W1", 2), _req(inds, torch.int32, "inds", 1)
-    _req(Wnat, torch.bfloat16, "Wnat", 2), _req(WnatT, torch.bfloat16, "WnatT", 2)
+    _req(Wnat, half(), "Wnat", 2), _req(WnatT, half(), "WnatT", 2)
     r, D = W1.shape
     if tuple(Wnat.shape) != (D, D) or tuple(WnatT.shape) != (D, D) or inds.numel() < r \
             or not (W1.is_contiguous() and Wnat.is_contiguous() and WnatT.is_contiguous()):
@@ -379,8 +409,8 @@ def patchify(images: torch.Tensor, patch: int, Kp: int, out: Optional[torch.Tens
     if C != 3 or S != S2 or not images.is_contiguous():
         raise ValueError("patchify: expected contiguous [B,3,S,S]")
     Np = (S // patch) ** 2
-    cols = out if out is not None else torch.empty(B * Np, Kp, device=images.device, dtype=torch.bfloat16)
-    if tuple(cols.shape) != (B * Np, Kp) or cols.dtype != torch.bfloat16 or not cols.is_contiguous():
+    cols = out if out is not None else torch.empty(B * Np, Kp, device=images.device, dtype=half())
+    if tuple(cols.shape) != (B * Np, Kp) or cols.dtype != half() or not cols.is_contiguous():
         raise ValueError("patchify: bad out buffer")
     check(lib().apla_patchify(images.data_ptr(), cols.data_ptr(), B, S, patch, Kp, _stream()), "apla_patchify")
     return cols
@@ -388,7 +418,7 @@ def patchify(images: torch.Tensor, patch: int, Kp: int, out: Optional[torch.Tens
 
 def assemble_tokens(patches: torch.Tensor, cls_token: torch.Tensor, pos: torch.Tensor, B: int, Np: int,
                     res_dtype=torch.float32, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    _req(patches, torch.bfloat16, "patches", 2), _req(cls_token, torch.float32, "cls"), _req(pos, torch.float32, "pos", 2)
+    _req(patches, half(), "patches", 2), _req(cls_token, torch.float32, "cls"), _req(pos, torch.float32, "pos", 2)
     D = patches.shape[1]
     if patches.shape[0] != B * Np or cls_token.numel() != D or tuple(pos.shape) != (Np + 1, D) or not pos.is_contiguous():
         raise ValueError("assemble_tokens: shape mismatch")

@@ -49,14 +49,14 @@ def build_model(backbone, r, n_classes, img, patch, seed=0):
     return Classifier(mp, dict(which_GPUs="0"))
 
 
-def time_dominant_kernel(M, D, F, iters=20):
+def time_dominant_kernel(M, D, F, hdt=torch.bfloat16, iters=20):
     """Live HIP-event timing of the dominant kernel: the fc1 GEMM+GELU launch (largest single share of step FLOPs)."""
     from apla_amd import ops
     dev = "cuda"
-    a = torch.randn(M, D, device=dev).to(torch.bfloat16)
-    w = (torch.randn(F, D, device=dev) * D ** -0.5).to(torch.bfloat16)
+    a = torch.randn(M, D, device=dev).to(hdt)
+    w = (torch.randn(F, D, device=dev) * D ** -0.5).to(hdt)
     b = torch.zeros(F, device=dev)
-    h = torch.empty(M, F, device=dev, dtype=torch.bfloat16)
+    h = torch.empty(M, F, device=dev, dtype=hdt)
     g = torch.empty_like(h)
     for _ in range(3):
         ops.gemm_nt(a, w, b, epilogue=ops.EPI_GELU, aux_out=g, out=h)
@@ -101,6 +101,9 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch")
     ap.add_argument("--partial-size", type=int, default=192)
     ap.add_argument("--classes", type=int, default=1000)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"],
+                    help="16-bit operand type (bf16 = BASELINE config 2; fp16 = the reference's autocast dtype, needs --loss-scale)")
+    ap.add_argument("--loss-scale", type=float, default=None, help="static loss scale (default 1 for bf16, 1024 for fp16)")
     ap.add_argument("--res-dtype", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--grad-dtype", default="bf16", choices=["fp32", "bf16"])
     ap.add_argument("--no-graphs", action="store_true")
@@ -126,11 +129,15 @@ def main():
 
     from apla_amd.engine import AplaTrainEngine, OptimConfig
     img, patch = 224, 16
-    dt = {"fp32": torch.float32, "bf16": torch.bfloat16}
+    dt = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}
+    hdt = dt[args.dtype]
+    loss_scale = args.loss_scale if args.loss_scale is not None else (1024.0 if args.dtype == "fp16" else 1.0)
+    if args.res_dtype == "bf16" or args.grad_dtype == "bf16":  # "bf16" on these switches means "the 16-bit operand type"
+        dt["bf16"] = hdt
     model = build_model(args.backbone, args.partial_size, args.classes, img, patch, seed=0)  # same seed => same indices on all ranks
     eng = AplaTrainEngine(model, args.batch, img, res_dtype=dt[args.res_dtype], grad_dtype=dt[args.grad_dtype],
                           optim=OptimConfig(lr=1e-4, weight_decay=1e-5, grad_clipping=1.0), process_group=pg,
-                          use_graphs=not args.no_graphs)
+                          use_graphs=not args.no_graphs, compute_dtype=hdt, loss_scale=loss_scale)
     g = torch.Generator(device="cuda").manual_seed(rank)  # each rank owns its shard of the global batch
     images = torch.randn(args.batch, 3, img, img, device="cuda", generator=g)
     labels = torch.randint(0, args.classes, (args.batch,), device="cuda", generator=g)
@@ -162,17 +169,20 @@ def main():
     if rank == 0:
         bb = model.backbone
         M = args.batch * eng.N
-        k_ms, k_tf = time_dominant_kernel(M, bb.embed_dim, eng.blocks[0].F)
+        from apla_amd import ops as _ops
+        with _ops.use_half(hdt):
+            k_ms, k_tf = time_dominant_kernel(M, bb.embed_dim, eng.blocks[0].F, hdt)
         gf = STEP_GF_PER_IMG.get(args.backbone)
         step_tf = img_s / world * gf / 1e3 if gf else None
         out = {
             "metric": "images/sec, ViT-B/16 APLA training step bs=128/GPU (whole job)", "value": round(img_s, 1),
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
+            "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.backbone}/16 dinov2-shaped APLA partial_size={args.partial_size} full training "
                                    f"step (fwd+CE+bwd+allreduce+clip+AdamW), 224x224, C={args.classes}, "
-                                   f"bs={args.batch}/GPU, residual {args.res_dtype}, grad stream {args.grad_dtype}",
+                                   f"bs={args.batch}/GPU, residual {args.res_dtype}, grad stream {args.grad_dtype if args.grad_dtype == 'fp32' else args.dtype}"
+                                   + (f", loss scale {loss_scale:g}" if loss_scale != 1.0 else ""),
                        "global_batch": world * args.batch, "parallelism": f"dp{world}",
                        "hip_graphs": not args.no_graphs},
             "images_per_sec_per_gpu": round(img_s / world, 1), "peak_mem_gib": round(peak_mem, 2),

@@ -1,0 +1,107 @@
+"""The fp16 build of the library (libapla_hip_f16.so: same sources, -DAPLA_FP16) — the reference's own autocast dtype
+(defaults/trainer.py:121-138).  Same kernels and layouts with IEEE-half operands: 11 significand bits instead of 8, so
+operand rounding is 8x smaller.  Kernel checks use 1/8 of the bf16 tolerances; the end-to-end check is the north-star
+number: logits of BASELINE config 1 within 1e-3 (max-abs / max-abs) of what the REFERENCE code produced on the CPU."""
+import pytest
+import torch
+
+from conftest import load_golden, rel_err, t
+from oracle import apla_oracle as O
+from test_engine_gpu import build_classifier, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+F16_OUT = 8e-4   # bf16 tests use 6e-3 for a 16-bit-rounded output of O(1) dynamic range; fp16 rounds 8x finer
+LOGIT_TOL_F16 = 1e-3
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def hf(x):
+    h = x.to(torch.float16)
+    return h, h.double()
+
+
+def test_fp16_library_identity():
+    from apla_amd import ops, _lib
+    with ops.use_half(torch.float16):
+        assert ops.half() == torch.float16 and _lib.lib().apla_operand_dtype() == _lib.APLA_F16
+    assert ops.half() == torch.bfloat16 and _lib.lib().apla_operand_dtype() == _lib.APLA_BF16
+    # the wrappers refuse the other build's tensors instead of reinterpreting bits
+    with pytest.raises(TypeError):
+        ops.gemm_nt(torch.zeros(128, 64, device="cuda", dtype=torch.float16), torch.zeros(128, 64, device="cuda", dtype=torch.float16))
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 768, 768), (25216, 256, 128)])
+def test_fp16_gemm_epilogues(M, N, K):
+    from apla_amd import ops
+    a, ad = hf(rnd(M, K, seed=1))
+    w, wd = hf(rnd(N, K, scale=K ** -0.5, seed=2))
+    bias = rnd(N, seed=3)
+    ref = ad @ wd.t() + bias.double()
+    with ops.use_half(torch.float16):
+        out = ops.gemm_nt(a.cuda(), w.cuda(), bias.cuda())
+        assert out.dtype == torch.float16 and rel_err(out.cpu(), ref) < F16_OUT
+        g = torch.empty(M, N, device="cuda", dtype=torch.float16)
+        h = ops.gemm_nt(a.cuda(), w.cuda(), bias.cuda(), epilogue=ops.EPI_GELU, aux_out=g)
+        assert rel_err(h.cpu(), O.gelu_fwd(ref)) < F16_OUT and rel_err(g.cpu(), O.gelu_grad(ref)) < F16_OUT
+        mul, muld = hf(rnd(M, N, seed=4))
+        out = ops.gemm_nt(a.cuda(), w.cuda(), None, epilogue=ops.EPI_MUL, aux_in=mul.cuda())
+        assert rel_err(out.cpu(), (ad @ wd.t()) * muld) < F16_OUT
+
+
+def test_fp16_attention_and_layernorm():
+    from apla_amd import ops
+    B, N, H = 2, 197, 2
+    D, scale = 64 * H, 64 ** -0.5
+    qkv, qkvd = hf(rnd(B, N, 3 * D, seed=31))
+    oref, lref = O.attention_fwd(qkvd, H, scale)
+    with ops.use_half(torch.float16):
+        o, lse = ops.attn_fwd(qkv.cuda().reshape(B * N, 3 * D), B, N, H, scale)
+        assert rel_err(o.cpu().reshape(B, N, D), oref) < F16_OUT
+        do, dod = hf(rnd(B, N, D, seed=32) * 1e-2)
+        dref = O.attention_bwd(dod, qkvd, o.cpu().double().reshape(B, N, D), lref, H, scale)
+        dqkv = ops.attn_bwd(qkv.cuda().reshape(B * N, 3 * D), o, do.cuda().reshape(B * N, D), lse, B, N, H, scale)
+        assert rel_err(dqkv.cpu().reshape(B, N, 3 * D), dref) < 4e-3   # bf16 tests: 2e-2
+        x = rnd(B * N, D, seed=33)
+        gam, bet = 1 + 0.2 * rnd(D, seed=34), 0.1 * rnd(D, seed=35)
+        y, mean, rstd = ops.layernorm_fwd(x.cuda(), gam.cuda(), bet.cuda(), 1e-6)
+        yref, _, _ = O.layernorm_fwd(x.double(), gam.double(), bet.double(), 1e-6)
+        assert y.dtype == torch.float16 and rel_err(y.cpu(), yref) < F16_OUT
+
+
+def test_fp16_engine_cfg1_logits_within_1e3_of_reference():
+    """BASELINE config 1 with fp16 operands and a static loss scale: logits against the REFERENCE's CPU output within the
+    north-star 1e-3; loss, gradients and the first AdamW step within (tighter than) the bf16 tolerances."""
+    from apla_amd.engine import AplaTrainEngine, OptimConfig
+    g = load_golden("g5_cfg1_vits.npz")
+    tp = dict(img_size=[224], patch_size=16, pretrained_type="dinov2", is_memory_efficient=True,
+              block_conf=dict(has_layerscale=True, layerscale_init_values=1.0))
+    model = build_classifier("vit_small", 64, 10, tp, seed=0)
+    gen = torch.Generator().manual_seed(0)
+    images = torch.randn(8, 3, 224, 224, generator=gen)
+    labels = torch.randint(0, 10, (8,), generator=gen)
+    S = 1024.0
+    eng = AplaTrainEngine(model, 8, 224, optim=OptimConfig(lr=1e-4, weight_decay=1e-5, grad_clipping=1.0),
+                          compute_dtype=torch.float16, loss_scale=S)
+    eng.set_batch(images.cuda(), labels.cuda())
+    eng.forward_backward()
+    torch.cuda.synchronize()
+    e_logits = rel_err(eng.logits.cpu(), g["logits"])
+    print(f"cfg1 fp16 logits rel err {e_logits:.3e}; loss {float(eng.loss):.6f} vs ref {float(g['loss']):.6f}")
+    assert e_logits < LOGIT_TOL_F16
+    assert abs(float(eng.loss) - float(g["loss"])) < 1e-3
+    for i in (0, 5, 11):
+        for nm in ("proj_weight1", "proj_bias1"):
+            e = rel_l2(eng.grads()[f"backbone.blocks.{i}.attn.{nm}"].cpu() / S, g[f"g.blocks.{i}.attn.{nm}"])
+            assert e < 1e-2, (i, nm, e)
+    assert rel_l2(eng.grads()["fc.weight"].cpu() / S, g["g.fc.weight"]) < 1e-2
+    eng.optimizer_step()
+    torch.cuda.synchronize()
+    assert abs(float(eng.grad_norm) - float(g["gnorm"])) < 1e-2 * float(g["gnorm"])
+    sd = model.state_dict()
+    for nm in ("backbone.blocks.5.attn.proj_weight1", "fc.weight"):
+        ref_after = t(g["after." + nm.replace("backbone.", "")])
+        assert float((sd[nm].cpu() - ref_after).abs().max()) < 2.5e-4
