@@ -44,6 +44,9 @@ SIGNATURES = {
                                     c_void_p]),
     "apla_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_float, c_float, c_float,
                                 c_float, c_float, c_int, c_float, c_float, c_void_p, c_void_p]),
+    "apla_adamw_step_dynamic": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_float, c_float, c_float,
+                                        c_float, c_float, c_float, c_float, c_void_p, c_int, c_float, c_float, c_int,
+                                        c_void_p, c_void_p]),
     "apla_patchify": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "apla_assemble_tokens": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                      c_void_p]),

@@ -44,9 +44,12 @@ def optimizer_state_dict(engine) -> dict:
     """The engine's AdamW state as a ``torch.optim.AdamW(get_params_groups(model)).state_dict()`` (CPU tensors)."""
     reg, no_reg = _group_order(engine.model)
     oc, state, idx = engine.optim, {}, 0
+    steps = float(engine.step_count)
+    if getattr(engine, "dynamic_scale", False):  # steps actually taken (skipped overflow steps do not count)
+        steps = float(engine.scaler[3 * (engine._scaler_calls & 1) + 2])
     for name in reg + no_reg:
         off, k, shape = engine.slices[name]
-        state[idx] = {"step": torch.tensor(float(engine.step_count)),
+        state[idx] = {"step": torch.tensor(steps),
                       "exp_avg": engine.exp_avg[off:off + k].view(shape).detach().cpu().clone(),
                       "exp_avg_sq": engine.exp_avg_sq[off:off + k].view(shape).detach().cpu().clone()}
         idx += 1
@@ -81,13 +84,18 @@ def load_optimizer_state_dict(engine, osd: dict):
 def session_dict(engine, *, iters: int = 0, epoch: int = 0, parameters: Optional[dict] = None,
                  best_val_target: float = 0.0, original_state: Optional[dict] = None) -> dict:
     """What ``Trainer.save_session`` stores (defaults/bases.py:456-464); ``torch.save`` it to interchange."""
-    return {"iters": iters,
-            "state_dict": {k: v.detach().cpu().clone() for k, v in engine.model.state_dict().items()},
-            "original_state": original_state,
-            "optimizer": optimizer_state_dict(engine),
-            "epoch": epoch,
-            "parameters": parameters,
-            "best_val_target": best_val_target}
+    out = {"iters": iters,
+           "state_dict": {k: v.detach().cpu().clone() for k, v in engine.model.state_dict().items()},
+           "original_state": original_state,
+           "optimizer": optimizer_state_dict(engine),
+           "epoch": epoch,
+           "parameters": parameters,
+           "best_val_target": best_val_target}
+    if getattr(engine, "dynamic_scale", False):  # GradScaler.state_dict() layout (defaults/bases.py:465-466)
+        slot = 3 * (engine._scaler_calls & 1)
+        out["scaler"] = {"scale": float(engine.scaler[slot]), "growth_factor": 2.0, "backoff_factor": 0.5,
+                         "growth_interval": 2000, "_growth_tracker": int(engine.scaler[slot + 1])}
+    return out
 
 
 def load_session(engine, session: dict, load_optimizer: bool = True):
@@ -104,4 +112,10 @@ def load_session(engine, session: dict, load_optimizer: bool = True):
     engine.refresh_frozen_copies()
     if load_optimizer and session.get("optimizer") is not None:
         load_optimizer_state_dict(engine, session["optimizer"])
+    if getattr(engine, "dynamic_scale", False):
+        sc = session.get("scaler") or {}
+        scale, tracker = float(sc.get("scale", 65536.0)), float(sc.get("_growth_tracker", 0))
+        steps = float(engine.step_count)
+        engine.scaler.copy_(torch.tensor([scale, tracker, steps, scale, tracker, steps, scale, 0.0]))
+        engine._scaler_calls = 0
     return session.get("iters", 0), session.get("epoch", 0)

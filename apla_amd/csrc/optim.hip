@@ -55,7 +55,93 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
     p[i] = pi; m[i] = mi; v[i] = vi; g[i] = gi;
   }
 }
+// ---- dynamic loss scaling (torch.cuda.amp.GradScaler semantics, defaults/trainer.py:129-138) kept on the device ----
+// scaler[0..2] / scaler[3..5]: two slots of {scale, growth_tracker, optimizer steps taken}; a call reads slot `parity` and
+// writes slot parity^1 (no workgroup ever reads what another one writes in the same launch); scaler[6] = the scale the NEXT
+// backward must use (read by the step's loss-gradient scaling), scaler[7] = 1 if this call skipped the update.
+__global__ __launch_bounds__(256) void sumsq_dyn_kernel(const float* __restrict__ g, long n, float grad_scale,
+                                                        const float* __restrict__ scaler, int parity,
+                                                        float* __restrict__ ws) {
+  __shared__ float red[4];
+  const float gs = grad_scale / scaler[3 * parity];
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)NPART * 256) {
+    const float v = g[i] * gs;
+    s += v * v;
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) ws[2 + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void adamw_dyn_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, const uint8_t* __restrict__ decay, long n,
+                                                        float lr, float wd, float b1, float b2, float eps, float max_norm,
+                                                        float grad_scale, float* __restrict__ scaler, int parity,
+                                                        float growth, float backoff, int interval,
+                                                        float* __restrict__ ws) {
+  __shared__ float coef_s, bc1_s, bc2s_s;
+  if (threadIdx.x < 64) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < NPART; i += 64) s += ws[2 + i];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) {
+      const float* cur = scaler + 3 * parity;
+      const float scale = cur[0], tracker = cur[1], steps = cur[2];
+      const float norm = sqrtf(s);
+      const bool ok = isfinite(norm);
+      float coef = 1.0f;
+      if (max_norm > 0.f) { coef = max_norm / (norm + 1e-6f); coef = coef < 1.0f ? coef : 1.0f; }
+      coef_s = ok ? coef * grad_scale / scale : __builtin_nanf("");
+      const float t = steps + 1.0f;  // torch AdamW bias corrections with the count of steps actually taken
+      bc1_s = 1.0f - powf(b1, t);
+      bc2s_s = sqrtf(1.0f - powf(b2, t));
+      if (blockIdx.x == 0) {
+        float* nxt = scaler + 3 * (parity ^ 1);
+        float nscale = scale, ntr = tracker + 1.0f;
+        if (!ok) { nscale = scale * backoff; ntr = 0.f; }
+        else if (ntr >= (float)interval) { nscale = scale * growth; ntr = 0.f; }
+        nxt[0] = nscale; nxt[1] = ntr; nxt[2] = ok ? t : steps;
+        scaler[6] = nscale;
+        scaler[7] = ok ? 0.f : 1.f;
+        ws[0] = s; ws[1] = norm;
+      }
+    }
+  }
+  __syncthreads();
+  const float coef = coef_s;
+  if (coef != coef) return;
+  const float step_size = lr / bc1_s, bc2_sqrt = bc2s_s;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float gi = g[i] * coef;
+    float pi = p[i];
+    if (decay[i]) pi *= (1.0f - lr * wd);
+    const float mi = m[i] * b1 + gi * (1.0f - b1);
+    const float vi = v[i] * b2 + gi * gi * (1.0f - b2);
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    pi -= step_size * (mi / denom);
+    p[i] = pi; m[i] = mi; v[i] = vi; g[i] = gi;
+  }
+}
 }  // namespace
+
+extern "C" int apla_adamw_step_dynamic(float* params, float* grads, float* exp_avg, float* exp_avg_sq,
+                                       const uint8_t* decay_mask, long n, float lr, float weight_decay, float beta1,
+                                       float beta2, float eps, float max_norm, float grad_scale, float* scaler,
+                                       int parity, float growth_factor, float backoff_factor, int growth_interval,
+                                       float* norm_ws, hipStream_t stream) {
+  APLA_REQUIRE(params && grads && exp_avg && exp_avg_sq && decay_mask && norm_ws && scaler && n > 0, "apla_adamw_step_dynamic: bad arguments");
+  APLA_REQUIRE((parity == 0 || parity == 1) && growth_factor >= 1.f && backoff_factor > 0.f && backoff_factor <= 1.f && growth_interval >= 1,
+               "apla_adamw_step_dynamic: bad scaler settings");
+  hipLaunchKernelGGL(sumsq_dyn_kernel, dim3(NPART), dim3(256), 0, stream, grads, n, grad_scale, scaler, parity, norm_ws);
+  APLA_CHECK_LAUNCH("apla_adamw_step_dynamic[sumsq]");
+  long blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(adamw_dyn_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, params, grads, exp_avg, exp_avg_sq, decay_mask, n, lr, weight_decay, beta1, beta2, eps, max_norm, grad_scale, scaler, parity, growth_factor, backoff_factor, growth_interval, norm_ws);
+  APLA_CHECK_LAUNCH("apla_adamw_step_dynamic[update]");
+  return APLA_OK;
+}
 
 extern "C" int apla_adamw_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq,
                                const uint8_t* decay_mask, long n, float lr, float weight_decay, float beta1,

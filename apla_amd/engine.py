@@ -93,7 +93,11 @@ class AplaTrainEngine:
         if compute_dtype not in (torch.bfloat16, torch.float16):
             raise TypeError("compute_dtype must be torch.bfloat16 (default) or torch.float16")
         self.hdt = compute_dtype                  # 16-bit operand type: selects libapla_hip.so / libapla_hip_f16.so
-        self.loss_scale = float(loss_scale)       # static loss scale for fp16 gradients (the reference's GradScaler role)
+        # loss scale for fp16 gradients: a float (static) or "dynamic" = GradScaler semantics kept on the device
+        self.dynamic_scale = loss_scale == "dynamic"
+        self.loss_scale = 1.0 if self.dynamic_scale else float(loss_scale)
+        self.scaler = None   # device float32[8], see ops.adamw_step_dynamic
+        self._scaler_calls = 0
         self.res_dtype, self.grad_dtype = res_dtype, (grad_dtype or compute_dtype)
         self.optim = optim or OptimConfig()
         self.pg = process_group
@@ -102,6 +106,8 @@ class AplaTrainEngine:
         self.scale = bb.blocks[0].attn.scale
         self.step_count = 0
         self._graphs = None
+        if self.dynamic_scale:
+            self.scaler = ops.new_scaler_state(self.device)
         with ops.use_half(self.hdt):
             self._build_flat_params()
             self._build_frozen_layout()
@@ -316,7 +322,9 @@ class AplaTrainEngine:
         ops.sgemm_small(self.xn, self._param_view("fc.weight"), trans_b=True, bias=self._param_view("fc.bias"),
                         out=self.logits)
         ops.cross_entropy(self.logits, self.labels, dlogits=self.dlogits, row_loss=self.row_loss, loss=self.loss)
-        if self.loss_scale != 1.0:
+        if self.dynamic_scale:
+            self.dlogits.mul_(self.scaler[6])   # device scalar written by the previous optimizer step (graph-safe)
+        elif self.loss_scale != 1.0:
             self.dlogits.mul_(self.loss_scale)  # every gradient carries the scale until the optimizer divides it out
 
     def _backward_head(self):
@@ -430,6 +438,13 @@ class AplaTrainEngine:
         """Fused clip + AdamW on the flat buffer (DDP mean = grad_scale 1/world)."""
         self.step_count += 1
         oc = self.optim
+        if self.dynamic_scale:
+            ops.adamw_step_dynamic(self.flat_params, self.flat_grads, self.exp_avg, self.exp_avg_sq, self.decay_mask,
+                                   self.scaler, self._scaler_calls & 1, lr=oc.lr if lr is None else lr,
+                                   weight_decay=oc.weight_decay, betas=oc.betas, eps=oc.eps,
+                                   max_norm=oc.grad_clipping or 0.0, grad_scale=1.0 / self.world, norm_ws=self.norm_ws)
+            self._scaler_calls += 1
+            return
         ops.adamw_step(self.flat_params, self.flat_grads, self.exp_avg, self.exp_avg_sq, self.decay_mask,
                        lr=oc.lr if lr is None else lr, weight_decay=oc.weight_decay, betas=oc.betas, eps=oc.eps,
                        step=self.step_count, max_norm=oc.grad_clipping or 0.0, grad_scale=1.0 / (self.world * self.loss_scale),

@@ -403,6 +403,33 @@ def adamw_step(params, grads, exp_avg, exp_avg_sq, decay_mask, *, lr, weight_dec
                                 norm_ws.data_ptr(), _stream()), "apla_adamw_step")
 
 
+def adamw_step_dynamic(params, grads, exp_avg, exp_avg_sq, decay_mask, scaler, parity: int, *, lr, weight_decay,
+                       betas=(0.9, 0.999), eps=1e-8, max_norm: float = 0.0, grad_scale: float = 1.0,
+                       growth_factor: float = 2.0, backoff_factor: float = 0.5, growth_interval: int = 2000,
+                       norm_ws: torch.Tensor):
+    """Fused unscale + clip + AdamW + GradScaler.update on the device; `scaler` is the float32[8] state described at
+    include/apla_hip.h:apla_adamw_step_dynamic (use ``new_scaler_state``)."""
+    for t_, nm in ((params, "params"), (grads, "grads"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+        _req(t_, torch.float32, nm, 1)
+    _req(decay_mask, torch.uint8, "decay_mask", 1), _req(norm_ws, torch.float32, "norm_ws", 1)
+    _req(scaler, torch.float32, "scaler", 1)
+    n = params.numel()
+    if not (grads.numel() == exp_avg.numel() == exp_avg_sq.numel() == decay_mask.numel() == n) or norm_ws.numel() < 512 \
+            or scaler.numel() < 8 or not scaler.is_contiguous() or parity not in (0, 1):
+        raise ValueError("adamw_step_dynamic: buffer sizes / parity")
+    check(lib().apla_adamw_step_dynamic(params.data_ptr(), grads.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
+                                        decay_mask.data_ptr(), n, float(lr), float(weight_decay), float(betas[0]),
+                                        float(betas[1]), float(eps), float(max_norm), float(grad_scale), scaler.data_ptr(),
+                                        int(parity), float(growth_factor), float(backoff_factor), int(growth_interval),
+                                        norm_ws.data_ptr(), _stream()), "apla_adamw_step_dynamic")
+
+
+def new_scaler_state(device, init_scale: float = 65536.0, steps: int = 0) -> torch.Tensor:
+    """Device state of the dynamic loss scaler: both slots start at (init_scale, 0, steps); [6] = init_scale, [7] = 0."""
+    return torch.tensor([init_scale, 0.0, float(steps), init_scale, 0.0, float(steps), init_scale, 0.0],
+                        dtype=torch.float32, device=device)
+
+
 def patchify(images: torch.Tensor, patch: int, Kp: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _req(images, torch.float32, "images", 4)
     B, C, S, S2 = images.shape

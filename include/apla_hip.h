@@ -159,6 +159,20 @@ int apla_adamw_step(float* params, float* grads, float* exp_avg, float* exp_avg_
                     long n, float lr, float weight_decay, float beta1, float beta2, float eps, int step,
                     float max_norm, float grad_scale, float* norm_ws, hipStream_t stream);
 
+/* The same step under DYNAMIC loss scaling — torch.cuda.amp.GradScaler (defaults/trainer.py:129-138:
+ * scaler.scale(loss).backward(); unscale_; clip; scaler.step; scaler.update) without a host round trip.  The gradients in
+ * `grads` carry the current loss scale; `scaler` is a device float[8]: [0..2] and [3..5] are two slots of {scale,
+ * growth_tracker, optimizer steps actually taken}; this call reads slot `parity` and writes slot parity^1 (the caller
+ * alternates parity 0,1,0,… per call), [6] receives the scale the NEXT backward must apply to the loss gradient, [7] is set
+ * to 1 if this call skipped the update.  Unscale by grad_scale/scale, clip as above; if the global norm is not finite the
+ * parameters and moments are left untouched, scale *= backoff_factor and the tracker resets; otherwise the AdamW update
+ * runs with bias corrections from the count of steps actually taken, and after growth_interval consecutive finite steps
+ * scale *= growth_factor.  GradScaler defaults: scale 65536, growth 2, backoff 0.5, interval 2000. */
+int apla_adamw_step_dynamic(float* params, float* grads, float* exp_avg, float* exp_avg_sq, const uint8_t* decay_mask,
+                            long n, float lr, float weight_decay, float beta1, float beta2, float eps, float max_norm,
+                            float grad_scale, float* scaler, int parity, float growth_factor, float backoff_factor,
+                            int growth_interval, float* norm_ws, hipStream_t stream);
+
 /* Patch embedding front end (vit.py:291-307, 387-396): images fp32 [B,3,S,S] -> im2col bf16 [B*Np, Kp] with
  * Kp = round_up(3*p*p, 64) (zero padded); then (after the GEMM) tokens[b,0] = cls+pos[0], tokens[b,1+t] =
  * patches[b,t] + pos[1+t] in residual dtype. */

@@ -105,3 +105,26 @@ def test_fp16_engine_cfg1_logits_within_1e3_of_reference():
     for nm in ("backbone.blocks.5.attn.proj_weight1", "fc.weight"):
         ref_after = t(g["after." + nm.replace("backbone.", "")])
         assert float((sd[nm].cpu() - ref_after).abs().max()) < 2.5e-4
+
+
+def test_fp16_engine_dynamic_loss_scale_recovers_from_overflow():
+    """loss_scale="dynamic": an absurd initial scale overflows the fp16 gradient stream; the step is skipped on the device,
+    the scale backs off until the gradients are finite, and training proceeds (loss goes down) — no host sync involved."""
+    from apla_amd.engine import AplaTrainEngine, OptimConfig
+    from test_engine_gpu import small_vit
+    model = small_vit(depth=2, r=64)
+    eng = AplaTrainEngine(model, 4, 32, optim=OptimConfig(lr=2e-3, weight_decay=0.0, grad_clipping=1.0),
+                          compute_dtype=torch.float16, loss_scale="dynamic")
+    eng.scaler.copy_(torch.tensor([2.0 ** 40, 0, 0, 2.0 ** 40, 0, 0, 2.0 ** 40, 0]))
+    g = torch.Generator().manual_seed(0)
+    images, labels = torch.randn(4, 3, 32, 32, generator=g).cuda(), torch.randint(0, 10, (4,), generator=g).cuda()
+    before = eng.flat_params.clone()
+    eng.train_step(images, labels)
+    torch.cuda.synchronize()
+    assert float(eng.scaler[7]) == 1.0 and torch.equal(before, eng.flat_params)      # skipped, weights untouched
+    assert float(eng.scaler[6]) == 2.0 ** 39
+    losses = []
+    for _ in range(40):
+        losses.append(float(eng.train_step(images, labels)))
+    assert float(eng.scaler[7]) == 0.0 and float(eng.scaler[6]) < 2.0 ** 30
+    assert losses[-1] < losses[0] - 0.2

@@ -412,3 +412,49 @@ def test_attention_bwd_cls_only(ops, B, N, H):
     for i, nm in enumerate(("dq", "dk", "dv")):
         assert rel_err(got[..., i * D:(i + 1) * D], ref[..., i * D:(i + 1) * D]) < 1e-2, nm
     assert float(got[:, 1:, :D].abs().max()) == 0.0 if N > 1 else True
+
+
+# ------------------------------------------------------------------------------------------- dynamic loss scaling
+def test_adamw_dynamic_loss_scaling_matches_gradscaler_semantics(ops):
+    """apla_adamw_step_dynamic == scaler.unscale_ + clip_grad_norm_ + scaler.step(AdamW) + scaler.update() of
+    torch.cuda.amp.GradScaler (defaults/trainer.py:129-138), replayed on the CPU with torch.optim.AdamW: finite steps
+    update with bias corrections counted over steps actually taken, an overflowing step is skipped and halves the scale,
+    `growth_interval` consecutive finite steps double it."""
+    n, world = 5000, 2
+    g = torch.Generator().manual_seed(7)
+    p0 = torch.randn(n, generator=g)
+    decay = (torch.rand(n, generator=g) < 0.7)
+    pr = torch.nn.Parameter(p0[decay].clone())       # decayed group
+    pn = torch.nn.Parameter(p0[~decay].clone())      # not decayed
+    opt = torch.optim.AdamW([{"params": [pr]}, {"params": [pn], "weight_decay": 0.0}], lr=1e-2, weight_decay=0.1)
+    scale, tracker, interval = 1024.0, 0, 3
+    params = p0.clone().cuda()
+    m, v = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    ws = torch.zeros(512, device="cuda")
+    st = ops.new_scaler_state("cuda", init_scale=scale)
+    for it in range(9):
+        true_grad = torch.randn(n, generator=g) * (3.0 if it % 2 else 0.05)     # some steps clip, some do not
+        scaled = true_grad * scale * world                                       # what backward + SUM all-reduce leave behind
+        if it in (2, 6):
+            scaled[17] = float("inf") if it == 2 else float("nan")
+        grads = scaled.clone().cuda()
+        ops.adamw_step_dynamic(params, grads, m, v, decay.to(torch.uint8).cuda(), st, it & 1, lr=1e-2, weight_decay=0.1,
+                               max_norm=1.0, grad_scale=1.0 / world, growth_interval=interval, norm_ws=ws)
+        # reference
+        unscaled = scaled / (scale * world)
+        if torch.isfinite(unscaled).all():
+            pr.grad, pn.grad = unscaled[decay].clone(), unscaled[~decay].clone()
+            gn = torch.nn.utils.clip_grad_norm_([pr, pn], 1.0)
+            opt.step()
+            tracker += 1
+            if tracker == interval:
+                scale, tracker = scale * 2.0, 0
+            assert abs(float(ws[1]) - float(gn)) < 1e-4 * float(gn)
+            assert float(st[7]) == 0.0
+        else:
+            scale, tracker = scale * 0.5, 0
+            assert float(st[7]) == 1.0
+        ref = torch.empty(n)
+        ref[decay], ref[~decay] = pr.detach(), pn.detach()
+        assert rel_err(params.cpu(), ref) < 1e-5, it
+        assert float(st[6]) == scale and float(st[3 * ((it + 1) & 1)]) == scale and float(st[3 * ((it + 1) & 1) + 1]) == tracker
