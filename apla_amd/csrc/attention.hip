@@ -606,6 +606,47 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(const bf16* __restrict_
   }
 }
 
+// ------------------------------------------------------------------------------------------------ forward, CLS query only
+// Last block of the ViT: the classifier reads x[:, 0] after the final norm (vit.py:416-419), so of this block's attention
+// output only the CLS row of every sequence is ever used.  One query against all keys: a rank-1, HBM-bound pass over K
+// and V.  One workgroup per (b, h); lane = head-dim element; each wave walks keys wave, wave+4, ... with its own online
+// softmax state, and the four states are merged in a fixed order.  Writes o[b*N] (this head's 64 columns) and lse[b, h, 0].
+__global__ __launch_bounds__(256) void attn_fwd_cls_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
+                                                           float* __restrict__ lse, int N, int H, float scale) {
+  __shared__ float sm[4], sl[4], sacc[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y, h = blockIdx.x;
+  const int D = H * 64;
+  const long ld = 3L * D;
+  const bf16* base = qkv + (long)b * N * ld + h * 64;
+  const float q0 = (float)base[lane] * scale;
+  float m = -INFINITY, l = 0.f, acc = 0.f;
+  for (int k = wave; k < N; k += 4) {
+    const float kv = (float)base[(long)k * ld + D + lane], vv = (float)base[(long)k * ld + 2 * D + lane];
+    const float s = wave_sum(q0 * kv);
+    const float mn = fmaxf(m, s);
+    const float a = __expf(m - mn), pr = __expf(s - mn);
+    l = l * a + pr;
+    acc = acc * a + pr * vv;
+    m = mn;
+  }
+  if (lane == 0) { sm[wave] = m; sl[wave] = l; }
+  sacc[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0) {
+    const float M = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+    float L = 0.f, O = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float e = __expf(sm[w] - M);  // a wave that saw no key has m = -inf, l = 0: contributes nothing
+      L += sl[w] * e;
+      O += sacc[w][lane] * e;
+    }
+    o[(long)b * N * D + h * 64 + lane] = (bf16)(O / L);
+    if (lane == 0) lse[((long)b * H + h) * N] = M + __logf(L);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ backward, CLS-only dO
 // Last block of the ViT: only the CLS query (row 0 of every sequence) carries gradient into the attention output (final
 // norm + x[:,0], vit.py:416-419).  Then dV[k] = P[0,k] dO[0], dK[k] = scale dS[0,k] q[0], dQ[0] = scale sum_k dS[0,k] K[k]
@@ -705,6 +746,14 @@ extern "C" int apla_attn_varlen_bwd(const void* qkv, const void* o, const void* 
   APLA_REQUIRE(apla_aligned16(qkv) && apla_aligned16(o) && apla_aligned16(d_o) && apla_aligned16(dqkv), "apla_attn_varlen_bwd: pointers must be 16-byte aligned");
   APLA_REQUIRE(S <= 65535 && H <= 65535, "apla_attn_varlen_bwd: S/H exceed grid limits");
   return launch_attn_bwd(qkv, o, d_o, lse, delta, dqkv, cu_seqlens, total, S, max_n, H, scale, stream, "apla_attn_varlen_bwd");
+}
+
+extern "C" int apla_attn_fwd_cls(const void* qkv, void* o, float* lse, int B, int N, int H, float scale,
+                                 hipStream_t stream) {
+  APLA_REQUIRE(qkv && o && lse && B > 0 && N > 0 && H > 0 && B <= 65535, "apla_attn_fwd_cls: bad arguments");
+  hipLaunchKernelGGL(attn_fwd_cls_kernel, dim3(H, B), dim3(256), 0, stream, (const bf16*)qkv, (bf16*)o, lse, N, H, scale);
+  APLA_CHECK_LAUNCH("apla_attn_fwd_cls");
+  return APLA_OK;
 }
 
 extern "C" int apla_attn_probs(const void* qkv, const float* lse, float* attn, int B, int N, int H, float scale,

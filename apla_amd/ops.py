@@ -123,7 +123,7 @@ def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps:
                   out_dtype=None, rows: Optional[int] = None, row_stride: Optional[int] = None,
                   out: Optional[torch.Tensor] = None, mean: Optional[torch.Tensor] = None,
                   rstd: Optional[torch.Tensor] = None, add: Optional[torch.Tensor] = None,
-                  x_out: Optional[torch.Tensor] = None):
+                  x_out: Optional[torch.Tensor] = None, add_row_stride: Optional[int] = None):
     """x: [M,D] residual stream (fp32|bf16).  With rows/row_stride given, x (and add / x_out) are flat buffers and row m
     starts at m*row_stride (CLS-row selection).  With ``add`` (bf16 branch output) the residual update x_out = x + add is
     fused (x_out may alias x).  Returns (y [M,D], mean [M], rstd [M])."""
@@ -155,8 +155,9 @@ def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps:
                 raise ValueError("layernorm_fwd: add / x_out shape")
             adds, xouts = add.stride(0), x_out.stride(0)
         else:
-            adds = xouts = row_stride
-            if (M - 1) * row_stride + D > add.numel() or (M - 1) * row_stride + D > x_out.numel():
+            xouts = row_stride
+            adds = row_stride if add_row_stride is None else add_row_stride  # e.g. a compact [M, D] branch added into strided rows
+            if (M - 1) * adds + D > add.numel() or (M - 1) * row_stride + D > x_out.numel():
                 raise ValueError("layernorm_fwd: strided add / x_out exceed their buffers")
     rc = lib().apla_layernorm_fwd(x.data_ptr(), _DT[x.dtype], xs, gamma.data_ptr(), beta.data_ptr(), out.data_ptr(),
                                   _DT[out.dtype], out.stride(0), mean.data_ptr(), rstd.data_ptr(), M, D, float(eps),
@@ -315,6 +316,17 @@ def attn_varlen_bwd(qkv: torch.Tensor, o: torch.Tensor, do: torch.Tensor, lse: t
                                      dqkv.data_ptr(), cu_seqlens.data_ptr(), S, total, int(max_n), H, float(scale),
                                      _stream()), "apla_attn_varlen_bwd")
     return dqkv
+
+
+def attn_fwd_cls(qkv: torch.Tensor, B: int, N: int, H: int, scale: float, *, o: torch.Tensor, lse: torch.Tensor):
+    """Attention output of the CLS query of every sequence only: fills row b*N of o [B*N, H*64] and lse[:, :, 0]."""
+    _req(qkv, half(), "qkv", 2), _req(o, half(), "o", 2), _req(lse, torch.float32, "lse", 3)
+    if tuple(qkv.shape) != (B * N, 3 * H * 64) or tuple(o.shape) != (B * N, H * 64) or tuple(lse.shape) != (B, H, N) \
+            or not (qkv.is_contiguous() and o.is_contiguous() and lse.is_contiguous()):
+        raise ValueError("attn_fwd_cls: shape mismatch / non-contiguous operand")
+    check(lib().apla_attn_fwd_cls(qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), B, N, H, float(scale), _stream()),
+          "apla_attn_fwd_cls")
+    return o, lse
 
 
 def attn_bwd_cls(qkv: torch.Tensor, o: torch.Tensor, do_cls: torch.Tensor, lse: torch.Tensor, B: int, N: int, H: int,

@@ -118,6 +118,11 @@ int apla_attn_set_variant(int variant);
 int apla_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv, int B,
                   int N, int H, float scale, hipStream_t stream);
 
+/* Attention forward for the CLS query only (last block: the head reads x[:, 0] after the final norm, vit.py:416-419, so
+ * the other rows of this block's attention output are dead).  Same qkv layout as apla_attn_fwd; writes row b*N of o (all
+ * heads) and lse[b, h, 0]; the other rows of o / entries of lse are left untouched. */
+int apla_attn_fwd_cls(const void* qkv, void* o, float* lse, int B, int N, int H, float scale, hipStream_t stream);
+
 /* Attention backward when only the CLS query (token 0 of every sequence) has a non-zero output gradient — the last ViT
  * block under `x[:,0]` pooling (utils/transformers/vit.py:416-419).  do_cls is compact [B, H*64] (the CLS rows of dO);
  * writes the full dqkv [B*N, 3*H*64] (dq is zero except token 0).  Same math as apla_attn_bwd, rank-1 per head. */
