@@ -71,6 +71,18 @@ def time_dominant_kernel(M, D, F, hdt=torch.bfloat16, iters=20):
     return ms, 2.0 * M * D * F / (ms * 1e-3) / 1e12
 
 
+def executed_gflop_per_image(bb, eng, n_classes):
+    """SURVEY §8a formula minus what the CLS-only last block skips: forward proj + ffn + att + the Q third of qkv, backward
+    proj dX + ffn dX + 2*att (the rows that never reach x[:, 0])."""
+    N, D, L, F, r = eng.N, bb.embed_dim, bb.depth, eng.blocks[0].F, eng.blocks[0].r
+    qkv, proj, att = 2 * N * D * 3 * D, 2 * N * D * D, 4 * N * N * D
+    ffn = (2 * N * D * 2 * F + 2 * N * F * D) if eng.swiglu else 4 * N * D * F
+    fwd = L * (qkv + proj + att + ffn) + 2 * eng.Np * 3 * eng.patch ** 2 * D + 2 * D * n_classes
+    bwd = (L - 1) * (qkv + proj + ffn + 2 * att) + ffn + L * 2 * N * r * D + 4 * D * n_classes
+    dead = (proj + ffn + att + qkv // 3) + (proj + ffn + 2 * att) if L > 1 else 0
+    return round((fwd + bwd - dead) / 1e9, 2)
+
+
 def cpu_baseline(backbone, r, n_classes, img, patch, sample_bs, threads):
     """The CPU oracle (a port of the reference step) timed on this box's host cores on a bounded sample."""
     from oracle import apla_oracle as O
@@ -194,7 +206,10 @@ def main():
                          "kernel_ms": round(k_ms, 4),
                          "step_achieved": round(step_tf, 1) if step_tf else None,
                          "step_frac": round(step_tf / PEAK_BF16_TFLOPS, 4) if step_tf else None,
-                         "step_gflop_per_image": gf},
+                         "step_gflop_per_image": gf,
+                         # dead rows of the last block (everything but CLS after its attention, forward and backward) are
+                         # not computed: FLOPs actually executed per image, for the reader who wants the honest MFMA rate
+                         "step_gflop_per_image_executed": executed_gflop_per_image(bb, eng, args.classes)},
         }
         if world == 1 and not args.no_cpu_baseline:
             threads = min(64, os.cpu_count() or 1)
