@@ -43,6 +43,8 @@ SIGNATURES = {
                              c_int, c_void_p]),
     "apla_pack_proj_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                     c_void_p]),
+    "apla_pack_proj_rows_batched": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                            c_int, c_void_p]),
     "apla_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_float, c_float, c_float,
                                 c_float, c_float, c_int, c_float, c_float, c_void_p, c_void_p]),
     "apla_adamw_step_dynamic": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_float, c_float, c_float,

@@ -287,6 +287,27 @@ __global__ __launch_bounds__(256) void pack_proj_rows_kernel(const float* __rest
   if (threadIdx.x == 0 && b1 != nullptr) bnat[row] = g * b1[j];
 }
 
+// all blocks of a model in one launch: block l's trainable rows sit at flat + l*block_stride (W1 [r,D] then b1 [r])
+__global__ __launch_bounds__(256) void pack_proj_rows_batched_kernel(const float* __restrict__ flat, long block_stride,
+                                                                     const int32_t* __restrict__ inds_all,
+                                                                     const float* __restrict__ gamma_all,
+                                                                     bf16* __restrict__ Wnat_all, bf16* __restrict__ WnatT_all,
+                                                                     float* __restrict__ bnat_all, int r, int D) {
+  const int j = blockIdx.x, l = blockIdx.y;
+  const float* W1 = flat + (long)l * block_stride;
+  const float* b1 = W1 + (long)r * D;
+  const int row = inds_all[(long)l * D + j];
+  const float g = gamma_all != nullptr ? gamma_all[(long)l * D + row] : 1.0f;
+  bf16* Wnat = Wnat_all + (long)l * D * D;
+  bf16* WnatT = WnatT_all + (long)l * D * D;
+  for (int k = threadIdx.x; k < D; k += 256) {
+    const bf16 v = (bf16)(g * W1[(size_t)j * D + k]);
+    Wnat[(size_t)row * D + k] = v;
+    WnatT[(size_t)k * D + row] = v;
+  }
+  if (threadIdx.x == 0) bnat_all[(long)l * D + row] = g * b1[j];
+}
+
 }  // namespace
 
 extern "C" long apla_dw_workspace_bytes(int M, int r, int D) {
@@ -320,5 +341,15 @@ extern "C" int apla_pack_proj_rows(const float* W1, const float* b1, const int32
   APLA_REQUIRE(b1 == nullptr || bnat != nullptr, "apla_pack_proj_rows: bnat required with b1");
   hipLaunchKernelGGL(pack_proj_rows_kernel, dim3(r), dim3(256), 0, stream, W1, b1, inds, gamma, (bf16*)Wnat, (bf16*)WnatT, bnat, r, D);
   APLA_CHECK_LAUNCH("apla_pack_proj_rows");
+  return APLA_OK;
+}
+
+extern "C" int apla_pack_proj_rows_batched(const float* flat, long block_stride, const int32_t* inds_all,
+                                           const float* gamma_all, void* Wnat_all, void* WnatT_all, float* bnat_all,
+                                           int L, int r, int D, hipStream_t stream) {
+  APLA_REQUIRE(flat && inds_all && Wnat_all && WnatT_all && bnat_all && L > 0 && L <= 65535 && r > 0 && r <= D &&
+               block_stride >= (long)r * D + r, "apla_pack_proj_rows_batched: bad arguments");
+  hipLaunchKernelGGL(pack_proj_rows_batched_kernel, dim3(r, L), dim3(256), 0, stream, flat, block_stride, inds_all, gamma_all, (bf16*)Wnat_all, (bf16*)WnatT_all, bnat_all, r, D);
+  APLA_CHECK_LAUNCH("apla_pack_proj_rows_batched");
   return APLA_OK;
 }

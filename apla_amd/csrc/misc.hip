@@ -37,8 +37,10 @@ __global__ __launch_bounds__(256) void assemble_tokens_kernel(const bf16* __rest
   }
 }
 
-// C[i,j] (+)= sum_k A[i*sai + k*sak] * B[k*sbk + j*sbj] (+ bias[j]); 32x32 tile per workgroup, 128-deep K chunks (the
-// head GEMMs are latency-bound: few, long dependent load->barrier->FMA rounds), fp32 FMA.
+// C[i,j] (+)= sum_k A[i*sai + k*sak] * B[k*sbk + j*sbj] (+ bias[j]); fp32 FMA, 32x32 tile per workgroup, 128-deep K chunks.
+// The head GEMMs are tiny (0.2 GFLOP) and latency-bound: the next chunk is fetched into registers while the current one
+// is multiplied out of LDS, and the element -> (row, k) maps of the staging loads are fixed per thread (no index
+// arithmetic inside the loop).
 constexpr int SG_BK = 128;
 __global__ __launch_bounds__(256) void sgemm_small_kernel(const float* __restrict__ A, long sai, long sak,
                                                           const float* __restrict__ Bm, long sbk, long sbj,
@@ -47,25 +49,44 @@ __global__ __launch_bounds__(256) void sgemm_small_kernel(const float* __restric
   __shared__ float As[32][SG_BK + 1], Bs[SG_BK][33];
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;  // 16 x 16 threads, 2x2 outputs each
   const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+  // staging maps: element e = tid + 256*u of a 32 x 128 tile; the faster-varying global index follows the thread index
+  const bool a_kfast = sak <= sai, b_jfast = sbj <= sbk;
+  int ai[16], ak[16], bk[16], bj[16];
+  long aoff[16], boff[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int e = threadIdx.x + 256 * u;
+    ai[u] = a_kfast ? e >> 7 : e & 31;
+    ak[u] = a_kfast ? e & 127 : e >> 5;
+    bk[u] = b_jfast ? e >> 5 : e & 127;
+    bj[u] = b_jfast ? e & 31 : e >> 7;
+    aoff[u] = (long)(i0 + ai[u]) * sai + (long)ak[u] * sak;
+    boff[u] = (long)bk[u] * sbk + (long)(j0 + bj[u]) * sbj;
+  }
+  float ar[16], br[16];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      ar[u] = (i0 + ai[u] < M && k0 + ak[u] < K) ? A[aoff[u] + (long)k0 * sak] : 0.f;
+      br[u] = (j0 + bj[u] < N && k0 + bk[u] < K) ? Bm[boff[u] + (long)k0 * sbk] : 0.f;
+    }
+  };
   float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+  fetch(0);
   for (int k0 = 0; k0 < K; k0 += SG_BK) {
-    for (int e = threadIdx.x; e < 32 * SG_BK; e += 256) {
-      {  // A tile As[i][k]: let the faster-varying global index follow the thread index
-        const int i = sak <= sai ? e / SG_BK : e % 32, k = sak <= sai ? e % SG_BK : e / 32;
-        As[i][k] = (i0 + i < M && k0 + k < K) ? A[(long)(i0 + i) * sai + (long)(k0 + k) * sak] : 0.f;
-      }
-      {
-        const int k = sbj <= sbk ? e / 32 : e % SG_BK, j = sbj <= sbk ? e % 32 : e / SG_BK;
-        Bs[k][j] = (j0 + j < N && k0 + k < K) ? Bm[(long)(k0 + k) * sbk + (long)(j0 + j) * sbj] : 0.f;
-      }
+    __syncthreads();  // previous chunk fully consumed
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      As[ai[u]][ak[u]] = ar[u];
+      Bs[bk[u]][bj[u]] = br[u];
     }
     __syncthreads();
+    if (k0 + SG_BK < K) fetch(k0 + SG_BK);
 #pragma unroll 16
     for (int k = 0; k < SG_BK; ++k) {
       const float a0 = As[ty][k], a1 = As[ty + 16][k], b0 = Bs[k][tx], b1 = Bs[k][tx + 16];
       acc[0][0] += a0 * b0; acc[0][1] += a0 * b1; acc[1][0] += a1 * b0; acc[1][1] += a1 * b1;
     }
-    __syncthreads();
   }
 #pragma unroll
   for (int u = 0; u < 2; ++u)

@@ -110,6 +110,7 @@ class AplaTrainEngine:
         self.scale = bb.blocks[0].attn.scale
         self.step_count = 0
         self._graphs = None
+        self._pack_batched = None
         if self.dynamic_scale:
             self.scaler = ops.new_scaler_state(self.device)
         with ops.use_half(self.hdt):
@@ -213,7 +214,15 @@ class AplaTrainEngine:
                 if gam1 is not None:
                     Wn[fi] *= gam1[fi, None]
                     bn[fi] *= gam1[fi]
-            st.Wnat, st.WnatT, st.bnat = Wn.to(ops.half()), Wn.t().contiguous().to(ops.half()), bn
+            if i == 0:  # one allocation for all blocks: the per-step re-scatter is a single launch when r is uniform
+                L_ = len(bb.blocks)
+                self.Wnat_all = torch.empty(L_, D, D, device=dev, dtype=ops.half())
+                self.WnatT_all = torch.empty(L_, D, D, device=dev, dtype=ops.half())
+                self.bnat_all = torch.empty(L_, D, device=dev)
+            self.Wnat_all[i].copy_(Wn)
+            self.WnatT_all[i].copy_(Wn.t())
+            self.bnat_all[i].copy_(bn)
+            st.Wnat, st.WnatT, st.bnat = self.Wnat_all[i], self.WnatT_all[i], self.bnat_all[i]
             mlp = blk.mlp
             if self.swiglu:
                 st.F = mlp.w3.in_features
@@ -291,11 +300,30 @@ class AplaTrainEngine:
         if self._graphs is not None:
             raise RuntimeError("frozen weights cannot be replaced after hipGraph capture; load the checkpoint before the first step")
         self._build_frozen_layout()
+        self._pack_batched = None  # LayerScale gammas may have changed
 
     # ------------------------------------------------------------------ step pieces
     @_half_mode
     def refresh_weights(self):
         """Re-scatter the trainable projection rows (fp32 masters -> natural-order bf16 weight, its transpose, bias)."""
+        if self._pack_batched is None:  # uniform partial size and back-to-back (W1, b1) pairs in the flat buffer?
+            rs = {st.r for st in self.blocks}
+            offs = [self.slices[st.W1_name][0] for st in self.blocks]
+            stride = self.blocks[0].r * self.D + self.blocks[0].r
+            ok = len(rs) == 1 and all(o == offs[0] + k * stride for k, o in enumerate(offs)) and \
+                all(self.slices[st.b1_name][0] == self.slices[st.W1_name][0] + st.r * self.D for st in self.blocks) and \
+                len({st.gamma1 is None for st in self.blocks}) == 1
+            if ok:
+                self._inds_all = torch.stack([st.inds for st in self.blocks]).contiguous()
+                self._gamma_all = None if self.blocks[0].gamma1 is None else torch.stack([st.gamma1 for st in self.blocks]).contiguous()
+                self._pack_batched = (offs[0], stride)
+            else:
+                self._pack_batched = False
+        if self._pack_batched:
+            off0, stride = self._pack_batched
+            ops.pack_proj_rows_batched(self.flat_params[off0:], stride, self._inds_all, self._gamma_all, self.Wnat_all,
+                                       self.WnatT_all, self.bnat_all, self.blocks[0].r)
+            return
         for st in self.blocks:
             ops.pack_proj_rows(self._param_view(st.W1_name), self._param_view(st.b1_name), st.inds, st.gamma1,
                                st.Wnat, st.WnatT, st.bnat)

@@ -401,6 +401,25 @@ def pack_proj_rows(W1: torch.Tensor, b1: Optional[torch.Tensor], inds: torch.Ten
                                     WnatT.data_ptr(), _ptr(bnat), r, D, _stream()), "apla_pack_proj_rows")
 
 
+def pack_proj_rows_batched(flat: torch.Tensor, block_stride: int, inds_all: torch.Tensor, gamma_all: Optional[torch.Tensor],
+                           Wnat_all: torch.Tensor, WnatT_all: torch.Tensor, bnat_all: torch.Tensor, r: int):
+    """pack_proj_rows for all L blocks in one launch; see include/apla_hip.h:apla_pack_proj_rows_batched."""
+    _req(flat, torch.float32, "flat", 1), _req(inds_all, torch.int32, "inds_all", 2)
+    _req(Wnat_all, half(), "Wnat_all", 3), _req(WnatT_all, half(), "WnatT_all", 3), _req(bnat_all, torch.float32, "bnat_all", 2)
+    L, D = inds_all.shape
+    if tuple(Wnat_all.shape) != (L, D, D) or tuple(WnatT_all.shape) != (L, D, D) or tuple(bnat_all.shape) != (L, D) \
+            or flat.numel() < (L - 1) * block_stride + r * D + r or block_stride < r * D + r \
+            or not (inds_all.is_contiguous() and Wnat_all.is_contiguous() and WnatT_all.is_contiguous() and bnat_all.is_contiguous()):
+        raise ValueError("pack_proj_rows_batched: shape mismatch")
+    if gamma_all is not None:
+        _req(gamma_all, torch.float32, "gamma_all", 2)
+        if tuple(gamma_all.shape) != (L, D) or not gamma_all.is_contiguous():
+            raise ValueError("pack_proj_rows_batched: gamma_all shape")
+    check(lib().apla_pack_proj_rows_batched(flat.data_ptr(), int(block_stride), inds_all.data_ptr(), _ptr(gamma_all),
+                                            Wnat_all.data_ptr(), WnatT_all.data_ptr(), bnat_all.data_ptr(), L, r, D,
+                                            _stream()), "apla_pack_proj_rows_batched")
+
+
 def adamw_step(params, grads, exp_avg, exp_avg_sq, decay_mask, *, lr, weight_decay, betas=(0.9, 0.999), eps=1e-8,
                step: int, max_norm: float = 0.0, grad_scale: float = 1.0, norm_ws: torch.Tensor):
     for t_, nm in ((params, "params"), (grads, "grads"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):

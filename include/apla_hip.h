@@ -154,6 +154,13 @@ int apla_proj_dw(const void* dyg, const void* x, int ldx, const float* row_scale
 int apla_pack_proj_rows(const float* W1, const float* b1, const int32_t* inds, const float* gamma, void* Wnat,
                         void* WnatT, float* bnat, int r, int D, hipStream_t stream);
 
+/* The same for all L blocks of a model in one launch (the per-step re-scatter after the optimizer): block l's fp32 masters
+ * are W1 = flat + l*block_stride ([r,D]) followed by b1 ([r]) — the layout of the flat trainable buffer; inds_all [L,D],
+ * gamma_all [L,D] or NULL, Wnat_all / WnatT_all [L,D,D] bf16, bnat_all [L,D]. */
+int apla_pack_proj_rows_batched(const float* flat, long block_stride, const int32_t* inds_all, const float* gamma_all,
+                                void* Wnat_all, void* WnatT_all, float* bnat_all, int L, int r, int D,
+                                hipStream_t stream);
+
 /* Fused global-norm clip + AdamW over the flat trainable buffer (defaults/trainer.py:127-138,
  * defaults/wrappers.py:205-221): grads are first multiplied by grad_scale (1/world for DDP mean), the global L2
  * norm is reduced on device (no host sync), clip coefficient = min(1, max_norm/(norm+1e-6)) (max_norm <= 0 disables),
