@@ -33,7 +33,7 @@ enum { APLA_BF16 = 0, APLA_F16 = 1, APLA_F32 = 2 };
  * configuration) or IEEE fp16 (libapla_hip_f16.so, compiled with -DAPLA_FP16: the reference's own autocast dtype,
  * trainer.py:121-138, 8x smaller operand rounding).  Same entry points, same layouts, same MFMA rate; every pointer
  * documented as "bf16" below is fp16 in that build, and dtype arguments take APLA_F16 instead of APLA_BF16 (passing the
- * other build's code returns APLA_EINVAL).  Returns APLA_BF16 or APLA_F16. */
+ * other build's code returns APLA_ENOSYS / APLA_EINVAL).  Returns APLA_BF16 or APLA_F16. */
 int apla_operand_dtype(void);
 
 /* GEMM epilogues */

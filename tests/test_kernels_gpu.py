@@ -458,3 +458,40 @@ def test_adamw_dynamic_loss_scaling_matches_gradscaler_semantics(ops):
         ref[decay], ref[~decay] = pr.detach(), pn.detach()
         assert rel_err(params.cpu(), ref) < 1e-5, it
         assert float(st[6]) == scale and float(st[3 * ((it + 1) & 1)]) == scale and float(st[3 * ((it + 1) & 1) + 1]) == tracker
+
+
+# ------------------------------------------------------------------------------------------- C-ABI error conventions
+def test_cabi_error_codes_and_messages(ops):
+    """SURVEY §8b error conventions at the raw C-ABI: 0 OK, -22 (EINVAL) bad shape / alignment / null pointers with a
+    message in apla_last_error(), and the other build's dtype code is refused — nothing is launched on a bad call."""
+    from apla_amd._lib import APLA_BF16, APLA_F16, APLA_F32, lib
+    L = lib()
+    a = torch.zeros(256, 128, device="cuda", dtype=torch.bfloat16)
+    w = torch.zeros(128, 128, device="cuda", dtype=torch.bfloat16)
+    out = torch.zeros(256, 128, device="cuda", dtype=torch.bfloat16)
+    s = torch.cuda.current_stream().cuda_stream
+
+    def gemm(M=256, N=128, K=128, aptr=None, dtype=APLA_BF16, epi=0):
+        return L.apla_gemm_nt(a.data_ptr() if aptr is None else aptr, 128, w.data_ptr(), 128, None, out.data_ptr(), 128,
+                              M, N, K, epi, dtype, None, 0, None, 0, s)
+    assert gemm() == 0
+    for bad in (dict(N=100), dict(K=72), dict(M=0), dict(aptr=a.data_ptr() + 2), dict(dtype=APLA_F16), dict(epi=1)):
+        rc = gemm(**bad)
+        assert rc == (-38 if "dtype" in bad else -22), (bad, rc)   # -ENOSYS: unsupported dtype; -EINVAL: shapes / pointers
+        assert len(L.apla_last_error()) > 0
+    assert L.apla_operand_dtype() == APLA_BF16 and L.apla_version() >= 100
+    # layernorm: feature size not a multiple of the vector width (D % 4), and the fp16 code on the bf16 build
+    x = torch.zeros(8, 104, device="cuda")
+    g = torch.ones(104, device="cuda")
+    y = torch.zeros(8, 104, device="cuda", dtype=torch.bfloat16)
+    st = torch.zeros(8, device="cuda")
+    rc = L.apla_layernorm_fwd(x.data_ptr(), APLA_F32, 104, g.data_ptr(), g.data_ptr(), y.data_ptr(), APLA_BF16, 104,
+                              st.data_ptr(), st.data_ptr(), 8, 102, 1e-6, None, 0, None, 0, s)
+    assert rc == -22 and b"D%4" in L.apla_last_error()
+    x = torch.zeros(8, 128, device="cuda")
+    g = torch.ones(128, device="cuda")
+    y = torch.zeros(8, 128, device="cuda", dtype=torch.bfloat16)
+    rc = L.apla_layernorm_fwd(x.data_ptr(), APLA_F32, 128, g.data_ptr(), g.data_ptr(), y.data_ptr(), APLA_F16, 128,
+                              st.data_ptr(), st.data_ptr(), 8, 128, 1e-6, None, 0, None, 0, s)
+    assert rc in (-22, -38)
+    torch.cuda.synchronize()
