@@ -162,10 +162,17 @@ class AplaTrainEngine:
             off += k
         self.n_trainable = n_total
         self.names = [n for n, _ in named]
-        # all-reduce chunks in backward order: [second half of blocks + head] first, then the first half; the cut is
-        # exactly where _segment_a / _segment_b split the backward
-        split = self.slices[self.names[2 * (self.L // 2)]][0] if self.L > 1 else 0
-        self.chunks = [(split, n_total), (0, split)] if split > 0 else [(0, n_total)]
+        # The backward is cut into segments at block boundaries; the gradients a segment produced are all-reduced (one chunk
+        # of the flat buffer each, in backward order) while the next segment runs.  Only the last chunk's exchange is exposed,
+        # so with world > 1 the backward is cut in four (the exposed chunk is the first quarter of the blocks); a single
+        # process keeps two segments (nothing to overlap, fewer graph launches).
+        n_seg = min(4 if self.world > 1 else 2, max(self.L, 1))
+        # segment s ends after the backward of block cut[s]; cut[-1] = 0.  e.g. L = 12, four segments: [9, 6, 3, 0]
+        self.seg_cuts = [(self.L * (n_seg - 1 - s)) // n_seg for s in range(n_seg)]
+        bounds = [self.slices[self.names[2 * c]][0] for c in self.seg_cuts]       # start offset of block cut[s]'s tensors
+        his = [n_total] + bounds[:-1]
+        self.chunks = [(lo, hi) for lo, hi in zip(bounds, his)]
+        assert self.chunks[-1][0] == 0 and all(hi > lo for lo, hi in self.chunks)
         self.exchanger = GradExchanger(self.flat_grads, self.chunks, self.pg)
 
     def _grad_view(self, name):
@@ -453,32 +460,36 @@ class AplaTrainEngine:
         ops.gemm_nt(self.dqkv, st.WqkvT, None, out=self.dln)
         ops.layernorm_bwd(self.dln, self.x[i], st.g1, self.mean1[i], self.rstd1[i], dres=self.G, out=self.G, out_bf16=copy)
 
-    def _segment_a(self):
-        self.refresh_weights()
-        self._forward()
-        self._backward_head()
-        self._backward_last_block()
-        for i in range(self.L - 2, self.L // 2 - 1, -1):
-            self._backward_block(i)
-
-    def _segment_b(self):
-        for i in range(self.L // 2 - 1, -1, -1):
+    def _segment(self, k):
+        """Segment k of the step: segment 0 = weight re-scatter + forward + head + the backward down to block seg_cuts[0];
+        segment k > 0 = the backward of blocks seg_cuts[k-1]-1 .. seg_cuts[k]."""
+        if k == 0:
+            self.refresh_weights()
+            self._forward()
+            self._backward_head()
+            self._backward_last_block()
+            hi = self.L - 1
+        else:
+            hi = self.seg_cuts[k - 1]
+        for i in range(hi - 1, self.seg_cuts[k] - 1, -1):
             self._backward_block(i)
 
     def _capture(self):
+        n = len(self.seg_cuts)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):  # warm-up outside capture (lazy module loading, allocator)
-            self._segment_a()
-            self._segment_b()
+            for k in range(n):
+                self._segment(k)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(ga):
-            self._segment_a()
-        with torch.cuda.graph(gb, pool=ga.pool()):
-            self._segment_b()
-        self._graphs = (ga, gb)
+        graphs = []
+        for k in range(n):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, **({"pool": graphs[0].pool()} if graphs else {})):
+                self._segment(k)
+            graphs.append(g)
+        self._graphs = tuple(graphs)
 
     # ------------------------------------------------------------------ public API
     def set_batch(self, images: torch.Tensor, labels: torch.Tensor):
@@ -492,9 +503,11 @@ class AplaTrainEngine:
         backward has been enqueued."""
         if self.use_graphs and self._graphs is None:
             self._capture()
-        segs = ((self._graphs[0].replay, self._graphs[1].replay) if self.use_graphs else (self._segment_a, self._segment_b))
-        for k, run in enumerate(segs):
-            run()
+        for k in range(len(self.seg_cuts)):
+            if self.use_graphs:
+                self._graphs[k].replay()
+            else:
+                self._segment(k)
             self.exchanger.launch_chunk(k)   # RCCL all-reduce of what this segment produced, on the side stream
         self.exchanger.wait()
 

@@ -31,7 +31,7 @@ def _worker(outdir, use_graphs):
     sl = slice(rank * 4, rank * 4 + 4)
     eng = AplaTrainEngine(small_vit(depth=4, r=64), 4, 32, optim=OptimConfig(lr=1e-3, weight_decay=1e-2, grad_clipping=1.0),
                           process_group=dist.group.WORLD, use_graphs=use_graphs)
-    assert eng.world == 2 and len(eng.chunks) == 2
+    assert eng.world == 2 and len(eng.chunks) == 4 and len(eng.seg_cuts) == 4
     for _ in range(3):
         eng.train_step(images[sl].cuda(), labels[sl].cuda())
     torch.cuda.synchronize()
