@@ -133,8 +133,8 @@ class AplaTrainEngine:
                 W1, b1, r = a.proj.weight, a.proj.bias, self.D
                 inds = torch.arange(self.D)
                 names = (f"backbone.blocks.{i}.attn.proj.weight", f"backbone.blocks.{i}.attn.proj.bias")
-            if r % 64 != 0 or self.D % 128 != 0:
-                raise NotImplementedError(f"engine needs partial_size % 64 == 0 and dim % 128 == 0 (r={r}, D={self.D})")
+            if self.D % 128 != 0:
+                raise NotImplementedError(f"engine needs dim % 128 == 0 (D={self.D})")
             expect += list(names)
             self.blocks_train.append((W1, b1, inds, r))
         expect += ["fc.weight", "fc.bias"]
@@ -201,6 +201,9 @@ class AplaTrainEngine:
             st = _BlockState()
             W1p, b1p, inds, r = self.blocks_train[i]
             st.r = r
+            # the dW kernel works on multiples of 64 rows: a partial size like 8 (the shipped configs) is padded with the next
+            # entries of the block's index permutation (frozen features); their gradient rows are computed and dropped
+            st.r_pad = (r + 63) // 64 * 64
             st.inds = inds.to(dev).int().contiguous()
             st.g1, st.b1 = f32(blk.norm1.weight), f32(blk.norm1.bias)
             st.g2, st.b2 = f32(blk.norm2.weight), f32(blk.norm2.bias)
@@ -210,7 +213,7 @@ class AplaTrainEngine:
             gam1 = f32(blk.ls1.gamma) if hasattr(blk.ls1, "gamma") else None
             gam2 = f32(blk.ls2.gamma) if hasattr(blk.ls2, "gamma") else None
             st.gamma1 = gam1
-            st.row_scale = gam1[st.inds[:r].long()].contiguous() if gam1 is not None else None
+            st.row_scale = gam1[st.inds[:st.r_pad].long()].contiguous() if gam1 is not None else None
             # natural-order merged projection; frozen rows written here, trainable rows by pack_proj_rows
             Wn = torch.zeros(D, D, device=dev)
             bn = torch.zeros(D, device=dev)
@@ -289,15 +292,17 @@ class AplaTrainEngine:
         self.dO = e(M, D)
         self.dqkv = e(M, 3 * D)
         self.delta = e(B, H, N, dt=torch.float32)
-        rmax = max(st.r for st in self.blocks)
+        rmax = max(st.r_pad for st in self.blocks)
+        self.dW_tmp = e(rmax, D, dt=torch.float32) if any(st.r_pad != st.r for st in self.blocks) else None
+        self.db_tmp = e(rmax, dt=torch.float32) if self.dW_tmp is not None else None
         # CLS-only backward of the last block (compact [B, .] operands)
         self.dact_cls, self.dln_cls, self.dO_cls = e(B, Fsave), e(B, D), e(B, D)
         self.dyg_cls = e(B * rmax)
         self.dyg = e(M * rmax)
         self.dw_ws = ops.dw_workspace(M, rmax, D, dev)
         for st in self.blocks:
-            if ops.lib().apla_dw_workspace_bytes(M, st.r, D) > self.dw_ws.numel() * 4:
-                self.dw_ws = ops.dw_workspace(M, st.r, D, dev)
+            if ops.lib().apla_dw_workspace_bytes(M, st.r_pad, D) > self.dw_ws.numel() * 4:
+                self.dw_ws = ops.dw_workspace(M, st.r_pad, D, dev)
 
     @_half_mode
     def refresh_frozen_copies(self):
@@ -408,6 +413,16 @@ class AplaTrainEngine:
         ops.layernorm_bwd(self.dxn, self.x[self.L], self.gf, self.meanf, self.rstdf, out=self.G,
                           out_bf16=None if self.Gb is self.G else self.Gb, rows=B, row_stride=N * D)
 
+    def _proj_dw(self, st, dyg, o):
+        """dW1 / db1 of one block into the flat gradient buffer (through a padded temporary when r is not a multiple of 64)."""
+        if st.r_pad == st.r:
+            ops.proj_dw(dyg, o, self._grad_view(st.W1_name), self._grad_view(st.b1_name), row_scale=st.row_scale, workspace=self.dw_ws)
+            return
+        dW, db = self.dW_tmp[:st.r_pad], self.db_tmp[:st.r_pad]
+        ops.proj_dw(dyg, o, dW, db, row_scale=st.row_scale, workspace=self.dw_ws)
+        self._grad_view(st.W1_name).copy_(dW[:st.r])
+        self._grad_view(st.b1_name).copy_(db[:st.r])
+
     def _backward_block(self, i):
         st = self.blocks[i]
         B, N, H, M, D = self.B, self.N, self.H, self.M, self.D
@@ -418,11 +433,10 @@ class AplaTrainEngine:
         else:
             ops.gemm_nt(self.Gb, st.WoutT, None, epilogue=ops.EPI_MUL, aux_in=self.act_saved[i], out=self.dact)
             ops.gemm_nt(self.dact, st.Wfc1T, None, out=self.dln)
-        dyg = self.dyg[:M * st.r].view(M, st.r)
+        dyg = self.dyg[:M * st.r_pad].view(M, st.r_pad)
         ops.layernorm_bwd(self.dln, self.xmid[i], st.g2, self.mean2[i], self.rstd2[i], dres=self.G, out=self.G,
-                          out_bf16=copy, inds=st.inds, r=st.r, gathered=dyg)
-        ops.proj_dw(dyg, self.o[i], self._grad_view(st.W1_name), self._grad_view(st.b1_name), row_scale=st.row_scale,
-                    workspace=self.dw_ws)
+                          out_bf16=copy, inds=st.inds, r=st.r_pad, gathered=dyg)
+        self._proj_dw(st, dyg, self.o[i])
         if i == 0:
             return  # nothing upstream of block 0's projection is trainable
         ops.gemm_nt(self.Gb, st.WnatT, None, out=self.dO)
@@ -446,13 +460,12 @@ class AplaTrainEngine:
         else:
             ops.gemm_nt(cls(self.Gb), st.WoutT, None, epilogue=ops.EPI_MUL, aux_in=cls(self.act_saved[i]), out=self.dact_cls)
             ops.gemm_nt(self.dact_cls, st.Wfc1T, None, out=self.dln_cls)
-        dyg = self.dyg_cls[:B * st.r].view(B, st.r)
+        dyg = self.dyg_cls[:B * st.r_pad].view(B, st.r_pad)
         ops.layernorm_bwd(self.dln_cls, self.xmid[i], st.g2,
                           self.mean2_cls if self.cls_only_tail else self.mean2[i][::N].contiguous(),
                           self.rstd2_cls if self.cls_only_tail else self.rstd2[i][::N].contiguous(),
-                          dres=self.G, out=self.G, out_bf16=copy, inds=st.inds, r=st.r, gathered=dyg, rows=B, row_stride=N * D)
-        ops.proj_dw(dyg, cls(self.o[i]), self._grad_view(st.W1_name), self._grad_view(st.b1_name), row_scale=st.row_scale,
-                    workspace=self.dw_ws)
+                          dres=self.G, out=self.G, out_bf16=copy, inds=st.inds, r=st.r_pad, gathered=dyg, rows=B, row_stride=N * D)
+        self._proj_dw(st, dyg, cls(self.o[i]))
         if i == 0:
             return
         ops.gemm_nt(cls(self.Gb), st.WnatT, None, out=self.dO_cls)

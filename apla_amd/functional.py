@@ -245,17 +245,17 @@ class _AplaProjFn(torch.autograd.Function):
         dy2 = _as2d_bf16(dy)
         do = ops.gemm_nt(dy2, st.WnatT).reshape(ctx.shape) if ctx.needs_input_grad[0] else None
         r, D = W1.shape
-        dyg = ops.gather_cols(dy2, st.inds32, r)
-        dW1 = torch.empty(r, D, device=dy.device, dtype=torch.float32)
-        db1 = torch.empty(r, device=dy.device, dtype=torch.float32)
+        r_pad = (r + 63) // 64 * 64  # the dW kernel works on multiples of 64 rows: pad with the next (frozen) indices, drop their rows
+        dyg = ops.gather_cols(dy2, st.inds32, r_pad)
+        dW1 = torch.empty(r_pad, D, device=dy.device, dtype=torch.float32)
+        db1 = torch.empty(r_pad, device=dy.device, dtype=torch.float32)
         ops.proj_dw(dyg, o2, dW1, db1)
-        return do, dW1.to(W1.dtype), db1.to(b1.dtype), None
+        return do, dW1[:r].to(W1.dtype), db1[:r].to(b1.dtype), None
 
 
 def apla_projection(o, W1, b1, W2, b2, inds, state: AplaProjState):
-    if W1.shape[0] % 64 != 0 or W1.shape[1] % 128 != 0:
-        raise NotImplementedError(f"APLA HIP projection needs partial_size % 64 == 0 and dim % 128 == 0 "
-                                  f"(got r={W1.shape[0]}, dim={W1.shape[1]})")
+    if W1.shape[1] % 128 != 0:
+        raise NotImplementedError(f"APLA HIP projection needs dim % 128 == 0 (got dim={W1.shape[1]})")
     with torch.no_grad():
         state.refresh(W1, b1, W2, b2, inds)
     return _AplaProjFn.apply(o, W1, b1, state)

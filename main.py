@@ -1,0 +1,292 @@
+#!/usr/bin/env python
+"""`python main.py --params_path params/.../apla.yml [--batch_size ..] [--lr ..] [--gpu 0,1,..]` — the reference's entry
+point (src/main.py:18-55, 241-264) for the supervised APLA fine-tuning path, on the MI355X-native stack.
+
+Kept from the reference: the CLI flags that touch this path, the YAML schema (`__common__.yml` next to the given file is
+loaded first and the given file overrides it key by key — utils/helpfuns.py:114-134), the argument -> parameter overrides
+(main.py:58-158), model construction from `model_params` (defaults/models.py), the two AdamW groups, the per-iteration
+LinearWarmup / CosineAnnealingLR schedule, gradient clipping, one process per GPU.  The training step itself is
+`AplaTrainEngine.train_step` (fused forward + loss + backward + gradient exchange + clip + AdamW).
+
+NOT rebuilt (out of scope): the dataset zoo and torchvision transforms, wandb logging, evaluation / kNN, the
+SSL trainers (`--dinov2` etc. raise).  Data therefore comes from one of two sources:
+  * `dataset_params.dataset: "TensorFile"` + `data_location: file.pt` — a dict {"images": uint8|float [N,3,S,S],
+    "labels": int [N]} that is normalised (ImageNet mean/std) and served in shuffled batches from device memory;
+  * anything else — synthetic N(0,1) images with random labels of the shapes the YAML describes (a plumbing /
+    throughput run; announced loudly).
+"""
+import argparse
+import copy
+import math
+import os
+import sys
+import time
+
+import torch
+import yaml
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+KNOWN_CLASSES = {"NABirds": 555, "ImageNet": 1000, "CIFAR10": 10, "CIFAR100": 100, "ISIC2019": 8, "Flowers102": 102,
+                 "Food101": 101, "OxfordPets": 37, "StanfordCars": 196, "DTD": 47, "SUN397": 397}
+IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+
+
+def parse_arguments(argv=None):
+    p = argparse.ArgumentParser(description="APLA fine-tuning on MI355X (reference CLI surface, src/main.py:18-55)", allow_abbrev=False)
+    p.add_argument("--params_path", type=str, required=True)
+    p.add_argument("--gpu", type=str, help="comma-separated GPU ids: one process per GPU")
+    p.add_argument("--batch_size", type=int)
+    p.add_argument("--val_every", type=float)
+    p.add_argument("--log_every", type=int)
+    p.add_argument("--mixed_precision", action="store_true", default=False)
+    p.add_argument("--num_workers", type=str)
+    p.add_argument("--prefetch_factor", type=str)
+    p.add_argument("--lr", type=float)
+    p.add_argument("--warmup", type=int)
+    p.add_argument("--epochs", type=int)
+    p.add_argument("--wd", type=float)
+    p.add_argument("--dpr", type=float)
+    p.add_argument("--dr", type=float)
+    p.add_argument("--adr", type=float)
+    p.add_argument("--model_name", type=str)
+    p.add_argument("--pretrained_path", type=str)
+    p.add_argument("--save_dir", type=str)
+    p.add_argument("--debug", action="store_true", default=False)
+    p.add_argument("--dry", action="store_true", default=False, help="build everything, run a handful of iterations, save nothing")
+    p.add_argument("--job_id", type=str)
+    p.add_argument("--offline", action="store_true", default=False)
+    p.add_argument("--test", action="store_true", default=False)
+    p.add_argument("--knn", action="store_true", default=False)
+    for flag in ("byol", "simsiam", "dino", "dinov2"):
+        p.add_argument("--" + flag, action="store_true", default=False)
+    # additions of this implementation
+    p.add_argument("--steps_per_epoch", type=int, help="synthetic data only: iterations that make one epoch (default 100)")
+    p.add_argument("--n_classes", type=int, help="classes when the dataset name is not a known one")
+    p.add_argument("--dtype", choices=["bf16", "fp16"], default=None, help="16-bit operand type (default bf16; --mixed_precision alone keeps bf16)")
+    return p.parse_args(argv)
+
+
+def update_nested_values(dst: dict, src: dict):
+    """utils/helpfuns.py:114-134: dict values recurse (new sub-dicts are added whole), everything else overwrites."""
+    for k, v in src.items():
+        if isinstance(v, dict) and isinstance(dst.get(k), dict):
+            update_nested_values(dst[k], v)
+        else:
+            dst[k] = copy.deepcopy(v)
+    return dst
+
+
+def load_parameters(params_path: str) -> dict:
+    """__common__.yml of the same directory (one level up for '_others', main.py:244-247) overridden by the given file."""
+    d = os.path.dirname(os.path.abspath(params_path))
+    common = os.path.join(d, "..", "__common__.yml") if "_others" in params_path else os.path.join(d, "__common__.yml")
+    params = {}
+    if os.path.exists(common):
+        with open(common) as f:
+            params = yaml.safe_load(f) or {}
+    with open(params_path) as f:
+        update_nested_values(params, yaml.safe_load(f) or {})
+    return params
+
+
+def _set(params, path, value):
+    d = params
+    for k in path[:-1]:
+        d = d.setdefault(k, {})
+    d[path[-1]] = value
+
+
+def update_params_from_args(params: dict, args) -> dict:
+    """main.py:58-158 (the overrides that exist on this path)."""
+    opt = ("optimization_params", "default")
+    if args.warmup:
+        _set(params, opt + ("scheduler", "params", "LinearWarmup", "warmup_iters"), args.warmup)
+    if args.epochs:
+        _set(params, ("training_params", "epochs"), args.epochs)
+    if args.pretrained_path:
+        _set(params, ("transfer_learning_params", "pretrained_path"), args.pretrained_path)
+    if args.lr:
+        _set(params, opt + ("optimizer", "params", "lr"), args.lr)
+    if args.wd is not None:
+        _set(params, opt + ("optimizer", "params", "weight_decay"), args.wd)
+    for name, key in (("dpr", "drop_path_rate"), ("dr", "drop_rate"), ("adr", "attn_drop_rate")):
+        if getattr(args, name) is not None:
+            _set(params, ("model_params", "transformers_params", key), getattr(args, name))
+    if args.gpu:
+        _set(params, ("system_params", "which_GPUs"), args.gpu)
+    if args.model_name:
+        _set(params, ("training_params", "model_name"), args.model_name)
+    if args.save_dir:
+        _set(params, ("training_params", "save_dir"), args.save_dir)
+    if args.batch_size:
+        for loader in ("trainloader", "valloader", "testloader"):
+            _set(params, ("dataloader_params", loader, "batch_size"), args.batch_size)
+    if args.val_every is not None:
+        _set(params, ("training_params", "val_every"), args.val_every)
+    if args.log_every is not None:
+        _set(params, ("training_params", "log_every"), args.log_every)
+    if args.job_id is not None:
+        _set(params, ("training_params", "job_id"), args.job_id)
+    if args.mixed_precision:
+        _set(params, ("training_params", "use_mixed_precision"), True)
+    return params
+
+
+def resolve_run(params: dict, args) -> dict:
+    """Everything the training loop needs, derived from the merged parameters (no GPU involved: unit-testable)."""
+    if args.byol or args.simsiam or args.dino or args.dinov2:
+        raise NotImplementedError("the self-supervised trainers are out of scope here (SURVEY §8f-1); only the supervised APLA path runs")
+    if args.test or args.knn:
+        raise NotImplementedError("evaluation / kNN are out of scope here (SURVEY §2)")
+    mp = params["model_params"]
+    ad = mp.get("adaptation") or {}
+    if ad.get("mode") != "apla":
+        raise AssertionError("model_params.adaptation.mode must be 'apla' (defaults/models.py:34)")
+    ds = params.get("dataset_params", {})
+    tt = ds.get("train_transforms", {})
+    if tt.get("RandomResizedCrop", {}).get("apply"):
+        img = int(tt["RandomResizedCrop"]["size"])
+    elif tt.get("CenterCrop", {}).get("apply"):
+        img = int(tt["CenterCrop"]["height"])
+    elif tt.get("Resize", {}).get("apply"):
+        img = int(tt["Resize"]["height"])
+    else:
+        img = int(mp.get("transformers_params", {}).get("img_size", [224])[0])
+    n_classes = args.n_classes or mp.get("n_classes") or KNOWN_CLASSES.get(ds.get("dataset"))
+    if not n_classes:
+        raise ValueError(f"cannot tell the number of classes of dataset {ds.get('dataset')!r}: pass --n_classes")
+    opt = params["optimization_params"]["default"]
+    if opt["optimizer"]["type"] != "AdamW":
+        raise NotImplementedError("the fused optimizer implements AdamW (the type every shipped APLA config uses)")
+    sched = opt.get("scheduler", {})
+    types = sched.get("type") or []
+    types = [types] if not isinstance(types, list) else [t for t in types if t]
+    for t in types:
+        if t not in ("LinearWarmup", "CosineAnnealingLR"):
+            raise NotImplementedError(f"scheduler {t!r}: only LinearWarmup and CosineAnnealingLR are implemented")
+    tp = params.get("training_params", {})
+    gpus = str(params.get("system_params", {}).get("which_GPUs", "0"))
+    return dict(img=img, n_classes=int(n_classes), batch=int(params["dataloader_params"]["trainloader"]["batch_size"]),
+                lr=float(opt["optimizer"]["params"]["lr"]), wd=float(opt["optimizer"]["params"].get("weight_decay", 0.0)),
+                sched_types=types, sched_params=sched.get("params", {}), epochs=int(tp.get("epochs", 1)),
+                grad_clipping=float(tp.get("grad_clipping") or 0.0), log_every=int(tp.get("log_every", 25)),
+                model_name=tp.get("model_name", "model"), save_dir=tp.get("save_dir"), gpus=[g for g in gpus.split(",") if g != ""],
+                dataset=ds.get("dataset"), data_location=ds.get("data_location"),
+                pretrained_path=params.get("transfer_learning_params", {}).get("pretrained_path"))
+
+
+def make_schedule(run, steps_per_epoch):
+    from apla_amd.schedule import LRSchedule
+    sp = run["sched_params"]
+    warm = sp.get("LinearWarmup", {}) if "LinearWarmup" in run["sched_types"] else {}
+    return LRSchedule(run["lr"], use_warmup="LinearWarmup" in run["sched_types"], cosine="CosineAnnealingLR" in run["sched_types"],
+                      warmup_iters=int(warm.get("warmup_iters", 0) or 0), warmup_epochs=int(warm.get("warmup_epochs", 0) or 0),
+                      steps_per_epoch=steps_per_epoch, epochs=run["epochs"],
+                      cosine_eta_min=float(sp.get("CosineAnnealingLR", {}).get("eta_min", 0.0)))
+
+
+class TensorBatches:
+    """Shuffled, drop_last batches of a device-resident tensor dataset (or synthetic data), sharded over ranks."""
+
+    def __init__(self, run, rank, world, device, steps_per_epoch=None):
+        self.B, self.rank, self.world, self.device = run["batch"], rank, world, device
+        self.images = self.labels = None
+        if run["dataset"] == "TensorFile":
+            blob = torch.load(run["data_location"], map_location="cpu")
+            imgs, self.labels = blob["images"], blob["labels"].to(device).int()
+            imgs = imgs.float().div_(255.0) if imgs.dtype == torch.uint8 else imgs.float()
+            mean, std = torch.tensor(IMAGENET_MEAN).view(1, 3, 1, 1), torch.tensor(IMAGENET_STD).view(1, 3, 1, 1)
+            self.images = ((imgs - mean) / std).to(device)
+            self.steps = self.images.shape[0] // (self.B * world)
+        else:
+            print(f"\033[93m[main] no loader for dataset {run['dataset']!r} at {run['data_location']!r}: SYNTHETIC N(0,1) images / random "
+                  f"labels [{self.B},3,{run['img']},{run['img']}], {run['n_classes']} classes\033[0m", flush=True)
+            self.steps = steps_per_epoch or 100
+            self.shape, self.C = (self.B, 3, run["img"], run["img"]), run["n_classes"]
+
+    def epoch(self, epoch):
+        g = torch.Generator(device=self.device).manual_seed(1000 * epoch + (0 if self.images is not None else self.rank))
+        if self.images is None:
+            for _ in range(self.steps):
+                yield torch.randn(self.shape, device=self.device, generator=g), torch.randint(0, self.C, (self.B,), device=self.device, generator=g)
+            return
+        perm = torch.randperm(self.images.shape[0], device=self.device, generator=g)  # same permutation on every rank (DistributedSampler)
+        for s in range(self.steps):
+            idx = perm[(s * self.world + self.rank) * self.B:(s * self.world + self.rank + 1) * self.B]
+            yield self.images[idx], self.labels[idx]
+
+
+def main(params, args):
+    import torch.distributed as dist
+    from apla_amd import checkpoint as ckpt
+    from apla_amd.dist import dist_average_tensor, init_from_env, is_rank0, synchronize
+    from apla_amd.engine import AplaTrainEngine, OptimConfig
+    from apla_amd.models import Classifier
+    run = resolve_run(params, args)
+    rank, world, local = init_from_env()
+    dev = torch.device("cuda", local if world > 1 else int(run["gpus"][0]) if run["gpus"] else 0)
+    torch.cuda.set_device(dev)
+    torch.manual_seed(0)  # identical construction (weights, indices) on every rank; multi-GPU runs should still pass inds_path
+    mp = copy.deepcopy(params["model_params"])
+    mp["n_classes"] = run["n_classes"]
+    mp.setdefault("transformers_params", {})["img_size"] = [run["img"]]
+    pretrained = bool(mp.get("pretrained"))
+    mp["pretrained"] = False  # no network here: weights come from --pretrained_path or stay at their initialisation
+    model = Classifier(mp, params.get("system_params", {"which_GPUs": "0"}))
+    if run["pretrained_path"]:
+        sd = torch.load(run["pretrained_path"], map_location="cpu")
+        sd = sd.get("state_dict", sd)
+        missing = model.load_state_dict(sd, strict=False)
+        if is_rank0():
+            print(f"[main] loaded {run['pretrained_path']}: {len(missing.missing_keys)} missing, {len(missing.unexpected_keys)} unexpected keys")
+    elif pretrained and is_rank0():
+        print("\033[93m[main] model_params.pretrained is true but there is no network and no --pretrained_path: random initialisation\033[0m")
+    hdt = torch.float16 if args.dtype == "fp16" else torch.bfloat16
+    eng = AplaTrainEngine(model, run["batch"], run["img"], device=dev, process_group=dist.group.WORLD if world > 1 else None,
+                          optim=OptimConfig(lr=run["lr"], weight_decay=run["wd"], grad_clipping=run["grad_clipping"]),
+                          compute_dtype=hdt, loss_scale="dynamic" if hdt == torch.float16 else 1.0)
+    data = TensorBatches(run, rank, world, dev, args.steps_per_epoch)
+    sched = make_schedule(run, data.steps)
+    epochs = 1 if args.dry else run["epochs"]
+    iters, t0, seen = 0, time.perf_counter(), 0
+    if is_rank0():
+        print(f"[main] {mp['backbone_type']} APLA r={mp['adaptation']['params']['partial_size']}  {world} GPU(s) x bs {run['batch']}  "
+              f"{epochs} epoch(s) x {data.steps} it  lr {run['lr']} wd {run['wd']} schedule {run['sched_types'] or 'constant'}", flush=True)
+    for epoch in range(epochs):
+        for images, labels in data.epoch(epoch):
+            loss = eng.train_step(images, labels, lr=sched.lr)
+            sched.step()
+            iters += 1
+            seen += run["batch"] * world
+            if iters % run["log_every"] == 0 or iters == 1:
+                loss = dist_average_tensor(loss)
+                if is_rank0():
+                    torch.cuda.synchronize()
+                    dt = time.perf_counter() - t0
+                    print(f"[main] epoch {epoch} it {iters}: train_loss {float(loss):.4f}  lr {sched.lr:.3e}  "
+                          f"grad_norm {float(eng.grad_norm):.3f}  {seen / dt:.0f} images/s", flush=True)
+            if args.dry and iters >= 5:
+                break
+    synchronize()
+    if is_rank0() and run["save_dir"] and not (args.dry or args.debug):
+        os.makedirs(run["save_dir"], exist_ok=True)
+        path = os.path.join(run["save_dir"], run["model_name"] + ".pth")
+        torch.save(ckpt.session_dict(eng, iters=iters, epoch=epochs, parameters=params), path)
+        print(f"[main] saved {path}")
+    return float(loss)
+
+
+if __name__ == "__main__":
+    _args = parse_arguments()
+    print(f"\nUSING PARAMS FROM PATH: {os.path.abspath(_args.params_path)}\n")
+    _params = update_params_from_args(load_parameters(_args.params_path), _args)
+    _gpus = [g for g in str(_params.get("system_params", {}).get("which_GPUs", "0")).split(",") if g != ""]
+    if len(_gpus) > 1 and "RANK" not in os.environ:
+        from apla_amd.dist import launch
+        os.environ.setdefault("HIP_VISIBLE_DEVICES", ",".join(_gpus))
+        launch(main, (_params, _args), n_procs=len(_gpus))
+    else:
+        main(_params, _args)

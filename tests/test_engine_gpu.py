@@ -4,6 +4,8 @@ vectors produced by the actual reference (tests/golden/g5_cfg1_vits.npz: ViT-S/1
 Tolerances (stated, per SURVEY §7 "hard parts"): the reference CPU path is fp32; the HIP path multiplies in bf16 with
 fp32 accumulation and an fp32 residual stream.  We require  max|logits - ref| / max|ref| <= 1e-2  and
 |loss - ref| <= 5e-3 in that mode, gradients within 3e-2 relative L2.  Index selection is bit-exact (CPU test)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -149,6 +151,34 @@ def test_engine_large_geometries_vs_oracle(name, kw, B):
         assert rel_l2(gr.cpu(), grads_ref[n2]) < GRAD_TOL, n
 
 
+@pytest.mark.parametrize("r", [8, 100])
+def test_engine_partial_size_not_multiple_of_64(r):
+    """The shipped configs use small ranks (params/finetune/**/apla.yml: partial_size 8): any 0 < r <= D must work — the dW
+    kernel pads the trainable index set to a multiple of 64 with frozen features and drops their rows."""
+    from apla_amd.engine import AplaTrainEngine, OptimConfig
+    model = small_vit(depth=3, r=r)
+    p = oracle_params(model)
+    B = 4
+    g = torch.Generator().manual_seed(4)
+    images, labels = torch.randn(B, 3, 32, 32, generator=g), torch.randint(0, 10, (B,), generator=g)
+    cfg = dict(patch=16, depth=3, heads=2, r=r)
+    logits_ref, ctx = O.vit_forward(images.double(), p, cfg)
+    loss_ref, dl = O.cross_entropy_fwd_bwd(logits_ref, labels)
+    grads_ref = O.vit_backward(dl, ctx, p, cfg)
+    eng = AplaTrainEngine(model, B, 32, optim=OptimConfig(lr=1e-3, weight_decay=1e-2, grad_clipping=1.0))
+    eng.set_batch(images.cuda(), labels.cuda())
+    eng.forward_backward()
+    torch.cuda.synchronize()
+    assert rel_err(eng.logits.cpu(), logits_ref) < LOGIT_TOL
+    for n, gr in eng.grads().items():
+        n2 = n[len("backbone."):] if n.startswith("backbone.") else n
+        assert gr.shape == grads_ref[n2].shape and rel_l2(gr.cpu(), grads_ref[n2]) < GRAD_TOL, n
+    eng.optimizer_step()
+    eng.train_step()
+    torch.cuda.synchronize()
+    assert np.isfinite(float(eng.loss))
+
+
 def test_engine_cfg1_matches_reference_golden():
     """BASELINE config 1 (ViT-S/16, r=64, C=10, bs=8): same seed-built weights as the reference (digests checked in the
     CPU suite), same inputs; logits/loss/grads against what the REFERENCE code produced."""
@@ -229,3 +259,18 @@ def test_session_checkpoint_interchange_with_torch_adamw():
     a = eng.train_step(images.cuda(), labels.cuda()).clone()
     b = eng2.train_step(images.cuda(), labels.cuda()).clone()
     assert torch.equal(a, b) and torch.equal(eng.flat_params, eng2.flat_params)
+
+
+def test_main_entry_point_trains_on_synthetic_data(tmp_path):
+    """python main.py --params_path <apla.yml> (reference CLI + YAML schema, partial_size 8 as in the shipped configs): runs the
+    fused engine for two epochs of synthetic batches, follows the LR schedule and writes a reference-layout session file."""
+    import main
+    path = os.path.join(os.path.dirname(__file__), "params", "tiny", "apla.yml")
+    args = main.parse_arguments(["--params_path", path, "--steps_per_epoch", "6", "--save_dir", str(tmp_path), "--lr", "0.002"])
+    params = main.update_params_from_args(main.load_parameters(path), args)
+    loss = main.main(params, args)
+    assert np.isfinite(loss)
+    sess = torch.load(tmp_path / "tiny.pth", weights_only=False)
+    assert sess["iters"] == 12 and "backbone.blocks.0.attn.proj_weight1" in sess["state_dict"]
+    assert tuple(sess["state_dict"]["backbone.blocks.0.attn.proj_weight1"].shape) == (8, 384)
+    assert float(sess["optimizer"]["state"][0]["step"]) == 12.0

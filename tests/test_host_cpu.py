@@ -202,3 +202,30 @@ def test_pretrained_backbone_loading_rules():
     assert torch.equal(a.proj_weight1, src.blocks[0].attn.proj.weight[a.inds[:64]])
     with pytest.raises(RuntimeError):
         ckpt.load_pretrained_backbone(dst, sd)
+
+
+# ----------------------------------------------------------------------------------------------- main.py entry point
+def test_main_parameter_resolution():
+    """src/main.py:241-253 + :58-158: __common__.yml overridden key by key by the given file, then by the CLI flags."""
+    import os
+    import main
+    path = os.path.join(os.path.dirname(__file__), "params", "tiny", "apla.yml")
+    args = main.parse_arguments(["--params_path", path])
+    params = main.update_params_from_args(main.load_parameters(path), args)
+    opt = params["optimization_params"]["default"]
+    assert opt["optimizer"]["params"] == {"lr": 0.00003, "weight_decay": 1e-5}          # lr overridden, wd inherited
+    assert opt["scheduler"]["type"] == ["LinearWarmup", "CosineAnnealingLR"]
+    assert opt["scheduler"]["params"]["LinearWarmup"] == {"warmup_epochs": 0, "warmup_iters": 3}
+    assert opt["scheduler"]["params"]["CosineAnnealingLR"]["eta_min"] == 1e-6
+    assert params["model_params"]["adaptation"]["params"]["partial_size"] == 8
+    run = main.resolve_run(params, args)
+    assert (run["img"], run["n_classes"], run["batch"], run["epochs"], run["grad_clipping"]) == (32, 10, 4, 2, 1.0)
+    sched = main.make_schedule(run, steps_per_epoch=10)
+    assert sched.warmup_iters == 3 and sched.T_max == 2 * 10 - 3
+    args = main.parse_arguments(["--params_path", path, "--batch_size", "16", "--lr", "0.01", "--wd", "0", "--warmup", "7",
+                                 "--epochs", "5", "--gpu", "0,1", "--log_every", "1"])
+    run = main.resolve_run(main.update_params_from_args(main.load_parameters(path), args), args)
+    assert (run["batch"], run["lr"], run["wd"], run["epochs"], run["gpus"], run["log_every"]) == (16, 0.01, 0.0, 5, ["0", "1"], 1)
+    assert main.make_schedule(run, 10).warmup_iters == 7
+    with pytest.raises(NotImplementedError):
+        main.resolve_run(params, main.parse_arguments(["--params_path", path, "--dinov2"]))

@@ -30,7 +30,8 @@ def oracle_params(m):
     return {"a." + k: (v.detach().cpu() if k == "inds" else v.detach().double().cpu()) for k, v in m.state_dict().items()}
 
 
-@pytest.mark.parametrize("B,N,dim,heads,r", [(2, 197, 256, 4, 64), (3, 50, 128, 2, 128), (1, 257, 384, 6, 192)])
+@pytest.mark.parametrize("B,N,dim,heads,r", [(2, 197, 256, 4, 64), (3, 50, 128, 2, 128), (1, 257, 384, 6, 192), (2, 197, 128, 2, 8),
+                                             (2, 64, 256, 4, 100)])
 def test_apla_attention_module_fwd_bwd(B, N, dim, heads, r):
     from apla_amd.apla import APLA_Attention
     m = make_module(APLA_Attention, dim, heads, r, seed=5)
