@@ -103,8 +103,11 @@ __global__ __launch_bounds__(256) void sgemm_small_kernel(const float* __restric
 }
 
 // one workgroup per sample: softmax cross-entropy, dlogits = (softmax - onehot) / B, row loss
+// labels == nullptr: soft targets [B, C] (rows sum to 1: timm Mixup / label smoothing feed nn.CrossEntropyLoss probabilities,
+// utils/_utils.py:424-441): loss_b = lse - sum_c t_bc * logit_bc, dlogits = (softmax - t) / B
 __global__ __launch_bounds__(256) void cross_entropy_kernel(const float* __restrict__ logits, int ldl,
                                                             const int32_t* __restrict__ labels,
+                                                            const float* __restrict__ targets, int ldt,
                                                             float* __restrict__ dlogits, float* __restrict__ row_loss,
                                                             int B, int C) {
   __shared__ float red[4];
@@ -128,13 +131,35 @@ __global__ __launch_bounds__(256) void cross_entropy_kernel(const float* __restr
   if (threadIdx.x == 0) bc = red[0] + red[1] + red[2] + red[3];
   __syncthreads();
   const float lse = mx + __logf(bc);
-  const int y = labels[b];
   const float invB = 1.0f / (float)B;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    const float pr = __expf(lr[c] - lse);
-    dlogits[(size_t)b * ldl + c] = (pr - (c == y ? 1.0f : 0.0f)) * invB;
+  if (labels != nullptr) {
+    const int y = labels[b];
+    for (int c = threadIdx.x; c < C; c += 256) {
+      const float pr = __expf(lr[c] - lse);
+      dlogits[(size_t)b * ldl + c] = (pr - (c == y ? 1.0f : 0.0f)) * invB;
+    }
+    if (threadIdx.x == 0) row_loss[b] = lse - lr[y];
+    return;
   }
-  if (threadIdx.x == 0) row_loss[b] = lse - lr[y];
+  const float* tr = targets + (size_t)b * ldt;
+  float dot = 0.f, tsum = 0.f;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float t = tr[c];
+    dot += t * lr[c];
+    tsum += t;
+  }
+  dot = wave_sum(dot);
+  tsum = wave_sum(tsum);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = dot; }
+  __syncthreads();
+  const float dall = red[0] + red[1] + red[2] + red[3];
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = tsum; }
+  __syncthreads();
+  const float tall = red[0] + red[1] + red[2] + red[3];  // 1 for proper probability rows; kept general like torch
+  for (int c = threadIdx.x; c < C; c += 256) dlogits[(size_t)b * ldl + c] = (__expf(lr[c] - lse) * tall - tr[c]) * invB;
+  if (threadIdx.x == 0) row_loss[b] = tall * lse - dall;  // -sum_c t_c log p_c
 }
 
 __global__ __launch_bounds__(256) void mean_kernel(const float* __restrict__ v, float* __restrict__ out, int n) {
@@ -194,10 +219,20 @@ extern "C" int apla_sgemm_small(const float* A, long sai, long sak, const float*
 extern "C" int apla_cross_entropy(const float* logits, int ldl, const int32_t* labels, float* dlogits,
                                   float* row_loss, float* loss, int B, int C, hipStream_t stream) {
   APLA_REQUIRE(logits && labels && dlogits && row_loss && loss && B > 0 && C > 0 && ldl >= C, "apla_cross_entropy: bad arguments");
-  hipLaunchKernelGGL(cross_entropy_kernel, dim3(B), dim3(256), 0, stream, logits, ldl, labels, dlogits, row_loss, B, C);
+  hipLaunchKernelGGL(cross_entropy_kernel, dim3(B), dim3(256), 0, stream, logits, ldl, labels, (const float*)nullptr, 0, dlogits, row_loss, B, C);
   APLA_CHECK_LAUNCH("apla_cross_entropy");
   hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, stream, (const float*)row_loss, loss, B);
   APLA_CHECK_LAUNCH("apla_cross_entropy[mean]");
+  return APLA_OK;
+}
+
+extern "C" int apla_cross_entropy_soft(const float* logits, int ldl, const float* targets, int ldt, float* dlogits,
+                                       float* row_loss, float* loss, int B, int C, hipStream_t stream) {
+  APLA_REQUIRE(logits && targets && dlogits && row_loss && loss && B > 0 && C > 0 && ldl >= C && ldt >= C, "apla_cross_entropy_soft: bad arguments");
+  hipLaunchKernelGGL(cross_entropy_kernel, dim3(B), dim3(256), 0, stream, logits, ldl, (const int32_t*)nullptr, targets, ldt, dlogits, row_loss, B, C);
+  APLA_CHECK_LAUNCH("apla_cross_entropy_soft");
+  hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, stream, (const float*)row_loss, loss, B);
+  APLA_CHECK_LAUNCH("apla_cross_entropy_soft[mean]");
   return APLA_OK;
 }
 

@@ -76,7 +76,7 @@ def _half_mode(fn):
 class AplaTrainEngine:
     def __init__(self, model: nn.Module, batch_size: int, img_size: int, device="cuda", res_dtype=torch.float32,
                  grad_dtype=None, optim: Optional[OptimConfig] = None, process_group=None, use_graphs: bool = True,
-                 compute_dtype=torch.bfloat16, loss_scale: float = 1.0):
+                 compute_dtype=torch.bfloat16, loss_scale: float = 1.0, soft_targets: bool = False):
         if not torch.cuda.is_available():
             raise AplaHipError("AplaTrainEngine needs an MI355X (no CPU fallback)")
         self.device = torch.device(device)
@@ -95,6 +95,8 @@ class AplaTrainEngine:
         if compute_dtype not in (torch.bfloat16, torch.float16):
             raise TypeError("compute_dtype must be torch.bfloat16 (default) or torch.float16")
         self.hdt = compute_dtype                  # 16-bit operand type: selects libapla_hip.so / libapla_hip_f16.so
+        # probability targets [B, C] instead of class ids (the reference's advanced_aug: Mixup / CutMix / label smoothing)
+        self.soft_targets = soft_targets
         # loss scale for fp16 gradients: a float (static) or "dynamic" = GradScaler semantics kept on the device
         self.dynamic_scale = loss_scale == "dynamic"
         self.loss_scale = 1.0 if self.dynamic_scale else float(loss_scale)
@@ -257,6 +259,7 @@ class AplaTrainEngine:
         e = lambda *s, dt=ops.half(): torch.empty(*s, device=dev, dtype=dt)  # noqa: E731
         self.images = e(B, 3, self.S, self.S, dt=torch.float32)
         self.labels = torch.zeros(B, device=dev, dtype=torch.int32)
+        self.targets = torch.zeros(B, self.C, device=dev, dtype=torch.float32) if self.soft_targets else None
         self.cols = e(B * self.Np, self.Kp)
         self.patches = e(B * self.Np, D)
         self.x = [e(M, D, dt=self.res_dtype) for _ in range(L + 1)]
@@ -378,7 +381,8 @@ class AplaTrainEngine:
                           add_row_stride=D if self.cls_only_tail else None, x_out=self.x[self.L])
         ops.sgemm_small(self.xn, self._param_view("fc.weight"), trans_b=True, bias=self._param_view("fc.bias"),
                         out=self.logits)
-        ops.cross_entropy(self.logits, self.labels, dlogits=self.dlogits, row_loss=self.row_loss, loss=self.loss)
+        ops.cross_entropy(self.logits, self.targets if self.soft_targets else self.labels, dlogits=self.dlogits,
+                          row_loss=self.row_loss, loss=self.loss)
         if self.dynamic_scale:
             self.dlogits.mul_(self.scaler[6])   # device scalar written by the previous optimizer step (graph-safe)
         elif self.loss_scale != 1.0:
@@ -507,7 +511,14 @@ class AplaTrainEngine:
     # ------------------------------------------------------------------ public API
     def set_batch(self, images: torch.Tensor, labels: torch.Tensor):
         self.images.copy_(images, non_blocking=True)
-        self.labels.copy_(labels.to(torch.int32), non_blocking=True)
+        if self.soft_targets:
+            if labels.ndim != 2:
+                raise ValueError("this engine was built with soft_targets=True: pass probability targets [B, C]")
+            self.targets.copy_(labels.float(), non_blocking=True)
+        else:
+            if labels.ndim != 1:
+                raise ValueError("class-id labels [B] expected (build the engine with soft_targets=True for probability targets)")
+            self.labels.copy_(labels.to(torch.int32), non_blocking=True)
 
     @_half_mode
     def forward_backward(self):

@@ -507,10 +507,18 @@ def sgemm_small(A: torch.Tensor, Bm: torch.Tensor, *, trans_a=False, trans_b=Fal
 
 
 def cross_entropy(logits: torch.Tensor, labels: torch.Tensor, *, dlogits=None, row_loss=None, loss=None):
-    """Returns (loss [1], dlogits [B,C], row_loss [B]); mean reduction."""
-    _req(logits, torch.float32, "logits", 2), _req(labels, torch.int32, "labels", 1)
+    """Returns (loss [1], dlogits [B,C], row_loss [B]); mean reduction.  `labels`: int32 [B] class ids, or float32 [B, C]
+    probability targets (Mixup / label smoothing), as nn.CrossEntropyLoss accepts both."""
+    _req(logits, torch.float32, "logits", 2)
     B, C = logits.shape
-    if labels.numel() != B or not logits.is_contiguous():
+    soft = labels.ndim == 2
+    if soft:
+        _req(labels, torch.float32, "targets", 2)
+        if tuple(labels.shape) != (B, C):
+            raise ValueError("cross_entropy: probability targets must be [B, C]")
+    else:
+        _req(labels, torch.int32, "labels", 1)
+    if (not soft and labels.numel() != B) or not logits.is_contiguous():
         raise ValueError("cross_entropy: labels length / logits must be contiguous")
     if dlogits is None:
         dlogits = torch.empty(B, C, device=logits.device, dtype=torch.float32)
@@ -520,6 +528,11 @@ def cross_entropy(logits: torch.Tensor, labels: torch.Tensor, *, dlogits=None, r
         loss = torch.empty(1, device=logits.device, dtype=torch.float32)
     if tuple(dlogits.shape) != (B, C) or not dlogits.is_contiguous() or row_loss.numel() != B or loss.numel() < 1:
         raise ValueError("cross_entropy: bad output buffers")
+    if soft:
+        check(lib().apla_cross_entropy_soft(logits.data_ptr(), logits.stride(0), labels.data_ptr(), labels.stride(0),
+                                            dlogits.data_ptr(), row_loss.data_ptr(), loss.data_ptr(), B, C, _stream()),
+              "apla_cross_entropy_soft")
+        return loss, dlogits, row_loss
     check(lib().apla_cross_entropy(logits.data_ptr(), logits.stride(0), labels.data_ptr(), dlogits.data_ptr(),
                                    row_loss.data_ptr(), loss.data_ptr(), B, C, _stream()), "apla_cross_entropy")
     return loss, dlogits, row_loss

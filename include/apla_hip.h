@@ -201,6 +201,11 @@ int apla_sgemm_small(const float* A, long sai, long sak, const float* Bm, long s
                      float* C, long ldc, int M, int N, int K, int accumulate, hipStream_t stream);
 int apla_cross_entropy(const float* logits, int ldl, const int32_t* labels, float* dlogits, float* row_loss,
                        float* loss, int B, int C, hipStream_t stream);
+/* The same with probability targets [B, C] (fp32, rows sum to 1): what nn.CrossEntropyLoss receives when the reference's
+ * `advanced_aug` (timm Mixup / CutMix / label smoothing, utils/_utils.py:424-441, defaults/wrappers.py:137-139) is on.
+ * row_loss[b] = -sum_c t_bc log softmax(logits_b)_c ; dlogits = (softmax * sum_c t_bc - t) / B ; loss = mean(row_loss). */
+int apla_cross_entropy_soft(const float* logits, int ldl, const float* targets, int ldt, float* dlogits, float* row_loss,
+                            float* loss, int B, int C, hipStream_t stream);
 int apla_colsum(const float* X, long ld, float* out, int M, int N, hipStream_t stream);
 
 #ifdef __cplusplus

@@ -169,13 +169,23 @@ def resolve_run(params: dict, args) -> dict:
             raise NotImplementedError(f"scheduler {t!r}: only LinearWarmup and CosineAnnealingLR are implemented")
     tp = params.get("training_params", {})
     gpus = str(params.get("system_params", {}).get("which_GPUs", "0"))
+    # inds_path in the shipped files is relative to the reference's src/ working directory ("../params/…"): accept it as
+    # given, else look for the file next to the parameter file
+    ap = ad.setdefault("params", {})
+    if ap.get("inds_path") and not os.path.exists(ap["inds_path"]):
+        cand = os.path.join(os.path.dirname(os.path.abspath(args.params_path)), os.path.basename(ap["inds_path"]))
+        if os.path.exists(cand):
+            ap["inds_path"] = cand
+    adv = bool(tt.get("advanced_aug"))
+    adv_params = tt.get("advanced_aug_params", {}) if adv else {}
     return dict(img=img, n_classes=int(n_classes), batch=int(params["dataloader_params"]["trainloader"]["batch_size"]),
                 lr=float(opt["optimizer"]["params"]["lr"]), wd=float(opt["optimizer"]["params"].get("weight_decay", 0.0)),
                 sched_types=types, sched_params=sched.get("params", {}), epochs=int(tp.get("epochs", 1)),
                 grad_clipping=float(tp.get("grad_clipping") or 0.0), log_every=int(tp.get("log_every", 25)),
                 model_name=tp.get("model_name", "model"), save_dir=tp.get("save_dir"), gpus=[g for g in gpus.split(",") if g != ""],
                 dataset=ds.get("dataset"), data_location=ds.get("data_location"),
-                pretrained_path=params.get("transfer_learning_params", {}).get("pretrained_path"))
+                pretrained_path=params.get("transfer_learning_params", {}).get("pretrained_path"),
+                soft_targets=adv, label_smoothing=float(adv_params.get("label_smoothing", 0.0)))
 
 
 def make_schedule(run, steps_per_epoch):
@@ -247,7 +257,8 @@ def main(params, args):
     hdt = torch.float16 if args.dtype == "fp16" else torch.bfloat16
     eng = AplaTrainEngine(model, run["batch"], run["img"], device=dev, process_group=dist.group.WORLD if world > 1 else None,
                           optim=OptimConfig(lr=run["lr"], weight_decay=run["wd"], grad_clipping=run["grad_clipping"]),
-                          compute_dtype=hdt, loss_scale="dynamic" if hdt == torch.float16 else 1.0)
+                          compute_dtype=hdt, loss_scale="dynamic" if hdt == torch.float16 else 1.0,
+                          soft_targets=run["soft_targets"])
     data = TensorBatches(run, rank, world, dev, args.steps_per_epoch)
     sched = make_schedule(run, data.steps)
     epochs = 1 if args.dry else run["epochs"]
@@ -257,6 +268,10 @@ def main(params, args):
               f"{epochs} epoch(s) x {data.steps} it  lr {run['lr']} wd {run['wd']} schedule {run['sched_types'] or 'constant'}", flush=True)
     for epoch in range(epochs):
         for images, labels in data.epoch(epoch):
+            if run["soft_targets"]:  # advanced_aug: the criterion receives probability targets (here: label smoothing only;
+                # Mixup / CutMix are data-side augmentations of the out-of-scope input pipeline)
+                eps_ = run["label_smoothing"]
+                labels = torch.nn.functional.one_hot(labels.long(), run["n_classes"]).float() * (1 - eps_) + eps_ / run["n_classes"]
             loss = eng.train_step(images, labels, lr=sched.lr)
             sched.step()
             iters += 1

@@ -358,6 +358,14 @@ def cross_entropy_fwd_bwd(logits: Tensor, labels: Tensor):
     return loss, dl / B
 
 
+def cross_entropy_soft_fwd_bwd(logits: Tensor, targets: Tensor):
+    """nn.CrossEntropyLoss with probability targets [B, C] (what timm's Mixup hands the criterion when the reference's
+    advanced_aug is on, utils/_utils.py:424-441): loss = mean_b( -sum_c t_bc log softmax(logits_b)_c )."""
+    logp = torch.log_softmax(logits, -1)
+    B = logits.shape[0]
+    return -(targets * logp).sum(-1).mean(), (torch.exp(logp) * targets.sum(-1, keepdim=True) - targets) / B
+
+
 def vit_forward(images: Tensor, p: Dict[str, Tensor], cfg: Dict, keep_ctx: bool = True):
     """VisionTransformer.forward_features + Classifier head (vit.py:387-419, defaults/models.py:81-92).
     cfg: dict(patch, depth, heads, r, swiglu, eps).  ``p`` holds backbone keys as in the reference

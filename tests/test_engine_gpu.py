@@ -274,3 +274,28 @@ def test_main_entry_point_trains_on_synthetic_data(tmp_path):
     assert sess["iters"] == 12 and "backbone.blocks.0.attn.proj_weight1" in sess["state_dict"]
     assert tuple(sess["state_dict"]["backbone.blocks.0.attn.proj_weight1"].shape) == (8, 384)
     assert float(sess["optimizer"]["state"][0]["step"]) == 12.0
+
+
+def test_engine_soft_targets_step():
+    """advanced_aug path: probability targets through the fused step (logits/grads vs the oracle with the soft CE)."""
+    from apla_amd.engine import AplaTrainEngine, OptimConfig
+    model = small_vit(depth=2)
+    p = oracle_params(model)
+    B = 4
+    g = torch.Generator().manual_seed(9)
+    images = torch.randn(B, 3, 32, 32, generator=g)
+    tgt = torch.softmax(torch.randn(B, 10, generator=g) * 2, -1)
+    cfg = dict(patch=16, depth=2, heads=2, r=64)
+    logits_ref, ctx = O.vit_forward(images.double(), p, cfg)
+    loss_ref, dl = O.cross_entropy_soft_fwd_bwd(logits_ref, tgt.double())
+    grads_ref = O.vit_backward(dl, ctx, p, cfg)
+    eng = AplaTrainEngine(model, B, 32, soft_targets=True)
+    eng.set_batch(images.cuda(), tgt.cuda())
+    eng.forward_backward()
+    torch.cuda.synchronize()
+    assert abs(float(eng.loss) - float(loss_ref)) < 5e-3
+    for n, gr in eng.grads().items():
+        n2 = n[len("backbone."):] if n.startswith("backbone.") else n
+        assert rel_l2(gr.cpu(), grads_ref[n2]) < GRAD_TOL, n
+    with pytest.raises(ValueError):
+        eng.set_batch(images.cuda(), torch.zeros(B, dtype=torch.long, device="cuda"))

@@ -495,3 +495,22 @@ def test_cabi_error_codes_and_messages(ops):
                               st.data_ptr(), st.data_ptr(), 8, 128, 1e-6, None, 0, None, 0, s)
     assert rc in (-22, -38)
     torch.cuda.synchronize()
+
+
+def test_cross_entropy_soft_targets(ops):
+    """Probability targets (timm Mixup / label smoothing under the reference's advanced_aug): loss and dlogits vs the fp64 oracle,
+    and one-hot targets reproduce the class-id path."""
+    B, C = 37, 1000
+    logits = rnd(B, C, scale=3.0, seed=51)
+    g = torch.Generator().manual_seed(52)
+    y1, y2 = torch.randint(0, C, (B,), generator=g), torch.randint(0, C, (B,), generator=g)
+    lam = torch.rand(B, 1, generator=g)
+    tgt = torch.full((B, C), 0.1 / C)
+    tgt += 0.9 * (lam * torch.nn.functional.one_hot(y1, C) + (1 - lam) * torch.nn.functional.one_hot(y2, C))   # mixup + smoothing
+    loss_ref, dl_ref = O.cross_entropy_soft_fwd_bwd(logits.double(), tgt.double())
+    loss, dl, _ = ops.cross_entropy(dev(logits), dev(tgt))
+    assert abs(float(loss) - float(loss_ref)) < 1e-5 * abs(float(loss_ref)) and rel_err(dl.cpu(), dl_ref) < F32_OUT
+    hard = torch.nn.functional.one_hot(y1, C).float()
+    l1, d1, _ = ops.cross_entropy(dev(logits), dev(hard))
+    l2, d2, _ = ops.cross_entropy(dev(logits), dev(y1.int()))
+    assert abs(float(l1) - float(l2)) < 1e-6 * float(l2) and rel_err(d1.cpu(), d2.cpu().double()) < 1e-6

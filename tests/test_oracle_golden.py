@@ -140,3 +140,14 @@ def test_g7_data_parallel_mean_semantics():
     a, b = grads_of(images[:2], labels[:2]), grads_of(images[2:], labels[2:])
     for n in full:
         assert rel_err((a[n] + b[n]) / 2, full[n]) < 1e-12, n
+
+
+def test_oracle_soft_cross_entropy_matches_torch():
+    """nn.CrossEntropyLoss with probability targets (what the reference's criterion computes under advanced_aug)."""
+    g = torch.Generator().manual_seed(0)
+    logits = torch.randn(9, 17, generator=g, dtype=torch.float64, requires_grad=True)
+    t = torch.softmax(torch.randn(9, 17, generator=g, dtype=torch.float64), -1)
+    ref = torch.nn.CrossEntropyLoss()(logits, t)
+    ref.backward()
+    loss, dl = O.cross_entropy_soft_fwd_bwd(logits.detach(), t)
+    assert torch.allclose(loss, ref.detach(), atol=1e-12) and torch.allclose(dl, logits.grad, atol=1e-12)
