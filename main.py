@@ -242,7 +242,8 @@ def main(params, args):
     torch.manual_seed(0)  # identical construction (weights, indices) on every rank; multi-GPU runs should still pass inds_path
     mp = copy.deepcopy(params["model_params"])
     mp["n_classes"] = run["n_classes"]
-    mp.setdefault("transformers_params", {})["img_size"] = [run["img"]]
+    # transformers_params.img_size stays what the YAML says (518 for dinov2 weights: their pos_embed has 37x37+1 entries);
+    # the engine interpolates it once to the training resolution (vit.py:421-437)
     pretrained = bool(mp.get("pretrained"))
     mp["pretrained"] = False  # no network here: weights come from --pretrained_path or stay at their initialisation
     model = Classifier(mp, params.get("system_params", {"which_GPUs": "0"}))
