@@ -207,6 +207,61 @@ extern "C" int apla_assemble_tokens(const void* patches, int ldp, const float* c
   return APLA_OK;
 }
 
+// ---- input side: uint8 images -> normalised fp32 batch, per-sample horizontal flip, Mixup / CutMix against a partner ----
+// dst[b,c,y,x] = norm(src[b,c,y,fx_b]) mixed with the partner sample p = perm[b] (its own flip flag applies to it):
+//   box == nullptr (Mixup):  lam_b * own + (1 - lam_b) * partner
+//   box != nullptr (CutMix): partner inside [y0,y1) x [x0,x1) of box[b], own elsewhere
+// One thread = four consecutive x of one (b, c, y) row; src is CHW (hwc = 0) or HWC (hwc = 1) uint8.
+__global__ __launch_bounds__(256) void augment_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst,
+                                                      float m0, float m1, float m2, float s0, float s1, float s2,
+                                                      const uint8_t* __restrict__ flip, const int32_t* __restrict__ perm,
+                                                      const float* __restrict__ lam, const int32_t* __restrict__ box,
+                                                      int B, int S, int hwc) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const int xq = S / 4;
+  if (t >= (long)B * 3 * S * xq) return;
+  const int x0 = (int)(t % xq) * 4;
+  const int y = (int)((t / xq) % S), c = (int)((t / ((long)xq * S)) % 3), b = (int)(t / ((long)xq * S * 3));
+  const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), inv = 1.0f / (255.0f * (c == 0 ? s0 : (c == 1 ? s1 : s2)));
+  const float mo = mean / (c == 0 ? s0 : (c == 1 ? s1 : s2));
+  auto px = [&](int bb, int x) {
+    const int fx = (flip != nullptr && flip[bb]) ? S - 1 - x : x;
+    const long idx = hwc ? (((long)bb * S + y) * S + fx) * 3 + c : (((long)bb * 3 + c) * S + y) * S + fx;
+    return (float)src[idx] * inv - mo;
+  };
+  const int pb = perm != nullptr ? perm[b] : b;
+  const float l = lam != nullptr ? lam[b] : 1.0f;
+  f32x4 out;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int x = x0 + e;
+    float v = px(b, x);
+    if (perm != nullptr) {
+      if (box != nullptr) {
+        const int* bx = box + 4 * b;
+        if (y >= bx[0] && y < bx[1] && x >= bx[2] && x < bx[3]) v = px(pb, x);
+      } else if (l != 1.0f) {
+        v = l * v + (1.0f - l) * px(pb, x);
+      }
+    }
+    out[e] = v;
+  }
+  *(f32x4*)(dst + (((long)b * 3 + c) * S + y) * S + x0) = out;
+}
+
+extern "C" int apla_augment_images(const uint8_t* src, float* dst, const float* mean3, const float* std3,
+                                   const uint8_t* flip, const int32_t* perm, const float* lam, const int32_t* box,
+                                   int B, int S, int hwc, hipStream_t stream) {
+  APLA_REQUIRE(src && dst && mean3 && std3 && B > 0 && S > 0 && S % 4 == 0, "apla_augment_images: bad arguments (S %% 4 == 0 required)");
+  APLA_REQUIRE(apla_aligned16(dst) && (box == nullptr || perm != nullptr) && (lam == nullptr || perm != nullptr),
+               "apla_augment_images: dst must be 16-byte aligned; lam / box need perm");
+  APLA_REQUIRE(std3[0] > 0.f && std3[1] > 0.f && std3[2] > 0.f, "apla_augment_images: std must be positive");
+  const long n = (long)B * 3 * S * (S / 4);
+  hipLaunchKernelGGL(augment_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, src, dst, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], flip, perm, lam, box, B, S, hwc);
+  APLA_CHECK_LAUNCH("apla_augment_images");
+  return APLA_OK;
+}
+
 extern "C" int apla_sgemm_small(const float* A, long sai, long sak, const float* Bm, long sbk, long sbj,
                                 const float* bias, float* C, long ldc, int M, int N, int K, int accumulate,
                                 hipStream_t stream) {

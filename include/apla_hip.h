@@ -192,6 +192,17 @@ int apla_patchify(const float* images, void* cols, int B, int S, int patch, int 
 int apla_assemble_tokens(const void* patches, int ldp, const float* cls_token, const float* pos_embed, void* tokens,
                          int res_dtype, int B, int Np, int D, hipStream_t stream);
 
+/* Input side of the step (bases.py:69-231 ToTensor + Normalize + horizontal flip, utils/_utils.py:424-441
+ * timm Mixup / CutMix applied by the collate function): decoded uint8 images already in device memory ->
+ * the normalised fp32 batch the patch embedding reads, in one pass.  src uint8 [B,3,S,S] (hwc = 0) or [B,S,S,3] (hwc = 1);
+ * dst fp32 [B,3,S,S]; mean3 / std3: HOST pointers to three floats in [0,1] units (ImageNet statistics in the reference);
+ * flip uint8 [B] or NULL; perm int32 [B] partner sample or NULL; lam fp32 [B] Mixup weight of the own image or NULL (= 1);
+ * box int32 [B,4] = {y0, y1, x0, x1} CutMix rectangle taken from the partner, or NULL (Mixup).  All but mean3/std3 are
+ * device pointers.  The label side of Mixup is apla_cross_entropy_soft's probability targets. */
+int apla_augment_images(const uint8_t* src, float* dst, const float* mean3, const float* std3, const uint8_t* flip,
+                        const int32_t* perm, const float* lam, const int32_t* box, int B, int S, int hwc,
+                        hipStream_t stream);
+
 /* Classifier head on the normalised CLS features (defaults/models.py:64-65,86-87) and mean cross-entropy
  * (defaults/wrappers.py:312-316), fp32 throughout.  The head is [B,D]x[D,C] (0.2 GFLOP): plain fp32 FMA kernels.
  *   apla_sgemm_small : C[i,j] (+)= sum_k A[i*sai + k*sak] * B[k*sbk + j*sbj] (+ bias[j])   (any strides: NT/NN/TN)

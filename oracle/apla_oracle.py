@@ -345,6 +345,26 @@ def embed_tokens(images: Tensor, p: Dict[str, Tensor], patch: int) -> Tensor:
     return x + interpolate_pos_encoding(p["pos_embed"], x.shape[1] - 1)
 
 
+def augment_images(src_u8: Tensor, mean, std, flip=None, perm=None, lam=None, box=None) -> Tensor:
+    """ToTensor + Normalize (+ horizontal flip) per sample (defaults/bases.py:69-231) and timm-style Mixup / CutMix against
+    the partner sample perm[b] (utils/_utils.py:424-441): src uint8 [B,3,S,S] -> float64 [B,3,S,S]."""
+    x = src_u8.double() / 255.0
+    x = (x - torch.tensor(mean, dtype=torch.float64).view(1, 3, 1, 1)) / torch.tensor(std, dtype=torch.float64).view(1, 3, 1, 1)
+    if flip is not None:
+        x = torch.where(flip.bool().view(-1, 1, 1, 1), x.flip(-1), x)
+    if perm is None:
+        return x
+    partner = x[perm.long()]
+    if box is not None:
+        out = x.clone()
+        for b in range(x.shape[0]):
+            y0, y1, x0, x1 = [int(v) for v in box[b]]
+            out[b, :, y0:y1, x0:x1] = partner[b, :, y0:y1, x0:x1]
+        return out
+    l = lam.double().view(-1, 1, 1, 1)
+    return l * x + (1 - l) * partner
+
+
 def cross_entropy_fwd_bwd(logits: Tensor, labels: Tensor):
     """nn.CrossEntropyLoss (mean reduction), defaults/wrappers.py:312-316.  Returns loss, dlogits."""
     m = logits.max(-1, keepdim=True).values
