@@ -207,6 +207,107 @@ extern "C" int apla_assemble_tokens(const void* patches, int ldp, const float* c
   return APLA_OK;
 }
 
+// ---- self-distillation losses (DINO CLS-token loss, iBOT patch loss): rows of K prototypes (65 536 in the shipped config) ----
+// softmax_center: out[r,:] = softmax((x[r,:] - center) * inv_temp)   (teacher centering + sharpening; fp32 out)
+// distill_ce    : loss_r = -w_r * sum_k t[r,k] * log_softmax(s[r,:] * inv_temp)[k],  ds[r,:] (+)= w_r * inv_temp * (softmax * sum_k t - t)
+// One workgroup per row, three passes over the row (max, sum / target sums, write); the row stays in L2.
+template <typename T> __device__ __forceinline__ float ldf(const T* p, long i) { return (float)p[i]; }
+
+template <typename XT>
+__global__ __launch_bounds__(256) void softmax_center_kernel(const XT* __restrict__ x, long ldx, const float* __restrict__ center,
+                                                             float inv_temp, float* __restrict__ out, long ldo, int K) {
+  __shared__ float red[4];
+  __shared__ float bc;
+  const XT* xr = x + (long)blockIdx.x * ldx;
+  float* orow = out + (long)blockIdx.x * ldo;
+  float mx = -INFINITY;
+  for (int k = threadIdx.x; k < K; k += 256) mx = fmaxf(mx, (ldf(xr, k) - center[k]) * inv_temp);
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) bc = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  mx = bc;
+  float sm = 0.f;
+  for (int k = threadIdx.x; k < K; k += 256) sm += __expf((ldf(xr, k) - center[k]) * inv_temp - mx);
+  sm = wave_sum(sm);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sm;
+  __syncthreads();
+  const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
+  for (int k = threadIdx.x; k < K; k += 256) orow[k] = __expf((ldf(xr, k) - center[k]) * inv_temp - mx) * inv;
+}
+
+template <typename ST>
+__global__ __launch_bounds__(256) void distill_ce_kernel(const ST* __restrict__ s, long lds, const float* __restrict__ t, long ldt,
+                                                         float inv_temp, const float* __restrict__ row_weight, float weight,
+                                                         float* __restrict__ ds, long ldds, int accumulate,
+                                                         float* __restrict__ row_loss, int K) {
+  __shared__ float red[4];
+  __shared__ float bc;
+  const int r = blockIdx.x;
+  const ST* sr = s + (long)r * lds;
+  const float* tr = t + (long)r * ldt;
+  const float w = row_weight != nullptr ? row_weight[r] * weight : weight;
+  float mx = -INFINITY;
+  for (int k = threadIdx.x; k < K; k += 256) mx = fmaxf(mx, ldf(sr, k) * inv_temp);
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) bc = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  mx = bc;
+  float sm = 0.f, dot = 0.f, tsum = 0.f;
+  for (int k = threadIdx.x; k < K; k += 256) {
+    const float z = ldf(sr, k) * inv_temp, tv = tr[k];
+    sm += __expf(z - mx);
+    dot += tv * z;
+    tsum += tv;
+  }
+  float vals[3] = {sm, dot, tsum};
+  float tot[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const float v = wave_sum(vals[q]);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    tot[q] = red[0] + red[1] + red[2] + red[3];
+  }
+  const float lse = mx + __logf(tot[0]);
+  if (threadIdx.x == 0) row_loss[r] = w * (tot[2] * lse - tot[1]);
+  if (ds != nullptr) {
+    float* dr = ds + (long)r * ldds;
+    const float c = w * inv_temp;
+    for (int k = threadIdx.x; k < K; k += 256) {
+      const float g = c * (__expf(ldf(sr, k) * inv_temp - lse) * tot[2] - tr[k]);
+      dr[k] = accumulate ? dr[k] + g : g;
+    }
+  }
+}
+
+extern "C" int apla_softmax_center(const void* x, int x_dtype, long ldx, const float* center, float inv_temp, float* out,
+                                   long ldo, int R, int K, hipStream_t stream) {
+  APLA_REQUIRE(x && center && out && R > 0 && K > 0 && ldx >= K && ldo >= K && inv_temp > 0.f, "apla_softmax_center: bad arguments");
+  if (x_dtype == APLA_F32) hipLaunchKernelGGL(softmax_center_kernel<float>, dim3(R), dim3(256), 0, stream, (const float*)x, ldx, center, inv_temp, out, ldo, K);
+  else if (x_dtype == APLA_H16) hipLaunchKernelGGL(softmax_center_kernel<bf16>, dim3(R), dim3(256), 0, stream, (const bf16*)x, ldx, center, inv_temp, out, ldo, K);
+  else { apla_set_error("apla_softmax_center: unsupported dtype %d", x_dtype); return APLA_ENOSYS; }
+  APLA_CHECK_LAUNCH("apla_softmax_center");
+  return APLA_OK;
+}
+
+extern "C" int apla_distill_ce(const void* student, int s_dtype, long lds, const float* teacher_probs, long ldt, float inv_temp,
+                               const float* row_weight, float weight, float* dstudent, long ldds, int accumulate,
+                               float* row_loss, int R, int K, hipStream_t stream) {
+  APLA_REQUIRE(student && teacher_probs && row_loss && R > 0 && K > 0 && lds >= K && ldt >= K && inv_temp > 0.f &&
+               (dstudent == nullptr || ldds >= K), "apla_distill_ce: bad arguments");
+  if (s_dtype == APLA_F32) hipLaunchKernelGGL(distill_ce_kernel<float>, dim3(R), dim3(256), 0, stream, (const float*)student, lds, teacher_probs, ldt, inv_temp, row_weight, weight, dstudent, ldds, accumulate, row_loss, K);
+  else if (s_dtype == APLA_H16) hipLaunchKernelGGL(distill_ce_kernel<bf16>, dim3(R), dim3(256), 0, stream, (const bf16*)student, lds, teacher_probs, ldt, inv_temp, row_weight, weight, dstudent, ldds, accumulate, row_loss, K);
+  else { apla_set_error("apla_distill_ce: unsupported dtype %d", s_dtype); return APLA_ENOSYS; }
+  APLA_CHECK_LAUNCH("apla_distill_ce");
+  return APLA_OK;
+}
+
 // ---- input side: uint8 images -> normalised fp32 batch, per-sample horizontal flip, Mixup / CutMix against a partner ----
 // dst[b,c,y,x] = norm(src[b,c,y,fx_b]) mixed with the partner sample p = perm[b] (its own flip flag applies to it):
 //   box == nullptr (Mixup):  lam_b * own + (1 - lam_b) * partner

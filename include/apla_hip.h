@@ -192,6 +192,21 @@ int apla_patchify(const float* images, void* cols, int B, int S, int patch, int 
 int apla_assemble_tokens(const void* patches, int ldp, const float* cls_token, const float* pos_embed, void* tokens,
                          int res_dtype, int B, int Np, int D, hipStream_t stream);
 
+/* Self-distillation losses of the DINOv2-APLA step (dinov2/loss/dino_clstoken_loss.py,
+ * dinov2/loss/ibot_patch_loss.py) over rows of K prototype logits (K = 65 536 in the shipped config):
+ *   apla_softmax_center : out[r,:] = softmax((x[r,:] - center[:]) * inv_temp)    teacher centering + sharpening
+ *                         (DINOLoss.softmax_center_teacher, dino_clstoken_loss.py:29-32; x fp32 or 16-bit, out fp32)
+ *   apla_distill_ce     : row_loss[r] = -w_r * sum_k t[r,k] * log_softmax(s[r,:] * inv_temp)[k] with w_r = weight *
+ *                         (row_weight ? row_weight[r] : 1); dstudent[r,:] (+)= w_r * inv_temp * (softmax * sum_k t[r,k] - t[r,:])
+ *                         (the double loop of DINOLoss.forward, :65-77, is a sum over targets: pass t = sum of the teacher
+ *                         views; iBOTPatchLoss.forward_masked, ibot_patch_loss.py:103-121, is the row_weight form).
+ *                         dstudent may be NULL (loss only); accumulate != 0 adds into it.  student fp32 or 16-bit. */
+int apla_softmax_center(const void* x, int x_dtype, long ldx, const float* center, float inv_temp, float* out, long ldo,
+                        int R, int K, hipStream_t stream);
+int apla_distill_ce(const void* student, int s_dtype, long lds, const float* teacher_probs, long ldt, float inv_temp,
+                    const float* row_weight, float weight, float* dstudent, long ldds, int accumulate, float* row_loss,
+                    int R, int K, hipStream_t stream);
+
 /* Input side of the step (bases.py:69-231 ToTensor + Normalize + horizontal flip, utils/_utils.py:424-441
  * timm Mixup / CutMix applied by the collate function): decoded uint8 images already in device memory ->
  * the normalised fp32 batch the patch embedding reads, in one pass.  src uint8 [B,3,S,S] (hwc = 0) or [B,S,S,3] (hwc = 1);

@@ -345,6 +345,27 @@ def embed_tokens(images: Tensor, p: Dict[str, Tensor], patch: int) -> Tensor:
     return x + interpolate_pos_encoding(p["pos_embed"], x.shape[1] - 1)
 
 
+def softmax_center(x: Tensor, center: Tensor, temp: float) -> Tensor:
+    """Teacher centering + sharpening, dinov2/loss/dino_clstoken_loss.py:29-32 (and ibot_patch_loss.py:39-52)."""
+    return torch.softmax((x - center) / temp, dim=-1)
+
+
+def distill_ce(student: Tensor, teacher_probs: Tensor, temp: float, row_weight=None):
+    """Per-row cross-entropy between a teacher distribution and the student's log-softmax at temperature `temp` — the summand of
+    DINOLoss.forward (dino_clstoken_loss.py:65-77) and iBOTPatchLoss.forward_masked (ibot_patch_loss.py:103-121).
+    Returns (sum_r w_r * ce_r, d/d student)."""
+    logp = torch.log_softmax(student / temp, -1)
+    ce = -(teacher_probs * logp).sum(-1)
+    w = torch.ones_like(ce) if row_weight is None else row_weight
+    grad = (torch.exp(logp) * teacher_probs.sum(-1, keepdim=True) - teacher_probs) * (w / temp).unsqueeze(-1)
+    return (w * ce).sum(), grad
+
+
+def center_ema(center: Tensor, teacher_output: Tensor, momentum: float) -> Tensor:
+    """DINOLoss.apply_center_update for one process (dino_clstoken_loss.py:85-98): EMA of the teacher's batch mean."""
+    return center * momentum + teacher_output.mean(0, keepdim=True) * (1 - momentum)
+
+
 def augment_images(src_u8: Tensor, mean, std, flip=None, perm=None, lam=None, box=None) -> Tensor:
     """ToTensor + Normalize (+ horizontal flip) per sample (defaults/bases.py:69-231) and timm-style Mixup / CutMix against
     the partner sample perm[b] (utils/_utils.py:424-441): src uint8 [B,3,S,S] -> float64 [B,3,S,S]."""

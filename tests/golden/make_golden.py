@@ -232,6 +232,62 @@ def g9_lr_schedule():
     print("g9_lr_schedule.json", {k: len(v["lr"]) for k, v in out.items()})
 
 
+def g10_ssl_losses():
+    """DINO CLS-token loss and iBOT patch loss of the reference (self_supervised/dinov2/loss/*.py, pure torch: loaded from
+    the files in place), run for two iterations so the centre EMA is exercised: inputs, teacher distributions, losses,
+    gradients wrt the student logits, centres."""
+    import importlib.util
+    def load(name):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(REF_SRC, "self_supervised", "dinov2", "loss", name + ".py"))
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        return m
+    DINOLoss, iBOT = load("dino_clstoken_loss").DINOLoss, load("ibot_patch_loss").iBOTPatchLoss
+    g = torch.Generator().manual_seed(11)
+    K, n, n_local = 512, 6, 3
+    arrs = {"meta": np.array([K, n, n_local])}
+    dino = DINOLoss(K, student_temp=0.1, center_momentum=0.9)
+    for it in range(2):
+        teacher = torch.randn(2 * n, K, generator=g) * 2
+        tprobs = dino.softmax_center_teacher(teacher, teacher_temp=0.05).view(2, n, K)
+        dino.update_center(teacher)
+        s_glob = (torch.randn(2 * n, K, generator=g)).requires_grad_(True)
+        s_loc = (torch.randn(n_local * n, K, generator=g)).requires_grad_(True)
+        loss_g = dino(student_output_list=[s_glob], teacher_out_softmaxed_centered_list=[tprobs.flatten(0, 1)])
+        loss_l = dino(student_output_list=s_loc.chunk(n_local), teacher_out_softmaxed_centered_list=tprobs)
+        (loss_g + loss_l).backward()
+        arrs.update({f"dino{it}.teacher": npy(teacher), f"dino{it}.tprobs": npy(tprobs), f"dino{it}.s_glob": npy(s_glob),
+                     f"dino{it}.s_loc": npy(s_loc), f"dino{it}.loss_g": npy(loss_g), f"dino{it}.loss_l": npy(loss_l),
+                     f"dino{it}.ds_glob": npy(s_glob.grad), f"dino{it}.ds_loc": npy(s_loc.grad)})
+    dino.apply_center_update()
+    arrs["dino.center"] = npy(dino.center)
+    ibot = iBOT(K, student_temp=0.1, center_momentum=0.9)
+    B, N = 4, 9
+    for it in range(2):
+        masks = torch.rand(B, N, generator=g) < 0.4
+        masks[0, 0] = True
+        n_masked = int(masks.sum())
+        t_tok = torch.randn(n_masked, K, generator=g) * 2
+        tprobs = ibot.softmax_center_teacher(t_tok.unsqueeze(0), teacher_temp=0.05).squeeze(0)
+        ibot.update_center(t_tok.unsqueeze(0))
+        s_tok = torch.randn(n_masked + 3, K, generator=g).requires_grad_(True)   # padded buffer as in models.py ("upperbound")
+        t_pad = torch.cat([tprobs, torch.zeros(3, K)])
+        mw = (1 / masks.sum(-1).clamp(min=1.0)).unsqueeze(-1).expand_as(masks)[masks]
+        loss = ibot.forward_masked(s_tok, t_pad, student_masks_flat=masks, n_masked_patches=n_masked, masks_weight=mw)
+        loss.backward()
+        arrs.update({f"ibot{it}.masks": npy(masks), f"ibot{it}.t_tok": npy(t_tok), f"ibot{it}.tprobs": npy(tprobs),
+                     f"ibot{it}.s_tok": npy(s_tok), f"ibot{it}.loss": npy(loss), f"ibot{it}.ds": npy(s_tok.grad)})
+    # dense form: (B, N, K) tokens with a mask
+    s3, t3 = torch.randn(B, N, K, generator=g).requires_grad_(True), torch.softmax(torch.randn(B, N, K, generator=g), -1)
+    m3 = torch.rand(B, N, generator=g) < 0.5
+    l3 = ibot(s3, t3, m3)
+    l3.backward()
+    arrs.update({"ibotd.s": npy(s3), "ibotd.t": npy(t3), "ibotd.m": npy(m3), "ibotd.loss": npy(l3), "ibotd.ds": npy(s3.grad)})
+    ibot.apply_center_update()
+    arrs["ibot.center"] = npy(ibot.center)
+    save("g10_ssl_losses.npz", **arrs)
+
+
 def classifier_step(model, fc, images, labels, lr=1e-4, wd=1e-5, clip=1.0):
     """defaults/trainer.py:106-151 (no AMP) with the param groups of defaults/wrappers.py:205-221."""
     named = [(n, p_) for n, p_ in list(model.named_parameters()) + [("fc." + n, p_) for n, p_ in fc.named_parameters()]
@@ -331,3 +387,4 @@ if __name__ == "__main__":
     g5_tiny()
     g5_cfg1()
     g9_lr_schedule()
+    g10_ssl_losses()

@@ -151,3 +151,30 @@ def test_oracle_soft_cross_entropy_matches_torch():
     ref.backward()
     loss, dl = O.cross_entropy_soft_fwd_bwd(logits.detach(), t)
     assert torch.allclose(loss, ref.detach(), atol=1e-12) and torch.allclose(dl, logits.grad, atol=1e-12)
+
+
+def test_g10_ssl_losses_oracle():
+    """G10: DINO / iBOT losses of the reference classes (two iterations, centre EMA) reproduced by the oracle's restatement."""
+    g = load_golden("g10_ssl_losses.npz")
+    K, n, n_local = [int(v) for v in g["meta"]]
+    center = torch.zeros(1, K, dtype=torch.float64)
+    for it in range(2):
+        teacher = t(g[f"dino{it}.teacher"], torch.float64)
+        tp = O.softmax_center(teacher, center, 0.05)
+        assert rel_err(tp, g[f"dino{it}.tprobs"].reshape(2 * n, K)) < 2e-6
+        center = O.center_ema(center, teacher, 0.9)          # applied lazily by the reference at the next call
+        tp2 = tp.view(2, n, K)
+        s_glob, s_loc = t(g[f"dino{it}.s_glob"], torch.float64), t(g[f"dino{it}.s_loc"], torch.float64)
+        lg, dg = O.distill_ce(s_glob, tp, 0.1, torch.full((2 * n,), 1.0 / (2 * n), dtype=torch.float64))
+        assert abs(float(lg) - float(g[f"dino{it}.loss_g"])) < 2e-6 * abs(float(lg)) and rel_err(dg, g[f"dino{it}.ds_glob"]) < 2e-6
+        tsum = tp2[0] + tp2[1]
+        ll, dl = 0.0, []
+        for chunk in s_loc.chunk(n_local):
+            l, d = O.distill_ce(chunk, tsum, 0.1, torch.full((n,), 1.0 / n, dtype=torch.float64))
+            ll, dl = ll + l, dl + [d]
+        assert abs(float(ll) - float(g[f"dino{it}.loss_l"])) < 2e-6 * abs(float(ll)) and rel_err(torch.cat(dl), g[f"dino{it}.ds_loc"]) < 2e-6
+    assert rel_err(center, g["dino.center"]) < 2e-6
+    s3, t3, m3 = t(g["ibotd.s"], torch.float64), t(g["ibotd.t"], torch.float64), t(g["ibotd.m"]).bool()
+    w = m3.double() / m3.double().sum(-1, keepdim=True).clamp(min=1.0) / m3.shape[0]
+    l3, d3 = O.distill_ce(s3.reshape(-1, K), t3.reshape(-1, K), 0.1, w.reshape(-1))
+    assert abs(float(l3) - float(g["ibotd.loss"])) < 2e-6 * abs(float(l3)) and rel_err(d3.reshape(s3.shape), g["ibotd.ds"]) < 2e-6
