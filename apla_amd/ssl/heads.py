@@ -1,0 +1,105 @@
+"""DINO projection head, KoLeo regulariser and the EMA teacher update of the DINOv2-APLA step.
+
+* ``DINOHead`` — self_supervised/dinov2/layers/dino_head.py:12-40: 3-layer MLP (GELU), L2-normalised bottleneck,
+  weight-normalised prototype layer with the norm frozen at 1.  Same parameter names (``mlp.{0,2,4}.{weight,bias}``,
+  ``last_layer.weight_g / weight_v``).  The products run on the HIP GEMM (`apla_gemm_nt`); the weight gradients of the
+  three MLP layers on the TN MFMA kernel (`apla_proj_dw`), and the [K, 256] prototype gradient — a plain GEMM with the few
+  hundred token rows as its reduction axis — on the vendor library (fp32), as plain library GEMMs may.
+* ``KoLeoLoss`` — dinov2/loss/koleo_loss.py:17-45 (a [B, B] nearest-neighbour search on the CLS tokens: torch ops, fp32).
+* ``update_teacher`` — dinov2/models.py:443-453: teacher = m * teacher + (1 - m) * student over the trainable tensors.
+"""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .. import functional as AF
+from .. import ops
+
+
+class _ProtoLinear(torch.autograd.Function):
+    """y = x @ W^T for the [K, 256] prototype matrix: forward and dX on the MFMA GEMM, dW = dy^T x on the vendor GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, W):
+        x2 = AF._as2d_bf16(x)
+        Wh = W.detach().to(ops.half()).contiguous()
+        y = ops.gemm_nt(x2, Wh)
+        ctx.save_for_backward(x2, Wh)
+        ctx.shape = x.shape
+        return y.reshape(*x.shape[:-1], W.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, Wh = ctx.saved_tensors
+        dy2 = AF._as2d_bf16(dy)
+        dx = ops.gemm_nt(dy2, Wh.t().contiguous()).reshape(ctx.shape) if ctx.needs_input_grad[0] else None
+        dW = torch.mm(dy2.float().t(), x2.float()) if ctx.needs_input_grad[1] else None
+        return dx, dW
+
+
+class DINOHead(nn.Module):
+    def __init__(self, in_dim, out_dim, use_bn=False, nlayers=3, hidden_dim=2048, bottleneck_dim=256, mlp_bias=True):
+        super().__init__()
+        if use_bn:
+            raise NotImplementedError("use_bn is false in the shipped configs")
+        nlayers = max(nlayers, 1)
+        if nlayers == 1:
+            self.mlp = nn.Linear(in_dim, bottleneck_dim, bias=mlp_bias)
+        else:
+            layers = [nn.Linear(in_dim, hidden_dim, bias=mlp_bias), nn.GELU()]
+            for _ in range(nlayers - 2):
+                layers += [nn.Linear(hidden_dim, hidden_dim, bias=mlp_bias), nn.GELU()]
+            layers.append(nn.Linear(hidden_dim, bottleneck_dim, bias=mlp_bias))
+            self.mlp = nn.Sequential(*layers)
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.trunc_normal_(m.weight, std=0.02)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+        self.last_layer = nn.utils.weight_norm(nn.Linear(bottleneck_dim, out_dim, bias=False))
+        self.last_layer.weight_g.data.fill_(1)
+
+    def forward(self, x):
+        mods = [self.mlp] if isinstance(self.mlp, nn.Linear) else list(self.mlp)
+        for m in mods:
+            x = AF.linear(x, m.weight, m.bias) if isinstance(m, nn.Linear) else F.gelu(x.float()).to(x.dtype)
+        x = F.normalize(x.float(), dim=-1, p=2, eps=1e-12)
+        v, g = self.last_layer.weight_v, self.last_layer.weight_g
+        W = v * (g / v.norm(dim=1, keepdim=True))           # torch.nn.utils.weight_norm, dim=0
+        return _ProtoLinear.apply(x, W)
+
+
+class KoLeoLoss(nn.Module):
+    """Kozachenko-Leonenko entropic regulariser (Sablayrolles et al. 2018), koleo_loss.py:17-45."""
+
+    def __init__(self):
+        super().__init__()
+        self.pdist = nn.PairwiseDistance(2, eps=1e-8)
+
+    def pairwise_NNs_inner(self, x):
+        dots = torch.mm(x, x.t())
+        n = x.shape[0]
+        dots.view(-1)[:: (n + 1)].fill_(-1)
+        return torch.max(dots, dim=1)[1]
+
+    def forward(self, student_output, eps=1e-8):
+        x = F.normalize(student_output.float(), eps=eps, p=2, dim=-1)
+        with torch.no_grad():
+            idx = self.pairwise_NNs_inner(x.detach().clone())
+        return -torch.log(self.pdist(x, x[idx]) + eps).mean()
+
+
+@torch.no_grad()
+def update_teacher(student: nn.Module, teacher: nn.Module, m: float):
+    """EMA of the student's TRAINABLE tensors into the teacher (dinov2/models.py:443-453 walks the same-named parameter
+    lists and uses torch._foreach_mul_/_foreach_add_); frozen tensors are identical in both and stay untouched."""
+    sp = dict(student.named_parameters())
+    t_list, s_list = [], []
+    for name, tp in teacher.named_parameters():
+        if name in sp and sp[name].requires_grad:
+            t_list.append(tp)
+            s_list.append(sp[name].detach())
+    if t_list:
+        torch._foreach_mul_(t_list, m)
+        torch._foreach_add_(t_list, s_list, alpha=1 - m)
+    return len(t_list)

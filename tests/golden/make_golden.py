@@ -288,6 +288,39 @@ def g10_ssl_losses():
     save("g10_ssl_losses.npz", **arrs)
 
 
+def g11_ssl_head_koleo():
+    """DINOHead (dinov2/layers/dino_head.py) and KoLeoLoss (dinov2/loss/koleo_loss.py) of the reference, loaded from the files
+    in place: parameters, inputs, outputs and gradients."""
+    import importlib.util
+    def load(sub, name):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(REF_SRC, "self_supervised", "dinov2", sub, name + ".py"))
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        return m
+    DINOHead = load("layers", "dino_head").DINOHead
+    KoLeo = load("loss", "koleo_loss").KoLeoLoss
+    torch.manual_seed(21)
+    head = DINOHead(in_dim=128, out_dim=512, hidden_dim=256, bottleneck_dim=128)
+    with torch.no_grad():
+        for p_ in head.mlp.parameters():
+            p_.add_(torch.randn_like(p_) * 0.05)     # biases are zero-initialised: make them count
+    g = torch.Generator().manual_seed(22)
+    x = torch.randn(37, 128, generator=g).requires_grad_(True)
+    w = torch.randn(37, 512, generator=g)
+    out = head(x)
+    (out * w).sum().backward()
+    arrs = {"head.x": npy(x), "head.w": npy(w), "head.out": npy(out), "head.dx": npy(x.grad)}
+    for k, v in head.state_dict().items():
+        arrs["head.p." + k] = npy(v)
+    for k, v in head.named_parameters():
+        arrs["head.g." + k] = npy(v.grad)
+    xk = torch.randn(16, 64, generator=g).requires_grad_(True)
+    lk = KoLeo()(xk)
+    lk.backward()
+    arrs.update({"koleo.x": npy(xk), "koleo.loss": npy(lk), "koleo.dx": npy(xk.grad)})
+    save("g11_ssl_head_koleo.npz", **arrs)
+
+
 def classifier_step(model, fc, images, labels, lr=1e-4, wd=1e-5, clip=1.0):
     """defaults/trainer.py:106-151 (no AMP) with the param groups of defaults/wrappers.py:205-221."""
     named = [(n, p_) for n, p_ in list(model.named_parameters()) + [("fc." + n, p_) for n, p_ in fc.named_parameters()]
@@ -388,3 +421,4 @@ if __name__ == "__main__":
     g5_cfg1()
     g9_lr_schedule()
     g10_ssl_losses()
+    g11_ssl_head_koleo()

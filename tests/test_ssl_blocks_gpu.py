@@ -1,0 +1,100 @@
+"""Building blocks of the DINOv2-APLA step on the GPU: DINOHead and KoLeoLoss against goldens produced by the
+REFERENCE modules (G11); the packed multi-crop backbone forward against one dense pass per resolution; the EMA teacher
+update.  bf16 GEMM tolerances as in tests/test_modules_gpu.py."""
+import copy
+
+import pytest
+import torch
+
+from conftest import load_golden, rel_err, t
+
+pytestmark = pytest.mark.gpu
+
+
+def test_dino_head_matches_reference():
+    from apla_amd.ssl import DINOHead
+    g = load_golden("g11_ssl_head_koleo.npz")
+    head = DINOHead(in_dim=128, out_dim=512, hidden_dim=256, bottleneck_dim=128)
+    sd = {k[len("head.p."):]: t(g[k]) for k in g.files if k.startswith("head.p.")}
+    assert set(sd) == set(head.state_dict())                    # same parameter names as the reference module
+    head.load_state_dict(sd)
+    head = head.cuda()
+    x = t(g["head.x"]).cuda().requires_grad_(True)
+    out = head(x)
+    assert rel_err(out.float().cpu(), g["head.out"]) < 1e-2
+    (out.float() * t(g["head.w"]).cuda()).sum().backward()
+    assert rel_err(x.grad.cpu(), g["head.dx"]) < 2e-2
+    for name, p in head.named_parameters():
+        assert rel_err(p.grad.cpu(), g["head.g." + name]) < 2e-2, name
+
+
+def test_koleo_matches_reference():
+    from apla_amd.ssl import KoLeoLoss
+    g = load_golden("g11_ssl_head_koleo.npz")
+    x = t(g["koleo.x"]).cuda().requires_grad_(True)
+    loss = KoLeoLoss()(x)
+    loss.backward()
+    assert abs(float(loss) - float(g["koleo.loss"])) < 1e-5 and rel_err(x.grad.cpu(), g["koleo.dx"]) < 1e-4
+
+
+def _student(seed=0):
+    from functools import partial
+    from apla_amd.apla import build_apla
+    from apla_amd.models import AttrDict
+    from apla_amd.ssl import DinoVisionTransformer
+    torch.manual_seed(seed)
+    bb = DinoVisionTransformer(img_size=[64], patch_size=16, embed_dim=128, depth=2, num_heads=2, qkv_bias=True,
+                               norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), block_conf=dict(has_layerscale=True, layerscale_init_values=1.0))
+    with torch.no_grad():
+        bb.mask_token.normal_(std=0.5)
+        for n, p in bb.named_parameters():
+            if p.ndim >= 2 and "pos_embed" not in n and "token" not in n:
+                p.normal_(std=0.06)
+    build_apla(AttrDict(partial_size=64), bb, "apla_attn_mem_eff")
+    return bb.cuda()
+
+
+def test_packed_multicrop_forward_equals_one_pass_per_resolution():
+    """forward_features_list([global crops, local crops], [masks, None]) packs 2x17 + 4x5 token sequences into one block-
+    diagonal pass per block; it must agree with running each resolution alone through the same modules (dense attention),
+    forward and backward (dinov2_vits.py:249-267, block.py:254-288)."""
+    bb = _student()
+    g = torch.Generator().manual_seed(1)
+    glob, loc = torch.randn(2, 3, 64, 64, generator=g).cuda(), torch.randn(4, 3, 32, 32, generator=g).cuda()
+    masks = (torch.rand(2, 16, generator=g) < 0.4).cuda()
+    outs = bb.forward_features_list([glob, loc], [masks, None])
+    assert outs[0]["x_norm_clstoken"].shape == (2, 128) and outs[0]["x_norm_patchtokens"].shape == (2, 16, 128)
+    assert outs[1]["x_norm_clstoken"].shape == (4, 128) and outs[1]["x_norm_patchtokens"].shape == (4, 4, 128)
+    loss = sum(o["x_norm_clstoken"].float().square().mean() + o["x_norm_patchtokens"].float().square().mean() for o in outs)
+    loss.backward()
+    packed_grads = {n: p.grad.clone() for n, p in bb.named_parameters() if p.grad is not None}
+    bb.zero_grad()
+    dense = [bb.forward_features_dict(glob, masks), bb.forward_features_dict(loc, None)]
+    for a, b in zip(outs, dense):
+        for key in ("x_norm_clstoken", "x_norm_patchtokens"):
+            assert rel_err(a[key].detach().float().cpu(), b[key].detach().double().cpu()) < 3e-3, key
+    loss2 = sum(o["x_norm_clstoken"].float().square().mean() + o["x_norm_patchtokens"].float().square().mean() for o in dense)
+    loss2.backward()
+    for n, p in bb.named_parameters():
+        if p.grad is not None:
+            assert rel_err(packed_grads[n].float().cpu(), p.grad.double().cpu()) < 2e-2, n
+    assert not bb.mask_token.requires_grad     # build_apla freezes everything but the selected projection rows (apla_vit.py:51-59)
+
+
+def test_update_teacher_ema_touches_only_trainable_tensors():
+    from apla_amd.ssl import update_teacher
+    student = _student(seed=0)
+    teacher = copy.deepcopy(student)
+    with torch.no_grad():
+        for p in student.parameters():
+            if p.requires_grad:
+                p.add_(1.0)
+    before = {n: p.detach().clone() for n, p in teacher.named_parameters()}
+    n = update_teacher(student, teacher, 0.9)
+    sp = dict(student.named_parameters())
+    assert n == sum(p.requires_grad for p in student.parameters()) and n > 0
+    for name, p in teacher.named_parameters():
+        if sp[name].requires_grad:
+            assert torch.allclose(p, before[name] * 0.9 + sp[name] * 0.1)
+        else:
+            assert torch.equal(p, before[name])
