@@ -22,7 +22,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # algorithmic work per image for the configs of BASELINE.md §3 (forward + APLA backward, GFLOP)
-STEP_GF_PER_IMG = {"vit_small": 18.76, "vit_base": 70.99}
+STEP_GF_PER_IMG = {("vit_small", 224, 16): 18.76, ("vit_base", 224, 16): 70.99, ("vit_base", 224, 14): 94.14,
+                   ("vit_large", 224, 14): 330.78, ("vit_giant", 518, 14): 7629.5}
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_dominant_kernel.json")  # written by tools/measure_round.sh (separate --pmc passes)
 
@@ -111,6 +112,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--backbone", default="vit_base")
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch")
+    ap.add_argument("--img", type=int, default=224, help="side measurements at the other BASELINE geometries (cfg 3: "
+                    "--backbone vit_large --patch 14 --batch 256 --partial-size 256; cfg 5: --backbone vit_giant --img 518 "
+                    "--patch 14 --batch 32 --partial-size 512 --dtype fp16); the default run is config 2")
+    ap.add_argument("--patch", type=int, default=16)
     ap.add_argument("--partial-size", type=int, default=192)
     ap.add_argument("--classes", type=int, default=1000)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"],
@@ -140,7 +145,7 @@ def main():
         pg = dist.group.WORLD
 
     from apla_amd.engine import AplaTrainEngine, OptimConfig
-    img, patch = 224, 16
+    img, patch = args.img, args.patch
     dt = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}
     hdt = dt[args.dtype]
     loss_scale = args.loss_scale if args.loss_scale is not None else (1024.0 if args.dtype == "fp16" else 1.0)
@@ -184,15 +189,17 @@ def main():
         from apla_amd import ops as _ops
         with _ops.use_half(hdt):
             k_ms, k_tf = time_dominant_kernel(M, bb.embed_dim, eng.blocks[0].F, hdt)
-        gf = STEP_GF_PER_IMG.get(args.backbone)
+        is_cfg2 = (args.backbone, img, patch, args.batch, args.partial_size) == ("vit_base", 224, 16, 128, 192)
+        gf = STEP_GF_PER_IMG.get((args.backbone, img, patch))
         step_tf = img_s / world * gf / 1e3 if gf else None
         out = {
-            "metric": "images/sec, ViT-B/16 APLA training step bs=128/GPU (whole job)", "value": round(img_s, 1),
+            "metric": "images/sec, ViT-B/16 APLA training step bs=128/GPU (whole job)" if is_cfg2 else
+                      f"images/sec, {args.backbone}/{patch} APLA training step bs={args.batch}/GPU (whole job; side measurement)", "value": round(img_s, 1),
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"{args.backbone}/16 dinov2-shaped APLA partial_size={args.partial_size} full training "
-                                   f"step (fwd+CE+bwd+allreduce+clip+AdamW), 224x224, C={args.classes}, "
+            "config": {"workload": f"{args.backbone}/{patch} dinov2-shaped APLA partial_size={args.partial_size} full training "
+                                   f"step (fwd+CE+bwd+allreduce+clip+AdamW), {img}x{img}, C={args.classes}, "
                                    f"bs={args.batch}/GPU, residual {args.res_dtype}, grad stream {args.grad_dtype if args.grad_dtype == 'fp32' else args.dtype}"
                                    + (f", loss scale {loss_scale:g}" if loss_scale != 1.0 else ""),
                        "global_batch": world * args.batch, "parallelism": f"dp{world}",
@@ -201,7 +208,7 @@ def main():
             "final_loss": round(loss, 4),
             "roofline": {"bound": "mfma", "kernel": f"gemm_pp2_kernel<GELU> (apla_gemm_nt, fc1+GELU launch) M={M} N={eng.blocks[0].F} K={bb.embed_dim}",
                          "achieved": round(k_tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(k_tf / PEAK_BF16_TFLOPS, 4), "traffic": dominant_kernel_traffic(),
+                         "frac": round(k_tf / PEAK_BF16_TFLOPS, 4), "traffic": dominant_kernel_traffic() if is_cfg2 else None,
                          "algorithmic_bytes": 2.0 * (M * bb.embed_dim + eng.blocks[0].F * bb.embed_dim + 2 * M * eng.blocks[0].F),
                          "kernel_ms": round(k_ms, 4),
                          "step_achieved": round(step_tf, 1) if step_tf else None,
