@@ -47,6 +47,9 @@ SIGNATURES = {
                                             c_int, c_void_p]),
     "apla_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_float, c_float, c_float,
                                 c_float, c_float, c_int, c_float, c_float, c_void_p, c_void_p]),
+    "apla_grad_sumsq": (c_int, [c_void_p, c_long, c_float, c_void_p, c_void_p]),
+    "apla_adamw_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_float, c_float, c_float,
+                                 c_float, c_float, c_int, c_float, c_float, c_void_p, c_void_p]),
     "apla_adamw_step_dynamic": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_float, c_float, c_float,
                                         c_float, c_float, c_float, c_float, c_void_p, c_int, c_float, c_float, c_int,
                                         c_void_p, c_void_p]),

@@ -143,6 +143,30 @@ extern "C" int apla_adamw_step_dynamic(float* params, float* grads, float* exp_a
   return APLA_OK;
 }
 
+// The two phases of apla_adamw_step as separate entry points: one global norm over the whole trainable buffer, then the
+// update applied per contiguous range with its own step count (torch.optim.AdamW keeps `step` per tensor and skips tensors
+// whose .grad is None — the DINOv2 trainer cancels the prototype layer's gradients during the first epoch AFTER clipping,
+// self_supervised/dinov2/trainer.py:84-90,127-130).
+extern "C" int apla_grad_sumsq(const float* grads, long n, float grad_scale, float* norm_ws, hipStream_t stream) {
+  APLA_REQUIRE(grads && norm_ws && n > 0, "apla_grad_sumsq: bad arguments");
+  hipLaunchKernelGGL(sumsq_kernel, dim3(NPART), dim3(256), 0, stream, grads, n, grad_scale, norm_ws);
+  APLA_CHECK_LAUNCH("apla_grad_sumsq");
+  return APLA_OK;
+}
+
+extern "C" int apla_adamw_apply(float* params, float* grads, float* exp_avg, float* exp_avg_sq, const uint8_t* decay_mask,
+                                long n, float lr, float weight_decay, float beta1, float beta2, float eps, int step,
+                                float max_norm, float grad_scale, float* norm_ws, hipStream_t stream) {
+  APLA_REQUIRE(params && grads && exp_avg && exp_avg_sq && decay_mask && norm_ws && n > 0 && step >= 1, "apla_adamw_apply: bad arguments");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  long blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, params, grads, exp_avg, exp_avg_sq, decay_mask, n, lr, weight_decay, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), max_norm, grad_scale, norm_ws);
+  APLA_CHECK_LAUNCH("apla_adamw_apply");
+  return APLA_OK;
+}
+
 extern "C" int apla_adamw_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq,
                                const uint8_t* decay_mask, long n, float lr, float weight_decay, float beta1,
                                float beta2, float eps, int step, float max_norm, float grad_scale, float* norm_ws,

@@ -1,6 +1,9 @@
-"""Pieces of the DINOv2-APLA self-supervised step that exist so far: the self-distillation losses, the
-projection head, KoLeo, the EMA teacher update and the multi-crop (packed) backbone forward.  The masking collate, the
-step glue (dinov2/models.py:207-441) and the SSL trainer are not built yet."""
-from .backbone import DinoVisionTransformer  # noqa: F401
+"""The DINOv2-APLA self-supervised step (reference self_supervised/dinov2/): losses, projection head, KoLeo,
+the multi-crop (packed) backbone, the masking collate and schedules, the student/teacher meta-architecture and the
+training iteration."""
+from .backbone import DinoVisionTransformer, MemEffAttention  # noqa: F401
+from .collate import CosineScheduler, MaskingGenerator, build_schedulers, collate_data_and_cast  # noqa: F401
 from .heads import DINOHead, KoLeoLoss, update_teacher  # noqa: F401
 from .losses import DINOLoss, iBOTPatchLoss  # noqa: F401
+from .models import DINOv2, build_model  # noqa: F401
+from .trainer import Dinov2Trainer  # noqa: F401

@@ -7,6 +7,7 @@ the same modules as the dense path — LayerNorm / qkv / projection / MLP are to
 sequence offsets to the block-diagonal attention kernels — so a list forward is ONE pass per block, not one per
 resolution.
 """
+import math
 from typing import List, Optional
 
 import torch
@@ -15,15 +16,58 @@ from torch import nn
 from .. import functional as AF
 from ..apla.appla_attn_mem_eff import APLA_MemEffAttention
 from ..nested import BlockDiagonalMask
-from ..vit import VisionTransformer
+from ..vit import Attention, VisionTransformer
+
+
+class MemEffAttention(Attention):
+    """dinov2/layers/attention.py:66-89: plain attention with the ``forward(x, attn_bias=None) -> x`` convention.  This is
+    the module the backbone keeps when ``partial_size: full`` leaves the projection un-split (apla_vit.py:66-75: the whole
+    ``attn.proj`` Linear is trainable; its dW runs on the same TN MFMA kernel with r = D)."""
+
+    def forward(self, x, attn_bias=None):
+        if attn_bias is None:
+            return super().forward(x)[0]
+        if not isinstance(attn_bias, BlockDiagonalMask):
+            raise TypeError(f"attn_bias must be an apla_amd.nested.BlockDiagonalMask, got {type(attn_bias).__name__}")
+        AF.require_no_dropout(self.attn_drop, self.training), AF.require_no_dropout(self.proj_drop, self.training)
+        if x.ndim != 3 or x.shape[0] != 1 or x.shape[1] != attn_bias.total:
+            raise ValueError(f"a packed batch must be [1, {attn_bias.total}, C]; got {tuple(x.shape)}")
+        qkv = AF.linear(x, self.qkv.weight, self.qkv.bias)
+        o = AF.attention_core_varlen(qkv, attn_bias.cu_seqlens(x.device), attn_bias.max_seqlen, self.num_heads, self.scale)
+        return AF.linear(o, self.proj.weight, self.proj.bias).to(x.dtype)
 
 
 class DinoVisionTransformer(VisionTransformer):
-    """apla_amd.vit.VisionTransformer + the learnable mask token and the list forward of the dinov2 backbone."""
+    """apla_amd.vit.VisionTransformer + what the dinov2 backbone adds (self_supervised/dinov2/dinov2_vits.py:41-350): the
+    learnable mask token, MemEffAttention blocks, the position-embedding resize with the 0.1 offset, the list forward and
+    the ``forward(x, masks=None, is_training=False)`` convention.  Parameter names are those of the dinov2 checkpoint."""
 
-    def __init__(self, *args, **kwargs):
+    def __init__(self, *args, interpolate_offset=0.1, interpolate_antialias=False, **kwargs):
         super().__init__(*args, **kwargs)
         self.mask_token = nn.Parameter(torch.zeros(1, self.embed_dim))
+        self.interpolate_offset, self.interpolate_antialias = interpolate_offset, interpolate_antialias
+        for blk in self.blocks:
+            blk.attn.__class__ = MemEffAttention   # same state, dinov2 calling convention
+        self._pos_cache = {}
+
+    def interpolate_pos_encoding(self, npatch: int) -> torch.Tensor:
+        """dinov2_vits.py:176-208 for square inputs: bicubic resize of the pretraining grid by the scale factor
+        (side + 0.1) / M — the "historical kludge" the checkpoints were trained with; it is NOT the size-based resize of
+        utils/transformers/vit.py.  The position table is frozen, so the result is cached per grid size."""
+        pe = self.pos_embed
+        N = pe.shape[1] - 1
+        if npatch == N:
+            return pe
+        key = (npatch, pe._version, pe.device)
+        if key not in self._pos_cache:
+            dim, M, side = pe.shape[-1], int(math.sqrt(N)), int(math.sqrt(npatch))
+            assert M * M == N and side * side == npatch
+            kw = {"scale_factor": (float(side + self.interpolate_offset) / M,) * 2} if self.interpolate_offset else {"size": (side, side)}
+            grid = nn.functional.interpolate(pe.detach().float()[:, 1:].reshape(1, M, M, dim).permute(0, 3, 1, 2), mode="bicubic",
+                                             antialias=self.interpolate_antialias, **kw)
+            assert grid.shape[-2:] == (side, side)
+            self._pos_cache = {key: torch.cat((pe.detach().float()[:, :1], grid.permute(0, 2, 3, 1).reshape(1, -1, dim)), dim=1)}
+        return self._pos_cache[key]
 
     def prepare_tokens_with_masks(self, x, masks: Optional[torch.Tensor] = None):
         x = self.patch_embed(x)
@@ -33,8 +77,8 @@ class DinoVisionTransformer(VisionTransformer):
         return x + self.interpolate_pos_encoding(x.shape[1] - 1).to(x.dtype)
 
     def _block_packed(self, blk, x, attn_bias):
-        if not isinstance(blk.attn, APLA_MemEffAttention):
-            raise NotImplementedError("the packed forward needs APLA_MemEffAttention blocks (build_apla(..., 'apla_attn_mem_eff'))")
+        if not isinstance(blk.attn, (APLA_MemEffAttention, MemEffAttention)):   # block.py:249
+            raise NotImplementedError("the packed forward needs (APLA_)MemEffAttention blocks (build_apla(..., 'apla_attn_mem_eff'))")
         x = x + blk.ls1(blk.attn(AF.layer_norm(x, blk.norm1), attn_bias=attn_bias))
         return x + blk.ls2(blk.mlp(AF.layer_norm(x, blk.norm2)))
 
@@ -54,3 +98,11 @@ class DinoVisionTransformer(VisionTransformer):
         if isinstance(x, (list, tuple)):
             return self.forward_features_list(list(x), list(masks) if masks is not None else [None] * len(x))
         return self.forward_features_list([x], [masks])[0]
+
+    def forward(self, *args, is_training=False, **kwargs):
+        """dinov2_vits.py:342-349: the feature dictionary while training, the CLS feature otherwise."""
+        x = args[0] if args else kwargs.pop("x")
+        ret = self.forward_features_dict(x, kwargs.get("masks"))
+        if is_training:
+            return ret
+        return ret["x_norm_clstoken"]

@@ -1,0 +1,69 @@
+"""The DINOv2-APLA training iteration (self_supervised/dinov2/trainer.py:57-162, ``Dinov2Trainer.global_step``).
+
+One iteration = schedules -> zero_grad -> teacher + student forward and the four losses (``DINOv2.forward``) -> backward
+through the HIP kernels -> gradient exchange (world > 1) -> global-norm clip -> last-layer freeze -> AdamW -> EMA teacher.
+What changes against the reference's loop is where things run, not what they compute:
+* clip + AdamW: ``FlatAdamW`` (apla_grad_sumsq / apla_adamw_apply over one flat buffer) instead of ``clip_grad_norm_`` +
+  ``torch.optim.AdamW`` walking a dozen tensors; ``possibly_cancel_last_layer_grads`` (trainer.py:84-90) becomes the
+  optimizer's ``skip=`` list — same effect: the prototype layer is left out of the update but not out of the norm;
+* data parallel: the reference wraps the model in DistributedDataParallel (wrappers.py:73-78).  The trainable set here is
+  one flat buffer, so the exchange is ONE all-reduce of it (RCCL, sum; the mean is folded into ``grad_scale``), plus the
+  centre all-reduces the losses already issue (losses.py).  No per-step barrier;
+* mixed precision: bf16 operands with fp32 accumulation inside the kernels — no GradScaler (``use_mixed_precision`` with
+  fp16 + dynamic scaling is implemented for the classification step only).
+"""
+from typing import Dict, Optional
+
+import torch
+import torch.distributed as dist
+
+from ..optim import FlatAdamW
+from .collate import build_schedulers
+from .models import DINOv2
+
+
+class Dinov2Trainer:
+    def __init__(self, model: DINOv2, *, iters_per_epoch: int, epochs: int, lr: float = 1e-4, weight_decay: float = 1e-5,
+                 eta_min: float = 1e-6, warmup_epochs: int = 0, grad_clipping: float = 0.0, freeze_last_layer_epochs: int = 0,
+                 momentum_teacher: float = 0.994, final_momentum_teacher: float = 1.0, warmup_teacher_temp: float = 0.04,
+                 teacher_temp: float = 0.07, warmup_teacher_temp_epochs: int = 30, schedules=None, process_group=None):
+        self.model = model
+        self.iters_per_epoch, self.total_iters = iters_per_epoch, iters_per_epoch * epochs
+        self.grad_clipping, self.freeze_last_for = grad_clipping, freeze_last_layer_epochs
+        (self.lr_schedule, self.wd_schedule, self.momentum_schedule, self.teacher_temp_schedule,
+         self.last_layer_lr_schedule) = schedules if schedules is not None else build_schedulers(
+            lr=lr, eta_min=eta_min, warmup_epochs=warmup_epochs, weight_decay=weight_decay, momentum_teacher=momentum_teacher,
+            final_momentum_teacher=final_momentum_teacher, warmup_teacher_temp=warmup_teacher_temp, teacher_temp=teacher_temp,
+            warmup_teacher_temp_epochs=warmup_teacher_temp_epochs, freeze_last_layer_epochs=freeze_last_layer_epochs,
+            iters_per_epoch=iters_per_epoch, total_iters=self.total_iters)
+        self.optimizer = FlatAdamW(model.student.named_parameters(), lr=lr, weight_decay=weight_decay)
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.iters, self.epoch = 1, 1    # the reference counts from 1 (bases.py; trainer.py:96-99 indexes the schedules with it)
+        self.loss: Optional[torch.Tensor] = None
+        self.loss_dict: Dict[str, torch.Tensor] = {}
+
+    def global_step(self, batch) -> torch.Tensor:
+        """``batch`` is the collate's dictionary (``batch['images']`` holds the crops and the mask bookkeeping)."""
+        it = self.iters
+        lr, wd = float(self.lr_schedule[it]), float(self.wd_schedule[it])
+        teacher_temp, mom = float(self.teacher_temp_schedule[it]), float(self.momentum_schedule[it])
+        opt = self.optimizer
+        opt.lr, opt.weight_decay = lr, wd     # apply_optim_scheduler: one lr for both groups, wd on the regularised group
+        opt.zero_grad()
+        loss, loss_dict = self.model(images=batch["images"], teacher_temp=teacher_temp)
+        loss.backward()
+        if self.world > 1:
+            dist.all_reduce(opt.grads, op=dist.ReduceOp.SUM, group=self.pg)
+        skip = ("dino_head.last_layer", "ibot_head.last_layer") if (self.freeze_last_for and self.epoch <= self.freeze_last_for) else ()
+        opt.step(max_norm=self.grad_clipping or 0.0, grad_scale=1.0 / self.world, skip=skip)
+        self.model.update_teacher(mom)
+        self.loss, self.loss_dict = loss.detach(), {k: v.detach() for k, v in loss_dict.items()}
+        self.iters += 1
+        if (self.iters - 1) % self.iters_per_epoch == 0:
+            self.epoch += 1
+        return self.loss
+
+    @property
+    def feature_extractor(self):
+        return self.model.teacher.backbone

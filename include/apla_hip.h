@@ -171,6 +171,17 @@ int apla_adamw_step(float* params, float* grads, float* exp_avg, float* exp_avg_
                     long n, float lr, float weight_decay, float beta1, float beta2, float eps, int step,
                     float max_norm, float grad_scale, float* norm_ws, hipStream_t stream);
 
+/* The two phases of apla_adamw_step on their own, for optimizers that keep a step count per tensor or skip tensors
+ * (torch.optim.AdamW skips parameters whose .grad is None; self_supervised/dinov2/trainer.py:84-90 cancels the prototype
+ * layer's gradients AFTER clip_grad_norm_ during the first epochs): apla_grad_sumsq leaves the 256 partial sums of
+ * (grads*grad_scale)^2 over [0, n) in norm_ws; apla_adamw_apply re-reduces them, derives the same clip coefficient and
+ * updates the n elements it is given (any sub-range of the buffer the norm was taken over) with bias corrections for
+ * `step`.  apla_adamw_step(…) == apla_grad_sumsq(…) followed by apla_adamw_apply(…) on the same range. */
+int apla_grad_sumsq(const float* grads, long n, float grad_scale, float* norm_ws, hipStream_t stream);
+int apla_adamw_apply(float* params, float* grads, float* exp_avg, float* exp_avg_sq, const uint8_t* decay_mask,
+                     long n, float lr, float weight_decay, float beta1, float beta2, float eps, int step,
+                     float max_norm, float grad_scale, float* norm_ws, hipStream_t stream);
+
 /* The same step under DYNAMIC loss scaling — torch.cuda.amp.GradScaler (defaults/trainer.py:129-138:
  * scaler.scale(loss).backward(); unscale_; clip; scaler.step; scaler.update) without a host round trip.  The gradients in
  * `grads` carry the current loss scale; `scaler` is a device float[8]: [0..2] and [3..5] are two slots of {scale,

@@ -321,6 +321,193 @@ def g11_ssl_head_koleo():
     save("g11_ssl_head_koleo.npz", **arrs)
 
 
+# ---------------------------------------------------------------- G12: DINOv2-APLA self-supervised step
+def _load_ref_dinov2():
+    """self_supervised/dinov2/{layers,loss,dinov2_vits,dinov2_utils} of the reference as a package, files in place."""
+    import importlib
+    import types
+    import warnings
+    warnings.filterwarnings("ignore", message=".*xFormers.*")
+    for name, sub in (("self_supervised", ("self_supervised",)), ("self_supervised.dinov2", ("self_supervised", "dinov2"))):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__path__ = [os.path.join(REF_SRC, *sub)]
+            sys.modules[name] = m
+    imp = lambda n: importlib.import_module("self_supervised.dinov2." + n)  # noqa: E731
+    return imp("layers"), imp("loss"), imp("dinov2_vits"), imp("dinov2_utils")
+
+
+def g12_ssl_step(tag="apla", partial_size=32):
+    """Two iterations of the DINOv2-APLA step (self_supervised/dinov2/models.py:207-453 + trainer.py:106-141) on a tiny
+    ViT/14, every numerical component being the reference's own class: DinoVisionTransformer (+ build_apla with an inds
+    JSON, 'apla_attn_mem_eff'; or partial_size 'full' with is_multi_gpu), DINOHead, DINOLoss, iBOTPatchLoss, KoLeoLoss,
+    MaskingGenerator / collate_data_and_cast (under random.seed), CosineScheduler, torch AdamW with the reference's two
+    parameter groups, clip_grad_norm_, the EMA teacher update.  The glue between them follows DINOv2.forward line by
+    line with ONE difference forced by the missing xformers: the student runs one dense pass per crop resolution instead
+    of the packed block-diagonal pass (the same function: attention never crosses crops), and the head inputs are
+    concatenated with torch.cat instead of BlockDiagonalMask.from_tensor_list (the head is token-wise).  The dense fallback of
+    APLA_MemEffAttention returns APLA_Attention's (x, attn) pair; the block needs x, so the pair is unpacked here."""
+    import copy
+    import random
+    from functools import partial
+    layers, loss_mod, vits, du = _load_ref_dinov2()
+    D, depth, heads, patch, pre, gsz, lsz = 128, 2, 2, 14, 70, 56, 28
+    K, hid, bott, B, n_local = 512, 256, 128, 3, 8   # kernel granularity: GEMM N % 128, K % 64
+    torch.manual_seed(31)
+    def backbone():
+        return vits.DinoVisionTransformer(img_size=pre, patch_size=patch, embed_dim=D, depth=depth, num_heads=heads, init_values=1.0,
+                                          ffn_layer="mlp", block_chunks=0, num_register_tokens=0, interpolate_antialias=False,
+                                          interpolate_offset=0.1, block_fn=partial(layers.NestedTensorBlock, attn_class=layers.MemEffAttention))
+    student_bb, teacher_bb = backbone(), backbone()
+    with torch.no_grad():   # "pretrained" weights: make every frozen tensor count (zero biases / unit scales hide mistakes)
+        for n_, p_ in student_bb.named_parameters():
+            if n_.endswith("gamma"):
+                p_.uniform_(0.5, 1.5)
+            elif p_.ndim == 1 or "token" in n_:
+                p_.normal_(std=0.1) if "norm" not in n_ or n_.endswith("bias") else p_.uniform_(0.8, 1.2)
+            elif "pos_embed" in n_:
+                p_.normal_(std=0.2)
+            else:
+                p_.normal_(std=0.06)
+    teacher_bb.load_state_dict(copy.deepcopy(student_bb.state_dict()))
+    g = torch.Generator().manual_seed(32)
+    if partial_size == "full":
+        cfg = Cfg(partial_size="full")
+        inds = None
+    else:
+        inds = {f"block_{i}": torch.randperm(D, generator=g)[:partial_size].tolist() for i in range(depth)}
+        tmp = tempfile.NamedTemporaryFile("w", suffix=".json", delete=False)
+        json.dump(inds, tmp)
+        tmp.close()
+        cfg = Cfg(partial_size=partial_size, inds_path=tmp.name)
+    multi = partial_size == "full"
+    student_bb = avit.build_apla(cfg, student_bb, "apla_attn_mem_eff", is_multi_gpu=multi)
+    teacher_bb = avit.build_apla(cfg, teacher_bb, "apla_attn_mem_eff", is_multi_gpu=multi)
+    if not multi:   # without xformers APLA_MemEffAttention falls back to APLA_Attention.forward, which returns (x, attn): keep x
+        for bb_ in (student_bb, teacher_bb):
+            for blk in bb_.blocks:
+                blk.attn.forward = (lambda x, attn_bias=None, _f=blk.attn.forward: _f(x)[0])
+    head = partial(layers.DINOHead, in_dim=D, out_dim=K, hidden_dim=hid, bottleneck_dim=bott, nlayers=3)
+    student = torch.nn.ModuleDict({"backbone": student_bb, "dino_head": head()})
+    teacher = torch.nn.ModuleDict({"backbone": teacher_bb, "dino_head": head()})
+    with torch.no_grad():
+        for p_ in student["dino_head"].mlp.parameters():
+            p_.add_(torch.randn(p_.shape, generator=g) * 0.05)
+    for k in student.keys():
+        teacher[k].load_state_dict(student[k].state_dict())
+    for p_ in teacher.parameters():
+        p_.requires_grad = False
+    dino_loss, ibot_loss, koleo = loss_mod.DINOLoss(K), loss_mod.iBOTPatchLoss(K), loss_mod.KoLeoLoss()
+    arrs = {"meta": np.array([D, depth, heads, patch, pre, gsz, lsz, K, hid, bott, B, n_local])}
+    for k_, v_ in student.state_dict().items():
+        arrs["init." + k_] = npy(v_)
+    if inds is not None:
+        arrs["inds"] = np.array([inds[f"block_{i}"] for i in range(depth)], dtype=np.int32)
+
+    # optimizer: defaults/wrappers.py:205-221 groups, AdamW lr/wd per iteration from the schedules (trainer.py:96-121)
+    reg, noreg = [], []
+    for n_, p_ in student.named_parameters():
+        if p_.requires_grad:
+            (noreg if n_.endswith(".bias") or p_.ndim == 1 else reg).append(p_)
+    opt = torch.optim.AdamW([{"params": reg}, {"params": noreg, "weight_decay": 0.0}], lr=1e-3, weight_decay=0.04)
+    total_iters = 6
+    lr_s = du.CosineScheduler(base_value=1e-3, final_value=1e-6, total_iters=total_iters, warmup_iters=2, start_warmup_value=0)
+    wd_s = du.CosineScheduler(base_value=0.04, final_value=1e-4, total_iters=total_iters)
+    mom_s = du.CosineScheduler(base_value=0.9, final_value=1.0, total_iters=total_iters)
+    tt_s = du.CosineScheduler(base_value=0.07, final_value=0.07, total_iters=3, warmup_iters=3, start_warmup_value=0.04)
+    arrs["sched.lr"], arrs["sched.wd"], arrs["sched.mom"] = lr_s.schedule, wd_s.schedule, mom_s.schedule
+    arrs["sched.tt"] = np.array([tt_s[i] for i in range(total_iters)])
+
+    n_tok = (gsz // patch) ** 2
+    mask_gen = du.MaskingGenerator(input_size=(gsz // patch, gsz // patch), max_num_patches=0.5 * gsz // patch * gsz // patch)
+    random.seed(5)
+    n_global, dino_w, ibot_w, koleo_w, clip = 2, 1.0, 1.0, 0.1, 3.0
+    for it in range(1, 3):   # trainer iterations start at 1
+        samples = [([torch.randn(3, gsz, gsz, generator=g) for _ in range(2)] + [torch.randn(3, lsz, lsz, generator=g) for _ in range(n_local)],
+                    torch.tensor(0)) for _ in range(B)]
+        data = du.collate_data_and_cast(samples, n_global_crops=2, n_local_crops=n_local, mask_ratio_tuple=(0.1, 0.5),
+                                        mask_probability=0.5, dtype=torch.float32, n_tokens=n_tok, mask_generator=mask_gen)["images"]
+        glob, loc, masks = data["collated_global_crops"], data["collated_local_crops"], data["collated_masks"]
+        idx, mw, upper = data["mask_indices_list"], data["masks_weight"], data["upperbound"]
+        n_masked = idx.shape[0]
+        lr, wd, ttemp, mom = lr_s[it], wd_s[it], tt_s[it], mom_s[it]
+        for gp in opt.param_groups:
+            gp["lr"] = lr
+        opt.param_groups[0]["weight_decay"] = wd
+        opt.zero_grad()
+        with torch.no_grad():   # models.py:231-300
+            tout = teacher["backbone"](glob, is_training=True)
+            tcls = tout["x_norm_clstoken"].chunk(2)
+            tcls = torch.cat((tcls[1], tcls[0]))
+            tpatch = tout["x_norm_patchtokens"]
+            ncls = tcls.shape[0]
+            buf = tpatch.new_zeros(upper + ncls, D)
+            buf[:ncls].copy_(tcls)
+            torch.index_select(tpatch.flatten(0, 1), dim=0, index=idx, out=buf[ncls:ncls + n_masked])
+            after = teacher["dino_head"](buf)
+            tcls_h, tpatch_h = after[:ncls], after[ncls:ncls + n_masked]
+            t_dino = dino_loss.softmax_center_teacher(tcls_h, teacher_temp=ttemp).view(2, -1, K)
+            dino_loss.update_center(tcls_h)
+            tpatch_h = tpatch_h.unsqueeze(0)
+            t_ibot = ibot_loss.softmax_center_teacher(tpatch_h[:, :n_masked], teacher_temp=ttemp).squeeze(0)
+            ibot_loss.update_center(tpatch_h[:n_masked])
+        sg = student["backbone"](glob, masks=masks, is_training=True)      # dense pass per resolution (see docstring)
+        sl = student["backbone"](loc, is_training=True)
+        s_loc_cls, s_glob_cls = sl["x_norm_clstoken"], sg["x_norm_clstoken"]
+        pbuf = sg["x_norm_patchtokens"].new_zeros(upper, D)
+        pbuf[:n_masked].copy_(torch.index_select(sg["x_norm_patchtokens"].flatten(0, 1), dim=0, index=idx))
+        outs = student["dino_head"](torch.cat([s_loc_cls, s_glob_cls, pbuf]))
+        o_loc, o_glob, o_patch = outs[:s_loc_cls.shape[0]], outs[s_loc_cls.shape[0]:s_loc_cls.shape[0] + s_glob_cls.shape[0]], \
+            outs[s_loc_cls.shape[0] + s_glob_cls.shape[0]:][:n_masked]
+        n_loc_terms, n_glob_terms = max(n_local * n_global, 1), (n_global - 1) * n_global
+        ld = {}
+        ld["dino_local_crops_loss"] = dino_loss(student_output_list=o_loc.chunk(n_local),
+                                                teacher_out_softmaxed_centered_list=t_dino) / (n_glob_terms + n_loc_terms)
+        total = dino_w * ld["dino_local_crops_loss"]
+        ld["dino_global_crops_loss"] = dino_loss(student_output_list=[o_glob], teacher_out_softmaxed_centered_list=[t_dino.flatten(0, 1)]) \
+            * 2 / (n_glob_terms + n_loc_terms)
+        total = total + dino_w * ld["dino_global_crops_loss"]
+        kl = koleo_w * sum(koleo(p_) for p_ in s_glob_cls.chunk(2))
+        total = total + kl
+        ld["koleo_loss"] = kl / 2
+        ib = ibot_loss.forward_masked(o_patch, t_ibot, student_masks_flat=masks, n_masked_patches=n_masked, masks_weight=mw) * 2 * (1.0 / n_global)
+        ld["ibot_loss"] = ib / 2
+        total = total + ibot_w * ib
+        total.backward()
+        gnorm = torch.nn.utils.clip_grad_norm_(student.parameters(), clip)
+        grads = {n_: npy(p_.grad) for n_, p_ in student.named_parameters() if p_.grad is not None}
+        if it == 1:   # freeze_last_layer for the first "epoch": trainer.py:84-90 (cancel_gradients sets .grad = None)
+            for n_, p_ in student.named_parameters():
+                if "dino_head.last_layer" in n_:
+                    p_.grad = None
+        opt.step()
+        with torch.no_grad():   # models.py:443-453
+            sp = [p_ for k in student.keys() for p_ in student[k].parameters()]
+            tp = [p_ for k in student.keys() for p_ in teacher[k].parameters()]
+            torch._foreach_mul_(tp, mom)
+            torch._foreach_add_(tp, sp, alpha=1 - mom)
+        pre_ = f"it{it}."
+        arrs.update({pre_ + "glob": npy(glob), pre_ + "loc": npy(loc), pre_ + "masks": npy(masks), pre_ + "mask_indices": npy(idx),
+                     pre_ + "masks_weight": npy(mw), pre_ + "upperbound": np.array(upper), pre_ + "hyper": np.array([lr, wd, ttemp, mom]),
+                     pre_ + "loss": npy(total), pre_ + "gnorm": npy(gnorm), pre_ + "t_dino": npy(t_dino[:, :, :64]),
+                     pre_ + "s_glob_cls": npy(s_glob_cls), pre_ + "s_loc_cls": npy(s_loc_cls)})
+        for k_, v_ in ld.items():
+            arrs[pre_ + "ld." + k_] = npy(v_)
+        for k_, v_ in grads.items():
+            arrs[pre_ + "g." + k_] = v_          # AFTER clipping (what the optimizer consumed)
+        for k_, p_ in student.named_parameters():
+            if p_.requires_grad:
+                arrs[pre_ + "student." + k_] = npy(p_)
+        for (k_, p_), (_, ps) in zip(teacher.named_parameters(), student.named_parameters()):
+            if ps.requires_grad:
+                arrs[pre_ + "teacher." + k_] = npy(p_)
+    dino_loss.apply_center_update()
+    ibot_loss.apply_center_update()
+    arrs["dino.center"], arrs["ibot.center"] = npy(dino_loss.center), npy(ibot_loss.center)
+    arrs["trainable"] = np.array([n_ for n_, p_ in student.named_parameters() if p_.requires_grad])
+    save(f"g12_ssl_step_{tag}.npz", **arrs)
+
+
 def classifier_step(model, fc, images, labels, lr=1e-4, wd=1e-5, clip=1.0):
     """defaults/trainer.py:106-151 (no AMP) with the param groups of defaults/wrappers.py:205-221."""
     named = [(n, p_) for n, p_ in list(model.named_parameters()) + [("fc." + n, p_) for n, p_ in fc.named_parameters()]
@@ -422,3 +609,5 @@ if __name__ == "__main__":
     g9_lr_schedule()
     g10_ssl_losses()
     g11_ssl_head_koleo()
+    g12_ssl_step("apla", 32)
+    g12_ssl_step("full", "full")

@@ -1,0 +1,118 @@
+"""The DINOv2-APLA training iteration on the MI355X against golden G12 — two iterations produced by the REFERENCE's own
+classes (backbone + build_apla, DINOHead, the three losses, collate, schedulers, torch AdamW, EMA): losses, clipped
+gradients, updated student and teacher parameters, centres.  Both adaptation modes of the shipped YAML: APLA rows with an
+index file, and ``partial_size: full`` under the multi-GPU rule.  bf16 operand tolerances as in tests/test_modules_gpu.py."""
+import json
+import os
+import tempfile
+
+import pytest
+import torch
+
+from conftest import load_golden, rel_err, t
+
+pytestmark = pytest.mark.gpu
+
+
+def build_from_golden(g, tag):
+    from functools import partial
+    from apla_amd.ssl import DINOv2, DinoVisionTransformer
+    D, depth, heads, patch, pre, gsz, lsz, K, hid, bott, B, n_local = [int(v) for v in g["meta"]]
+    def bb():
+        return DinoVisionTransformer(img_size=[pre], patch_size=patch, embed_dim=D, depth=depth, num_heads=heads, qkv_bias=True,
+                                     norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), block_conf=dict(has_layerscale=True, layerscale_init_values=1.0))
+    if tag == "apla":
+        f = tempfile.NamedTemporaryFile("w", suffix=".json", delete=False)
+        json.dump({f"block_{i}": [int(v) for v in g["inds"][i]] for i in range(depth)}, f)
+        f.close()
+        adaptation, gpus = dict(mode="apla", params=dict(partial_size=g["inds"].shape[1], inds_path=f.name)), "0"
+    else:
+        adaptation, gpus = dict(mode="apla", params=dict(partial_size="full")), "0,1"
+    params = dict(
+        model_params=dict(backbone_type="vit_tiny_test", pretrained=False, adaptation=adaptation,
+                          transformers_params=dict(student=dict(patch_size=patch, pre_img_size=pre)),
+                          dinov2=dict(centering="centering",
+                                      dino=dict(loss_weight=1.0, head_n_prototypes=K, head_bottleneck_dim=bott, head_nlayers=3,
+                                                head_hidden_dim=hid, koleo_loss_weight=0.1),
+                                      ibot=dict(loss_weight=1.0, mask_sample_probability=0.5, mask_ratio_min_max=[0.1, 0.5], separate_head=False))),
+        crops_params=dict(n_global_crops=2, n_local_crops=n_local), system_params=dict(which_GPUs=gpus))
+    model = DINOv2(params, backbones=(bb(), bb(), D))
+    sd = {k[len("init."):]: t(g[k]) for k in g.files if k.startswith("init.")}
+    missing, unexpected = model.student.load_state_dict(sd, strict=False)
+    assert not unexpected and not missing, (missing, unexpected)
+    for k in model.student.keys():
+        model.teacher[k].load_state_dict(model.student[k].state_dict())
+    return model.cuda().train()
+
+
+@pytest.mark.parametrize("tag", ["apla", "full"])
+def test_two_iterations_match_reference(tag):
+    from apla_amd.ssl import CosineScheduler, Dinov2Trainer
+    g = load_golden(f"g12_ssl_step_{tag}.npz")
+    model = build_from_golden(g, tag)
+    trainable = [str(n) for n in g["trainable"]]
+    assert [n for n, p in model.student.named_parameters() if p.requires_grad] == trainable
+    sched = (CosineScheduler(base_value=1e-3, final_value=1e-6, total_iters=6, warmup_iters=2, start_warmup_value=0),
+             CosineScheduler(base_value=0.04, final_value=1e-4, total_iters=6), CosineScheduler(base_value=0.9, final_value=1.0, total_iters=6),
+             CosineScheduler(base_value=0.07, final_value=0.07, total_iters=3, warmup_iters=3, start_warmup_value=0.04), None)
+    tr = Dinov2Trainer(model, iters_per_epoch=1, epochs=6, grad_clipping=3.0, freeze_last_layer_epochs=1, schedules=sched)
+    sp, tp = dict(model.student.named_parameters()), dict(model.teacher.named_parameters())
+    for it in (1, 2):
+        images = {"collated_global_crops": t(g[f"it{it}.glob"]), "collated_local_crops": t(g[f"it{it}.loc"]),
+                  "collated_masks": t(g[f"it{it}.masks"]), "mask_indices_list": t(g[f"it{it}.mask_indices"]),
+                  "masks_weight": t(g[f"it{it}.masks_weight"]), "upperbound": int(g[f"it{it}.upperbound"]),
+                  "n_masked_patches": torch.tensor([len(g[f"it{it}.mask_indices"])])}
+        before_last = {n: p.detach().clone() for n, p in sp.items() if "last_layer" in n}
+        loss = tr.global_step({"images": images})
+        torch.cuda.synchronize()
+        assert abs(float(loss) - float(g[f"it{it}.loss"])) < 2e-2 * float(g[f"it{it}.loss"])
+        for k, v in tr.loss_dict.items():
+            ref = float(g[f"it{it}.ld.{k}"])
+            assert abs(float(v) - ref) < 2e-2 * abs(ref) + 2e-3, (k, float(v), ref)
+        gn = float(tr.optimizer.grad_norm())
+        assert abs(gn - float(g[f"it{it}.gnorm"])) < 3e-2 * float(g[f"it{it}.gnorm"])
+        for n in trainable:     # the optimizer leaves the clipped gradients in place, like clip_grad_norm_
+            assert rel_err(sp[n].grad.cpu(), g[f"it{it}.g.{n}"]) < 4e-2, (it, n)
+        for n in trainable:
+            # Adam's first steps move every element by ~lr whatever the gradient's size: compare the UPDATE, loosely
+            ref_new, ref_old = t(g[f"it{it}.student.{n}"]), (t(g[f"it{it - 1}.student.{n}"]) if it > 1 else t(g["init." + n]))
+            upd, ref_upd = sp[n].detach().cpu() - ref_old, ref_new - ref_old
+            if it == 1 and "last_layer" in n:   # frozen for the first epoch: untouched
+                assert torch.equal(sp[n].detach(), before_last[n]) and float(ref_upd.abs().max()) == 0.0
+                continue
+            assert float((upd - ref_upd).abs().mean() / (ref_upd.abs().mean() + 1e-12)) < 0.15, (it, n)
+            assert rel_err(tp[n].detach().cpu(), g[f"it{it}.teacher.{n}"]) < 5e-3, (it, n)   # (1 - m) x a few sign-flipped lr steps
+    model.dino_loss.apply_center_update()
+    model.ibot_patch_loss.apply_center_update()
+    assert rel_err(model.dino_loss.center.cpu(), g["dino.center"]) < 2e-2
+    assert rel_err(model.ibot_patch_loss.center.cpu(), g["ibot.center"]) < 2e-2
+
+
+def test_flat_adamw_matches_torch_adamw():
+    """FlatAdamW (apla_grad_sumsq + apla_adamw_apply) against torch.optim.AdamW + clip_grad_norm_ with the reference's two
+    parameter groups, including a tensor skipped for the first two steps (its step count starts late)."""
+    from apla_amd.optim import FlatAdamW
+    torch.manual_seed(0)
+    shapes = {"a.weight": (33, 17), "a.bias": (33,), "last_layer.weight_v": (40, 8), "z.gamma": (19,)}
+    mine = {n: torch.nn.Parameter(torch.randn(s, device="cuda")) for n, s in shapes.items()}
+    ref = {n: torch.nn.Parameter(p.detach().clone()) for n, p in mine.items()}
+    reg = [p for n, p in ref.items() if not (n.endswith(".bias") or p.ndim == 1)]
+    noreg = [p for n, p in ref.items() if n.endswith(".bias") or p.ndim == 1]
+    topt = torch.optim.AdamW([{"params": reg}, {"params": noreg, "weight_decay": 0.0}], lr=1e-2, weight_decay=0.05)
+    fopt = FlatAdamW(mine.items(), lr=1e-2, weight_decay=0.05)
+    for step in range(4):
+        fopt.zero_grad()
+        topt.zero_grad()
+        for n in shapes:
+            gr = torch.randn(shapes[n], device="cuda") * (3.0 if step % 2 else 0.1)
+            mine[n].grad.add_(gr)
+            ref[n].grad = gr.clone()
+        tn = torch.nn.utils.clip_grad_norm_(list(ref.values()), 1.0)
+        if step < 2:
+            ref["last_layer.weight_v"].grad = None
+        topt.step()
+        fopt.step(max_norm=1.0, skip=("last_layer",) if step < 2 else ())
+        assert abs(float(fopt.grad_norm()) - float(tn)) < 1e-4 * float(tn)
+        for n in shapes:
+            assert torch.allclose(mine[n].detach(), ref[n].detach(), rtol=2e-5, atol=2e-6), (step, n)
+    assert fopt.steps == [4, 4, 2, 4]
