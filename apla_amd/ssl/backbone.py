@@ -60,13 +60,15 @@ class DinoVisionTransformer(VisionTransformer):
             return pe
         key = (npatch, pe._version, pe.device)
         if key not in self._pos_cache:
+            if any(k[1:] != key[1:] for k in self._pos_cache):   # the table changed (checkpoint load, .to(device)): start over
+                self._pos_cache = {}
             dim, M, side = pe.shape[-1], int(math.sqrt(N)), int(math.sqrt(npatch))
             assert M * M == N and side * side == npatch
             kw = {"scale_factor": (float(side + self.interpolate_offset) / M,) * 2} if self.interpolate_offset else {"size": (side, side)}
             grid = nn.functional.interpolate(pe.detach().float()[:, 1:].reshape(1, M, M, dim).permute(0, 3, 1, 2), mode="bicubic",
                                              antialias=self.interpolate_antialias, **kw)
             assert grid.shape[-2:] == (side, side)
-            self._pos_cache = {key: torch.cat((pe.detach().float()[:, :1], grid.permute(0, 2, 3, 1).reshape(1, -1, dim)), dim=1)}
+            self._pos_cache[key] = torch.cat((pe.detach().float()[:, :1], grid.permute(0, 2, 3, 1).reshape(1, -1, dim)), dim=1)
         return self._pos_cache[key]
 
     def prepare_tokens_with_masks(self, x, masks: Optional[torch.Tensor] = None):

@@ -137,8 +137,8 @@ def update_params_from_args(params: dict, args) -> dict:
 
 def resolve_run(params: dict, args) -> dict:
     """Everything the training loop needs, derived from the merged parameters (no GPU involved: unit-testable)."""
-    if args.byol or args.simsiam or args.dino or args.dinov2:
-        raise NotImplementedError("the self-supervised trainers are out of scope here (SURVEY §8f-1); only the supervised APLA path runs")
+    if args.byol or args.simsiam or args.dino:
+        raise NotImplementedError("BYOL / SimSiam / DINO trainers are out of scope here (SURVEY §2); --dinov2 and the supervised APLA path run")
     if args.test or args.knn:
         raise NotImplementedError("evaluation / kNN are out of scope here (SURVEY §2)")
     mp = params["model_params"]
@@ -229,7 +229,111 @@ class TensorBatches:
             yield self.images[idx], self.labels[idx]
 
 
+# self_supervised/dinov2/augmentation_strategy.json: repetition_strategy.n_augmentations = [1, 1, 8]; RandomResizedCrop sizes
+DINOV2_CROPS = dict(n_global_crops=2, n_local_crops=8, global_crops_size=224, local_crops_size=98, img_size=224)
+
+
+def resolve_dinov2_run(params: dict, args) -> dict:
+    """What Dinov2Trainer / DINOv2Wrapper read from the merged parameters (self_supervised/dinov2/trainer.py:7-80,
+    wrappers.py:36-71); no GPU involved."""
+    mp = params["model_params"]
+    opt = params["optimization_params"]["default"]
+    if opt["optimizer"]["type"] != "AdamW" or opt["scheduler"]["type"] != ["LinearWarmup", "CosineAnnealingLR"]:
+        raise NotImplementedError("the DINOv2 trainer implements AdamW with [LinearWarmup, CosineAnnealingLR] (trainer.py:8)")
+    tp, teacher = params.get("training_params", {}), mp["transformers_params"]["teacher"]
+    ap = (mp.get("adaptation") or {}).get("params", {})
+    if ap.get("inds_path") and not os.path.exists(ap["inds_path"]):
+        cand = os.path.join(os.path.dirname(os.path.abspath(args.params_path)), os.path.basename(ap["inds_path"]))
+        if os.path.exists(cand):
+            ap["inds_path"] = cand
+    gpus = [g for g in str(params.get("system_params", {}).get("which_GPUs", "0")).split(",") if g != ""]
+    return dict(batch=int(params["dataloader_params"]["trainloader"]["batch_size"]), epochs=int(tp.get("epochs", 1)),
+                lr=float(opt["optimizer"]["params"]["lr"]), wd=float(opt["optimizer"]["params"].get("weight_decay", 0.0)),
+                eta_min=float(opt["scheduler"]["params"]["CosineAnnealingLR"]["eta_min"]),
+                warmup_epochs=int(opt["scheduler"]["params"]["LinearWarmup"].get("warmup_epochs", 0) or 0),
+                grad_clipping=float(tp.get("grad_clipping") or 0.0), freeze_last=int(tp.get("freeze_last_layer_epochs", 0) or 0),
+                log_every=int(tp.get("log_every", 25)), teacher=dict(teacher), gpus=gpus, model_name=tp.get("model_name", "model"),
+                save_dir=tp.get("save_dir"), patch=int(mp["transformers_params"]["student"]["patch_size"]))
+
+
+def main_dinov2(params, args):
+    """--dinov2: the self-supervised DINOv2-APLA pretraining loop (main.py:166-207 -> DINOv2Wrapper + Dinov2Trainer) on
+    synthetic crops (the dataset zoo / PIL augmentations are out of scope): collate with iBOT masks on the host,
+    everything else on the GPU."""
+    import random
+    import torch.distributed as dist
+    from apla_amd.dist import dist_average_tensor, init_from_env, is_rank0, synchronize
+    from apla_amd.ssl import DINOv2, Dinov2Trainer, MaskingGenerator, collate_data_and_cast
+    from apla_amd.ssl.collate import synthetic_samples
+    run = resolve_dinov2_run(params, args)
+    rank, world, local = init_from_env()
+    dev = torch.device("cuda", local if world > 1 else int(run["gpus"][0]) if run["gpus"] else 0)
+    torch.cuda.set_device(dev)
+    torch.manual_seed(0)   # identical student / teacher / head initialisation on every rank
+    p = copy.deepcopy(params)
+    p["crops_params"] = dict(DINOV2_CROPS)
+    pretrained = bool(p["model_params"].get("pretrained"))
+    p["model_params"]["pretrained"] = False
+    model = DINOv2(p)
+    pp = params.get("transfer_learning_params", {}).get("pretrained_path") or args.pretrained_path
+    if pp:
+        sd = torch.load(pp, map_location="cpu")
+        missing, unexpected = model.student.backbone.load_state_dict(sd.get("state_dict", sd), strict=False)
+        model.teacher.backbone.load_state_dict(model.student.backbone.state_dict())
+        if is_rank0():
+            print(f"[main] loaded {pp} into student and teacher: {len(missing)} missing, {len(unexpected)} unexpected keys")
+    elif pretrained and is_rank0():
+        print("\033[93m[main] model_params.pretrained is true but there is no network and no --pretrained_path: random initialisation\033[0m")
+    model = model.to(dev).train()
+    steps = args.steps_per_epoch or 100
+    t = run["teacher"]
+    trainer = Dinov2Trainer(model, iters_per_epoch=steps, epochs=run["epochs"], lr=run["lr"], weight_decay=run["wd"], eta_min=run["eta_min"],
+                            warmup_epochs=run["warmup_epochs"], grad_clipping=run["grad_clipping"], freeze_last_layer_epochs=run["freeze_last"],
+                            momentum_teacher=t["momentum_teacher"], final_momentum_teacher=t["final_momentum_teacher"],
+                            warmup_teacher_temp=t["warmup_teacher_temp"], teacher_temp=t["teacher_temp"],
+                            warmup_teacher_temp_epochs=t["warmup_teacher_temp_epochs"], process_group=dist.group.WORLD if world > 1 else None)
+    c, ib = DINOV2_CROPS, p["model_params"]["dinov2"]["ibot"]
+    side = c["img_size"] // run["patch"]
+    mask_gen = MaskingGenerator(input_size=(side, side), max_num_patches=0.5 * c["img_size"] // run["patch"] * c["img_size"] // run["patch"])
+    random.seed(1000 + rank)
+    gen = torch.Generator().manual_seed(1000 + rank)
+    if is_rank0():
+        print(f"\033[93m[main] SYNTHETIC crops: {run['batch']} x (2 x {c['global_crops_size']} + 8 x {c['local_crops_size']}) per GPU\033[0m\n"
+              f"[main] DINOv2-APLA {p['model_params']['backbone_type']}/{run['patch']}  {world} GPU(s) x bs {run['batch']}  "
+              f"{len(trainer.optimizer.names)} trainable tensors, {trainer.optimizer.flat.numel():,} parameters", flush=True)
+    epochs = 1 if args.dry else run["epochs"]
+    t0, seen, loss = time.perf_counter(), 0, None
+    for epoch in range(epochs):
+        for _ in range(steps):
+            batch = collate_data_and_cast(synthetic_samples(run["batch"], c["global_crops_size"], c["local_crops_size"], c["n_local_crops"], gen),
+                                          n_global_crops=2, n_local_crops=c["n_local_crops"], mask_ratio_tuple=tuple(ib["mask_ratio_min_max"]),
+                                          mask_probability=ib["mask_sample_probability"], dtype=torch.float32, n_tokens=side * side,
+                                          mask_generator=mask_gen)
+            loss = trainer.global_step(batch)
+            seen += run["batch"] * world
+            it = trainer.iters - 1
+            if it % run["log_every"] == 0 or it == 1:
+                avg = dist_average_tensor(loss)
+                if is_rank0():
+                    torch.cuda.synchronize()
+                    terms = "  ".join(f"{k} {float(v):.4f}" for k, v in trainer.loss_dict.items())
+                    print(f"[main] epoch {trainer.epoch} it {it}: train_loss {float(avg):.4f}  {terms}  lr {trainer.optimizer.lr:.3e}  "
+                          f"{seen / (time.perf_counter() - t0):.0f} images/s", flush=True)
+            if args.dry and it >= 3:
+                break
+    synchronize()
+    if is_rank0() and run["save_dir"] and not (args.dry or args.debug):
+        os.makedirs(run["save_dir"], exist_ok=True)
+        path = os.path.join(run["save_dir"], run["model_name"] + ".pth")
+        torch.save({"state_dict": model.state_dict(), "optimizer": trainer.optimizer.state_dict(), "iters": trainer.iters,
+                    "epoch": trainer.epoch, "parameters": params}, path)   # bases.py:456-467 session layout
+        print(f"[main] saved {path}")
+    return float(loss)
+
+
 def main(params, args):
+    if args.dinov2:
+        return main_dinov2(params, args)
     import torch.distributed as dist
     from apla_amd import checkpoint as ckpt
     from apla_amd.dist import dist_average_tensor, init_from_env, is_rank0, synchronize

@@ -228,4 +228,20 @@ def test_main_parameter_resolution():
     assert (run["batch"], run["lr"], run["wd"], run["epochs"], run["gpus"], run["log_every"]) == (16, 0.01, 0.0, 5, ["0", "1"], 1)
     assert main.make_schedule(run, 10).warmup_iters == 7
     with pytest.raises(NotImplementedError):
-        main.resolve_run(params, main.parse_arguments(["--params_path", path, "--dinov2"]))
+        main.resolve_run(params, main.parse_arguments(["--params_path", path, "--dino"]))
+
+
+def test_main_dinov2_parameter_resolution():
+    """--dinov2: what DINOv2Wrapper / Dinov2Trainer read from the YAML (self_supervised/dinov2/trainer.py:7-80), with the
+    reference-relative inds_path found next to the parameter file."""
+    import os
+    import main
+    path = os.path.join(os.path.dirname(__file__), "params", "tiny_dinov2", "apla.yml")
+    args = main.parse_arguments(["--params_path", path, "--dinov2", "--batch_size", "3"])
+    params = main.update_params_from_args(main.load_parameters(path), args)
+    run = main.resolve_dinov2_run(params, args)
+    assert (run["batch"], run["epochs"], run["lr"], run["wd"], run["eta_min"], run["warmup_epochs"]) == (3, 3, 0.001, 0.04, 1e-6, 1)
+    assert (run["grad_clipping"], run["freeze_last"], run["patch"]) == (3.0, 1, 14) and run["teacher"]["momentum_teacher"] == 0.9
+    assert os.path.isabs(params["model_params"]["adaptation"]["params"]["inds_path"]) and \
+        os.path.exists(params["model_params"]["adaptation"]["params"]["inds_path"])
+    assert main.DINOV2_CROPS["n_local_crops"] == 8 and main.DINOV2_CROPS["local_crops_size"] == 98

@@ -116,3 +116,23 @@ def test_flat_adamw_matches_torch_adamw():
         for n in shapes:
             assert torch.allclose(mine[n].detach(), ref[n].detach(), rtol=2e-5, atol=2e-6), (step, n)
     assert fopt.steps == [4, 4, 2, 4]
+
+
+def test_main_dinov2_entry_point(tmp_path):
+    """python main.py --dinov2 --params_path <pretraining apla.yml>: ViT-S/14 student + teacher, 2 x 224 + 8 x 98 synthetic crops,
+    host collate with iBOT masks, three epochs of two iterations; writes the session file."""
+    import numpy as np
+    import main
+    path = os.path.join(os.path.dirname(__file__), "params", "tiny_dinov2", "apla.yml")
+    args = main.parse_arguments(["--params_path", path, "--dinov2", "--steps_per_epoch", "2", "--save_dir", str(tmp_path)])
+    params = main.update_params_from_args(main.load_parameters(path), args)
+    loss = main.main(params, args)
+    assert np.isfinite(loss)
+    sess = torch.load(tmp_path / "tiny_dinov2.pth", weights_only=False)
+    sd = sess["state_dict"]
+    assert sess["iters"] == 7 and tuple(sd["student.backbone.blocks.0.attn.proj_weight1"].shape) == (64, 384)
+    assert "teacher.dino_head.last_layer.weight_v" in sd and "dino_loss.center" in sd
+    names = sess["optimizer"]["param_names"]
+    last = [i for i, n in enumerate(names) if "last_layer" in n]
+    assert all(float(sess["optimizer"]["state"][i]["step"]) == 4.0 for i in last)        # frozen during the first epoch (2 of 6 steps)
+    assert float(sess["optimizer"]["state"][0]["step"]) == 6.0
