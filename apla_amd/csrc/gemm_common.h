@@ -264,6 +264,11 @@ template <int EPI, typename OutT> struct WideEpi {
 // the epilogue — which starts with all 160 accumulators live — then spills lane constants that the K loop reloads with
 // vmcnt(0) in front of every LDS-DMA.
 __device__ __forceinline__ void gelu8(f32x4 lo, f32x4 hi, bf16x8& h, bf16x8& g) {
+#if defined(APLA_ABL_NOGELU)  // diagnostic build: both outputs are the packed accumulators (store traffic without the VALU work)
+  h = Vec8IO<bf16>::pack(lo, hi);
+  g = h;
+  return;
+#endif
   typedef bf16 bf16x2_t __attribute__((ext_vector_type(2)));
   unsigned hp[4], gp[4];
 #pragma unroll

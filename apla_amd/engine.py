@@ -560,6 +560,21 @@ class AplaTrainEngine:
         self.optimizer_step(lr)
         return self.loss
 
+    @_half_mode
+    def forward_only(self, images, labels=None):
+        """Inference on one batch (the reference's ``model(images, return_embedding=True)`` under no_grad,
+        defaults/trainer.py:207-210, models.py:81-92): the step's own forward launch sequence with the current trainable rows,
+        no backward.  Returns (logits [B, C] fp32, features [B, D] fp32 = the final-norm CLS token, mean CE loss or None);
+        the tensors are the engine's buffers — clone what must outlive the next call."""
+        if images.shape[0] != self.B:
+            raise ValueError(f"this engine was built for batches of {self.B} images (got {images.shape[0]}); pad the last batch")
+        self.images.copy_(images, non_blocking=True)
+        if labels is not None and not self.soft_targets:
+            self.labels.copy_(labels.to(torch.int32), non_blocking=True)
+        self.refresh_weights()
+        self._forward()
+        return self.logits, self.xn, (self.loss if labels is not None and not self.soft_targets else None)
+
     @property
     def grad_norm(self):
         return self.norm_ws[1]

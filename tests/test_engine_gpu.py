@@ -299,3 +299,35 @@ def test_engine_soft_targets_step():
         assert rel_l2(gr.cpu(), grads_ref[n2]) < GRAD_TOL, n
     with pytest.raises(ValueError):
         eng.set_batch(images.cuda(), torch.zeros(B, dtype=torch.long, device="cuda"))
+
+
+def test_forward_only_and_evaluator():
+    """Inference path (defaults/trainer.py:162-243): forward_only gives the training forward's logits / loss without touching
+    the gradients; the Evaluator's loss and accuracy equal what torch computes from those logits; kNN on a bank built from the
+    same images finds each image as its own nearest neighbour."""
+    from apla_amd.engine import AplaTrainEngine, OptimConfig
+    from apla_amd.evaluate import Evaluator
+    model = small_vit(depth=2)
+    B = 4
+    eng = AplaTrainEngine(model, B, 32, optim=OptimConfig(), use_graphs=False)
+    g = torch.Generator().manual_seed(4)
+    batches = [(torch.randn(B, 3, 32, 32, generator=g).cuda(), torch.randint(0, 10, (B,), generator=g).cuda()) for _ in range(3)]
+    eng.set_batch(*batches[0])
+    eng.forward_backward()
+    ref_logits, ref_loss = eng.logits.clone(), eng.loss.clone()
+    grads = eng.flat_grads.clone()
+    logits, feats, loss = eng.forward_only(*batches[0])
+    assert torch.equal(logits, ref_logits) and torch.equal(loss, ref_loss) and torch.equal(eng.flat_grads, grads)
+    assert feats.shape == (B, 128) and feats.dtype == torch.float32
+    ev = Evaluator(eng, n_classes=10, knn_nhood=1)
+    assert ev.build_feature_bank(batches) == 3 * B and ev.feature_bank.shape == (128, 3 * B)
+    out = ev.evaluate(batches, mode="val", knn=True)
+    ls, correct = [], 0
+    for im, lb in batches:
+        lg, _, _ = eng.forward_only(im, lb)
+        ls.append(float(torch.nn.functional.cross_entropy(lg, lb.long())))
+        correct += int((lg.argmax(1) == lb).sum())
+    assert abs(out["val_loss"] - sum(ls) / 3) < 1e-5 and abs(out["val_accuracy"] - correct / (3 * B)) < 1e-9
+    assert out["knn_val_accuracy"] == 1.0        # k = 1 on its own bank: every image votes for its own label
+    with pytest.raises(ValueError):
+        eng.forward_only(batches[0][0][:2])

@@ -245,3 +245,27 @@ def test_main_dinov2_parameter_resolution():
     assert os.path.isabs(params["model_params"]["adaptation"]["params"]["inds_path"]) and \
         os.path.exists(params["model_params"]["adaptation"]["params"]["inds_path"])
     assert main.DINOV2_CROPS["n_local_crops"] == 8 and main.DINOV2_CROPS["local_crops_size"] == 98
+
+
+# ----------------------------------------------------------------------------------------------- kNN evaluation (trainer.py:392-455)
+def test_knn_predict_matches_bruteforce_vote():
+    from apla_amd.evaluate import knn_predict
+    g = torch.Generator().manual_seed(3)
+    B, D, N, C, k, temp = 7, 16, 50, 5, 9, 0.1
+    f = torch.nn.functional.normalize(torch.randn(B, D, generator=g), dim=1)
+    bank = torch.nn.functional.normalize(torch.randn(N, D, generator=g), dim=1).t().contiguous()
+    labels = torch.randint(0, C, (N,), generator=g)
+    got = knn_predict(f, bank, labels, k, temp, C)
+    sim = f @ bank
+    for b in range(B):                                  # the reference's one-hot formulation, sample by sample
+        order = sim[b].argsort(descending=True)[:k]
+        score = torch.zeros(C)
+        for j in order:
+            score[labels[j]] += torch.exp(sim[b, j] / temp)
+        assert torch.allclose(got[b], score / score.sum(), atol=1e-6)
+    multi = (torch.rand(C, N, generator=g) < 0.3).float()
+    got = knn_predict(f, bank, multi, k, temp, C, multi_label=True)
+    for b in range(B):
+        order = sim[b].argsort(descending=True)[:k]
+        w = torch.exp(sim[b, order] / temp)
+        assert torch.allclose(got[b], (multi[:, order] * (w / w.sum())).sum(1), atol=1e-6)

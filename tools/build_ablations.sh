@@ -17,6 +17,7 @@ build() {  # name source "defines"
   echo "built exp/libapla_$1.so"
 }
 build NOSTORE gemm_pp2 "-DAPLA_ABL_NOSTORE"          # ping-pong GEMM epilogue computes but does not store
+build NOGELU gemm_pp2 "-DAPLA_ABL_NOGELU"            # GELU epilogue without the GELU arithmetic (two stores of the accumulators)
 build NOREAD gemm_pp2 "-DAPLA_ABL_NOREAD"            # K loop without LDS fragment reads
 build NODMA gemm_pp2 "-DAPLA_ABL_NODMA"              # K loop without LDS-DMA
 build NOREADNODMA gemm_pp2 "-DAPLA_ABL_NOREAD -DAPLA_ABL_NODMA"   # MFMA + barriers only: the structure's floor
