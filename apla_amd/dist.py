@@ -65,19 +65,22 @@ def backward_order_chunks(offsets: Sequence[int], total: int, n_chunks: int = 2)
 
 
 class GradExchanger:
-    def __init__(self, flat_grads: torch.Tensor, chunks: Sequence[Tuple[int, int]], process_group=None):
+    def __init__(self, flat_grads: torch.Tensor, chunks: Sequence[Tuple[int, int]], process_group=None, always: bool = False):
+        """``always``: issue the collectives even in a group of one process (diagnostic: lets a single-GPU box run the real
+        RCCL calls on the side stream; an all-reduce over one rank leaves the buffer unchanged)."""
         self.flat = flat_grads
         self.chunks = list(chunks)
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_initialized() and (process_group is not None or ddp_is_on())) else 1
-        self._comm = torch.cuda.Stream() if (flat_grads.is_cuda and self.world > 1) else None
+        self.active = self.world > 1 or (always and dist.is_initialized() and process_group is not None)
+        self._comm = torch.cuda.Stream() if (flat_grads.is_cuda and self.active) else None
         covered = sorted(self.chunks)
         assert covered[0][0] == 0 and covered[-1][1] == flat_grads.numel() and all(
             covered[i][1] == covered[i + 1][0] for i in range(len(covered) - 1)), "chunks must tile the flat buffer"
 
     def launch_chunk(self, k: int):
         """Start the all-reduce of chunk k (call right after the backward segment that produced it was enqueued)."""
-        if self.world == 1 or k >= len(self.chunks):
+        if not self.active or k >= len(self.chunks):
             return
         lo, hi = self.chunks[k]
         view = self.flat[lo:hi]

@@ -168,14 +168,17 @@ class AplaTrainEngine:
         # of the flat buffer each, in backward order) while the next segment runs.  Only the last chunk's exchange is exposed,
         # so with world > 1 the backward is cut in four (the exposed chunk is the first quarter of the blocks); a single
         # process keeps two segments (nothing to overlap, fewer graph launches).
-        n_seg = min(4 if self.world > 1 else 2, max(self.L, 1))
+        # APLA_FORCE_EXCHANGE=1 (diagnostic): take the world > 1 path — four segments, collectives on the side stream — in a
+        # process group of ONE rank, so that a single-GPU box exercises the real RCCL calls between the graph replays
+        force = os.environ.get("APLA_FORCE_EXCHANGE") == "1" and self.pg is not None
+        n_seg = min(4 if (self.world > 1 or force) else 2, max(self.L, 1))
         # segment s ends after the backward of block cut[s]; cut[-1] = 0.  e.g. L = 12, four segments: [9, 6, 3, 0]
         self.seg_cuts = [(self.L * (n_seg - 1 - s)) // n_seg for s in range(n_seg)]
         bounds = [self.slices[self.names[2 * c]][0] for c in self.seg_cuts]       # start offset of block cut[s]'s tensors
         his = [n_total] + bounds[:-1]
         self.chunks = [(lo, hi) for lo, hi in zip(bounds, his)]
         assert self.chunks[-1][0] == 0 and all(hi > lo for lo, hi in self.chunks)
-        self.exchanger = GradExchanger(self.flat_grads, self.chunks, self.pg)
+        self.exchanger = GradExchanger(self.flat_grads, self.chunks, self.pg, always=force)
 
     def _grad_view(self, name):
         off, k, shape = self.slices[name]

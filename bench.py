@@ -138,10 +138,15 @@ def main():
         sys.exit("bench.py needs an MI355X (no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
     pg = None
-    if world > 1:
+    force_pg = world == 1 and os.environ.get("APLA_FORCE_EXCHANGE") == "1"   # diagnostic: the N > 1 code path on one rank
+    if world > 1 or force_pg:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if force_pg:
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         pg = dist.group.WORLD
 
     from apla_amd.engine import AplaTrainEngine, OptimConfig
@@ -225,7 +230,7 @@ def main():
                                    "sample": f"{n} full steps of the same model at bs={args.cpu_sample_bs} (fp32 oracle, "
                                              f"{dt_s:.2f} s/step, os.cpu_count()={os.cpu_count()})"}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_pg:
         torch.distributed.destroy_process_group()
 
 
