@@ -1,5 +1,6 @@
 // Shared pieces of the bf16 MFMA GEMM kernels (gemm_nt.hip: 128-wide tiles, gemm_wide.hip: 256-wide tiles).
 #pragma once
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -41,6 +42,10 @@ __device__ __forceinline__ void tile_coords(int t, int tiles_m, int tiles_n, int
 }
 // host: n-tiles per group so that a group's weight slice (bn x K bf16 per tile) stays around 2 MB, groups equalised
 static inline int pick_ngrp(int tiles_n, int bn, int K) {
+  if (const char* e = getenv("APLA_NGRP")) {  // diagnostic override (tools/gemm_bench.py): n-tiles per column group
+    const int v = atoi(e);
+    if (v >= 0) return v >= tiles_n ? 0 : v;
+  }
   const long tile_bytes = (long)bn * K * 2;
   if ((long)tiles_n * tile_bytes <= (5L << 19)) return 0;  // <= 2.5 MB: plain walk
   long per = (2L << 20) / tile_bytes;
