@@ -57,9 +57,9 @@ class APLA_Attention(nn.Module):
         o, lse = AF.attention_core(qkv, B, N, self.num_heads, self.scale)
         return qkv, o, lse
 
-    def _project(self, o):
+    def _project(self, o, gamma=None):
         return AF.apla_projection(o, self.proj_weight1, self.proj_bias1, self.proj_weight2, self.proj_bias2,
-                                  self.inds, self._proj_state)
+                                  self.inds, self._proj_state, gamma)
 
     def forward(self, x):
         AF.require_no_dropout(self.attn_drop, self.training), AF.require_no_dropout(self.proj_drop, self.training)

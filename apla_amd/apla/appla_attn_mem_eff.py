@@ -15,8 +15,12 @@ from ..nested import BlockDiagonalMask
 
 
 class APLA_MemEffAttention(APLA_Attention):
-    def forward(self, x, attn_bias=None):
+    def forward(self, x, attn_bias=None, ls_gamma=None):
+        """``ls_gamma`` (extension): the block's frozen LayerScale vector; when given the result is ls1(attention(x)), the
+        scale being folded into the projection GEMM (apla_amd/ssl/backbone.py uses it on the packed path)."""
         if attn_bias is None:
+            if ls_gamma is not None:
+                raise NotImplementedError("ls_gamma is implemented for the packed (attn_bias) path")
             y, _ = super().forward(x)
             return y
         if not isinstance(attn_bias, BlockDiagonalMask):
@@ -27,4 +31,4 @@ class APLA_MemEffAttention(APLA_Attention):
             raise ValueError(f"a packed batch must be [1, {attn_bias.total}, C]; got {tuple(x.shape)}")
         qkv = AF.linear(x, self.qkv.weight, self.qkv.bias)
         o = AF.attention_core_varlen(qkv, attn_bias.cu_seqlens(x.device), attn_bias.max_seqlen, self.num_heads, self.scale)
-        return self._project(o).to(x.dtype)
+        return self._project(o, ls_gamma).to(x.dtype)

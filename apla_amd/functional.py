@@ -98,6 +98,42 @@ def layer_norm(x, norm_module):
     return _LayerNormFn.apply(x, norm_module.weight, norm_module.bias, norm_module.eps)
 
 
+class _AddLayerNormFn(torch.autograd.Function):
+    """(x_new, y) = (x + branch, LayerNorm(x + branch)) in ONE pass over the residual stream (the residual update of
+    vit.py:284-285 fused into the following norm, as the fused engine does), and in backward ONE pass that adds the residual
+    gradient to the LayerNorm input gradient: d(x) = d(branch) = d(x_new) + LN_bwd(dy)."""
+
+    @staticmethod
+    def forward(ctx, x, branch, weight, bias, eps):
+        _require_cuda(x, "add_layer_norm")
+        if weight.requires_grad or bias.requires_grad:
+            raise NotImplementedError("trainable LayerNorm affine is outside the APLA path (all norms are frozen)")
+        x2 = x.reshape(-1, x.shape[-1])
+        x2 = (x2 if x2.dtype in (torch.float32, _BF) else x2.float()).contiguous()
+        b2 = _as2d_bf16(branch)
+        x_new = torch.empty_like(x2)
+        y, mean, rstd = ops.layernorm_fwd(x2, b_f32(weight), b_f32(bias), eps, add=b2, x_out=x_new)
+        ctx.save_for_backward(x_new, mean, rstd, weight)
+        ctx.shape, ctx.bdtype = x.shape, branch.dtype
+        return x_new.reshape(x.shape), y.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dx_new, dy):
+        x_new, mean, rstd, weight = ctx.saved_tensors
+        if dy is None:
+            d = dx_new.reshape(x_new.shape)
+        else:
+            dres = None if dx_new is None else dx_new.reshape(x_new.shape).to(x_new.dtype).contiguous()
+            d, _ = ops.layernorm_bwd(_as2d_bf16(dy), x_new, b_f32(weight), mean, rstd, dres=dres)
+        d = d.reshape(ctx.shape)
+        return d, d.to(ctx.bdtype), None, None, None
+
+
+def add_layer_norm(x, branch, norm_module):
+    """Returns (x + branch [dtype of x], LayerNorm(x + branch) [bf16])."""
+    return _AddLayerNormFn.apply(x, branch, norm_module.weight, norm_module.bias, norm_module.eps)
+
+
 # ------------------------------------------------------------------------------------------------ Linear
 class _LinearFn(torch.autograd.Function):
     """y = x W^T + b through apla_gemm_nt.  dX through the transposed copy; dW/db (full-rank, only for the
@@ -206,22 +242,30 @@ class AplaProjState:
         self.key = None
         self.Wnat = self.WnatT = self.bnat = self.inds32 = None
 
-    def refresh(self, W1, b1, W2, b2, inds):
+    def refresh(self, W1, b1, W2, b2, inds, gamma=None):
+        """``gamma``: a frozen LayerScale vector folded into the merged weight and bias (y = gamma * (o W^T + b))."""
         D = W1.shape[1]
         r = W1.shape[0]
-        key = (W2.data_ptr(), W2._version, b2._version, inds._version, str(W1.device), r, D)
+        key = (W2.data_ptr(), W2._version, b2._version, inds._version, str(W1.device), r, D,
+               None if gamma is None else (gamma.data_ptr(), gamma._version))
         if key != self.key:
             idx = inds.to(W1.device).long()
             Wn = torch.zeros(D, D, device=W1.device, dtype=torch.float32)
             Wn[idx[r:]] = W2.detach().float()
             bn = torch.zeros(D, device=W1.device, dtype=torch.float32)
             bn[idx[r:]] = b2.detach().float()
+            self.gamma = None
+            if gamma is not None:
+                self.gamma = gamma.detach().float().contiguous()
+                Wn *= self.gamma[:, None]
+                bn *= self.gamma
+                self.gamma_r = self.gamma[idx[:(r + 63) // 64 * 64]].contiguous()   # row scales of the dW step (padded rank)
             self.Wnat = Wn.to(_BF)
             self.WnatT = Wn.t().contiguous().to(_BF)
             self.bnat = bn
             self.inds32 = idx.int().contiguous()
             self.key = key
-        ops.pack_proj_rows(W1.detach().float().contiguous(), b1.detach().float().contiguous(), self.inds32, None,
+        ops.pack_proj_rows(W1.detach().float().contiguous(), b1.detach().float().contiguous(), self.inds32, self.gamma,
                            self.Wnat, self.WnatT, self.bnat)
 
 
@@ -249,43 +293,61 @@ class _AplaProjFn(torch.autograd.Function):
         dyg = ops.gather_cols(dy2, st.inds32, r_pad)
         dW1 = torch.empty(r_pad, D, device=dy.device, dtype=torch.float32)
         db1 = torch.empty(r_pad, device=dy.device, dtype=torch.float32)
-        ops.proj_dw(dyg, o2, dW1, db1)
+        ops.proj_dw(dyg, o2, dW1, db1, row_scale=st.gamma_r if st.gamma is not None else None)
         return do, dW1[:r].to(W1.dtype), db1[:r].to(b1.dtype), None
 
 
-def apla_projection(o, W1, b1, W2, b2, inds, state: AplaProjState):
+def apla_projection(o, W1, b1, W2, b2, inds, state: AplaProjState, gamma=None):
+    """``gamma`` (optional, frozen): the block's LayerScale vector, folded into the projection (ls1(proj(o)) in one GEMM)."""
     if W1.shape[1] % 128 != 0:
         raise NotImplementedError(f"APLA HIP projection needs dim % 128 == 0 (got dim={W1.shape[1]})")
+    if gamma is not None and gamma.requires_grad:
+        raise NotImplementedError("a trainable LayerScale cannot be folded into the projection")
     with torch.no_grad():
-        state.refresh(W1, b1, W2, b2, inds)
+        state.refresh(W1, b1, W2, b2, inds, gamma)
     return _AplaProjFn.apply(o, W1, b1, state)
 
 
 # ------------------------------------------------------------------------------------------------ MLPs
+def _scaled_w(w, gamma):      # gamma[:, None] * w  as bf16 (frozen LayerScale folded into the producing Linear)
+    return CACHE.get(w, f"bf16_g{id(gamma)}_{gamma._version}", lambda: (w.detach().float() * gamma.detach().float()[:, None]).to(_BF).contiguous())
+
+
+def _scaled_w_t(w, gamma):
+    return CACHE.get(w, f"bf16_gt{id(gamma)}_{gamma._version}",
+                     lambda: (w.detach().float() * gamma.detach().float()[:, None]).t().to(_BF).contiguous())
+
+
+def _scaled_b(b, gamma):
+    return None if b is None else CACHE.get(b, f"f32_g{id(gamma)}_{gamma._version}", lambda: (b.detach().float() * gamma.detach().float()).contiguous())
+
+
 class _MlpGeluFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2):
+    def forward(ctx, x, w1, b1, w2, b2, gamma):
         _require_cuda(x, "mlp")
         x2 = _as2d_bf16(x)
         gp = torch.empty(x2.shape[0], w1.shape[0], device=x.device, dtype=_BF)
         h = ops.gemm_nt(x2, w_bf16(w1), b_f32(b1), epilogue=ops.EPI_GELU, aux_out=gp)
-        y = ops.gemm_nt(h, w_bf16(w2), b_f32(b2))
-        ctx.save_for_backward(gp, w1, w2)
-        ctx.shape = x.shape
+        y = ops.gemm_nt(h, w_bf16(w2), b_f32(b2)) if gamma is None else ops.gemm_nt(h, _scaled_w(w2, gamma), _scaled_b(b2, gamma))
+        ctx.save_for_backward(gp, w1, w2, gamma if gamma is not None else torch.empty(0))
+        ctx.shape, ctx.has_gamma = x.shape, gamma is not None
         return y.reshape(x.shape[:-1] + (w2.shape[0],))
 
     @staticmethod
     def backward(ctx, dy):
-        gp, w1, w2 = ctx.saved_tensors
-        if w1.requires_grad or w2.requires_grad:
-            raise NotImplementedError("trainable MLP weights are outside the APLA path")
-        da = ops.gemm_nt(_as2d_bf16(dy), w_bf16_t(w2), epilogue=ops.EPI_MUL, aux_in=gp)
+        gp, w1, w2, gamma = ctx.saved_tensors
+        if w1.requires_grad or w2.requires_grad or (ctx.has_gamma and gamma.requires_grad):
+            raise NotImplementedError("trainable MLP weights / LayerScale are outside the APLA path")
+        w2t = _scaled_w_t(w2, gamma) if ctx.has_gamma else w_bf16_t(w2)
+        da = ops.gemm_nt(_as2d_bf16(dy), w2t, epilogue=ops.EPI_MUL, aux_in=gp)
         dx = ops.gemm_nt(da, w_bf16_t(w1))
-        return dx.reshape(ctx.shape), None, None, None, None
+        return dx.reshape(ctx.shape), None, None, None, None, None
 
 
-def mlp_gelu(x, w1, b1, w2, b2):
-    return _MlpGeluFn.apply(x, w1, b1, w2, b2).to(x.dtype)
+def mlp_gelu(x, w1, b1, w2, b2, gamma=None):
+    """fc2(GELU(fc1(x))); with ``gamma`` (a frozen LayerScale vector) the scale is folded into fc2: ls2(mlp(x))."""
+    return _MlpGeluFn.apply(x, w1, b1, w2, b2, gamma).to(x.dtype)
 
 
 def _interleave_rows(w):
