@@ -61,11 +61,13 @@ class APLA_Attention(nn.Module):
         return AF.apla_projection(o, self.proj_weight1, self.proj_bias1, self.proj_weight2, self.proj_bias2,
                                   self.inds, self._proj_state, gamma)
 
-    def forward(self, x):
+    def forward(self, x, ls_gamma=None):
+        """``ls_gamma`` (extension, used by VisionTransformer.run_blocks): the block's frozen LayerScale vector; when given,
+        x is ls1(attention(x)) with the scale folded into the projection GEMM."""
         AF.require_no_dropout(self.attn_drop, self.training), AF.require_no_dropout(self.proj_drop, self.training)
         B, N, _ = x.shape
         qkv, o, lse = self._attend(x)
-        y = self._project(o).to(x.dtype)
+        y = self._project(o, ls_gamma).to(x.dtype)
         attn = None
         if self.return_attn_matrix:
             attn = ops.attn_probs(qkv.detach().reshape(B * N, -1), lse, B, N, self.num_heads, self.scale)

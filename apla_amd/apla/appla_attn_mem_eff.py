@@ -19,9 +19,7 @@ class APLA_MemEffAttention(APLA_Attention):
         """``ls_gamma`` (extension): the block's frozen LayerScale vector; when given the result is ls1(attention(x)), the
         scale being folded into the projection GEMM (apla_amd/ssl/backbone.py uses it on the packed path)."""
         if attn_bias is None:
-            if ls_gamma is not None:
-                raise NotImplementedError("ls_gamma is implemented for the packed (attn_bias) path")
-            y, _ = super().forward(x)
+            y, _ = super().forward(x, ls_gamma)
             return y
         if not isinstance(attn_bias, BlockDiagonalMask):
             raise TypeError("attn_bias must be an apla_amd.nested.BlockDiagonalMask (the xformers mask class the reference "

@@ -16,7 +16,7 @@ from torch import nn
 from .. import functional as AF
 from ..apla.appla_attn_mem_eff import APLA_MemEffAttention
 from ..nested import BlockDiagonalMask
-from ..vit import Attention, Mlp, VisionTransformer
+from ..vit import Attention, VisionTransformer
 
 
 class MemEffAttention(Attention):
@@ -78,37 +78,13 @@ class DinoVisionTransformer(VisionTransformer):
         x = torch.cat((self.cls_token.expand(x.shape[0], -1, -1).to(x.dtype), x), dim=1)
         return x + self.interpolate_pos_encoding(x.shape[1] - 1).to(x.dtype)
 
-    def _run_blocks_packed(self, x, attn_bias):
-        """All blocks on the packed [1, total, D] tensor (block.py:254-288: x += ls1(attn(norm1 x)); x += ls2(mlp(norm2 x))) and
-        the final norm.  The residual stream is kept in fp32 and every residual add is fused into the LayerNorm that follows
-        it (AF.add_layer_norm: one pass forward, one pass backward); frozen LayerScale vectors are folded into the GEMM that
-        produces the branch (APLA projection / fc2).  Returns (x_prenorm fp32, x_norm bf16)."""
-        res, branch = x.float(), None
-        for blk in self.blocks:
-            if not isinstance(blk.attn, (APLA_MemEffAttention, MemEffAttention)):   # block.py:249
-                raise NotImplementedError("the packed forward needs (APLA_)MemEffAttention blocks (build_apla(..., 'apla_attn_mem_eff'))")
-            if branch is None:
-                h = AF.layer_norm(res, blk.norm1)
-            else:
-                res, h = AF.add_layer_norm(res, branch, blk.norm1)
-            g1 = blk.ls1.gamma if hasattr(blk.ls1, "gamma") else None
-            g2 = blk.ls2.gamma if hasattr(blk.ls2, "gamma") else None
-            if isinstance(blk.attn, APLA_MemEffAttention) and (g1 is None or not g1.requires_grad):
-                y = blk.attn(h, attn_bias=attn_bias, ls_gamma=g1)
-            else:
-                y = blk.ls1(blk.attn(h, attn_bias=attn_bias))
-            res, h = AF.add_layer_norm(res, y, blk.norm2)
-            if isinstance(blk.mlp, Mlp) and (g2 is None or not g2.requires_grad):
-                AF.require_no_dropout(blk.mlp.drop, self.training)
-                branch = AF.mlp_gelu(h, blk.mlp.fc1.weight, blk.mlp.fc1.bias, blk.mlp.fc2.weight, blk.mlp.fc2.bias, gamma=g2)
-            else:
-                branch = blk.ls2(blk.mlp(h))
-        return AF.add_layer_norm(res, branch, self.norm)
-
     def forward_features_list(self, x_list: List[torch.Tensor], masks_list: List[Optional[torch.Tensor]]):
         toks = [self.prepare_tokens_with_masks(x, m) for x, m in zip(x_list, masks_list)]
         attn_bias, x = BlockDiagonalMask.from_tensor_list(toks)
-        x_pre, x_nrm = self._run_blocks_packed(x, attn_bias)     # LayerNorm is token-wise: normalise packed, split afterwards
+        for blk in self.blocks:
+            if not isinstance(blk.attn, (APLA_MemEffAttention, MemEffAttention)):   # block.py:249
+                raise NotImplementedError("the packed forward needs (APLA_)MemEffAttention blocks (build_apla(..., 'apla_attn_mem_eff'))")
+        x_pre, x_nrm = self.run_blocks(x, attn_bias)     # LayerNorm is token-wise: normalise packed, split afterwards
         outs = []
         for xi, x_norm, masks in zip(attn_bias.split(x_pre), attn_bias.split(x_nrm), masks_list):
             outs.append({"x_norm_clstoken": x_norm[:, 0], "x_norm_regtokens": x_norm[:, 1:1], "x_norm_patchtokens": x_norm[:, 1:],

@@ -197,15 +197,42 @@ class VisionTransformer(nn.Module):
                                          recompute_scale_factor=False)
         return torch.cat((pe[:, :1], grid.permute(0, 2, 3, 1).reshape(1, -1, dim)), dim=1)
 
+    def run_blocks(self, x, attn_bias=None):
+        """All blocks + the final norm on a token tensor ([B, N, D], or packed [1, total, D] with a BlockDiagonalMask):
+        x += ls1(attn(norm1 x)); x += ls2(mlp(norm2 x)) (vit.py:279-288).  The residual stream is kept in fp32, every residual
+        add is fused into the LayerNorm that follows it (AF.add_layer_norm: one pass forward, one pass backward) and frozen
+        LayerScale vectors are folded into the GEMM that produces the branch (APLA projection / fc2) — what the fused engine
+        does, here for the autograd path.  Blocks whose attention / MLP are not the modules of this package, or whose
+        LayerScale is trainable, go through their own forward.  Returns (x_prenorm fp32, x_norm bf16)."""
+        res, branch = x.float(), None
+        for blk in self.blocks:
+            if branch is None:
+                h = AF.layer_norm(res, blk.norm1)
+            else:
+                res, h = AF.add_layer_norm(res, branch, blk.norm1)
+            g1, g2 = getattr(blk.ls1, "gamma", None), getattr(blk.ls2, "gamma", None)
+            kw = {} if attn_bias is None else {"attn_bias": attn_bias}
+            if hasattr(blk.attn, "_project") and (g1 is None or not g1.requires_grad):   # APLA attention: scale folded into the projection
+                y = blk.attn(h, ls_gamma=g1, **kw)
+                y = y[0] if isinstance(y, tuple) else y
+            else:
+                y = blk.attn(h, **kw)
+                y = blk.ls1(y[0] if isinstance(y, tuple) else y)
+            res, h = AF.add_layer_norm(res, y, blk.norm2)
+            if isinstance(blk.mlp, Mlp) and (g2 is None or not g2.requires_grad):
+                AF.require_no_dropout(blk.mlp.drop, self.training)
+                branch = AF.mlp_gelu(h, blk.mlp.fc1.weight, blk.mlp.fc1.bias, blk.mlp.fc2.weight, blk.mlp.fc2.bias, gamma=g2)
+            else:
+                branch = blk.ls2(blk.mlp(h))
+        return AF.add_layer_norm(res, branch, self.norm)
+
     def forward_features(self, x):
         x = self.patch_embed(x)
         B = x.shape[0]
         x = torch.cat((self.cls_token.expand(B, -1, -1).to(x.dtype), x), dim=1)
         x = x + self.interpolate_pos_encoding(x.shape[1] - 1).to(x.dtype)
         AF.require_no_dropout(self.pos_drop, self.training)
-        for blk in self.blocks:
-            x = blk(x)
-        x = AF.layer_norm(x, self.norm)
+        _, x = self.run_blocks(x)
         return x[:, 0]
 
     def forward(self, x):
