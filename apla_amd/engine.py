@@ -167,14 +167,18 @@ class AplaTrainEngine:
         self.names = [n for n, _ in named]
         # The backward is cut into segments at block boundaries; the gradients a segment produced are all-reduced (one chunk
         # of the flat buffer each, in backward order) while the next segment runs.  Only the last chunk's exchange is exposed,
-        # so with world > 1 the backward is cut in four (the exposed chunk is the first quarter of the blocks); a single
+        # so with world > 1 the backward is cut in four (the exposed chunk is block 0 alone); a single
         # process keeps two segments (nothing to overlap, fewer graph launches).
         # APLA_FORCE_EXCHANGE=1 (diagnostic): take the world > 1 path — four segments, collectives on the side stream — in a
         # process group of ONE rank, so that a single-GPU box exercises the real RCCL calls between the graph replays
         force = os.environ.get("APLA_FORCE_EXCHANGE") == "1" and self.pg is not None
         n_seg = min(4 if (self.world > 1 or force) else 2, max(self.L, 1))
-        # segment s ends after the backward of block cut[s]; cut[-1] = 0.  e.g. L = 12, four segments: [9, 6, 3, 0]
+        # segment s ends after the backward of block cut[s]; cut[-1] = 0.  e.g. L = 12, two segments: [6, 0]
         self.seg_cuts = [(self.L * (n_seg - 1 - s)) // n_seg for s in range(n_seg)]
+        if n_seg == 4 and self.L >= 8:
+            # exchanging: the LAST chunk is the one nothing overlaps, so it is made as small as possible — block 0 alone (its
+            # backward is also the shortest: no attention part) — and the other three share the rest: L = 12 -> [8, 4, 1, 0]
+            self.seg_cuts = [2 * self.L // 3, self.L // 3, 1, 0]
         bounds = [self.slices[self.names[2 * c]][0] for c in self.seg_cuts]       # start offset of block cut[s]'s tensors
         his = [n_total] + bounds[:-1]
         self.chunks = [(lo, hi) for lo, hi in zip(bounds, his)]

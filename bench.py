@@ -187,6 +187,11 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     img_s = world * args.batch * args.steps / elapsed
     peak_mem = torch.cuda.max_memory_allocated() / 2 ** 30
+    # dominant-kernel duration in its place inside the step: HIP events around every fc1+GELU launch of three further training
+    # steps (what a rocprofv3 kernel trace of this run shows for the kernel; profiles/*_kernel_stats.md).  Every rank runs
+    # these steps — they contain the gradient collectives.
+    k_ms = eng.time_fc1_launches(3)
+    sync()
 
     if rank == 0:
         bb = model.backbone
@@ -194,9 +199,6 @@ def main():
         from apla_amd import ops as _ops
         with _ops.use_half(hdt):
             iso_ms, _ = time_dominant_kernel(M, bb.embed_dim, eng.blocks[0].F, hdt)    # back-to-back launches of the same GEMM
-        # the figure that counts: HIP events around every fc1+GELU launch inside three further training steps (what a
-        # rocprofv3 kernel trace of this run shows for the kernel; profiles/*_kernel_stats.md)
-        k_ms = eng.time_fc1_launches(3)
         Fdim = eng.blocks[0].F * (2 if eng.swiglu else 1)
         k_tf = 2.0 * M * bb.embed_dim * Fdim / (k_ms * 1e-3) / 1e12
         is_cfg2 = (args.backbone, img, patch, args.batch, args.partial_size) == ("vit_base", 224, 16, 128, 192)
