@@ -98,3 +98,51 @@ def test_mem_eff_attention_rejects_foreign_bias():
     m = make_module(APLA_MemEffAttention, 128, 2, 64, seed=9).cuda()
     with pytest.raises(TypeError):
         m(torch.zeros(1, 10, 128, device="cuda"), attn_bias=torch.zeros(10, 10))
+
+
+def test_fused_block_loop_equals_block_by_block():
+    """VisionTransformer.run_blocks (fp32 residual stream, residual adds fused into the following LayerNorm, frozen
+    LayerScale folded into the APLA projection / fc2) against the plain composition of the same modules block by block
+    (x + ls1(attn(norm1 x)); x + ls2(mlp(norm2 x)), vit.py:279-288 — the path the goldens G4/G5 pin through the oracle),
+    with LayerScale != 1: outputs, input gradient and the APLA gradients (incl. the gamma row scales of dW1/db1)."""
+    from functools import partial
+    from apla_amd import functional as AF
+    from apla_amd.apla import build_apla
+    from apla_amd.models import AttrDict
+    from apla_amd.vit import VisionTransformer
+    torch.manual_seed(11)
+    bb = VisionTransformer(img_size=[32], patch_size=16, embed_dim=128, depth=3, num_heads=2, qkv_bias=True,
+                           norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), block_conf=dict(has_layerscale=True, layerscale_init_values=1.0))
+    with torch.no_grad():
+        for n, p in bb.named_parameters():
+            if n.endswith("gamma"):
+                p.uniform_(0.5, 1.5)
+            elif p.ndim >= 2 and "pos_embed" not in n and "token" not in n:
+                p.normal_(std=0.06)
+            elif p.ndim == 1:
+                p.normal_(std=0.1) if n.endswith("bias") else p.uniform_(0.8, 1.2)
+    build_apla(AttrDict(partial_size=40), bb, "apla_attn")     # a rank that is not a multiple of 64: padded dW rows + row scales
+    bb = bb.cuda()
+    x = torch.randn(3, 21, 128, generator=torch.Generator().manual_seed(12)).cuda()
+
+    def plain(xin):
+        h = xin.float()
+        for blk in bb.blocks:
+            h = h + blk.ls1(blk.attn(AF.layer_norm(h, blk.norm1))[0]).float()
+            h = h + blk.ls2(blk.mlp(AF.layer_norm(h, blk.norm2))).float()
+        return h, AF.layer_norm(h, bb.norm)
+
+    outs = {}
+    for name, fn in (("fused", bb.run_blocks), ("plain", plain)):
+        xg = x.clone().requires_grad_(True)
+        pre, nrm = fn(xg)
+        (nrm.float().square().mean() + 0.1 * pre.float().square().mean()).backward()
+        outs[name] = (pre.detach(), nrm.detach(), xg.grad.clone(),
+                      {n: p.grad.clone() for n, p in bb.named_parameters() if p.grad is not None})
+        bb.zero_grad()
+    f, p = outs["fused"], outs["plain"]
+    assert rel_err(f[0].cpu(), p[0].double().cpu()) < 5e-3 and rel_err(f[1].float().cpu(), p[1].double().cpu()) < 1e-2
+    assert rel_err(f[2].cpu(), p[2].double().cpu()) < GRAD_TOL
+    assert set(f[3]) == set(p[3]) and len(f[3]) == 6
+    for n in f[3]:
+        assert rel_err(f[3][n].cpu(), p[3][n].double().cpu()) < GRAD_TOL, n
