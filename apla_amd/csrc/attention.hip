@@ -75,6 +75,34 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* lds, int rbase, int c0, in
   return out;
 }
 
+// The same fragment by inline asm, waited for by hand.  Next to in-flight LDS-DMA (global_load_lds) hipcc puts
+// s_waitcnt vmcnt(0) in front of every ds_read_tr builtin it can see: in the key/query-blocked backward kernels that drained
+// the NEXT tile's DMA in the middle of the current tile's products (no overlap of loading and computing at all).  The asm
+// form is invisible to that pass: issue with tr_issue, then lds_landed() once per batch, which also pins the registers
+// behind the wait so that no consumer is scheduled above it.
+struct TrPair { bf16x4 lo, hi; };
+__device__ __forceinline__ void tr_issue(TrPair& f, const char* lds, int rbase, int c0, int lane) {
+  const int g = lane >> 4, i = lane & 15;
+  const int col = c0 + 16 * (g & 1) + 4 * (i & 3);
+  const int r = rbase + 4 * (g >> 1) + (i >> 2);
+  const unsigned a0 = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(lds + tile_off(r, col >> 3) + ((col & 4) << 1));
+  const unsigned a1 = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(lds + tile_off(r + 8, col >> 3) + ((col & 4) << 1));
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.lo) : "v"(a0));
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.hi) : "v"(a1));
+}
+template <int N>
+__device__ __forceinline__ void lds_landed(TrPair (&f)[N]) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < N; ++i) asm volatile("" : "+v"(f[i].lo), "+v"(f[i].hi));
+}
+__device__ __forceinline__ bf16x8 tr_join(const TrPair& f) {
+  bf16x8 out;
+  out[0] = f.lo[0]; out[1] = f.lo[1]; out[2] = f.lo[2]; out[3] = f.lo[3];
+  out[4] = f.hi[0]; out[5] = f.hi[1]; out[6] = f.hi[2]; out[7] = f.hi[3];
+  return out;
+}
+
 __device__ __forceinline__ bf16x8 acc_to_operand(const f32x16& a, int s) {
   bf16x8 o;
 #pragma unroll
@@ -417,6 +445,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restr
         s = MFMA_F32_32x32x16_H16(row_frag(Ks, kt * 32, ks, lane), qf[ks], s);
         dp = MFMA_F32_32x32x16_H16(row_frag(Vs, kt * 32, ks, lane), dof[ks], dp);
       }
+      // K^T fragments [sk][dt] of the dQ product (hand-waited asm reads: see tr_issue), issued BEFORE the softmax arithmetic so
+      // that they land behind it
+      TrPair kt_[4];
+#pragma unroll
+      for (int sk = 0; sk < 2; ++sk)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) tr_issue(kt_[2 * sk + dt], Ks, kt * 32 + 16 * sk, 32 * dt, lane);
       // dS^T (unscaled).  Only the sequence's last key tile needs the per-key mask: as one predicated loop hipcc emits the
       // compare/select pair for every element of every tile (45 % of this kernel's VALU instructions).
       if (kb * 64 + kt * 32 + 32 <= N) {
@@ -430,12 +465,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restr
           s[i] = p * (dp[i] - dl);
         }
       }
+      lds_landed(kt_);
 #pragma unroll
       for (int sk = 0; sk < 2; ++sk) {
         const bf16x8 dsb = acc_to_operand(s, sk);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
-          acc_dq[dt] = MFMA_F32_32x32x16_H16(tr_frag(Ks, kt * 32 + 16 * sk, 32 * dt, lane), dsb, acc_dq[dt]);
+          acc_dq[dt] = MFMA_F32_32x32x16_H16(tr_join(kt_[2 * sk + dt]), dsb, acc_dq[dt]);
       }
     }
   }
@@ -493,31 +529,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __rest
       const bf16* src = isd ? dobase + (long)gr * D + ch * 8 : base + (long)gr * ld + ch * 8;
       __builtin_amdgcn_global_load_lds(ATT_GLBP(src), ATT_LDSP(buf + (isd ? 8192 : 0) + pr * 1024), 16, 0, 0);
     }
+    {  // lse and delta of the 64 query rows: one 4-byte LDS-DMA per wave (lane-linear), no registers carried across the loop.
+       // Branch-free on purpose (even waves fetch lse, odd waves delta, twice each): a conditional block here is sunk by hipcc
+       // to the end of the iteration, right in front of the wait that needs it.
+      int qq = qb * 64 + lane;
+      qq = qq < N ? qq : N - 1;
+      const int which = wave_u & 1;
+      const float* sp = (which ? dlbase : lsebase) + qq;
+      __builtin_amdgcn_global_load_lds(ATT_GLBP(sp), ATT_LDSP(smem + 2 * 16384 + (qb & 1) * 512 + which * 256), 4, 0, 0);
+    }
   };
-  auto stat = [&](int qb, float& l, float& d) {
-    int qq = qb * 64 + tid;
-    qq = qq < N ? qq : N - 1;
-    l = lsebase[qq] * LOG2E;
-    d = dlbase[qq];
-  };
-  float* stats = (float*)(smem + 2 * 16384);  // [2 buffers][lse 64 | delta 64]
-  float lreg = 0.f, dreg = 0.f;
+  const float* stats = (const float*)(smem + 2 * 16384);  // [2 buffers][lse 64 | delta 64]
   issue(0);
-  if (tid < 64) {
-    stat(0, lreg, dreg);
-    stats[tid] = lreg; stats[64 + tid] = dreg;
-    if (nqb > 1) stat(1, lreg, dreg);
-  }
   for (int qb = 0; qb < nqb; ++qb) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // tile qb (and its lse/delta) is in LDS; every wave is done with tile qb-1
-    if (qb + 1 < nqb) {
-      issue(qb + 1);
-      if (tid < 64) {
-        stats[((qb + 1) & 1) * 128 + tid] = lreg; stats[((qb + 1) & 1) * 128 + 64 + tid] = dreg;
-        if (qb + 2 < nqb) stat(qb + 2, lreg, dreg);
-      }
-    }
+    if (qb + 1 < nqb) issue(qb + 1);
     const char* Qs = smem + (qb & 1) * 16384;
     const char* dOs = Qs + 8192;
     const float* lses = stats + (qb & 1) * 128;
@@ -534,12 +561,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __rest
         s = MFMA_F32_32x32x16_H16(row_frag(Qs, qt * 32, ks, lane), kf[ks], s);
         dp = MFMA_F32_32x32x16_H16(row_frag(dOs, qt * 32, ks, lane), vf[ks], dp);
       }
+      // dO^T [sk][dt] and Q^T [sk][dt] of the dV / dK products (hand-waited asm reads: see tr_issue), issued BEFORE the softmax
+      // arithmetic so that they land behind it
+      TrPair tf[8];
+#pragma unroll
+      for (int sk = 0; sk < 2; ++sk)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          tr_issue(tf[4 * sk + dt], dOs, qt * 32 + 16 * sk, 32 * dt, lane);
+          tr_issue(tf[4 * sk + 2 + dt], Qs, qt * 32 + 16 * sk, 32 * dt, lane);
+        }
       // P and dS (in place of dP).  Only the sequence's last query tile needs the per-row mask (see the dQ kernel).
       if (qb * 64 + qt * 32 + 32 <= N) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int r0 = qt * 32 + 8 * g + 4 * h2;
-          const f32x4 l4 = *(const f32x4*)(lses + r0), d4 = *(const f32x4*)(dls + r0);
+          const f32x4 l4 = *(const f32x4*)(lses + r0) * LOG2E, d4 = *(const f32x4*)(dls + r0);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int i = 4 * g + e;
@@ -552,7 +589,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __rest
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int r0 = qt * 32 + 8 * g + 4 * h2;
-          const f32x4 l4 = *(const f32x4*)(lses + r0), d4 = *(const f32x4*)(dls + r0);
+          const f32x4 l4 = *(const f32x4*)(lses + r0) * LOG2E, d4 = *(const f32x4*)(dls + r0);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int i = 4 * g + e;
@@ -563,13 +600,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __rest
           }
         }
       }
+      lds_landed(tf);
 #pragma unroll
       for (int sk = 0; sk < 2; ++sk) {
         const bf16x8 pb = acc_to_operand(s, sk), dsb = acc_to_operand(dp, sk);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
-          acc_dv[dt] = MFMA_F32_32x32x16_H16(tr_frag(dOs, qt * 32 + 16 * sk, 32 * dt, lane), pb, acc_dv[dt]);
-          acc_dk[dt] = MFMA_F32_32x32x16_H16(tr_frag(Qs, qt * 32 + 16 * sk, 32 * dt, lane), dsb, acc_dk[dt]);
+          acc_dv[dt] = MFMA_F32_32x32x16_H16(tr_join(tf[4 * sk + dt]), pb, acc_dv[dt]);
+          acc_dk[dt] = MFMA_F32_32x32x16_H16(tr_join(tf[4 * sk + 2 + dt]), dsb, acc_dk[dt]);
         }
       }
     }
