@@ -10,7 +10,7 @@ rm -rf $O && mkdir -p $O
 python -m pytest tests -m gpu -q -p no:cacheprovider > $O/pytest_gpu.txt 2>&1; tail -3 $O/pytest_gpu.txt
 python bench.py --steps 30 --warmup 5 > $O/bench.json 2> $O/bench.err; tail -c 1500 $O/bench.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline > $O/trace_bench.log 2>&1
-python3 tools/summarize_prof.py $(find $O/trace -name "*kernel_stats.csv") 11 > $O/kernel_stats.md
+python3 tools/summarize_prof.py $(find $O/trace -name "*kernel_stats.csv") 14 > $O/kernel_stats.md
 cp $(find $O/trace -name "*kernel_stats.csv") $O/kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -- python3 tools/gemm_one.py 3072 768 1 4 6 > /dev/null 2>&1
