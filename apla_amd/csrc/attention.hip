@@ -20,6 +20,11 @@
 
 namespace {
 
+#if defined(APLA_ABL_ATT_NOEXP)   // diagnostic build: no transcendental in the backward softmax recompute
+#define ATT_EXP2(x) (x)
+#else
+#define ATT_EXP2(x) __builtin_amdgcn_exp2f(x)
+#endif
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 
@@ -438,6 +443,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restr
     for (int kt = 0; kt < 2; ++kt) {
       if (kt == 1 && kb * 64 + 32 >= N) continue;  // fully masked key tile
       const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#if defined(APLA_ABL_ATT_NOS)   // diagnostic build: no S / dP products
+      f32x16 s = zero, dp = zero;
+      s[0] = (float)qf[0][0]; dp[0] = (float)dof[0][0];
+#else
       f32x16 s = MFMA_F32_32x32x16_H16(row_frag(Ks, kt * 32, 0, lane), qf[0], zero);
       f32x16 dp = MFMA_F32_32x32x16_H16(row_frag(Vs, kt * 32, 0, lane), dof[0], zero);
 #pragma unroll
@@ -445,26 +454,34 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restr
         s = MFMA_F32_32x32x16_H16(row_frag(Ks, kt * 32, ks, lane), qf[ks], s);
         dp = MFMA_F32_32x32x16_H16(row_frag(Vs, kt * 32, ks, lane), dof[ks], dp);
       }
+#endif
       // K^T fragments [sk][dt] of the dQ product (hand-waited asm reads: see tr_issue), issued BEFORE the softmax arithmetic so
       // that they land behind it
       TrPair kt_[4];
+#if defined(APLA_ABL_ATT_NOTR)   // diagnostic build: no transposed reads, no second-stage products
+      for (int i = 0; i < 4; ++i) { kt_[i].lo = bf16x4{}; kt_[i].hi = bf16x4{}; }
+#else
 #pragma unroll
       for (int sk = 0; sk < 2; ++sk)
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) tr_issue(kt_[2 * sk + dt], Ks, kt * 32 + 16 * sk, 32 * dt, lane);
+#endif
       // dS^T (unscaled).  Only the sequence's last key tile needs the per-key mask: as one predicated loop hipcc emits the
       // compare/select pair for every element of every tile (45 % of this kernel's VALU instructions).
       if (kb * 64 + kt * 32 + 32 <= N) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) s[i] = __builtin_amdgcn_exp2f(fmaf(s[i], c, -lse2)) * (dp[i] - dl);
+        for (int i = 0; i < 16; ++i) s[i] = ATT_EXP2(fmaf(s[i], c, -lse2)) * (dp[i] - dl);
       } else {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          float p = __builtin_amdgcn_exp2f(fmaf(s[i], c, -lse2));
+          float p = ATT_EXP2(fmaf(s[i], c, -lse2));
           if (kb * 64 + kt * 32 + acc_row(i, h2) >= N) p = 0.f;
           s[i] = p * (dp[i] - dl);
         }
       }
+#if defined(APLA_ABL_ATT_NOTR)
+      acc_dq[0][0] += s[0] + s[5]; acc_dq[1][0] += s[9] + s[15];
+#else
       lds_landed(kt_);
 #pragma unroll
       for (int sk = 0; sk < 2; ++sk) {
@@ -473,6 +490,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restr
         for (int dt = 0; dt < 2; ++dt)
           acc_dq[dt] = MFMA_F32_32x32x16_H16(tr_join(kt_[2 * sk + dt]), dsb, acc_dq[dt]);
       }
+#endif
     }
   }
   if (qvalid) store_acc_T(acc_dq, dqkv + ((long)sq.start + q) * ld + h * 64, h2, scale);
@@ -556,14 +574,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __rest
       f32x16 s, dp;
 #pragma unroll
       for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+#if defined(APLA_ABL_ATT_NOS)
+      s[0] = (float)kf[0][0]; dp[0] = (float)vf[0][0];
+#else
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         s = MFMA_F32_32x32x16_H16(row_frag(Qs, qt * 32, ks, lane), kf[ks], s);
         dp = MFMA_F32_32x32x16_H16(row_frag(dOs, qt * 32, ks, lane), vf[ks], dp);
       }
+#endif
       // dO^T [sk][dt] and Q^T [sk][dt] of the dV / dK products (hand-waited asm reads: see tr_issue), issued BEFORE the softmax
       // arithmetic so that they land behind it
       TrPair tf[8];
+#if defined(APLA_ABL_ATT_NOTR)
+      for (int i = 0; i < 8; ++i) { tf[i].lo = bf16x4{}; tf[i].hi = bf16x4{}; }
+#else
 #pragma unroll
       for (int sk = 0; sk < 2; ++sk)
 #pragma unroll
@@ -571,6 +596,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __rest
           tr_issue(tf[4 * sk + dt], dOs, qt * 32 + 16 * sk, 32 * dt, lane);
           tr_issue(tf[4 * sk + 2 + dt], Qs, qt * 32 + 16 * sk, 32 * dt, lane);
         }
+#endif
       // P and dS (in place of dP).  Only the sequence's last query tile needs the per-row mask (see the dQ kernel).
       if (qb * 64 + qt * 32 + 32 <= N) {
 #pragma unroll
@@ -580,7 +606,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __rest
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int i = 4 * g + e;
-            const float p = __builtin_amdgcn_exp2f(fmaf(s[i], c, -l4[e]));
+            const float p = ATT_EXP2(fmaf(s[i], c, -l4[e]));
             s[i] = p;
             dp[i] = p * (dp[i] - d4[e]);
           }
@@ -593,14 +619,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __rest
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int i = 4 * g + e;
-            float p = __builtin_amdgcn_exp2f(fmaf(s[i], c, -l4[e]));
+            float p = ATT_EXP2(fmaf(s[i], c, -l4[e]));
             if (qb * 64 + r0 + e >= N) p = 0.f;
             s[i] = p;
             dp[i] = p * (dp[i] - d4[e]);
           }
         }
       }
+#if defined(APLA_ABL_ATT_NOTR)
+      acc_dv[0][0] += s[0] + s[7]; acc_dk[0][0] += dp[3] + dp[12];
+      if (false)
+#else
       lds_landed(tf);
+#endif
 #pragma unroll
       for (int sk = 0; sk < 2; ++sk) {
         const bf16x8 pb = acc_to_operand(s, sk), dsb = acc_to_operand(dp, sk);
@@ -616,6 +647,186 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __rest
     bf16* orow = dqkv + ((long)sq.start + key) * ld + h * 64;
     store_acc_T(acc_dk, orow + D, h2, scale);
     store_acc_T(acc_dv, orow + 2 * D, h2, 1.0f);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ backward, short sequences
+// N <= 256: ONE workgroup per (b, h) with ceil(N/32) waves computes dQ, dK and dV.  At these lengths the backward is bound
+// by HBM traffic, not by its products (ablation builds: removing the exp, the S/dP products or the second-stage products
+// changes the split kernels by 0 / 20 / 25 %, while their 2 x 232 MB per layer at 5 TB/s are 93 us of the 150 us they take):
+// the split kernels read Q, K, V and dO of every head twice.  Here K, V, Q, dO of the head go global -> LDS ONCE (LDS-DMA,
+// 112 KB at N = 197), lse by 4-byte LDS-DMA, delta = rowsum(dO * O) is formed by the wave that owns the query rows; after
+// one barrier every wave first runs the dQ body for its 32 query rows (S^T, dP^T, dQ^T += K^T dS^T) and then the dK/dV body for
+// its 32 keys (S, dP, dV^T += dO^T P, dK^T += Q^T dS) on the resident tiles — the same seven products, the same fixed
+// summation order (bitwise equal to the split kernels), a third less HBM traffic, no further barrier.
+__global__ __launch_bounds__(512, 2) void attn_bwd_small_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
+                                                                const bf16* __restrict__ dout, const float* __restrict__ lse,
+                                                                float* __restrict__ delta, bf16* __restrict__ dqkv, int Nmax,
+                                                                int H, float scale, const int32_t* __restrict__ cu, int total) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // K, V, Q, dO tiles [NP][64] each, then lse [NP -> 64], delta [NP]
+  const int tid = threadIdx.x, lane = tid & 63, h2 = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nw = blockDim.x >> 6, NP = nw * 32;
+  const int b = blockIdx.y, h = blockIdx.x;
+  const Seq sq = seq_of(cu, b, Nmax, H, total);
+  const int N = sq.n;
+  if (N <= 0) return;
+  const int D = H * 64;
+  const long ld = 3L * D;
+  const bf16* base = qkv + (long)sq.start * ld + h * 64;
+  const bf16* dobase = dout + (long)sq.start * D + h * 64;
+  const float c = scale * LOG2E;
+  char* Ks = smem;
+  char* Vs = Ks + NP * 128;
+  char* Qs = Vs + NP * 128;
+  char* dOs = Qs + NP * 128;
+  float* lses = (float*)(dOs + NP * 128);   // filled in whole 64-float pieces (one 4-byte LDS-DMA per wave): rounded up to 64
+  float* dls = lses + ((NP + 63) & ~63);
+
+  // 4 tensors x NP/8 pieces of 8 rows x 128 B = 16 pieces per wave; swizzle on the source column (LDS side is lane-linear)
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    const int pc = wave * 16 + it;           // wave-uniform
+    const int t = pc / (NP / 8), pr = pc - t * (NP / 8);
+    const int row = pr * 8 + (lane >> 3);
+    const int f = (((row >> 1) & 1) << 2) | ((row >> 2) & 3);
+    const int ch = (lane & 7) ^ f;
+    const int gr = row < N ? row : N - 1;
+    const bf16* src = t == 3 ? dobase + (long)gr * D + ch * 8 : base + (t == 0 ? D : (t == 1 ? 2 * D : 0)) + (long)gr * ld + ch * 8;
+    __builtin_amdgcn_global_load_lds(ATT_GLBP(src), ATT_LDSP(smem + (t * NP + pr * 8) * 128), 16, 0, 0);
+  }
+  const float* lsebase = lse + sq.stat + (long)h * sq.stat_h;
+  if (wave * 64 < NP) {
+    int qq = wave * 64 + lane;
+    qq = qq < N ? qq : N - 1;
+    __builtin_amdgcn_global_load_lds(ATT_GLBP(lsebase + qq), ATT_LDSP((char*)lses + wave * 256), 4, 0, 0);
+  }
+
+  // own 32 rows: query rows of the dQ body, key rows of the dK/dV body
+  int r = wave * 32 + (lane & 31);
+  const bool rvalid = r < N;
+  if (!rvalid) r = N - 1;
+  bf16x8 qf[4], dof[4];
+  load_row_frags(qf, base + (long)r * ld, lane);
+  load_row_frags(dof, dobase + (long)r * D, lane);
+  float dl = 0.f;
+  {
+    bf16x8 of[4];
+    load_row_frags(of, o + ((long)sq.start + r) * D + h * 64, lane);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dl += (float)dof[ks][j] * (float)of[ks][j];
+  }
+  dl += __shfl_xor(dl, 32, 64);
+  const long statidx = sq.stat + (long)h * sq.stat_h + r;
+  if (rvalid && h2 == 0) delta[statidx] = dl;
+  if (h2 == 0) dls[wave * 32 + (lane & 31)] = dl;
+  const float lse2 = lse[statidx] * LOG2E;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (wave * 32 >= N) return;  // packed batches: waves past this sequence's end only helped loading
+
+  const int nt = (N + 31) / 32;  // 32-row tiles of this sequence
+  // ---------------------------------------------------------------- dQ for query rows `r`
+  {
+    f32x16 acc_dq[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc_dq[0][i] = 0.f; acc_dq[1][i] = 0.f; }
+    for (int t = 0; t < nt; ++t) {
+      const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      f32x16 s = MFMA_F32_32x32x16_H16(row_frag(Ks, t * 32, 0, lane), qf[0], zero);
+      f32x16 dp = MFMA_F32_32x32x16_H16(row_frag(Vs, t * 32, 0, lane), dof[0], zero);
+#pragma unroll
+      for (int ks = 1; ks < 4; ++ks) {
+        s = MFMA_F32_32x32x16_H16(row_frag(Ks, t * 32, ks, lane), qf[ks], s);
+        dp = MFMA_F32_32x32x16_H16(row_frag(Vs, t * 32, ks, lane), dof[ks], dp);
+      }
+      TrPair kt_[4];
+#pragma unroll
+      for (int sk = 0; sk < 2; ++sk)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) tr_issue(kt_[2 * sk + dt], Ks, t * 32 + 16 * sk, 32 * dt, lane);
+      if (t * 32 + 32 <= N) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[i] = ATT_EXP2(fmaf(s[i], c, -lse2)) * (dp[i] - dl);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          float p = ATT_EXP2(fmaf(s[i], c, -lse2));
+          if (t * 32 + acc_row(i, h2) >= N) p = 0.f;
+          s[i] = p * (dp[i] - dl);
+        }
+      }
+      lds_landed(kt_);
+#pragma unroll
+      for (int sk = 0; sk < 2; ++sk) {
+        const bf16x8 dsb = acc_to_operand(s, sk);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+          acc_dq[dt] = MFMA_F32_32x32x16_H16(tr_join(kt_[2 * sk + dt]), dsb, acc_dq[dt]);
+      }
+    }
+    if (rvalid) store_acc_T(acc_dq, dqkv + ((long)sq.start + r) * ld + h * 64, h2, scale);
+  }
+  // ---------------------------------------------------------------- dK, dV for key rows `r`
+  {
+    bf16x8 kf[4], vf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {  // own key rows as B operands (row on the lane), from the resident tiles
+      kf[ks] = row_frag(Ks, wave * 32, ks, lane);
+      vf[ks] = row_frag(Vs, wave * 32, ks, lane);
+    }
+    f32x16 acc_dk[2], acc_dv[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc_dk[0][i] = 0.f; acc_dk[1][i] = 0.f; acc_dv[0][i] = 0.f; acc_dv[1][i] = 0.f; }
+    for (int t = 0; t < nt; ++t) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        s = MFMA_F32_32x32x16_H16(row_frag(Qs, t * 32, ks, lane), kf[ks], s);
+        dp = MFMA_F32_32x32x16_H16(row_frag(dOs, t * 32, ks, lane), vf[ks], dp);
+      }
+      TrPair tf[8];
+#pragma unroll
+      for (int sk = 0; sk < 2; ++sk)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          tr_issue(tf[4 * sk + dt], dOs, t * 32 + 16 * sk, 32 * dt, lane);
+          tr_issue(tf[4 * sk + 2 + dt], Qs, t * 32 + 16 * sk, 32 * dt, lane);
+        }
+      const bool tail = t * 32 + 32 > N;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int r0 = t * 32 + 8 * g + 4 * h2;
+        const f32x4 l4 = *(const f32x4*)(lses + r0) * LOG2E, d4 = *(const f32x4*)(dls + r0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int i = 4 * g + e;
+          float p = ATT_EXP2(fmaf(s[i], c, -l4[e]));
+          if (tail && r0 + e >= N) p = 0.f;
+          s[i] = p;
+          dp[i] = p * (dp[i] - d4[e]);
+        }
+      }
+      lds_landed(tf);
+#pragma unroll
+      for (int sk = 0; sk < 2; ++sk) {
+        const bf16x8 pb = acc_to_operand(s, sk), dsb = acc_to_operand(dp, sk);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          acc_dv[dt] = MFMA_F32_32x32x16_H16(tr_join(tf[4 * sk + dt]), pb, acc_dv[dt]);
+          acc_dk[dt] = MFMA_F32_32x32x16_H16(tr_join(tf[4 * sk + 2 + dt]), dsb, acc_dk[dt]);
+        }
+      }
+    }
+    if (rvalid) {
+      bf16* orow = dqkv + ((long)sq.start + r) * ld + h * 64;
+      store_acc_T(acc_dk, orow + D, h2, scale);
+      store_acc_T(acc_dv, orow + 2 * D, h2, 1.0f);
+    }
   }
 }
 
@@ -743,9 +954,19 @@ static int launch_attn_fwd(const void* qkv, void* o, float* lse, const int32_t* 
 static int launch_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv,
                            const int32_t* cu, int total, int B, int N, int H, float scale, hipStream_t stream,
                            const char* who) {
+  if (N <= SMALL_MAX_ROWS && g_attn_variant != 1) {  // one workgroup per head, operands read from HBM once (see the kernel)
+    const int nw = (N + 31) / 32;
+    const size_t lds = (size_t)nw * 32 * (4 * 128 + 4) + (size_t)((nw * 32 + 63) & ~63) * 4;  // tiles + delta + lse (64-float pieces)
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipFuncSetAttribute((const void*)attn_bwd_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * (4 * 128 + 8));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(attn_bwd_small_kernel, dim3(H, B), dim3(64 * nw), lds, stream, (const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse, delta, (bf16*)dqkv, N, H, scale, cu, total);
+    APLA_CHECK_LAUNCH(who);
+    return APLA_OK;
+  }
   dim3 grid((N + 127) / 128, H, B);
-  // The backward stays key-blocked at every length: one-workgroup-per-head variants of dQ (K/V of the head in LDS) and of
-  // dK/dV (Q/dO in LDS) were built and measured 4 % and 7 % slower than these kernels.
   hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, stream, (const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse, delta, (bf16*)dqkv, N, H, scale, cu, total);
   APLA_CHECK_LAUNCH(who);
   hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, stream, (const bf16*)qkv, (const bf16*)d_o, lse, delta, (bf16*)dqkv, N, H, scale, cu, total);

@@ -514,3 +514,27 @@ def test_cross_entropy_soft_targets(ops):
     l1, d1, _ = ops.cross_entropy(dev(logits), dev(hard))
     l2, d2, _ = ops.cross_entropy(dev(logits), dev(y1.int()))
     assert abs(float(l1) - float(l2)) < 1e-6 * float(l2) and rel_err(d1.cpu(), d2.cpu().double()) < 1e-6
+
+
+@pytest.mark.parametrize("B,N", [(128, 197), (96, 50), (40, 256)])
+def test_attn_bwd_fused_short_sequence_kernel_equals_split_kernels_at_full_occupancy(B, N):
+    """The one-workgroup-per-head backward (N <= 256) against the query-/key-blocked kernels on identical inputs, with enough
+    heads to fill the chip several times over: bitwise equal (same products in the same order) and reproducible.  (A first
+    version let the 64-float lse DMA pieces spill into the delta rows next to them: invisible at the small batches of the
+    parity tests above, a race at full occupancy.)"""
+    from apla_amd._lib import lib
+    H = 12
+    g = torch.Generator(device="cuda").manual_seed(N)
+    qkv = torch.randn(B * N, 3 * 64 * H, device="cuda", generator=g).to(torch.bfloat16)
+    do = torch.randn(B * N, 64 * H, device="cuda", generator=g).to(torch.bfloat16)
+    scale = 64 ** -0.5
+    o, lse = ops.attn_fwd(qkv, B, N, H, scale)
+    old = lib().apla_attn_set_variant(0)
+    try:
+        a1 = ops.attn_bwd(qkv, o, do, lse, B, N, H, scale).clone()
+        a2 = ops.attn_bwd(qkv, o, do, lse, B, N, H, scale).clone()
+        lib().apla_attn_set_variant(1)
+        b1 = ops.attn_bwd(qkv, o, do, lse, B, N, H, scale).clone()
+    finally:
+        lib().apla_attn_set_variant(old)
+    assert torch.equal(a1, a2) and torch.equal(a1, b1)
