@@ -517,7 +517,7 @@ def test_cross_entropy_soft_targets(ops):
 
 
 @pytest.mark.parametrize("B,N", [(128, 197), (96, 50), (40, 256)])
-def test_attn_bwd_fused_short_sequence_kernel_equals_split_kernels_at_full_occupancy(B, N):
+def test_attn_bwd_fused_short_sequence_kernel_equals_split_kernels_at_full_occupancy(ops, B, N):
     """The one-workgroup-per-head backward (N <= 256) against the query-/key-blocked kernels on identical inputs, with enough
     heads to fill the chip several times over: bitwise equal (same products in the same order) and reproducible.  (A first
     version let the 64-float lse DMA pieces spill into the delta rows next to them: invisible at the small batches of the
