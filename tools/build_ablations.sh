@@ -23,3 +23,7 @@ build NODMA gemm_pp2 "-DAPLA_ABL_NODMA"              # K loop without LDS-DMA
 build NOREADNODMA gemm_pp2 "-DAPLA_ABL_NOREAD -DAPLA_ABL_NODMA"   # MFMA + barriers only: the structure's floor
 build SAMEK gemm_pp2 "-DAPLA_ABL_SAMEK"              # LDS-DMA always from the k = 0 slice (cache-resident source)
 build DWSLABS apla_dw "-DAPLA_ABL_DWSLABS"           # dW slab count from APLA_DW_SLABS
+# attention backward (tools/attn_split.py under rocprofv3 --kernel-trace --stats, APLA_ATTN variant 1 = split kernels)
+build ATT_NOEXP attention "-DAPLA_ABL_ATT_NOEXP"     # no transcendental in the softmax recompute
+build ATT_NOS attention "-DAPLA_ABL_ATT_NOS"         # split kernels without the S / dP products
+build ATT_NOTR attention "-DAPLA_ABL_ATT_NOTR"       # split kernels without the transposed reads and second-stage products
