@@ -13,6 +13,8 @@
 // tiles use one XOR swizzle that is conflict-free for both the ds_read_b128 row reads and the transposed reads.
 // dQ and dK/dV are produced by separate kernels so that no cross-workgroup reduction (atomics) is needed: results are
 // bitwise reproducible.  delta = rowsum(dO*O) is produced by the dQ kernel and consumed by the dKdV kernel.
+#include <stdlib.h>
+
 #include "common.h"
 
 #define ATT_LDSP(p) ((__attribute__((address_space(3))) void*)(p))
@@ -651,22 +653,26 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __rest
 }
 
 // ------------------------------------------------------------------------------------------------ backward, short sequences
-// N <= 256: ONE workgroup per (b, h) with ceil(N/32) waves computes dQ, dK and dV.  At these lengths the backward is bound
-// by HBM traffic, not by its products (ablation builds: removing the exp, the S/dP products or the second-stage products
-// changes the split kernels by 0 / 20 / 25 %, while their 2 x 232 MB per layer at 5 TB/s are 93 us of the 150 us they take):
-// the split kernels read Q, K, V and dO of every head twice.  Here K, V, Q, dO of the head go global -> LDS ONCE (LDS-DMA,
-// 112 KB at N = 197), lse by 4-byte LDS-DMA, delta = rowsum(dO * O) is formed by the wave that owns the query rows; after
-// one barrier every wave first runs the dQ body for its 32 query rows (S^T, dP^T, dQ^T += K^T dS^T) and then the dK/dV body for
-// its 32 keys (S, dP, dV^T += dO^T P, dK^T += Q^T dS) on the resident tiles — the same seven products, the same fixed
-// summation order (bitwise equal to the split kernels), a third less HBM traffic, no further barrier.
-__global__ __launch_bounds__(512, 2) void attn_bwd_small_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
+// N <= 256: ONE workgroup per (b, h) computes dQ, dK and dV.  At these lengths the backward is bound by HBM traffic, not by
+// its products (ablation builds: removing the exp, the S/dP products or the second-stage products changes the split kernels
+// by 0 / 20 / 25 %, while their 2 x 232 MB per layer at 5 TB/s are 93 us of the 150 us they take): the split kernels read
+// Q, K, V and dO of every head twice.  Here every operand of the head is read from HBM once:
+//   phase 1  K, V -> LDS (LDS-DMA), lse by 4-byte LDS-DMA; each wave, for its query blocks: delta = rowsum(dO * O) (to LDS and
+//            to the caller's buffer), then the dQ body (S^T, dP^T, dQ^T += K^T dS^T) over the resident key tiles;
+//   phase 2  the SAME LDS buffer is refilled with Q, dO; each wave, for its key blocks: the dK/dV body (S, dP,
+//            dV^T += dO^T P, dK^T += Q^T dS) over the resident query tiles.
+// Four waves per workgroup, wave w owns the 32-row blocks w and w+4: 58 KB of LDS at N = 197 and 256 threads, so TWO
+// workgroups share a CU and one's loads / stores run under the other's products (a first version with one 7-wave workgroup
+// per CU and all four tiles resident, 116 KB, serialised them: 139 us; the split kernels: 150 us).  Same seven products in
+// the same order as the split kernels: bitwise equal to them.
+__global__ __launch_bounds__(256, 2) void attn_bwd_small_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
                                                                 const bf16* __restrict__ dout, const float* __restrict__ lse,
                                                                 float* __restrict__ delta, bf16* __restrict__ dqkv, int Nmax,
-                                                                int H, float scale, const int32_t* __restrict__ cu, int total) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // K, V, Q, dO tiles [NP][64] each, then lse [NP -> 64], delta [NP]
+                                                                int H, float scale, const int32_t* __restrict__ cu, int total,
+                                                                int NP) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // two tiles [NP][64] (K,V then Q,dO), lse [NP -> 64], delta [NP]
   const int tid = threadIdx.x, lane = tid & 63, h2 = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nw = blockDim.x >> 6, NP = nw * 32;
   const int b = blockIdx.y, h = blockIdx.x;
   const Seq sq = seq_of(cu, b, Nmax, H, total);
   const int N = sq.n;
@@ -676,77 +682,80 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_small_kernel(const bf16* __re
   const bf16* base = qkv + (long)sq.start * ld + h * 64;
   const bf16* dobase = dout + (long)sq.start * D + h * 64;
   const float c = scale * LOG2E;
-  char* Ks = smem;
-  char* Vs = Ks + NP * 128;
-  char* Qs = Vs + NP * 128;
-  char* dOs = Qs + NP * 128;
-  float* lses = (float*)(dOs + NP * 128);   // filled in whole 64-float pieces (one 4-byte LDS-DMA per wave): rounded up to 64
+  char* TA = smem;             // K, later Q
+  char* TB = smem + NP * 128;  // V, later dO
+  float* lses = (float*)(TB + NP * 128);  // filled in whole 64-float pieces (one 4-byte LDS-DMA per wave): rounded up to 64
   float* dls = lses + ((NP + 63) & ~63);
-
-  // 4 tensors x NP/8 pieces of 8 rows x 128 B = 16 pieces per wave; swizzle on the source column (LDS side is lane-linear)
-#pragma unroll
-  for (int it = 0; it < 16; ++it) {
-    const int pc = wave * 16 + it;           // wave-uniform
-    const int t = pc / (NP / 8), pr = pc - t * (NP / 8);
-    const int row = pr * 8 + (lane >> 3);
-    const int f = (((row >> 1) & 1) << 2) | ((row >> 2) & 3);
-    const int ch = (lane & 7) ^ f;
-    const int gr = row < N ? row : N - 1;
-    const bf16* src = t == 3 ? dobase + (long)gr * D + ch * 8 : base + (t == 0 ? D : (t == 1 ? 2 * D : 0)) + (long)gr * ld + ch * 8;
-    __builtin_amdgcn_global_load_lds(ATT_GLBP(src), ATT_LDSP(smem + (t * NP + pr * 8) * 128), 16, 0, 0);
-  }
   const float* lsebase = lse + sq.stat + (long)h * sq.stat_h;
+  const int nt = (N + 31) / 32;   // 32-row blocks of this sequence
+  const int npc = NP / 8;         // 1 KB pieces (8 rows x 128 B) per tile
+
+  // both tiles of a phase: 2 * npc pieces, dealt round-robin to the four waves; swizzle on the source column (the LDS side
+  // of a DMA is lane-linear)
+  auto stage = [&](const bf16* srcA, long ldA, const bf16* srcB, long ldB) {
+    for (int pc = wave; pc < 2 * npc; pc += 4) {     // wave-uniform
+      const bool isb = pc >= npc;
+      const int pr = isb ? pc - npc : pc;
+      const int row = pr * 8 + (lane >> 3);
+      const int f = (((row >> 1) & 1) << 2) | ((row >> 2) & 3);
+      const int ch = (lane & 7) ^ f;
+      const int gr = row < N ? row : N - 1;
+      const bf16* src = isb ? srcB + (long)gr * ldB + ch * 8 : srcA + (long)gr * ldA + ch * 8;
+      __builtin_amdgcn_global_load_lds(ATT_GLBP(src), ATT_LDSP((isb ? TB : TA) + pr * 1024), 16, 0, 0);
+    }
+  };
+
+  // ================================================================ phase 1: K, V resident; delta and dQ per query block
+  stage(base + D, ld, base + 2 * D, ld);
   if (wave * 64 < NP) {
     int qq = wave * 64 + lane;
     qq = qq < N ? qq : N - 1;
     __builtin_amdgcn_global_load_lds(ATT_GLBP(lsebase + qq), ATT_LDSP((char*)lses + wave * 256), 4, 0, 0);
   }
-
-  // own 32 rows: query rows of the dQ body, key rows of the dK/dV body
-  int r = wave * 32 + (lane & 31);
-  const bool rvalid = r < N;
-  if (!rvalid) r = N - 1;
-  bf16x8 qf[4], dof[4];
-  load_row_frags(qf, base + (long)r * ld, lane);
-  load_row_frags(dof, dobase + (long)r * D, lane);
-  float dl = 0.f;
-  {
-    bf16x8 of[4];
-    load_row_frags(of, o + ((long)sq.start + r) * D + h * 64, lane);
+  for (int blk = wave, first = 1; blk < 8; blk += 4, first = 0) {   // the barrier below is reached by every wave exactly once
+    const bool active = blk < nt;
+    int r = blk * 32 + (lane & 31);
+    const bool rvalid = active && r < N;
+    if (r >= N) r = N - 1;
+    bf16x8 qf[4], dof[4];
+    float dl = 0.f, lse2 = 0.f;
+    if (active) {
+      load_row_frags(qf, base + (long)r * ld, lane);
+      load_row_frags(dof, dobase + (long)r * D, lane);
+      bf16x8 of[4];
+      load_row_frags(of, o + ((long)sq.start + r) * D + h * 64, lane);
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
+      for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) dl += (float)dof[ks][j] * (float)of[ks][j];
-  }
-  dl += __shfl_xor(dl, 32, 64);
-  const long statidx = sq.stat + (long)h * sq.stat_h + r;
-  if (rvalid && h2 == 0) delta[statidx] = dl;
-  if (h2 == 0) dls[wave * 32 + (lane & 31)] = dl;
-  const float lse2 = lse[statidx] * LOG2E;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (wave * 32 >= N) return;  // packed batches: waves past this sequence's end only helped loading
-
-  const int nt = (N + 31) / 32;  // 32-row tiles of this sequence
-  // ---------------------------------------------------------------- dQ for query rows `r`
-  {
+        for (int j = 0; j < 8; ++j) dl += (float)dof[ks][j] * (float)of[ks][j];
+      dl += __shfl_xor(dl, 32, 64);
+      const long statidx = sq.stat + (long)h * sq.stat_h + r;
+      if (rvalid && h2 == 0) delta[statidx] = dl;
+      if (h2 == 0) dls[blk * 32 + (lane & 31)] = dl;
+      lse2 = lse[statidx] * LOG2E;
+    }
+    if (first) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();   // K, V and lse have landed
+    }
+    if (!active) continue;
     f32x16 acc_dq[2];
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc_dq[0][i] = 0.f; acc_dq[1][i] = 0.f; }
     for (int t = 0; t < nt; ++t) {
       const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      f32x16 s = MFMA_F32_32x32x16_H16(row_frag(Ks, t * 32, 0, lane), qf[0], zero);
-      f32x16 dp = MFMA_F32_32x32x16_H16(row_frag(Vs, t * 32, 0, lane), dof[0], zero);
+      f32x16 s = MFMA_F32_32x32x16_H16(row_frag(TA, t * 32, 0, lane), qf[0], zero);
+      f32x16 dp = MFMA_F32_32x32x16_H16(row_frag(TB, t * 32, 0, lane), dof[0], zero);
 #pragma unroll
       for (int ks = 1; ks < 4; ++ks) {
-        s = MFMA_F32_32x32x16_H16(row_frag(Ks, t * 32, ks, lane), qf[ks], s);
-        dp = MFMA_F32_32x32x16_H16(row_frag(Vs, t * 32, ks, lane), dof[ks], dp);
+        s = MFMA_F32_32x32x16_H16(row_frag(TA, t * 32, ks, lane), qf[ks], s);
+        dp = MFMA_F32_32x32x16_H16(row_frag(TB, t * 32, ks, lane), dof[ks], dp);
       }
       TrPair kt_[4];
 #pragma unroll
       for (int sk = 0; sk < 2; ++sk)
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) tr_issue(kt_[2 * sk + dt], Ks, t * 32 + 16 * sk, 32 * dt, lane);
+        for (int dt = 0; dt < 2; ++dt) tr_issue(kt_[2 * sk + dt], TA, t * 32 + 16 * sk, 32 * dt, lane);
       if (t * 32 + 32 <= N) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) s[i] = ATT_EXP2(fmaf(s[i], c, -lse2)) * (dp[i] - dl);
@@ -769,14 +778,25 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_small_kernel(const bf16* __re
     }
     if (rvalid) store_acc_T(acc_dq, dqkv + ((long)sq.start + r) * ld + h * 64, h2, scale);
   }
-  // ---------------------------------------------------------------- dK, dV for key rows `r`
-  {
+  __syncthreads();   // every wave is done with K, V; all delta rows are in LDS
+
+  // ================================================================ phase 2: Q, dO resident; dK and dV per key block
+  stage(base, ld, dobase, D);
+  for (int blk = wave, first = 1; blk < 8; blk += 4, first = 0) {
+    const bool active = blk < nt;
+    int r = blk * 32 + (lane & 31);
+    const bool rvalid = active && r < N;
+    if (r >= N) r = N - 1;
     bf16x8 kf[4], vf[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {  // own key rows as B operands (row on the lane), from the resident tiles
-      kf[ks] = row_frag(Ks, wave * 32, ks, lane);
-      vf[ks] = row_frag(Vs, wave * 32, ks, lane);
+    if (active) {   // own key rows as B operands (row on the lane): just read by phase 1, L2 hits
+      load_row_frags(kf, base + D + (long)r * ld, lane);
+      load_row_frags(vf, base + 2 * D + (long)r * ld, lane);
     }
+    if (first) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();   // Q, dO have landed
+    }
+    if (!active) continue;
     f32x16 acc_dk[2], acc_dv[2];
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc_dk[0][i] = 0.f; acc_dk[1][i] = 0.f; acc_dv[0][i] = 0.f; acc_dv[1][i] = 0.f; }
@@ -786,16 +806,16 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_small_kernel(const bf16* __re
       for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        s = MFMA_F32_32x32x16_H16(row_frag(Qs, t * 32, ks, lane), kf[ks], s);
-        dp = MFMA_F32_32x32x16_H16(row_frag(dOs, t * 32, ks, lane), vf[ks], dp);
+        s = MFMA_F32_32x32x16_H16(row_frag(TA, t * 32, ks, lane), kf[ks], s);
+        dp = MFMA_F32_32x32x16_H16(row_frag(TB, t * 32, ks, lane), vf[ks], dp);
       }
       TrPair tf[8];
 #pragma unroll
       for (int sk = 0; sk < 2; ++sk)
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
-          tr_issue(tf[4 * sk + dt], dOs, t * 32 + 16 * sk, 32 * dt, lane);
-          tr_issue(tf[4 * sk + 2 + dt], Qs, t * 32 + 16 * sk, 32 * dt, lane);
+          tr_issue(tf[4 * sk + dt], TB, t * 32 + 16 * sk, 32 * dt, lane);
+          tr_issue(tf[4 * sk + 2 + dt], TA, t * 32 + 16 * sk, 32 * dt, lane);
         }
       const bool tail = t * 32 + 32 > N;
 #pragma unroll
@@ -935,7 +955,8 @@ __global__ __launch_bounds__(256) void attn_bwd_cls_kernel(const bf16* __restric
 
 }  // namespace
 
-static int g_attn_variant = 0;  // 0 = auto (short-sequence kernels when N <= 256), 1 = always the blocked kernels (tests)
+// 0 = auto (short-sequence kernels when N <= 256), 1 = always the blocked kernels (tests; APLA_ATTN_VARIANT=1 for A/B timing)
+static int g_attn_variant = [] { const char* e = getenv("APLA_ATTN_VARIANT"); return e ? atoi(e) : 0; }();
 extern "C" int apla_attn_set_variant(int v) { const int old = g_attn_variant; g_attn_variant = v; return old; }
 
 // B sequences of (at most) N tokens; cu == nullptr: uniform batch, else packed with cu[B+1] token offsets and `total` tokens
@@ -955,14 +976,14 @@ static int launch_attn_bwd(const void* qkv, const void* o, const void* d_o, cons
                            const int32_t* cu, int total, int B, int N, int H, float scale, hipStream_t stream,
                            const char* who) {
   if (N <= SMALL_MAX_ROWS && g_attn_variant != 1) {  // one workgroup per head, operands read from HBM once (see the kernel)
-    const int nw = (N + 31) / 32;
-    const size_t lds = (size_t)nw * 32 * (4 * 128 + 4) + (size_t)((nw * 32 + 63) & ~63) * 4;  // tiles + delta + lse (64-float pieces)
+    const int NP = (N + 31) / 32 * 32;
+    const size_t lds = (size_t)NP * (2 * 128 + 4) + (size_t)((NP + 63) & ~63) * 4;  // two tiles + delta + lse (64-float pieces)
     static bool attr_set = false;
-    if (!attr_set) {
-      hipFuncSetAttribute((const void*)attn_bwd_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * (4 * 128 + 8));
+    if (!attr_set) {   // > 64 KB of dynamic LDS at N > 224
+      hipFuncSetAttribute((const void*)attn_bwd_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * (2 * 128 + 8));
       attr_set = true;
     }
-    hipLaunchKernelGGL(attn_bwd_small_kernel, dim3(H, B), dim3(64 * nw), lds, stream, (const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse, delta, (bf16*)dqkv, N, H, scale, cu, total);
+    hipLaunchKernelGGL(attn_bwd_small_kernel, dim3(H, B), dim3(256), lds, stream, (const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse, delta, (bf16*)dqkv, N, H, scale, cu, total, NP);
     APLA_CHECK_LAUNCH(who);
     return APLA_OK;
   }
