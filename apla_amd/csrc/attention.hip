@@ -262,6 +262,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
 // every wave walks the keys on its own — no per-block staging through registers, no further barriers.  Two workgroups
 // per CU (56 KB of LDS each at N = 197).
 constexpr int SMALL_MAX_ROWS = 256;
+constexpr int SMALL_MAX_ROWS_BWD = 288;  // the fused backward also takes the 257-token sequences of ViT-*/14 at 224 px (9 blocks of 32 rows)
 
 __global__ __launch_bounds__(512, 4) void attn_fwd_small_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
                                                                 float* __restrict__ lse, int Nmax, int H, float scale,
@@ -653,7 +654,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __rest
 }
 
 // ------------------------------------------------------------------------------------------------ backward, short sequences
-// N <= 256: ONE workgroup per (b, h) computes dQ, dK and dV.  At these lengths the backward is bound by HBM traffic, not by
+// N <= 288: ONE workgroup per (b, h) computes dQ, dK and dV.  At these lengths the backward is bound by HBM traffic, not by
 // its products (ablation builds: removing the exp, the S/dP products or the second-stage products changes the split kernels
 // by 0 / 20 / 25 %, while their 2 x 232 MB per layer at 5 TB/s are 93 us of the 150 us they take): the split kernels read
 // Q, K, V and dO of every head twice.  Here every operand of the head is read from HBM once:
@@ -661,7 +662,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __rest
 //            to the caller's buffer), then the dQ body (S^T, dP^T, dQ^T += K^T dS^T) over the resident key tiles;
 //   phase 2  the SAME LDS buffer is refilled with Q, dO; each wave, for its key blocks: the dK/dV body (S, dP,
 //            dV^T += dO^T P, dK^T += Q^T dS) over the resident query tiles.
-// Four waves per workgroup, wave w owns the 32-row blocks w and w+4: 58 KB of LDS at N = 197 and 256 threads, so TWO
+// Four waves per workgroup, wave w owns the 32-row blocks w, w+4 (and w+8): 58 KB of LDS at N = 197 and 256 threads, so TWO
 // workgroups share a CU and one's loads / stores run under the other's products (a first version with one 7-wave workgroup
 // per CU and all four tiles resident, 116 KB, serialised them: 139 us; the split kernels: 150 us).  Same seven products in
 // the same order as the split kernels: bitwise equal to them.
@@ -707,12 +708,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_small_kernel(const bf16* __re
 
   // ================================================================ phase 1: K, V resident; delta and dQ per query block
   stage(base + D, ld, base + 2 * D, ld);
-  if (wave * 64 < NP) {
-    int qq = wave * 64 + lane;
+  for (int pc = wave; pc * 64 < NP; pc += 4) {   // 64-float pieces of lse
+    int qq = pc * 64 + lane;
     qq = qq < N ? qq : N - 1;
-    __builtin_amdgcn_global_load_lds(ATT_GLBP(lsebase + qq), ATT_LDSP((char*)lses + wave * 256), 4, 0, 0);
+    __builtin_amdgcn_global_load_lds(ATT_GLBP(lsebase + qq), ATT_LDSP((char*)lses + pc * 256), 4, 0, 0);
   }
-  for (int blk = wave, first = 1; blk < 8; blk += 4, first = 0) {   // the barrier below is reached by every wave exactly once
+  for (int blk = wave, first = 1; blk < SMALL_MAX_ROWS_BWD / 32 + 3; blk += 4, first = 0) {   // the barrier below is reached by every wave exactly once
     const bool active = blk < nt;
     int r = blk * 32 + (lane & 31);
     const bool rvalid = active && r < N;
@@ -782,7 +783,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_small_kernel(const bf16* __re
 
   // ================================================================ phase 2: Q, dO resident; dK and dV per key block
   stage(base, ld, dobase, D);
-  for (int blk = wave, first = 1; blk < 8; blk += 4, first = 0) {
+  for (int blk = wave, first = 1; blk < SMALL_MAX_ROWS_BWD / 32 + 3; blk += 4, first = 0) {
     const bool active = blk < nt;
     int r = blk * 32 + (lane & 31);
     const bool rvalid = active && r < N;
@@ -975,12 +976,12 @@ static int launch_attn_fwd(const void* qkv, void* o, float* lse, const int32_t* 
 static int launch_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv,
                            const int32_t* cu, int total, int B, int N, int H, float scale, hipStream_t stream,
                            const char* who) {
-  if (N <= SMALL_MAX_ROWS && g_attn_variant != 1) {  // one workgroup per head, operands read from HBM once (see the kernel)
+  if (N <= SMALL_MAX_ROWS_BWD && g_attn_variant != 1) {  // one workgroup per head, operands read from HBM once (see the kernel)
     const int NP = (N + 31) / 32 * 32;
     const size_t lds = (size_t)NP * (2 * 128 + 4) + (size_t)((NP + 63) & ~63) * 4;  // two tiles + delta + lse (64-float pieces)
     static bool attr_set = false;
     if (!attr_set) {   // > 64 KB of dynamic LDS at N > 224
-      hipFuncSetAttribute((const void*)attn_bwd_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * (2 * 128 + 8));
+      hipFuncSetAttribute((const void*)attn_bwd_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMALL_MAX_ROWS_BWD * (2 * 128 + 8) + 256);
       attr_set = true;
     }
     hipLaunchKernelGGL(attn_bwd_small_kernel, dim3(H, B), dim3(256), lds, stream, (const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse, delta, (bf16*)dqkv, N, H, scale, cu, total, NP);

@@ -516,7 +516,7 @@ def test_cross_entropy_soft_targets(ops):
     assert abs(float(l1) - float(l2)) < 1e-6 * float(l2) and rel_err(d1.cpu(), d2.cpu().double()) < 1e-6
 
 
-@pytest.mark.parametrize("B,N", [(128, 197), (96, 50), (40, 256)])
+@pytest.mark.parametrize("B,N", [(128, 197), (96, 50), (40, 256), (64, 257), (48, 288)])
 def test_attn_bwd_fused_short_sequence_kernel_equals_split_kernels_at_full_occupancy(ops, B, N):
     """The one-workgroup-per-head backward (N <= 256) against the query-/key-blocked kernels on identical inputs, with enough
     heads to fill the chip several times over: bitwise equal (same products in the same order) and reproducible.  (A first
