@@ -9,7 +9,6 @@ the parameter's version counter.  No function has a CPU path: CPU tensors raise 
 The fused whole-step path (apla_amd/engine.py) does not use autograd at all.
 """
 import weakref
-from typing import Optional
 
 import torch
 

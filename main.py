@@ -17,7 +17,6 @@ SSL trainers (`--dinov2` etc. raise).  Data therefore comes from one of two sour
 """
 import argparse
 import copy
-import math
 import os
 import sys
 import time
