@@ -138,8 +138,6 @@ def resolve_run(params: dict, args) -> dict:
     """Everything the training loop needs, derived from the merged parameters (no GPU involved: unit-testable)."""
     if args.byol or args.simsiam or args.dino:
         raise NotImplementedError("BYOL / SimSiam / DINO trainers are out of scope here (SURVEY §2); --dinov2 and the supervised APLA path run")
-    if args.test or args.knn:
-        raise NotImplementedError("evaluation / kNN are out of scope here (SURVEY §2)")
     mp = params["model_params"]
     ad = mp.get("adaptation") or {}
     if ad.get("mode") != "apla":
@@ -202,7 +200,7 @@ class TensorBatches:
 
     def __init__(self, run, rank, world, device, steps_per_epoch=None):
         self.B, self.rank, self.world, self.device = run["batch"], rank, world, device
-        self.images = self.labels = None
+        self.images = self.labels = self.val_images = self.val_labels = None
         if run["dataset"] == "TensorFile":
             blob = torch.load(run["data_location"], map_location="cpu")
             imgs, self.labels = blob["images"], blob["labels"].to(device).int()
@@ -210,11 +208,27 @@ class TensorBatches:
             mean, std = torch.tensor(IMAGENET_MEAN).view(1, 3, 1, 1), torch.tensor(IMAGENET_STD).view(1, 3, 1, 1)
             self.images = ((imgs - mean) / std).to(device)
             self.steps = self.images.shape[0] // (self.B * world)
+            if "val_images" in blob:
+                v = blob["val_images"]
+                v = v.float().div_(255.0) if v.dtype == torch.uint8 else v.float()
+                self.val_images, self.val_labels = ((v - mean) / std).to(device), blob["val_labels"].to(device).int()
         else:
             print(f"\033[93m[main] no loader for dataset {run['dataset']!r} at {run['data_location']!r}: SYNTHETIC N(0,1) images / random "
                   f"labels [{self.B},3,{run['img']},{run['img']}], {run['n_classes']} classes\033[0m", flush=True)
             self.steps = steps_per_epoch or 100
             self.shape, self.C = (self.B, 3, run["img"], run["img"]), run["n_classes"]
+
+    def eval_batches(self):
+        """Evaluation batches of the engine's batch size (drop_last): `val_images` / `val_labels` of the tensor file when it
+        has them, else the training tensors; three synthetic batches otherwise."""
+        if self.images is None:
+            g = torch.Generator(device=self.device).manual_seed(999)
+            for _ in range(3):
+                yield torch.randn(self.shape, device=self.device, generator=g), torch.randint(0, self.C, (self.B,), device=self.device, generator=g)
+            return
+        imgs, labs = (self.val_images, self.val_labels) if self.val_images is not None else (self.images, self.labels)
+        for s in range(imgs.shape[0] // self.B):
+            yield imgs[s * self.B:(s + 1) * self.B], labs[s * self.B:(s + 1) * self.B]
 
     def epoch(self, epoch):
         g = torch.Generator(device=self.device).manual_seed(1000 * epoch + (0 if self.images is not None else self.rank))
@@ -365,8 +379,10 @@ def main(params, args):
                           soft_targets=run["soft_targets"])
     data = TensorBatches(run, rank, world, dev, args.steps_per_epoch)
     sched = make_schedule(run, data.steps)
-    epochs = 1 if args.dry else run["epochs"]
-    iters, t0, seen = 0, time.perf_counter(), 0
+    epochs = 0 if args.test else (1 if args.dry else run["epochs"])   # --test: evaluate the loaded weights only (main.py:219-222)
+    iters, t0, seen, loss = 0, time.perf_counter(), 0, None
+    tp_knn = bool(params.get("training_params", {}).get("knn_eval")) and not args.dry
+    soft_engine = run["soft_targets"]   # an engine built for probability targets has no class-id loss to evaluate with
     if is_rank0():
         print(f"[main] {mp['backbone_type']} APLA r={mp['adaptation']['params']['partial_size']}  {world} GPU(s) x bs {run['batch']}  "
               f"{epochs} epoch(s) x {data.steps} it  lr {run['lr']} wd {run['wd']} schedule {run['sched_types'] or 'constant'}", flush=True)
@@ -390,12 +406,24 @@ def main(params, args):
             if args.dry and iters >= 5:
                 break
     synchronize()
-    if is_rank0() and run["save_dir"] and not (args.dry or args.debug):
+    if is_rank0() and run["save_dir"] and not (args.dry or args.debug or args.test):
         os.makedirs(run["save_dir"], exist_ok=True)
         path = os.path.join(run["save_dir"], run["model_name"] + ".pth")
         torch.save(ckpt.session_dict(eng, iters=iters, epoch=epochs, parameters=params), path)
         print(f"[main] saved {path}")
-    return float(loss)
+    if (args.test or args.knn or tp_knn) and is_rank0() and not soft_engine:
+        # Trainer.test / evaluate (defaults/trainer.py:162-345) on rank 0: loss + accuracy on the evaluation batches, optionally
+        # kNN metrics against a feature bank of the training batches (the evaluation split of a TensorFile is its
+        # `val_images` / `val_labels` entries when present, else the training tensors; synthetic data otherwise)
+        from apla_amd.evaluate import Evaluator
+        ev = Evaluator(eng, run["n_classes"], knn_nhood=int(params.get("dataset_params", {}).get("knn_nhood", 200)))
+        knn = bool(args.knn or tp_knn)
+        if knn:
+            ev.build_feature_bank(data.epoch(0))
+        metrics = ev.evaluate(data.eval_batches(), mode="test" if args.test else "val", knn=knn)
+        print("[main] " + "  ".join(f"{k} {v:.4f}" for k, v in metrics.items()), flush=True)
+        main.last_metrics = metrics
+    return float(loss) if loss is not None else float("nan")
 
 
 if __name__ == "__main__":

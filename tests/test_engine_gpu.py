@@ -389,3 +389,20 @@ def test_full_size_properties_cfg2():
     e3.forward_only(images, labels)
     torch.cuda.synchronize()
     assert rel_l2(e3.logits.cpu(), logits_full.cpu()) < 2e-3                          # (c)
+
+
+def test_main_evaluation_and_knn(tmp_path):
+    """main.py --knn / --test (src/main.py:219-222 -> Trainer.evaluate / test, defaults/trainer.py:162-345): train on synthetic
+    batches, then validation metrics + kNN metrics from a feature bank of the training batches; --test evaluates the saved
+    session without training and reproduces the same loss."""
+    import main
+    path = os.path.join(os.path.dirname(__file__), "params", "tiny", "apla.yml")
+    args = main.parse_arguments(["--params_path", path, "--steps_per_epoch", "3", "--save_dir", str(tmp_path), "--knn"])
+    main.main(main.update_params_from_args(main.load_parameters(path), args), args)
+    m1 = main.main.last_metrics
+    assert set(m1) == {"val_accuracy", "val_mean_per_class_accuracy", "val_loss", "knn_val_accuracy", "knn_val_mean_per_class_accuracy"}
+    assert np.isfinite(m1["val_loss"]) and 0.0 <= m1["val_accuracy"] <= 1.0 and 0.0 <= m1["knn_val_accuracy"] <= 1.0
+    args = main.parse_arguments(["--params_path", path, "--test", "--pretrained_path", str(tmp_path / "tiny.pth")])
+    main.main(main.update_params_from_args(main.load_parameters(path), args), args)
+    m2 = main.main.last_metrics
+    assert abs(m2["test_loss"] - m1["val_loss"]) < 1e-5 and m2["test_accuracy"] == m1["val_accuracy"]
