@@ -22,6 +22,9 @@ SIGNATURES = {
     "apla_gemm_nt": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                              c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "apla_gemm_set_variant": (c_int, [c_int]),
+    "apla_gemm_small_workspace_bytes": (c_long, [c_int, c_int, c_int]),
+    "apla_gemm_nt_small": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                   c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_long, c_void_p]),
     "apla_attn_set_variant": (c_int, [c_int]),
     "apla_layernorm_fwd": (c_int, [c_void_p, c_int, c_long, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                    c_void_p, c_int, c_int, c_float, c_void_p, c_long, c_void_p, c_long, c_void_p]),

@@ -114,6 +114,8 @@ class AplaTrainEngine:
         self._graphs = None
         self._pack_batched = None
         self._fc1_events = None
+        self._small_ws = {}
+        self.cls_small_gemm = os.environ.get("APLA_NO_SMALL_GEMM") != "1"   # diagnostic switch for A/B timing
         if self.dynamic_scale:
             self.scaler = ops.new_scaler_state(self.device)
         with ops.use_half(self.hdt):
@@ -369,7 +371,7 @@ class AplaTrainEngine:
             if i == self.L - 1 and self.cls_only_tail:
                 # last block: K and V for every token, Q for the CLS rows only (the only query that is ever used)
                 ops.gemm_nt(self.ln_out, st.Wqkv[D:], None if st.bqkv is None else st.bqkv[D:], out=self.qkv[i][:, D:])
-                ops.gemm_nt(self.ln_out.view(B, N * D)[:, :D], st.Wqkv[:D], None if st.bqkv is None else st.bqkv[:D],
+                self._gemm_rows(self.ln_out.view(B, N * D)[:, :D], st.Wqkv[:D], None if st.bqkv is None else st.bqkv[:D],
                             out=self.qkv[i].view(B, N * 3 * D)[:, :D])
                 self._forward_last_block_tail(st, i)
                 break
@@ -403,6 +405,20 @@ class AplaTrainEngine:
         elif self.loss_scale != 1.0:
             self.dlogits.mul_(self.loss_scale)  # every gradient carries the scale until the optimizer divides it out
 
+    def _gemm_rows(self, a, w, bias=None, **kw):
+        """GEMM on the B CLS rows of the last block: the split-K few-row kernel where it applies (STORE / GELU / MUL epilogues,
+        K % 128 == 0), else apla_gemm_nt."""
+        epi = kw.get("epilogue", ops.EPI_STORE)
+        M, K, N = a.shape[0], a.shape[1], w.shape[0]
+        if epi in (ops.EPI_STORE, ops.EPI_GELU, ops.EPI_MUL) and self.cls_small_gemm:
+            key = (M, N, K)
+            if key not in self._small_ws:
+                self._small_ws[key] = ops.gemm_small_workspace(M, N, K, self.device)
+            ws = self._small_ws[key]
+            if ws is not None:
+                return ops.gemm_nt_small(a, w, bias, workspace=ws, **kw)
+        return ops.gemm_nt(a, w, bias, **kw)
+
     def _forward_last_block_tail(self, st, i):
         """Block L-1 after its qkv GEMM.  The head reads only x[:, 0] of this block's output (vit.py:416-419) and rows do not
         mix after the attention, so everything from the attention on runs for the B CLS rows only: one query per head
@@ -412,14 +428,14 @@ class AplaTrainEngine:
         B, N, H, D = self.B, self.N, self.H, self.D
         cls = lambda t: t.view(B, -1)[:, :t.shape[1]]          # rows b*N of a [B*N, C] buffer as a strided [B, C] view
         ops.attn_fwd_cls(self.qkv[i], B, N, H, self.scale, o=self.o[i], lse=self.lse[i])
-        ops.gemm_nt(cls(self.o[i]), st.Wnat, st.bnat, out=self.branch_cls)
+        self._gemm_rows(cls(self.o[i]), st.Wnat, st.bnat, out=self.branch_cls)
         ops.layernorm_fwd(self.x[i], st.g2, st.b2, self.eps, out=self.ln_cls, mean=self.mean2_cls, rstd=self.rstd2_cls,
                           rows=B, row_stride=N * D, add=self.branch_cls, add_row_stride=D, x_out=self.xmid[i])
         if self.swiglu:
             ops.gemm_nt(self.ln_cls, st.W12, st.b12, epilogue=ops.EPI_SWIGLU, aux_out=cls(self.act_saved[i]), out=self.h_cls)
         else:
-            ops.gemm_nt(self.ln_cls, st.Wfc1, st.bfc1, epilogue=ops.EPI_GELU, aux_out=cls(self.act_saved[i]), out=self.h_cls)
-        ops.gemm_nt(self.h_cls, st.Wout, st.bout, out=self.branch_cls)
+            self._gemm_rows(self.ln_cls, st.Wfc1, st.bfc1, epilogue=ops.EPI_GELU, aux_out=cls(self.act_saved[i]), out=self.h_cls)
+        self._gemm_rows(self.h_cls, st.Wout, st.bout, out=self.branch_cls)
 
     def _backward_head(self):
         B, N, D = self.B, self.N, self.D
@@ -477,8 +493,8 @@ class AplaTrainEngine:
             ops.gemm_nt(cls(self.Gb), st.WoutT, None, epilogue=ops.EPI_SWIGLU_BWD, aux_in=cls(self.act_saved[i]), out=self.dact_cls)
             ops.gemm_nt(self.dact_cls, st.W12T, None, out=self.dln_cls)
         else:
-            ops.gemm_nt(cls(self.Gb), st.WoutT, None, epilogue=ops.EPI_MUL, aux_in=cls(self.act_saved[i]), out=self.dact_cls)
-            ops.gemm_nt(self.dact_cls, st.Wfc1T, None, out=self.dln_cls)
+            self._gemm_rows(cls(self.Gb), st.WoutT, None, epilogue=ops.EPI_MUL, aux_in=cls(self.act_saved[i]), out=self.dact_cls)
+            self._gemm_rows(self.dact_cls, st.Wfc1T, None, out=self.dln_cls)
         dyg = self.dyg_cls[:B * st.r_pad].view(B, st.r_pad)
         ops.layernorm_bwd(self.dln_cls, self.xmid[i], st.g2,
                           self.mean2_cls if self.cls_only_tail else self.mean2[i][::N].contiguous(),
@@ -487,7 +503,7 @@ class AplaTrainEngine:
         self._proj_dw(st, dyg, cls(self.o[i]))
         if i == 0:
             return
-        ops.gemm_nt(cls(self.Gb), st.WnatT, None, out=self.dO_cls)
+        self._gemm_rows(cls(self.Gb), st.WnatT, None, out=self.dO_cls)
         ops.attn_bwd_cls(self.qkv[i], self.o[i], self.dO_cls, self.lse[i], B, N, H, self.scale, dqkv=self.dqkv)
         ops.gemm_nt(self.dqkv, st.WqkvT, None, out=self.dln)
         ops.layernorm_bwd(self.dln, self.x[i], st.g1, self.mean1[i], self.rstd1[i], dres=self.G, out=self.G, out_bf16=copy)

@@ -119,6 +119,42 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = Non
     return out
 
 
+def gemm_small_workspace(M: int, N: int, K: int, device) -> Optional[torch.Tensor]:
+    """Workspace of gemm_nt_small for this shape, or None when the few-row kernel does not take it."""
+    nbytes = lib().apla_gemm_small_workspace_bytes(M, N, K)
+    return None if nbytes < 0 else torch.empty(nbytes // 4, device=device, dtype=torch.float32)
+
+
+def gemm_nt_small(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, workspace: torch.Tensor,
+                  epilogue: int = EPI_STORE, out: Optional[torch.Tensor] = None, out_dtype=None,
+                  aux_in: Optional[torch.Tensor] = None, aux_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """gemm_nt for few rows (split-K, two launches); see include/apla_hip.h:apla_gemm_nt_small."""
+    _req(a, half(), "a", 2), _req(w, half(), "w", 2), _req(workspace, torch.float32, "workspace", 1)
+    M, K, lda = _rows2d(a, "a")
+    N, Kw, ldw = _rows2d(w, "w")
+    if K != Kw:
+        raise ValueError(f"gemm_nt_small: K mismatch {K} vs {Kw}")
+    if bias is not None:
+        _req(bias, torch.float32, "bias", 1)
+        if bias.numel() != N:
+            raise ValueError("gemm_nt_small: bias length != N")
+    if out is None:
+        out = torch.empty(M, N, device=a.device, dtype=out_dtype or half())
+    _req(out, None, "out", 2)
+    if tuple(out.shape) != (M, N):
+        raise ValueError("gemm_nt_small: out shape")
+    for t_, nm in ((aux_in, "aux_in"), (aux_out, "aux_out")):
+        if t_ is not None:
+            _req(t_, None, nm, 2)
+            if tuple(t_.shape) != (M, N):
+                raise ValueError(f"gemm_nt_small: {nm} shape")
+    check(lib().apla_gemm_nt_small(a.data_ptr(), lda, w.data_ptr(), ldw, _ptr(bias), out.data_ptr(), out.stride(0), M, N, K, epilogue,
+                                   _DT[out.dtype], _ptr(aux_in), aux_in.stride(0) if aux_in is not None else 0, _ptr(aux_out),
+                                   aux_out.stride(0) if aux_out is not None else 0, workspace.data_ptr(), workspace.numel() * 4,
+                                   _stream()), "apla_gemm_nt_small")
+    return out
+
+
 def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-6, *,
                   out_dtype=None, rows: Optional[int] = None, row_stride: Optional[int] = None,
                   out: Optional[torch.Tensor] = None, mean: Optional[torch.Tensor] = None,

@@ -68,6 +68,17 @@ int apla_gemm_nt(const void* A, int lda, const void* W, int ldw, const float* bi
  * Returns the previous value.  All variants compute the same results (tests/test_kernels_gpu.py). */
 int apla_gemm_set_variant(int variant);
 
+/* apla_gemm_nt for FEW rows (the CLS-only tail of the last block: projection / MLP / Q of Block.forward on the B rows that
+ * reach x[:, 0], vit.py:279-288,416-419): the K axis is split over K/64 (K <= 1536) or K/128 slices so that a few hundred
+ * workgroups run instead of N/128; fp32 partial tiles go to `workspace` (apla_gemm_small_workspace_bytes(M, N, K) bytes,
+ * caller-owned) and a second launch sums them in a fixed order, adds the bias and applies the epilogue (STORE, RESIDUAL,
+ * MUL, GELU with the argument meaning of apla_gemm_nt).  Needs N % 64 == 0, K % 128 == 0, M <= 4096.  Same result as
+ * apla_gemm_nt up to the summation order of the fp32 accumulation. */
+long apla_gemm_small_workspace_bytes(int M, int N, int K);
+int apla_gemm_nt_small(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int M, int N,
+                       int K, int epilogue, int out_dtype, const void* aux_in, int ld_aux_in, void* aux_out,
+                       int ld_aux_out, void* workspace, long workspace_bytes, hipStream_t stream);
+
 /* y = LayerNorm(x [+ add_in])*gamma+beta (y_dtype bf16, or f32 for the classifier-head input), saving mean/rstd (fp32).
  * x rows are `x_row_stride` elements apart so the final-norm-on-CLS-rows case (vit.py:416-419) needs no gather.
  * If add_in != NULL (bf16 [M,D], the branch output of the preceding projection / fc2 GEMM) the residual update

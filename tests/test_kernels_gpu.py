@@ -538,3 +538,40 @@ def test_attn_bwd_fused_short_sequence_kernel_equals_split_kernels_at_full_occup
     finally:
         lib().apla_attn_set_variant(old)
     assert torch.equal(a1, a2) and torch.equal(a1, b1)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 768, 768), (128, 768, 3072), (128, 3072, 768), (37, 128, 256), (300, 192, 1536)])
+def test_gemm_nt_small_few_rows(ops, M, N, K):
+    """The split-K few-row GEMM (CLS-only tail of the last block) against fp64 on the same bf16 operands, every epilogue it
+    implements, strided A rows (the CLS rows of a [B*N, D] buffer are N*D elements apart) and a strided output."""
+    g = torch.Generator().manual_seed(M + N + K)
+    stride = 3 * K                                                  # rows of A sit `stride` elements apart
+    abuf = (torch.randn(M, stride, generator=g) * 0.5).to(torch.bfloat16).cuda()
+    a = abuf[:, :K]
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(torch.bfloat16).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    ws = ops.gemm_small_workspace(M, N, K, "cuda")
+    assert ws is not None and ws.numel() * 4 == (K // (64 if K <= 1536 else 128)) * M * N * 4
+    ref = a.double() @ w.double().t() + bias.double()
+    out = ops.gemm_nt_small(a, w, bias, workspace=ws, out_dtype=torch.float32)
+    assert rel_err(out.cpu(), ref.cpu()) < F32_OUT
+    obuf = torch.zeros(M, 2 * N, device="cuda", dtype=torch.bfloat16)
+    ops.gemm_nt_small(a, w, bias, workspace=ws, out=obuf[:, :N])
+    assert rel_err(obuf[:, :N].float().cpu(), ref.cpu()) < 6e-3 and float(obuf[:, N:].abs().max()) == 0.0
+    assert torch.equal(ops.gemm_nt_small(a, w, bias, workspace=ws), obuf[:, :N])               # reproducible
+    gp = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    h = ops.gemm_nt_small(a, w, bias, workspace=ws, epilogue=ops.EPI_GELU, aux_out=gp)
+    r = ref.float()
+    phi = 0.5 * (1 + torch.erf(r / math.sqrt(2)))
+    assert rel_err(h.float().cpu(), (r * phi).cpu()) < 6e-3
+    assert rel_err(gp.float().cpu(), (phi + r * torch.exp(-0.5 * r * r) / math.sqrt(2 * math.pi)).cpu()) < 6e-3
+    mul = torch.randn(M, N, generator=g).to(torch.bfloat16).cuda()
+    out = ops.gemm_nt_small(a, w, None, workspace=ws, epilogue=ops.EPI_MUL, aux_in=mul)
+    assert rel_err(out.float().cpu(), ((ref - bias.double()) * mul.double()).cpu()) < 6e-3
+    res = torch.randn(M, N, generator=g).cuda()
+    out = ops.gemm_nt_small(a, w, bias, workspace=ws, epilogue=ops.EPI_RESIDUAL, aux_in=res, out_dtype=torch.float32)
+    assert rel_err(out.cpu(), (ref + res.double()).cpu()) < F32_OUT
+    if N % 128 == 0 and K % 64 == 0:   # same operands through the tiled kernel: equal up to the fp32 summation order
+        assert rel_err(ops.gemm_nt(a, w, bias, out_dtype=torch.float32).cpu(), ops.gemm_nt_small(a, w, bias, workspace=ws, out_dtype=torch.float32).cpu()) < 1e-5
+    with pytest.raises(Exception):
+        ops.gemm_nt_small(a, w, bias, workspace=ws[:16])
