@@ -8,7 +8,8 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_long, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libapla_hip.so")          # bf16 operands (default)
+# bf16 operands (default).  APLA_LIB=<path> substitutes another build of the library (tools/build_ablations.sh: A/B timing)
+LIB_PATH = os.environ.get("APLA_LIB") or os.path.join(HERE, "libapla_hip.so")
 LIB_PATH_F16 = os.path.join(HERE, "libapla_hip_f16.so")  # fp16 operands (same sources, -DAPLA_FP16)
 
 APLA_BF16, APLA_F16, APLA_F32 = 0, 1, 2
