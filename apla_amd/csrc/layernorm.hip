@@ -3,6 +3,8 @@
 //
 // Backward computes only dX (gamma/beta are frozen under APLA) and fuses (a) the residual-gradient add and (b) the
 // gather of the r APLA-trainable columns of the result (bf16) that the column-masked dW1 kernel consumes.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -142,7 +144,8 @@ __global__ __launch_bounds__(256) void gather_cols_kernel(const ResT* __restrict
 
 inline int ln_grid(int M) {
   int g = (M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
-  return g < 4096 ? g : 4096;
+  static const int cap = [] { const char* e = getenv("APLA_LN_GRID"); return e ? atoi(e) : 4096; }();   // diagnostic override
+  return g < cap ? g : cap;
 }
 
 }  // namespace
