@@ -90,6 +90,10 @@ def lib(operand=None):
             raise AplaHipError(
                 f"{path} not found: the APLA HIP kernels are not built. Run `python -m apla_amd.build` "
                 "(needs hipcc, targets gfx950). There is no CPU fallback.")
+        # torch first: it ships its own libamdhip64; loaded before ours, the dynamic linker binds libapla_hip.so to that same
+        # runtime (same SONAME).  The other order leaves two HIP runtimes in the process and ours without a device context
+        # ("no ROCm-capable device is detected" at the first launch).
+        import torch  # noqa: F401
         handle = ctypes.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the .so does not export a declared symbol
