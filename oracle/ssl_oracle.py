@@ -119,6 +119,25 @@ def state_from_golden(g):
                 ibot_center=dict(value=torch.zeros(1, 1, K, dtype=DT), pending=None))
 
 
+def state_from_state_dict(sd, trainable, cfg):
+    """Oracle state from a student state_dict in the reference's naming (student.backbone.* / dino_head.* without the
+    'student.' prefix); the teacher starts as a copy (models.py:175-177)."""
+    conv = lambda v: v.detach().cpu().to(DT) if v.is_floating_point() else v.detach().cpu().clone()   # noqa: E731
+    student = {k: conv(v) for k, v in sd.items()}
+    teacher = {k: v.clone() for k, v in student.items()}
+    K = cfg["K"]
+    return dict(cfg=cfg, student=student, teacher=teacher, trainable=list(trainable),
+                adam={n: dict(step=0, m=torch.zeros_like(student[n]), v=torch.zeros_like(student[n])) for n in trainable},
+                dino_center=dict(value=torch.zeros(1, K, dtype=DT), pending=None),
+                ibot_center=dict(value=torch.zeros(1, 1, K, dtype=DT), pending=None))
+
+
+def batch_from_collate(images):
+    """The collate's dictionary (apla_amd.ssl.collate_data_and_cast(...)["images"]) in the oracle's form."""
+    return dict(glob=images["collated_global_crops"].to(DT), loc=images["collated_local_crops"].to(DT), masks=images["collated_masks"],
+                idx=images["mask_indices_list"].long(), masks_weight=images["masks_weight"].to(DT), upperbound=int(images["upperbound"]))
+
+
 def batch_from_golden(g, it):
     f = lambda k: torch.from_numpy(g[f"it{it}.{k}"])   # noqa: E731
     return dict(glob=f("glob").to(DT), loc=f("loc").to(DT), masks=f("masks"), idx=f("mask_indices").long(),

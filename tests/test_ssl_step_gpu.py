@@ -136,3 +136,69 @@ def test_main_dinov2_entry_point(tmp_path):
     last = [i for i, n in enumerate(names) if "last_layer" in n]
     assert all(float(sess["optimizer"]["state"][i]["step"]) == 4.0 for i in last)        # frozen during the first epoch (2 of 6 steps)
     assert float(sess["optimizer"]["state"][0]["step"]) == 6.0
+
+
+def test_iteration_vs_oracle_at_another_geometry():
+    """One iteration at a geometry no golden covers (D = 256, 4 heads, depth 3, 1024 prototypes, 4 local crops, r = 96 — a rank
+    that is not a multiple of 64 —, LayerScale != 1) against the float64 SSL oracle (which G12 pins to the reference):
+    losses, gradient norm and every trainable gradient."""
+    import random
+    from functools import partial
+    from oracle import ssl_oracle as SO
+    from apla_amd.ssl import DINOv2, DinoVisionTransformer, Dinov2Trainer, MaskingGenerator, collate_data_and_cast
+    from apla_amd.ssl.collate import synthetic_samples
+    D, depth, heads, patch, pre, gsz, lsz, K, n_local, B, r = 256, 3, 4, 14, 70, 56, 28, 1024, 4, 4, 96
+    torch.manual_seed(5)
+    def bb():
+        m = DinoVisionTransformer(img_size=[pre], patch_size=patch, embed_dim=D, depth=depth, num_heads=heads, qkv_bias=True,
+                                  norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), block_conf=dict(has_layerscale=True, layerscale_init_values=1.0))
+        with torch.no_grad():
+            for n, p in m.named_parameters():
+                if n.endswith("gamma"):
+                    p.uniform_(0.5, 1.5)
+                elif "pos_embed" in n or "token" in n:
+                    p.normal_(std=0.2)
+                elif p.ndim >= 2:
+                    p.normal_(std=0.05)
+                else:
+                    p.normal_(std=0.1) if n.endswith("bias") else p.uniform_(0.8, 1.2)
+        return m
+    g = torch.Generator().manual_seed(6)
+    f = tempfile.NamedTemporaryFile("w", suffix=".json", delete=False)
+    json.dump({f"block_{i}": torch.randperm(D, generator=g)[:r].tolist() for i in range(depth)}, f)
+    f.close()
+    params = dict(
+        model_params=dict(backbone_type="vit_test", pretrained=False, adaptation=dict(mode="apla", params=dict(partial_size=r, inds_path=f.name)),
+                          transformers_params=dict(student=dict(patch_size=patch, pre_img_size=pre)),
+                          dinov2=dict(centering="centering",
+                                      dino=dict(loss_weight=1.0, head_n_prototypes=K, head_bottleneck_dim=128, head_nlayers=3,
+                                                head_hidden_dim=384, koleo_loss_weight=0.1),
+                                      ibot=dict(loss_weight=1.0, mask_sample_probability=0.5, mask_ratio_min_max=[0.1, 0.5], separate_head=False))),
+        crops_params=dict(n_global_crops=2, n_local_crops=n_local), system_params=dict(which_GPUs="0"))
+    model = DINOv2(params, backbones=(bb(), bb(), D))
+    with torch.no_grad():
+        for p in model.student.dino_head.mlp.parameters():
+            p.add_(torch.randn(p.shape, generator=g) * 0.05)
+    for k in model.student.keys():
+        model.teacher[k].load_state_dict(model.student[k].state_dict())
+    trainable = [n for n, p in model.student.named_parameters() if p.requires_grad]
+    st = SO.state_from_state_dict(model.student.state_dict(), trainable, dict(D=D, depth=depth, heads=heads, patch=patch, K=K, n_local=n_local))
+    model = model.cuda().train()
+    random.seed(7)
+    mg = MaskingGenerator(input_size=(gsz // patch, gsz // patch), max_num_patches=0.5 * gsz // patch * gsz // patch)
+    batch = collate_data_and_cast(synthetic_samples(B, gsz, lsz, n_local, g), n_global_crops=2, n_local_crops=n_local, mask_ratio_tuple=(0.1, 0.5),
+                                  mask_probability=0.5, dtype=torch.float32, n_tokens=(gsz // patch) ** 2, mask_generator=mg)
+    ref = SO.train_iteration(st, SO.batch_from_collate(batch["images"]), hyper=[1e-3, 0.04, 0.05, 0.99], clip=3.0, freeze_last=False)
+    from apla_amd.ssl import CosineScheduler
+    const = lambda v: CosineScheduler(base_value=v, final_value=v, total_iters=4)   # noqa: E731
+    tr = Dinov2Trainer(model, iters_per_epoch=2, epochs=2, grad_clipping=3.0, freeze_last_layer_epochs=0,
+                       schedules=(const(1e-3), const(0.04), const(0.99), const(0.05), None))
+    loss = tr.global_step(batch)
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(ref["loss"])) < 2e-2 * float(ref["loss"])
+    for k, v in tr.loss_dict.items():
+        assert abs(float(v) - float(ref["loss_dict"][k])) < 2e-2 * abs(float(ref["loss_dict"][k])) + 2e-3, k
+    assert abs(float(tr.optimizer.grad_norm()) - float(ref["gnorm"])) < 3e-2 * float(ref["gnorm"])
+    sp = dict(model.student.named_parameters())
+    for n in trainable:
+        assert rel_err(sp[n].grad.cpu(), ref["grads"][n]) < 4e-2, n
