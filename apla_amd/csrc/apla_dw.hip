@@ -353,3 +353,62 @@ extern "C" int apla_pack_proj_rows_batched(const float* flat, long block_stride,
   APLA_CHECK_LAUNCH("apla_pack_proj_rows_batched");
   return APLA_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ composite operator entry points
+// The APLA projection as ONE forward and ONE backward call (the operator granularity SURVEY section 8b lists), composed of the
+// entry points above and apla_gemm_nt / apla_gather_cols.  No additional kernels.
+extern "C" int apla_gemm_nt(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int M, int N,
+                            int K, int epilogue, int out_dtype, const void* aux_in, int ld_aux_in, void* aux_out,
+                            int ld_aux_out, hipStream_t stream);
+extern "C" int apla_gather_cols(const void* src, int res_dtype, long src_row_stride, const int32_t* inds, int r, void* out, int M,
+                                int D, hipStream_t stream);
+
+static inline int proj_r_pad(int r) { return (r + TJ - 1) / TJ * TJ; }   // the dW kernel works on multiples of 64 rows
+
+extern "C" long apla_proj_workspace_bytes(int M, int D, int r) {
+  if (M <= 0 || D <= 0 || r <= 0 || r > D || D % TK != 0 || proj_r_pad(r) > D) return -1;
+  const int rp = proj_r_pad(r);
+  const long dw = apla_dw_workspace_bytes(M, rp, D);
+  if (dw < 0) return -1;
+  // [dyg M x rp 16-bit | dW rp x D fp32 | db rp fp32 | slab partials], each 256-byte aligned
+  auto al = [](long v) { return (v + 255) / 256 * 256; };
+  return al((long)M * rp * 2) + al((long)rp * D * 4) + al((long)rp * 4) + dw;
+}
+
+extern "C" int apla_proj_fwd(const void* x, const void* Wnat, const float* bnat, const int32_t* inds, void* y, int M, int D, int r,
+                             hipStream_t stream) {
+  (void)inds; (void)r;   // the natural-order weight already holds the scatter (apla_pack_proj_rows): one GEMM
+  APLA_REQUIRE(x && Wnat && y && M > 0 && D > 0, "apla_proj_fwd: bad arguments");
+  return apla_gemm_nt(x, D, Wnat, D, bnat, y, D, M, D, D, APLA_EPI_STORE, APLA_H16, nullptr, 0, nullptr, 0, stream);
+}
+
+extern "C" int apla_proj_bwd(const void* dy, const void* x, const void* WnatT, const int32_t* inds, void* dx, float* dW1, float* db1,
+                             void* workspace, long workspace_bytes, int M, int D, int r, int accumulate, hipStream_t stream) {
+  APLA_REQUIRE(dy && x && inds && dW1 && db1 && workspace && M > 0 && D > 0 && r > 0, "apla_proj_bwd: bad arguments");
+  const long need = apla_proj_workspace_bytes(M, D, r);
+  APLA_REQUIRE(need > 0 && workspace_bytes >= need && apla_aligned16(workspace), "apla_proj_bwd: workspace (need %ld bytes, 16-byte aligned)", need);
+  const int rp = proj_r_pad(r);
+  auto al = [](long v) { return (v + 255) / 256 * 256; };
+  char* ws = (char*)workspace;
+  void* dyg = ws;
+  float* dWp = (float*)(ws + al((long)M * rp * 2));
+  float* dbp = (float*)((char*)dWp + al((long)rp * D * 4));
+  void* part = (char*)dbp + al((long)rp * 4);
+  int rc = APLA_OK;
+  if (dx != nullptr) {   // dX = dY * Wnat  (through the transposed copy: NT GEMM)
+    APLA_REQUIRE(WnatT != nullptr, "apla_proj_bwd: WnatT required for dx");
+    rc = apla_gemm_nt(dy, D, WnatT, D, nullptr, dx, D, M, D, D, APLA_EPI_STORE, APLA_H16, nullptr, 0, nullptr, 0, stream);
+    if (rc != APLA_OK) return rc;
+  }
+  // the r trainable columns of dY (padded with the next, frozen, indices: their rows are dropped below), then the masked dW
+  rc = apla_gather_cols(dy, APLA_H16, D, inds, rp, dyg, M, D, stream);
+  if (rc != APLA_OK) return rc;
+  const bool direct = rp == r;   // no padding: the dW kernel writes (or accumulates into) the caller's buffers
+  rc = apla_proj_dw(dyg, x, D, nullptr, direct ? dW1 : dWp, direct ? db1 : dbp, part, M, rp, D, direct ? accumulate : 0, stream);
+  if (rc != APLA_OK || direct) return rc;
+  if (accumulate) { apla_set_error("apla_proj_bwd: accumulate needs r %% 64 == 0"); return APLA_ENOSYS; }
+  hipError_t e = hipMemcpyAsync(dW1, dWp, (size_t)r * D * 4, hipMemcpyDeviceToDevice, stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(db1, dbp, (size_t)r * 4, hipMemcpyDeviceToDevice, stream);
+  if (e != hipSuccess) { apla_set_error("apla_proj_bwd: copy failed: %s", hipGetErrorString(e)); return APLA_EIO; }
+  return APLA_OK;
+}

@@ -145,6 +145,22 @@ int apla_attn_bwd_cls(const void* qkv, const void* o, const void* do_cls, const 
 int apla_attn_probs(const void* qkv, const float* lse, float* attn, int B, int N, int H, float scale,
                     hipStream_t stream);
 
+/* The APLA output projection as one forward and one backward operator (appla_attn.py:62-79 and its autograd), composed of
+ * the entry points of this header — no kernels of their own.
+ *   apla_proj_fwd:  y[M,D] = x[M,D] @ Wnat^T + bnat, Wnat = the natural-order merged weight kept by apla_pack_proj_rows
+ *                   (row inds[j] = proj_weight1[j] for j < r, the frozen rows elsewhere): the two F.linear + two scatter_
+ *                   calls of the reference are one GEMM.  `inds` / `r` are accepted for symmetry and not read.
+ *   apla_proj_bwd:  dx[M,D] = dy @ Wnat (through WnatT, the transposed copy; dx may be NULL), dW1[r,D] / db1[r] fp32 = the
+ *                   gradient of the r trainable rows only (gather of dy[:, inds[:r]], then apla_proj_dw); any r
+ *                   (non-multiples of 64 are padded inside the workspace; `accumulate` needs r % 64 == 0).
+ * `inds` is the int32 device vector of the module's `inds` buffer (length D, trainable rows first).  Workspace:
+ * apla_proj_workspace_bytes(M, D, r) bytes, caller-owned, 16-byte aligned.  16-bit activations, D % 128 == 0. */
+long apla_proj_workspace_bytes(int M, int D, int r);
+int apla_proj_fwd(const void* x, const void* Wnat, const float* bnat, const int32_t* inds, void* y, int M, int D, int r,
+                  hipStream_t stream);
+int apla_proj_bwd(const void* dy, const void* x, const void* WnatT, const int32_t* inds, void* dx, float* dW1, float* db1,
+                  void* workspace, long workspace_bytes, int M, int D, int r, int accumulate, hipStream_t stream);
+
 /* Column-masked weight gradient of the APLA projection:
  *   dW1[j,:] (+)= row_scale[j] * sum_m dyg[m,j] * x[m,:]     dW1 fp32 [r,D]
  *   db1[j]   (+)= row_scale[j] * sum_m dyg[m,j]              db1 fp32 [r]

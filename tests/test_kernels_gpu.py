@@ -575,3 +575,50 @@ def test_gemm_nt_small_few_rows(ops, M, N, K):
         assert rel_err(ops.gemm_nt(a, w, bias, out_dtype=torch.float32).cpu(), ops.gemm_nt_small(a, w, bias, workspace=ws, out_dtype=torch.float32).cpu()) < 1e-5
     with pytest.raises(Exception):
         ops.gemm_nt_small(a, w, bias, workspace=ws[:16])
+
+
+@pytest.mark.parametrize("M,D,r", [(394, 256, 64), (257, 384, 40), (64, 128, 128)])
+def test_apla_proj_fwd_bwd_operators(ops, M, D, r):
+    """apla_proj_fwd / apla_proj_bwd — the projection as one forward and one backward operator of the C-ABI — called
+    through ctypes with raw pointers, against the reference formulas of appla_attn.py:62-79 in float64: two linears scattered
+    to their output columns; dX through both parts, dW1 / db1 for the r trainable rows only."""
+    from apla_amd._lib import check, lib
+    g = torch.Generator().manual_seed(M + r)
+    x = (torch.randn(M, D, generator=g) * 0.5).to(torch.bfloat16)
+    dy = torch.randn(M, D, generator=g).to(torch.bfloat16)
+    W1, W2 = torch.randn(r, D, generator=g) * 0.05, torch.randn(D - r, D, generator=g) * 0.05
+    b1, b2 = torch.randn(r, generator=g) * 0.1, torch.randn(D - r, generator=g) * 0.1
+    inds = torch.randperm(D, generator=g)
+    xd, dyd = x.double(), dy.double()
+    yref = torch.empty(M, D, dtype=torch.float64)
+    yref[:, inds[:r]] = xd @ W1.double().t() + b1.double()
+    yref[:, inds[r:]] = xd @ W2.double().t() + b2.double()
+    Wn = torch.zeros(D, D, dtype=torch.float64)
+    Wn[inds[:r]], Wn[inds[r:]] = W1.double(), W2.double()
+    dxref = dyd @ Wn
+    dW1ref, db1ref = dyd[:, inds[:r]].t() @ xd, dyd[:, inds[:r]].sum(0)
+    # device state: natural-order merged weight built by apla_pack_proj_rows from the module's parameters
+    Wnf = torch.zeros(D, D)
+    Wnf[inds[r:]] = W2
+    bn = torch.zeros(D)
+    bn[inds[r:]] = b2
+    Wnat, WnatT, bnat = Wnf.to(torch.bfloat16).cuda(), Wnf.t().contiguous().to(torch.bfloat16).cuda(), bn.cuda()
+    i32 = inds.int().cuda()
+    ops.pack_proj_rows(W1.cuda(), b1.cuda(), i32, None, Wnat, WnatT, bnat)
+    xg, dyg = x.cuda(), dy.cuda()
+    y = torch.empty(M, D, device="cuda", dtype=torch.bfloat16)
+    s = torch.cuda.current_stream().cuda_stream
+    check(lib().apla_proj_fwd(xg.data_ptr(), Wnat.data_ptr(), bnat.data_ptr(), i32.data_ptr(), y.data_ptr(), M, D, r, s), "apla_proj_fwd")
+    assert rel_err(y.float().cpu(), yref) < 6e-3
+    nbytes = lib().apla_proj_workspace_bytes(M, D, r)
+    assert nbytes > 0
+    ws = torch.empty(nbytes, device="cuda", dtype=torch.uint8)
+    dx = torch.empty(M, D, device="cuda", dtype=torch.bfloat16)
+    dW1, db1 = torch.empty(r, D, device="cuda"), torch.empty(r, device="cuda")
+    check(lib().apla_proj_bwd(dyg.data_ptr(), xg.data_ptr(), WnatT.data_ptr(), i32.data_ptr(), dx.data_ptr(), dW1.data_ptr(), db1.data_ptr(),
+                              ws.data_ptr(), nbytes, M, D, r, 0, s), "apla_proj_bwd")
+    torch.cuda.synchronize()
+    assert rel_err(dx.float().cpu(), dxref) < 6e-3
+    assert rel_err(dW1.cpu(), dW1ref) < 2e-5 * 50 and rel_err(db1.cpu(), db1ref) < 1e-4   # fp32 accumulation of bf16 products
+    assert lib().apla_proj_bwd(dyg.data_ptr(), xg.data_ptr(), WnatT.data_ptr(), i32.data_ptr(), dx.data_ptr(), dW1.data_ptr(), db1.data_ptr(),
+                               ws.data_ptr(), 16, M, D, r, 0, s) == -22      # workspace too small: -EINVAL, nothing launched
