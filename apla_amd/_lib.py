@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("APLA_LIB") or os.path.join(HERE, "libapla_hip.so")
 LIB_PATH_F16 = os.path.join(HERE, "libapla_hip_f16.so")  # fp16 operands (same sources, -DAPLA_FP16)
 
 APLA_BF16, APLA_F16, APLA_F32 = 0, 1, 2
-EPI_STORE, EPI_GELU, EPI_RESIDUAL, EPI_MUL, EPI_SWIGLU, EPI_SWIGLU_BWD = 0, 1, 2, 3, 4, 5
+EPI_STORE, EPI_GELU, EPI_RESIDUAL, EPI_MUL, EPI_SWIGLU, EPI_SWIGLU_BWD, EPI_GELU_FWD = 0, 1, 2, 3, 4, 5, 6
 
 # name -> (restype, argtypes); must list every symbol of include/apla_hip.h (tests/test_cabi.py checks this)
 SIGNATURES = {

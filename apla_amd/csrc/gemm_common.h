@@ -70,6 +70,19 @@ __device__ __forceinline__ void gelu_and_grad(float a, float& h, float& g) {
   h = a * phi;
   g = fmaf(a * E, 0.3989422804014327f, phi);
 }
+// GELU alone (the no-grad forward): the same Phi as gelu_and_grad, without the Gaussian term of the derivative
+__device__ __forceinline__ float gelu_only(float a) {
+  const float x = fabsf(a) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
+  float poly = fmaf(t, 1.061405429f, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  poly *= t;
+  const float E = __builtin_amdgcn_exp2f(a * a * -0.72134752044448170f);
+  const float q = 0.5f * poly * E;
+  return a * (a >= 0.f ? 1.0f - q : q);
+}
 __device__ __forceinline__ float sigmoid_f(float a) { return 1.0f / (1.0f + __expf(-a)); }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -206,6 +219,11 @@ __device__ __forceinline__ void persist_epilogue(const GemmParams& p, f32x4 (&ac
         }
         Vec8IO<bf16>::store((bf16*)p.C + (size_t)m * p.ldc + n, hl, hh);
         Vec8IO<bf16>::store((bf16*)p.aux_out + (size_t)m * p.ld_aux_out + n, gl, gh);
+      } else if constexpr (EPI == APLA_EPI_GELU_FWD) {
+        f32x4 hl, hh;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { hl[e] = gelu_only(lo[e]); hh[e] = gelu_only(hi[e]); }
+        Vec8IO<bf16>::store((bf16*)p.C + (size_t)m * p.ldc + n, hl, hh);
       } else if constexpr (EPI == APLA_EPI_SWIGLU) {
         // columns come in (x1_i, x2_i) pairs: 8 columns = 4 hidden units
         Vec8IO<bf16>::store((bf16*)p.aux_out + (size_t)m * p.ld_aux_out + n, lo, hi);
@@ -261,7 +279,8 @@ template <int EPI, typename OutT> struct WideEpi {
   static constexpr int L = HAS_AUX ? (sizeof(AuxT) == 4 ? 8 : 4) : 0;                       // aux loads per row
   static constexpr int S = (EPI == APLA_EPI_GELU) ? 8 : ((EPI == APLA_EPI_MUL) ? 4 : (sizeof(OutT) == 4 ? 8 : 4));  // stores per row
   static constexpr int NST = 5 * S;
-  static constexpr bool LINES = !HAS_AUX && sizeof(OutT) == 2 && (EPI == APLA_EPI_STORE || EPI == APLA_EPI_GELU);  // whole-line stores via LDS
+  static constexpr bool LINES = !HAS_AUX && sizeof(OutT) == 2 &&
+                                (EPI == APLA_EPI_STORE || EPI == APLA_EPI_GELU || EPI == APLA_EPI_GELU_FWD);  // whole-line stores via LDS
 };
 
 // GELU and GELU' of 8 accumulator values, packed to bf16.  Four values at a time, each group's packed results pinned by an
@@ -294,6 +313,28 @@ __device__ __forceinline__ void gelu8(f32x4 lo, f32x4 hi, bf16x8& h, bf16x8& g) 
   typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
   h = __builtin_bit_cast(bf16x8, u32x4_t{hp[0], hp[1], hp[2], hp[3]});
   g = __builtin_bit_cast(bf16x8, u32x4_t{gp[0], gp[1], gp[2], gp[3]});
+}
+
+// GELU alone of 8 accumulator values, packed to bf16 (same structure and pinning as gelu8)
+__device__ __forceinline__ void gelu8_fwd(f32x4 lo, f32x4 hi, bf16x8& h) {
+  typedef bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  unsigned hp[4];
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const f32x4 a = half ? hi : lo;
+    float x[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x[e] = gelu_only(a[e]);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      bf16x2_t hh;
+      hh[0] = (bf16)x[2 * e]; hh[1] = (bf16)x[2 * e + 1];
+      hp[2 * half + e] = __builtin_bit_cast(unsigned, hh);
+    }
+    asm volatile("" : "+v"(hp[2 * half]), "+v"(hp[2 * half + 1]));
+  }
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  h = __builtin_bit_cast(bf16x8, u32x4_t{hp[0], hp[1], hp[2], hp[3]});
 }
 
 // bf16 outputs without a second operand go through a per-wave 2 KB LDS buffer `tbuf` (16 rows x 128 B, 16-B chunk c of row
@@ -345,7 +386,18 @@ __device__ __forceinline__ void wide_epilogue(const GemmParams& p, f32x4 (&acc)[
 #endif
     };
     auto run = [&](auto FULL) {
-      if constexpr (EPI == APLA_EPI_STORE) {
+      if constexpr (EPI == APLA_EPI_GELU_FWD) {   // like GELU below, one output: no cross-step registers
+#pragma unroll
+        for (int k = 0; k < 10; ++k) {
+          const int i = k >> 1, h = k & 1;
+          bf16x8 hc0, hc1, n0_, n1_;
+          gelu8_fwd(acc[i][4 * h], acc[i][4 * h + 1], hc0);
+          gelu8_fwd(acc[i][4 * h + 2], acc[i][4 * h + 3], hc1);
+          stage(hc0, hc1, n0_, n1_);
+          commit(FULL, (bf16*)p.C, p.ldc, i, h, n0_, n1_);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else if constexpr (EPI == APLA_EPI_STORE) {
         bf16x8 p0, p1;  // step k-1, read back and waiting to be stored
 #pragma unroll
         for (int k = 0; k <= 10; ++k) {

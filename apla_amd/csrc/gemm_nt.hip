@@ -46,6 +46,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
         for (int e = 0; e < 4; ++e) { float hh, gg; gelu_and_grad(v[e], hh, gg); h[e] = hh; g[e] = gg; }
         Vec4IO<bf16>::store((bf16*)p.C + (size_t)m * p.ldc + n, h);
         Vec4IO<bf16>::store((bf16*)p.aux_out + (size_t)m * p.ld_aux_out + n, g);
+      } else if constexpr (EPI == APLA_EPI_GELU_FWD) {
+        f32x4 h;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h[e] = gelu_only(v[e]);
+        Vec4IO<bf16>::store((bf16*)p.C + (size_t)m * p.ldc + n, h);
       } else if constexpr (EPI == APLA_EPI_RESIDUAL) {
         f32x4 r = Vec4IO<OutT>::load((const OutT*)p.aux_in + (size_t)m * p.ld_aux_in + n);
         Vec4IO<OutT>::store((OutT*)p.C + (size_t)m * p.ldc + n, r + v);
@@ -340,6 +345,9 @@ extern "C" int apla_gemm_nt(const void* A, int lda, const void* W, int ldw, cons
     case APLA_EPI_GELU:
       APLA_REQUIRE(aux_out && apla_aligned16(aux_out) && ld_aux_out % 4 == 0 && ld_aux_out >= N && ldc >= N, "apla_gemm_nt[gelu]: aux_out [M,N] bf16 required");
       return launch<APLA_EPI_GELU, bf16>(p, stream);
+    case APLA_EPI_GELU_FWD:
+      APLA_REQUIRE(ldc >= N && out_dtype == APLA_H16, "apla_gemm_nt[gelu_fwd]: 16-bit output [M,N]");
+      return launch<APLA_EPI_GELU_FWD, bf16>(p, stream);
     case APLA_EPI_RESIDUAL:
       APLA_REQUIRE(aux_in && apla_aligned16(aux_in) && ld_aux_in % 4 == 0 && ld_aux_in >= N && ldc >= N, "apla_gemm_nt[residual]: aux_in [M,N] required");
       if (out_dtype == APLA_H16) return launch<APLA_EPI_RESIDUAL, bf16>(p, stream);

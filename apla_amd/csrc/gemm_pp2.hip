@@ -261,6 +261,8 @@ int apla_gemm_pp2_launch(const GemmParams& p_in, int epilogue, int out_dtype, hi
       if (out_dtype == APLA_F32) PP2_LAUNCH(APLA_EPI_STORE, float); else PP2_LAUNCH(APLA_EPI_STORE, bf16);
     case APLA_EPI_GELU:
       PP2_LAUNCH(APLA_EPI_GELU, bf16);
+    case APLA_EPI_GELU_FWD:
+      PP2_LAUNCH(APLA_EPI_GELU_FWD, bf16);
     default:
       return APLA_ENOSYS;
   }

@@ -86,6 +86,11 @@ __global__ __launch_bounds__(256) void gemm_small_reduce_kernel(const float* __r
   } else if constexpr (EPI == APLA_EPI_MUL) {
     v *= Vec4IO<bf16>::load((const bf16*)aux_in + (size_t)m * ld_in + n);
     Vec4IO<OutT>::store(C + (size_t)m * ldc + n, v);
+  } else if constexpr (EPI == APLA_EPI_GELU_FWD) {
+    f32x4 h;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) h[e] = gelu_only(v[e]);
+    Vec4IO<OutT>::store(C + (size_t)m * ldc + n, h);
   } else {  // GELU: h and gelu'
     f32x4 h, g;
 #pragma unroll
@@ -132,6 +137,10 @@ extern "C" int apla_gemm_nt_small(const void* A, int lda, const void* W, int ldw
     case APLA_EPI_MUL:
       APLA_REQUIRE(!f32 && aux_in && apla_aligned16(aux_in) && ld_aux_in % 4 == 0 && ld_aux_in >= N, "apla_gemm_nt_small[mul]: aux_in [M,N] bf16 required, 16-bit output");
       SMALL_REDUCE(APLA_EPI_MUL, bf16);
+      break;
+    case APLA_EPI_GELU_FWD:
+      APLA_REQUIRE(!f32, "apla_gemm_nt_small[gelu_fwd]: 16-bit output");
+      SMALL_REDUCE(APLA_EPI_GELU_FWD, bf16);
       break;
     case APLA_EPI_GELU:
       APLA_REQUIRE(!f32 && aux_out && apla_aligned16(aux_out) && ld_aux_out % 4 == 0 && ld_aux_out >= N, "apla_gemm_nt_small[gelu]: aux_out [M,N] bf16 required, 16-bit output");

@@ -353,7 +353,9 @@ class AplaTrainEngine:
             ops.pack_proj_rows(self._param_view(st.W1_name), self._param_view(st.b1_name), st.inds, st.gamma1,
                                st.Wnat, st.WnatT, st.bnat)
 
-    def _forward(self):
+    def _forward(self, inference: bool = False):
+        """``inference``: the no-grad forward of forward_only — fc1 runs the forward-only GELU epilogue (GELU' is neither
+        computed nor stored); everything else is the training forward."""
         B, N, H, D = self.B, self.N, self.H, self.D
         ops.patchify(self.images, self.patch, self.Kp, out=self.cols)
         ops.gemm_nt(self.cols, self.Wpe, self.bpe, out=self.patches)
@@ -386,6 +388,8 @@ class AplaTrainEngine:
                 e0.record()
             if self.swiglu:
                 ops.gemm_nt(self.ln_out, st.W12, st.b12, epilogue=ops.EPI_SWIGLU, aux_out=self.act_saved[i], out=self.h)
+            elif inference:
+                ops.gemm_nt(self.ln_out, st.Wfc1, st.bfc1, epilogue=ops.EPI_GELU_FWD, out=self.h)
             else:
                 ops.gemm_nt(self.ln_out, st.Wfc1, st.bfc1, epilogue=ops.EPI_GELU, aux_out=self.act_saved[i], out=self.h)
             if ev is not None:
@@ -603,7 +607,7 @@ class AplaTrainEngine:
         if labels is not None and not self.soft_targets:
             self.labels.copy_(labels.to(torch.int32), non_blocking=True)
         self.refresh_weights()
-        self._forward()
+        self._forward(inference=True)
         return self.logits, self.xn, (self.loss if labels is not None and not self.soft_targets else None)
 
     @_half_mode

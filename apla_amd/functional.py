@@ -345,7 +345,13 @@ class _MlpGeluFn(torch.autograd.Function):
 
 
 def mlp_gelu(x, w1, b1, w2, b2, gamma=None):
-    """fc2(GELU(fc1(x))); with ``gamma`` (a frozen LayerScale vector) the scale is folded into fc2: ls2(mlp(x))."""
+    """fc2(GELU(fc1(x))); with ``gamma`` (a frozen LayerScale vector) the scale is folded into fc2: ls2(mlp(x)).  Without
+    autograd (evaluation, the EMA teacher) fc1 runs the forward-only GELU epilogue: GELU' is neither computed nor stored."""
+    if not torch.is_grad_enabled():
+        _require_cuda(x, "mlp")
+        h = ops.gemm_nt(_as2d_bf16(x), w_bf16(w1), b_f32(b1), epilogue=ops.EPI_GELU_FWD)
+        y = ops.gemm_nt(h, w_bf16(w2), b_f32(b2)) if gamma is None else ops.gemm_nt(h, _scaled_w(w2, gamma), _scaled_b(b2, gamma))
+        return y.reshape(x.shape[:-1] + (w2.shape[0],)).to(x.dtype)
     return _MlpGeluFn.apply(x, w1, b1, w2, b2, gamma).to(x.dtype)
 
 

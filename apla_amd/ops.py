@@ -9,7 +9,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import (APLA_BF16, APLA_F16, APLA_F32, EPI_GELU, EPI_MUL, EPI_RESIDUAL, EPI_STORE, EPI_SWIGLU,  # noqa: F401
+from ._lib import (APLA_BF16, APLA_F16, APLA_F32, EPI_GELU, EPI_GELU_FWD, EPI_MUL, EPI_RESIDUAL, EPI_STORE, EPI_SWIGLU,  # noqa: F401
                    EPI_SWIGLU_BWD, check, lib)
 
 _DT = {torch.bfloat16: APLA_BF16, torch.float16: APLA_F16, torch.float32: APLA_F32}
@@ -113,6 +113,8 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = Non
         raise ValueError("gemm_nt: epilogue needs aux_in")
     if epilogue not in (EPI_STORE, EPI_RESIDUAL) and out.dtype != half():
         raise TypeError("gemm_nt: this epilogue writes bf16")
+    if epilogue == EPI_GELU_FWD and aux_out is not None:
+        raise ValueError("gemm_nt: EPI_GELU_FWD saves nothing (use EPI_GELU to get gelu')")
     rc = lib().apla_gemm_nt(a.data_ptr(), lda, w.data_ptr(), ldw, _ptr(bias), out.data_ptr(), out.stride(0), M, N, K,
                             epilogue, _DT[out.dtype], _ptr(aux_in), ld_in, _ptr(aux_out), ld_out, _stream())
     check(rc, "apla_gemm_nt")

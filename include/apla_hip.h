@@ -44,8 +44,9 @@ enum {
   APLA_EPI_MUL = 3,       /* C = (acc (+bias)) * aux_in; aux_in bf16 [M,N]                      -> bf16         */
   APLA_EPI_SWIGLU = 4,    /* weight rows interleaved (x1_i,x2_i): C[:, i] = silu(x1)*x2 bf16 [M,N/2];
                              aux_out = (acc+bias) bf16 [M,N] (saved for backward)                               */
-  APLA_EPI_SWIGLU_BWD = 5 /* acc = dh [M,N]; aux_in = saved x12 interleaved [M,2N];
+  APLA_EPI_SWIGLU_BWD = 5, /* acc = dh [M,N]; aux_in = saved x12 interleaved [M,2N];
                              C[:,2i] = dh*x2*silu'(x1), C[:,2i+1] = dh*silu(x1)       -> bf16 [M,2N]            */
+  APLA_EPI_GELU_FWD = 6    /* C = gelu(acc+bias) bf16, nothing saved: the no-grad forward (evaluation, EMA teacher)          */
 };
 
 const char* apla_last_error(void);

@@ -622,3 +622,31 @@ def test_apla_proj_fwd_bwd_operators(ops, M, D, r):
     assert rel_err(dW1.cpu(), dW1ref) < 2e-5 * 50 and rel_err(db1.cpu(), db1ref) < 1e-4   # fp32 accumulation of bf16 products
     assert lib().apla_proj_bwd(dyg.data_ptr(), xg.data_ptr(), WnatT.data_ptr(), i32.data_ptr(), dx.data_ptr(), dW1.data_ptr(), db1.data_ptr(),
                                ws.data_ptr(), 16, M, D, r, 0, s) == -22      # workspace too small: -EINVAL, nothing launched
+
+
+@pytest.mark.parametrize("M,N,K,variant", [(2500, 512, 256, 4), (300, 256, 128, 4), (300, 256, 128, 0), (128, 768, 768, -1)])
+def test_gemm_gelu_forward_only_epilogue(ops, M, N, K, variant):
+    """APLA_EPI_GELU_FWD (the no-grad forward: evaluation, EMA teacher) writes the same h as APLA_EPI_GELU bit for bit and saves
+    nothing: ping-pong (M >= 2048), persistent, simple and few-row kernels."""
+    from apla_amd._lib import lib
+    g = torch.Generator().manual_seed(M + N)
+    a = (torch.randn(M, K, generator=g) * 0.7).to(torch.bfloat16).cuda()
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(torch.bfloat16).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    gp = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    if variant < 0:
+        ws = ops.gemm_small_workspace(M, N, K, "cuda")
+        h_ref = ops.gemm_nt_small(a, w, bias, workspace=ws, epilogue=ops.EPI_GELU, aux_out=gp)
+        h = ops.gemm_nt_small(a, w, bias, workspace=ws, epilogue=ops.EPI_GELU_FWD)
+    else:
+        old = lib().apla_gemm_set_variant(variant)
+        try:
+            h_ref = ops.gemm_nt(a, w, bias, epilogue=ops.EPI_GELU, aux_out=gp)
+            h = ops.gemm_nt(a, w, bias, epilogue=ops.EPI_GELU_FWD)
+        finally:
+            lib().apla_gemm_set_variant(old)
+        with pytest.raises(ValueError):
+            ops.gemm_nt(a, w, bias, epilogue=ops.EPI_GELU_FWD, aux_out=gp)
+    assert torch.equal(h, h_ref)
+    r = (a.double() @ w.double().t() + bias.double()).float()
+    assert rel_err(h.float().cpu(), (r * 0.5 * (1 + torch.erf(r / math.sqrt(2)))).cpu()) < 6e-3
