@@ -10,13 +10,17 @@
 namespace {
 
 constexpr int MAXC = 8;  // row chunks of 4 elements per lane: D <= 64*4*MAXC = 2048 (kernels are instantiated per chunk count)
-constexpr int ROWS_PER_BLOCK = 4;
+#ifndef APLA_LN_ROWS
+#define APLA_LN_ROWS 4
+#endif
+constexpr int ROWS_PER_BLOCK = APLA_LN_ROWS;  // one wave per row
+constexpr int LN_THREADS = 64 * ROWS_PER_BLOCK;
 
 // Optional fused residual add: x_new = x + add (add = bf16 branch output of the previous GEMM) is formed in registers,
 // written to xout and normalised in the same pass — the "x = x + branch" of vit.py:284-285 costs no kernel of its own and
 // no fp32 read-modify-write in a GEMM epilogue.
 template <typename ResT, typename YT, int NC>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const ResT* x, long xs, const float* __restrict__ gamma,
+__global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const ResT* x, long xs, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, YT* __restrict__ y, int ldy,
                                                      float* __restrict__ mean_o, float* __restrict__ rstd_o, int M,
                                                      int D, float eps, const bf16* __restrict__ add, long adds,
@@ -73,7 +77,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const ResT* x, long xs, con
 // dx_out = dres_in + ((dy*g) - mean(dy*g) - xhat*mean(dy*g*xhat)) * rstd ; optional bf16 copy of dx_out (GEMM operand
 // when the gradient stream is fp32) and optional gather of the APLA-trainable columns.
 template <typename XT, typename DYT, typename GT, bool GATHER, int NC>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const DYT* __restrict__ dy, int lddy, const XT* __restrict__ x,
+__global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const DYT* __restrict__ dy, int lddy, const XT* __restrict__ x,
                                                      long xs, const float* __restrict__ gamma,
                                                      const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                      const GT* dres, GT* dx, long dxs, bf16* __restrict__ dxb, long dbs,
@@ -134,7 +138,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const DYT* __restrict__ dy,
 }
 
 template <typename ResT>
-__global__ __launch_bounds__(256) void gather_cols_kernel(const ResT* __restrict__ src, long ss,
+__global__ __launch_bounds__(LN_THREADS) void gather_cols_kernel(const ResT* __restrict__ src, long ss,
                                                           const int32_t* __restrict__ inds, int r,
                                                           bf16* __restrict__ out, int M) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -160,7 +164,7 @@ extern "C" int apla_layernorm_fwd(const void* x, int res_dtype, long x_row_strid
   APLA_REQUIRE(apla_aligned16(x) && apla_aligned16(gamma) && apla_aligned16(beta) && (((uintptr_t)y) & 7) == 0, "apla_layernorm_fwd: alignment");
   APLA_REQUIRE(add_in == nullptr || (x_out != nullptr && add_row_stride % 4 == 0 && add_row_stride >= D && x_out_row_stride % 4 == 0 && x_out_row_stride >= D),
                "apla_layernorm_fwd: fused residual add needs x_out and valid strides");
-#define LN_FWD_NC(T, Y, NCV) hipLaunchKernelGGL((ln_fwd_kernel<T, Y, NCV>), dim3(ln_grid(M)), dim3(256), 0, stream, (const T*)x, x_row_stride, gamma, beta, (Y*)y, ldy, mean, rstd, M, D, eps, (const bf16*)add_in, add_row_stride, (T*)x_out, x_out_row_stride)
+#define LN_FWD_NC(T, Y, NCV) hipLaunchKernelGGL((ln_fwd_kernel<T, Y, NCV>), dim3(ln_grid(M)), dim3(LN_THREADS), 0, stream, (const T*)x, x_row_stride, gamma, beta, (Y*)y, ldy, mean, rstd, M, D, eps, (const bf16*)add_in, add_row_stride, (T*)x_out, x_out_row_stride)
 #define LN_FWD(T, Y)                                    \
   do {                                                  \
     const int nc_ = (D + 255) / 256;                    \
@@ -198,7 +202,7 @@ extern "C" int apla_layernorm_bwd(const void* dy, int dy_dtype, int lddy, const 
   const bool gather = gather_out != nullptr;
   const size_t lds = gather ? (size_t)ROWS_PER_BLOCK * D * sizeof(float) : 0;
 #define LN_BWD_NC(X, Y, G, GA, NCV)                                                                                    \
-  hipLaunchKernelGGL((ln_bwd_kernel<X, Y, G, GA, NCV>), dim3(ln_grid(M)), dim3(256), lds, stream, (const Y*)dy, lddy,  \
+  hipLaunchKernelGGL((ln_bwd_kernel<X, Y, G, GA, NCV>), dim3(ln_grid(M)), dim3(LN_THREADS), lds, stream, (const Y*)dy, lddy,  \
                      (const X*)x, x_row_stride, gamma, mean, rstd, (const G*)dres_in, (G*)dx_out, dx_row_stride,       \
                      (bf16*)dx_bf16_copy, copy_row_stride, inds, r, (bf16*)gather_out, M, D)
 #define LN_BWD(X, Y, G, GA)                             \
@@ -239,9 +243,9 @@ extern "C" int apla_gather_cols(const void* src, int res_dtype, long src_row_str
                                 void* out, int M, int D, hipStream_t stream) {
   APLA_REQUIRE(src && inds && out && M > 0 && r > 0 && r <= D, "apla_gather_cols: bad arguments");
   if (res_dtype == APLA_F32)
-    hipLaunchKernelGGL(gather_cols_kernel<float>, dim3(ln_grid(M)), dim3(256), 0, stream, (const float*)src, src_row_stride, inds, r, (bf16*)out, M);
+    hipLaunchKernelGGL(gather_cols_kernel<float>, dim3(ln_grid(M)), dim3(LN_THREADS), 0, stream, (const float*)src, src_row_stride, inds, r, (bf16*)out, M);
   else if (res_dtype == APLA_H16)
-    hipLaunchKernelGGL(gather_cols_kernel<bf16>, dim3(ln_grid(M)), dim3(256), 0, stream, (const bf16*)src, src_row_stride, inds, r, (bf16*)out, M);
+    hipLaunchKernelGGL(gather_cols_kernel<bf16>, dim3(ln_grid(M)), dim3(LN_THREADS), 0, stream, (const bf16*)src, src_row_stride, inds, r, (bf16*)out, M);
   else {
     apla_set_error("apla_gather_cols: bad res_dtype %d", res_dtype);
     return APLA_ENOSYS;
