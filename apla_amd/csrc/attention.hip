@@ -818,18 +818,34 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_small_kernel(const bf16* __re
           tr_issue(tf[4 * sk + dt], TB, t * 32 + 16 * sk, 32 * dt, lane);
           tr_issue(tf[4 * sk + 2 + dt], TA, t * 32 + 16 * sk, 32 * dt, lane);
         }
-      const bool tail = t * 32 + 32 > N;
+      // P and dS (in place of dP).  Only the sequence's last query tile needs the per-row mask: as one predicated loop hipcc emits
+      // the compare/select pair for every element of every tile.
+      if (t * 32 + 32 <= N) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int r0 = t * 32 + 8 * g + 4 * h2;
-        const f32x4 l4 = *(const f32x4*)(lses + r0) * LOG2E, d4 = *(const f32x4*)(dls + r0);
+        for (int g = 0; g < 4; ++g) {
+          const int r0 = t * 32 + 8 * g + 4 * h2;
+          const f32x4 l4 = *(const f32x4*)(lses + r0) * LOG2E, d4 = *(const f32x4*)(dls + r0);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int i = 4 * g + e;
-          float p = ATT_EXP2(fmaf(s[i], c, -l4[e]));
-          if (tail && r0 + e >= N) p = 0.f;
-          s[i] = p;
-          dp[i] = p * (dp[i] - d4[e]);
+          for (int e = 0; e < 4; ++e) {
+            const int i = 4 * g + e;
+            const float p = ATT_EXP2(fmaf(s[i], c, -l4[e]));
+            s[i] = p;
+            dp[i] = p * (dp[i] - d4[e]);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int r0 = t * 32 + 8 * g + 4 * h2;
+          const f32x4 l4 = *(const f32x4*)(lses + r0) * LOG2E, d4 = *(const f32x4*)(dls + r0);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int i = 4 * g + e;
+            float p = ATT_EXP2(fmaf(s[i], c, -l4[e]));
+            if (r0 + e >= N) p = 0.f;
+            s[i] = p;
+            dp[i] = p * (dp[i] - d4[e]);
+          }
         }
       }
       lds_landed(tf);
