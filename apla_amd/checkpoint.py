@@ -31,6 +31,55 @@ def load_pretrained_backbone(backbone: torch.nn.Module, sd: Dict[str, torch.Tens
     return backbone.load_state_dict(clean_pretrained_state_dict(sd, pretrained_type), strict=strict)
 
 
+def _strip_prefix(sd, prefix):
+    return {(k[len(prefix):] if k.startswith(prefix) else k): v for k, v in sd.items()}
+
+
+def read_state_dict(path: str) -> Dict[str, torch.Tensor]:
+    """A checkpoint file's weights: the ``state_dict`` entry of a session file (defaults/bases.py:456-467) or the file itself
+    (a bare dinov2 / timm state dict); DDP's ``module.`` prefix removed."""
+    sd = torch.load(path, map_location="cpu", weights_only=False)
+    if isinstance(sd, dict) and "state_dict" in sd and isinstance(sd["state_dict"], dict):
+        sd = sd["state_dict"]
+    return _strip_prefix(sd, "module.")
+
+
+def is_apla_state_dict(sd: Dict[str, torch.Tensor]) -> bool:
+    """Does the state dict come from a model AFTER the APLA split (``attn.proj_weight1`` …, appla_attn.py:37-45)?"""
+    return any(k.endswith("attn.proj_weight1") for k in sd)
+
+
+def load_apla_state_dict(model: torch.nn.Module, sd: Dict[str, torch.Tensor]):
+    """The reference's rule for APLA / session checkpoints (utils/pretrained_loader.py:27-30): no key of the model may be
+    missing, and the only unexpected keys allowed are ``partial_size`` entries.  Raises otherwise."""
+    res = model.load_state_dict(sd, strict=False)
+    if res.missing_keys:
+        raise KeyError(f"checkpoint lacks {len(res.missing_keys)} keys of the model, e.g. {res.missing_keys[:4]}")
+    bad = [k for k in res.unexpected_keys if "partial_size" not in k]
+    if bad:
+        raise KeyError(f"checkpoint has {len(bad)} keys the model does not know, e.g. {bad[:4]}")
+    return res
+
+
+def build_classifier_from_checkpoint(path: str, model_params, system_params):
+    """Classifier (apla_amd.models) initialised from a checkpoint file of either kind:
+    * an APLA / session checkpoint (split projection, ``backbone.`` prefix): build, then load with the reference's strict rule;
+    * an unsplit backbone (dinov2 / timm names, with or without a ``backbone.`` prefix; a classification head, if any, is
+      ignored): loaded into the ViT before ``build_apla`` splits ``attn.proj`` — so the frozen weights and the trainable rows
+      both start from the pretrained projection, as in the reference.
+    Returns (model, kind) with kind in {"apla", "backbone"}."""
+    from .models import Classifier
+    sd = read_state_dict(path)
+    if is_apla_state_dict(sd):
+        model = Classifier(model_params, system_params)
+        load_apla_state_dict(model, sd)
+        return model, "apla"
+    if any(k.startswith("backbone.") for k in sd):
+        sd = {k[len("backbone."):]: v for k, v in sd.items() if k.startswith("backbone.")}
+    sd = {k: v for k, v in sd.items() if not (k.startswith("fc.") or k.startswith("head."))}
+    return Classifier(model_params, system_params, backbone_state_dict=sd), "backbone"
+
+
 def _group_order(model: torch.nn.Module):
     """Names of the trainable parameters in torch-optimizer index order: group 0 (decayed) then group 1."""
     reg, no_reg = [], []
@@ -44,9 +93,10 @@ def optimizer_state_dict(engine) -> dict:
     """The engine's AdamW state as a ``torch.optim.AdamW(get_params_groups(model)).state_dict()`` (CPU tensors)."""
     reg, no_reg = _group_order(engine.model)
     oc, state, idx = engine.optim, {}, 0
-    steps = float(engine.step_count)
     if getattr(engine, "dynamic_scale", False):  # steps actually taken (skipped overflow steps do not count)
         steps = float(engine.scaler[3 * (engine._scaler_calls & 1) + 2])
+    else:
+        steps = float(getattr(engine, "applied_steps", engine.step_count))
     for name in reg + no_reg:
         off, k, shape = engine.slices[name]
         state[idx] = {"step": torch.tensor(steps),
@@ -79,6 +129,8 @@ def load_optimizer_state_dict(engine, osd: dict):
     if len(steps) > 1:
         raise ValueError(f"per-tensor step counts differ ({sorted(steps)}): the fused optimizer keeps one step count")
     engine.step_count = steps.pop() if steps else 0
+    if hasattr(engine, "norm_ws"):
+        engine.norm_ws[260:262] = 0.0   # skipped-update counters (apla_adamw_step): the restored step count is "applied steps"
 
 
 def session_dict(engine, *, iters: int = 0, epoch: int = 0, parameters: Optional[dict] = None,

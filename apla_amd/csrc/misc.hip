@@ -134,6 +134,13 @@ __global__ __launch_bounds__(256) void cross_entropy_kernel(const float* __restr
   const float invB = 1.0f / (float)B;
   if (labels != nullptr) {
     const int y = labels[b];
+    if ((unsigned)y >= (unsigned)C) {
+      // a class id outside [0, C) (wrong n_classes, an ignore_index of -1 …): torch's CrossEntropyLoss raises; a kernel cannot,
+      // so the row contributes no gradient and its loss is NaN — the mean loss of the batch turns NaN and the caller sees it
+      for (int c = threadIdx.x; c < C; c += 256) dlogits[(size_t)b * ldl + c] = 0.f;
+      if (threadIdx.x == 0) row_loss[b] = __builtin_nanf("");
+      return;
+    }
     for (int c = threadIdx.x; c < C; c += 256) {
       const float pr = __expf(lr[c] - lse);
       dlogits[(size_t)b * ldl + c] = (pr - (c == y ? 1.0f : 0.0f)) * invB;

@@ -25,8 +25,12 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
                                                     float* __restrict__ v, const uint8_t* __restrict__ decay, long n,
                                                     float lr, float wd, float b1, float b2, float eps, float bc1,
                                                     float bc2_sqrt, float max_norm, float grad_scale,
-                                                    float* __restrict__ ws) {
-  __shared__ float coef_s;
+                                                    float* __restrict__ ws, int track_step) {
+  // track_step > 0 (apla_adamw_step): ws[260 + (step & 1)] holds the number of updates SKIPPED so far (non-finite gradient
+  // norm); this call reads that slot and block 0 writes the new count into the other slot, which the next call (step + 1)
+  // reads — no workgroup reads what another writes in the same launch.  The bias corrections then use the count of updates
+  // actually applied, as GradScaler + torch.optim.AdamW do (a skipped step does not advance `step`).
+  __shared__ float coef_s, bc1_s, bc2s_s;
   if (threadIdx.x < 64) {
     float s = 0.f;
     for (int i = threadIdx.x; i < NPART; i += 64) s += ws[2 + i];
@@ -36,21 +40,34 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
       float coef = 1.0f;
       if (max_norm > 0.f) { coef = max_norm / (norm + 1e-6f); coef = coef < 1.0f ? coef : 1.0f; }
       // a non-finite norm (fp16 gradients that overflowed under the loss scale) skips the update, like GradScaler.step
-      coef_s = isfinite(norm) ? coef * grad_scale : __builtin_nanf("");
+      const bool ok = isfinite(norm);
+      coef_s = ok ? coef * grad_scale : __builtin_nanf("");
+      float c1 = bc1, c2s = bc2_sqrt;
+      if (track_step > 0) {
+        const float skipped = ws[260 + (track_step & 1)];
+        if (skipped > 0.f) {
+          const float t = fmaxf((float)track_step - skipped, 1.0f);
+          c1 = 1.0f - powf(b1, t);
+          c2s = sqrtf(1.0f - powf(b2, t));
+        }
+        if (blockIdx.x == 0) ws[260 + ((track_step + 1) & 1)] = skipped + (ok ? 0.f : 1.f);
+      }
+      bc1_s = c1; bc2s_s = c2s;
       if (blockIdx.x == 0) { ws[0] = s; ws[1] = norm; }
     }
   }
   __syncthreads();
   const float coef = coef_s;
   if (coef != coef) return;
-  const float step_size = lr / bc1;
+  const float step_size = lr / bc1_s;
+  const float bc2_sqrt_ = bc2s_s;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     const float gi = g[i] * coef;
     float pi = p[i];
     if (decay[i]) pi *= (1.0f - lr * wd);
     const float mi = m[i] * b1 + gi * (1.0f - b1);
     const float vi = v[i] * b2 + gi * gi * (1.0f - b2);
-    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    const float denom = sqrtf(vi) / bc2_sqrt_ + eps;
     pi -= step_size * (mi / denom);
     p[i] = pi; m[i] = mi; v[i] = vi; g[i] = gi;
   }
@@ -162,7 +179,7 @@ extern "C" int apla_adamw_apply(float* params, float* grads, float* exp_avg, flo
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   long blocks = (n + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, params, grads, exp_avg, exp_avg_sq, decay_mask, n, lr, weight_decay, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), max_norm, grad_scale, norm_ws);
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, params, grads, exp_avg, exp_avg_sq, decay_mask, n, lr, weight_decay, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), max_norm, grad_scale, norm_ws, 0);
   APLA_CHECK_LAUNCH("apla_adamw_apply");
   return APLA_OK;
 }
@@ -178,7 +195,7 @@ extern "C" int apla_adamw_step(float* params, float* grads, float* exp_avg, floa
   APLA_CHECK_LAUNCH("apla_adamw_step[sumsq]");
   long blocks = (n + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, params, grads, exp_avg, exp_avg_sq, decay_mask, n, lr, weight_decay, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), max_norm, grad_scale, norm_ws);
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, params, grads, exp_avg, exp_avg_sq, decay_mask, n, lr, weight_decay, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), max_norm, grad_scale, norm_ws, step);
   APLA_CHECK_LAUNCH("apla_adamw_step[update]");
   return APLA_OK;
 }

@@ -71,12 +71,20 @@ class GradExchanger:
         self.flat = flat_grads
         self.chunks = list(chunks)
         self.pg = process_group
-        self.world = dist.get_world_size(process_group) if (dist.is_initialized() and (process_group is not None or ddp_is_on())) else 1
+        self.world = self.world_of(process_group)
         self.active = self.world > 1 or (always and dist.is_initialized() and process_group is not None)
         self._comm = torch.cuda.Stream() if (flat_grads.is_cuda and self.active) else None
         covered = sorted(self.chunks)
         assert covered[0][0] == 0 and covered[-1][1] == flat_grads.numel() and all(
             covered[i][1] == covered[i + 1][0] for i in range(len(covered) - 1)), "chunks must tile the flat buffer"
+
+    @staticmethod
+    def world_of(process_group=None) -> int:
+        """Ranks an exchanger built with this group sums over: the group's size, or the default group's when none is given and
+        torch.distributed is initialised, else 1."""
+        if dist.is_available() and dist.is_initialized() and (process_group is not None or ddp_is_on()):
+            return dist.get_world_size(process_group)
+        return 1
 
     def launch_chunk(self, k: int):
         """Start the all-reduce of chunk k (call right after the backward segment that produced it was enqueued)."""

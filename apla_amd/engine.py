@@ -105,7 +105,7 @@ class AplaTrainEngine:
         self.res_dtype, self.grad_dtype = res_dtype, (grad_dtype or compute_dtype)
         self.optim = optim or OptimConfig()
         self.pg = process_group
-        self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
+        self.world = 1   # set from the GradExchanger below: ONE source for "how many ranks sum into the gradient buffer"
         self.use_graphs = use_graphs
         # diagnostic switch: APLA_FULL_LAST_BLOCK=1 runs the last block's forward on all rows (A/B of the CLS-only tail)
         self.cls_only_tail = os.environ.get("APLA_FULL_LAST_BLOCK") != "1"
@@ -174,6 +174,7 @@ class AplaTrainEngine:
         # APLA_FORCE_EXCHANGE=1 (diagnostic): take the world > 1 path — four segments, collectives on the side stream — in a
         # process group of ONE rank, so that a single-GPU box exercises the real RCCL calls between the graph replays
         force = os.environ.get("APLA_FORCE_EXCHANGE") == "1" and self.pg is not None
+        self.world = GradExchanger.world_of(self.pg)
         n_seg = min(4 if (self.world > 1 or force) else 2, max(self.L, 1))
         # segment s ends after the backward of block cut[s]; cut[-1] = 0.  e.g. L = 12, two segments: [6, 0]
         self.seg_cuts = [(self.L * (n_seg - 1 - s)) // n_seg for s in range(n_seg)]
@@ -186,6 +187,9 @@ class AplaTrainEngine:
         self.chunks = [(lo, hi) for lo, hi in zip(bounds, his)]
         assert self.chunks[-1][0] == 0 and all(hi > lo for lo, hi in self.chunks)
         self.exchanger = GradExchanger(self.flat_grads, self.chunks, self.pg, always=force)
+        # the optimizer divides by exactly the number of ranks the exchanger sums over (process_group=None with an initialised
+        # default group of N ranks exchanges over those N ranks: the 1/world of the DDP mean must follow)
+        assert self.world == self.exchanger.world, (self.world, self.exchanger.world)
 
     def _grad_view(self, name):
         off, k, shape = self.slices[name]
@@ -633,6 +637,19 @@ class AplaTrainEngine:
     @property
     def grad_norm(self):
         return self.norm_ws[1]
+
+    @property
+    def skipped_steps(self) -> int:
+        """Optimizer steps skipped so far because the gradient norm was not finite (static loss-scale / bf16 path; the dynamic
+        scaler keeps its own count).  Reads device memory: call it at logging cadence, not every step."""
+        if self.dynamic_scale:
+            return int(self._scaler_calls - float(self.scaler[3 * (self._scaler_calls & 1) + 2])) if self._scaler_calls else 0
+        return int(float(self.norm_ws[260 + ((self.step_count + 1) & 1)]))
+
+    @property
+    def applied_steps(self) -> int:
+        """Updates actually applied = what torch.optim.AdamW would report as ``step`` (skipped steps do not count)."""
+        return self.step_count - self.skipped_steps
 
     def grads(self):
         return {n: self._grad_view(n) for n in self.names}

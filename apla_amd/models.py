@@ -34,7 +34,11 @@ class AttrDict(dict):
 
 
 class Classifier(nn.Module):
-    def __init__(self, model_params, system_params):
+    def __init__(self, model_params, system_params, backbone_state_dict=None):
+        """``backbone_state_dict``: an UNSPLIT pretrained backbone (dinov2 / timm key names, ``attn.proj.*`` still whole) to load
+        into the freshly built ViT BEFORE ``build_apla`` splits the projection — what the reference's ``pretrained: true`` does
+        inside the ViT factory (utils/transformers/vit.py:545-560 -> transformers_utils.download_weights) before
+        defaults/models.py:49-54 calls build_apla.  Loaded strictly: a key mismatch raises."""
         super().__init__()
         mp = AttrDict(model_params)
         sp = AttrDict(system_params)
@@ -50,6 +54,9 @@ class Classifier(nn.Module):
         if not hasattr(vit, self.backbone_type):
             raise ValueError(f"unknown backbone_type {self.backbone_type}")
         model = getattr(vit, self.backbone_type)(pretrained=mp.get("pretrained", False), **tp)
+        if backbone_state_dict is not None:
+            from .checkpoint import load_pretrained_backbone
+            load_pretrained_backbone(model, backbone_state_dict, tp.get("pretrained_type", "dinov2"), strict=True)
         self.backbone = build_apla(config=mp.adaptation.params, model=model, attn_class="apla_attn",
                                    is_multi_gpu=len(str(sp.get("which_GPUs", "0")).split(",")) > 1)
         self.backbone.fc = nn.Identity()

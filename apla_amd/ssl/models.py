@@ -56,8 +56,12 @@ def _wrap(cfg):
 
 
 class DINOv2(nn.Module):
-    def __init__(self, params, backbones=None):
-        """``backbones`` = (student, teacher, embed_dim) overrides build_model (tests use small geometries)."""
+    def __init__(self, params, backbones=None, backbone_state_dict=None):
+        """``backbones`` = (student, teacher, embed_dim) overrides build_model (tests use small geometries).
+        ``backbone_state_dict``: pretrained weights for BOTH backbones (the reference loads the torch.hub dinov2 weights into
+        student and teacher before ``build_apla``, models.py:78-114).  An unsplit backbone (``attn.proj.*`` whole) is loaded
+        strictly before the split; a state dict saved after the split (``attn.proj_weight1`` …, optionally under
+        ``student.backbone.``) is loaded strictly after it.  A key mismatch raises."""
         super().__init__()
         params = _wrap(params)
         self.wrapper_params = params
@@ -70,13 +74,31 @@ class DINOv2(nn.Module):
         if backbones is None and getattr(mp, "pretrained", False):
             raise RuntimeError("no network here: load LVD-142M weights with apla_amd.checkpoint.load_pretrained and pass "
                                "pretrained: false")
+        split_sd = None
+        if backbone_state_dict is not None:
+            from ..checkpoint import is_apla_state_dict, load_pretrained_backbone
+            sd = dict(backbone_state_dict)
+            if any(k.startswith("student.backbone.") for k in sd):
+                sd = {k[len("student.backbone."):]: v for k, v in sd.items() if k.startswith("student.backbone.")}
+            elif any(k.startswith("backbone.") for k in sd):
+                sd = {k[len("backbone."):]: v for k, v in sd.items() if k.startswith("backbone.")}
+            if is_apla_state_dict(sd):
+                split_sd = sd
+            else:
+                load_pretrained_backbone(student_bb, sd, "dinov2", strict=True)
         teacher_bb.load_state_dict(deepcopy(student_bb.state_dict()))
+        if split_sd is not None and "adaptation" not in mp:
+            raise KeyError("the checkpoint holds a split APLA projection but the configuration has no adaptation section")
         if "adaptation" in mp:
             ad = mp.adaptation
             assert ad.mode == "apla", "Only supports adaptation with APLA"
             multi = len(str(params.system_params.which_GPUs).split(",")) > 1
             student_bb = build_apla(config=ad.params, model=student_bb, attn_class="apla_attn_mem_eff", is_multi_gpu=multi)
             teacher_bb = build_apla(config=ad.params, model=teacher_bb, attn_class="apla_attn_mem_eff", is_multi_gpu=multi)
+            if split_sd is not None:
+                from ..checkpoint import load_apla_state_dict
+                load_apla_state_dict(student_bb, split_sd)
+                load_apla_state_dict(teacher_bb, split_sd)
         self.do_dino = dino_p.loss_weight > 0
         self.do_koleo = dino_p.koleo_loss_weight > 0
         self.do_ibot = ibot_p.loss_weight > 0

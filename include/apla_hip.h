@@ -193,7 +193,11 @@ int apla_pack_proj_rows_batched(const float* flat, long block_stride, const int3
  * defaults/wrappers.py:205-221): grads are first multiplied by grad_scale (1/world for DDP mean), the global L2
  * norm is reduced on device (no host sync), clip coefficient = min(1, max_norm/(norm+1e-6)) (max_norm <= 0 disables),
  * weight decay applies to elements with decay_mask[i] != 0 (uint8).  `norm_ws` = 512 floats workspace:
- * [0] sum of squares, [1] resulting grad norm (pre-clip), [2..257] per-workgroup partials (deterministic reduction).
+ * [0] sum of squares, [1] resulting grad norm (pre-clip), [2..257] per-workgroup partials (deterministic reduction),
+ * [260], [261] number of updates skipped so far because the norm was not finite (two slots: the call with step s reads
+ * slot s&1 and writes slot (s+1)&1, so `step` must advance by one per call; zero the workspace before the first).  A skipped
+ * update leaves params / moments untouched and does not count for the bias corrections (GradScaler.step semantics,
+ * defaults/trainer.py:133-138): they use step - skipped.
  * Grads are overwritten with the scaled+clipped values (as clip_grad_norm_ does in place). */
 int apla_adamw_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, const uint8_t* decay_mask,
                     long n, float lr, float weight_decay, float beta1, float beta2, float eps, int step,

@@ -8,8 +8,13 @@ loaded first and the given file overrides it key by key — utils/helpfuns.py:11
 LinearWarmup / CosineAnnealingLR schedule, gradient clipping, one process per GPU.  The training step itself is
 `AplaTrainEngine.train_step` (fused forward + loss + backward + gradient exchange + clip + AdamW).
 
-NOT rebuilt (out of scope): the dataset zoo and torchvision transforms, wandb logging, evaluation / kNN, the
-SSL trainers (`--dinov2` etc. raise).  Data therefore comes from one of two sources:
+Also here: `--dinov2` (the DINOv2-APLA self-supervised step, src/main.py:169-171 -> apla_amd/ssl), `--test` / `--knn`
+(validation + kNN evaluation on the engine's forward, defaults/trainer.py:162-345 -> apla_amd/evaluate.py), and
+`--pretrained_path`: an APLA / session checkpoint is loaded strictly (utils/pretrained_loader.py:27-30), an unsplit dinov2 /
+timm backbone is loaded before `build_apla` splits the projection (apla_amd/checkpoint.py).
+
+NOT rebuilt (out of scope): the dataset zoo and torchvision transforms, wandb logging, the BYOL / SimSiam /
+DINO-v1 trainers.  Data therefore comes from one of two sources:
   * `dataset_params.dataset: "TensorFile"` + `data_location: file.pt` — a dict {"images": uint8|float [N,3,S,S],
     "labels": int [N]} that is normalised (ImageNet mean/std) and served in shuffled batches from device memory;
   * anything else — synthetic N(0,1) images with random labels of the shapes the YAML describes (a plumbing /
@@ -204,6 +209,7 @@ class TensorBatches:
         if run["dataset"] == "TensorFile":
             blob = torch.load(run["data_location"], map_location="cpu")
             imgs, self.labels = blob["images"], blob["labels"].to(device).int()
+            self._check_labels(self.labels, run["n_classes"], "labels")
             imgs = imgs.float().div_(255.0) if imgs.dtype == torch.uint8 else imgs.float()
             mean, std = torch.tensor(IMAGENET_MEAN).view(1, 3, 1, 1), torch.tensor(IMAGENET_STD).view(1, 3, 1, 1)
             self.images = ((imgs - mean) / std).to(device)
@@ -212,11 +218,20 @@ class TensorBatches:
                 v = blob["val_images"]
                 v = v.float().div_(255.0) if v.dtype == torch.uint8 else v.float()
                 self.val_images, self.val_labels = ((v - mean) / std).to(device), blob["val_labels"].to(device).int()
+                self._check_labels(self.val_labels, run["n_classes"], "val_labels")
         else:
             print(f"\033[93m[main] no loader for dataset {run['dataset']!r} at {run['data_location']!r}: SYNTHETIC N(0,1) images / random "
                   f"labels [{self.B},3,{run['img']},{run['img']}], {run['n_classes']} classes\033[0m", flush=True)
             self.steps = steps_per_epoch or 100
             self.shape, self.C = (self.B, 3, run["img"], run["img"]), run["n_classes"]
+
+    @staticmethod
+    def _check_labels(labels, n_classes, what):
+        """torch's CrossEntropyLoss raises on a class id outside [0, C); the fused CE kernel can only poison the loss with NaN, so
+        the file is validated once here (a wrong --n_classes, a dataset missing from KNOWN_CLASSES, an ignore_index of -1 …)."""
+        lo, hi = int(labels.min()), int(labels.max())
+        if lo < 0 or hi >= n_classes:
+            raise ValueError(f"TensorFile {what}: class ids span [{lo}, {hi}] but the model has n_classes = {n_classes}")
 
     def eval_batches(self):
         """Evaluation batches of the engine's batch size (drop_last): `val_images` / `val_labels` of the tensor file when it
@@ -278,6 +293,7 @@ def main_dinov2(params, args):
     from apla_amd.dist import dist_average_tensor, init_from_env, is_rank0, synchronize
     from apla_amd.ssl import DINOv2, Dinov2Trainer, MaskingGenerator, collate_data_and_cast
     from apla_amd.ssl.collate import synthetic_samples
+    from apla_amd.checkpoint import read_state_dict as ckpt_read
     run = resolve_dinov2_run(params, args)
     rank, world, local = init_from_env()
     dev = torch.device("cuda", local if world > 1 else int(run["gpus"][0]) if run["gpus"] else 0)
@@ -287,14 +303,10 @@ def main_dinov2(params, args):
     p["crops_params"] = dict(DINOV2_CROPS)
     pretrained = bool(p["model_params"].get("pretrained"))
     p["model_params"]["pretrained"] = False
-    model = DINOv2(p)
     pp = params.get("transfer_learning_params", {}).get("pretrained_path") or args.pretrained_path
-    if pp:
-        sd = torch.load(pp, map_location="cpu")
-        missing, unexpected = model.student.backbone.load_state_dict(sd.get("state_dict", sd), strict=False)
-        model.teacher.backbone.load_state_dict(model.student.backbone.state_dict())
-        if is_rank0():
-            print(f"[main] loaded {pp} into student and teacher: {len(missing)} missing, {len(unexpected)} unexpected keys")
+    model = DINOv2(p, backbone_state_dict=ckpt_read(pp) if pp else None)
+    if pp and is_rank0():
+        print(f"[main] loaded {pp} into student and teacher")
     elif pretrained and is_rank0():
         print("\033[93m[main] model_params.pretrained is true but there is no network and no --pretrained_path: random initialisation\033[0m")
     model = model.to(dev).train()
@@ -363,15 +375,17 @@ def main(params, args):
     # the engine interpolates it once to the training resolution (vit.py:421-437)
     pretrained = bool(mp.get("pretrained"))
     mp["pretrained"] = False  # no network here: weights come from --pretrained_path or stay at their initialisation
-    model = Classifier(mp, params.get("system_params", {"which_GPUs": "0"}))
+    sp = params.get("system_params", {"which_GPUs": "0"})
     if run["pretrained_path"]:
-        sd = torch.load(run["pretrained_path"], map_location="cpu")
-        sd = sd.get("state_dict", sd)
-        missing = model.load_state_dict(sd, strict=False)
+        # an APLA / session checkpoint is loaded strictly after the split (utils/pretrained_loader.py:27-30); an unsplit dinov2 /
+        # timm backbone is loaded BEFORE build_apla, as the reference's ViT factory does — a mismatch raises either way
+        model, kind = ckpt.build_classifier_from_checkpoint(run["pretrained_path"], mp, sp)
         if is_rank0():
-            print(f"[main] loaded {run['pretrained_path']}: {len(missing.missing_keys)} missing, {len(missing.unexpected_keys)} unexpected keys")
-    elif pretrained and is_rank0():
-        print("\033[93m[main] model_params.pretrained is true but there is no network and no --pretrained_path: random initialisation\033[0m")
+            print(f"[main] loaded {run['pretrained_path']} ({'APLA / session checkpoint' if kind == 'apla' else 'unsplit backbone, before build_apla'})")
+    else:
+        model = Classifier(mp, sp)
+        if pretrained and is_rank0():
+            print("\033[93m[main] model_params.pretrained is true but there is no network and no --pretrained_path: random initialisation\033[0m")
     hdt = torch.float16 if args.dtype == "fp16" else torch.bfloat16
     eng = AplaTrainEngine(model, run["batch"], run["img"], device=dev, process_group=dist.group.WORLD if world > 1 else None,
                           optim=OptimConfig(lr=run["lr"], weight_decay=run["wd"], grad_clipping=run["grad_clipping"]),

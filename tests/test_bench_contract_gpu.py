@@ -27,5 +27,29 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and 0.05 < rf["frac"] < 1.0
     assert abs(rf["achieved"] - 2 * 25216 * 768 * 3072 / (rf["kernel_ms"] * 1e-3) / 1e12) < 0.01 * rf["achieved"]   # algorithmic FLOP / in-place duration
     assert rf["traffic"] is None or rf["traffic"] > rf["algorithmic_bytes"] * 0.9
+    assert rf["traffic"] is None or (rf["traffic_source"]["stored"] is True and rf["traffic_source"]["file"].startswith("profiles/"))
+    assert rf["peak_measured"] is None or 1000.0 < rf["peak_measured"] < 2600.0     # tools/mfma_peak on this GPU
+    assert rf["step_frac_executed"] <= rf["step_frac"] and rf["step_gflop_per_image_executed"] < rf["step_gflop_per_image"]
+    assert d["ms_per_step_median"] > 0 and d["ranks_seen"] == 1
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "images/s" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+    par = d["parity"]      # config 1 through the same build and dtype, against the reference's CPU logits
+    assert par["dtype"] == "bf16" and par["tol_asserted"] == 8e-3 and par["logits_rel_vs_reference_cfg1"] < par["tol_asserted"]
+
+
+def test_bench_selflaunch_two_ranks():
+    """`python bench.py --gpus 2` starts its two ranks itself (reference: src/utils/launch.py:49-58).  With two
+    GPUs it must print one line with n_gpus = 2 and ranks_seen = 2 (counted by an RCCL all-reduce).  On a one-GPU box rank 1
+    has no device: the parent must then report the failure — stop rank 0, exit non-zero, print no JSON — instead of hanging."""
+    import torch
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+           "--no-cpu-baseline", "--no-parity", "--no-peak-probe"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if torch.cuda.device_count() >= 2:
+        assert r.returncode == 0, r.stderr[-2000:]
+        d = json.loads(lines[0])
+        assert len(lines) == 1 and d["n_gpus"] == 2 and d["ranks_seen"] == 2
+    else:
+        assert r.returncode != 0 and not lines and "rank 1 exited" in r.stderr

@@ -77,3 +77,32 @@ def test_single_process_exchanger_is_identity():
     ex = GradExchanger(flat, [(5, 10), (0, 5)])
     ex.launch_chunk(0), ex.launch_chunk(1), ex.wait()
     assert ex.grad_scale == 1.0 and torch.equal(flat, torch.arange(10, dtype=torch.float32))
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` with no launcher environment must start the two ranks itself and print ONE JSON line with
+    n_gpus = 2.  Here (no GPU) the children run --launcher-check: the same spawn / rendezvous / MAX-over-ranks
+    plumbing over gloo without the GPU step."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--launcher-check"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["steps"] == 3
+
+
+def test_bench_parent_fails_when_a_rank_fails():
+    """A failed child means the parent exits non-zero (and takes the other ranks down with it)."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    # without --launcher-check the ranks need a GPU: in this container every child exits with the "needs an MI355X" message
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--no-cpu-baseline", "--no-peak-probe", "--no-parity"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -2,8 +2,11 @@
 vectors produced by the actual reference (tests/golden/g5_cfg1_vits.npz: ViT-S/16, r=64, bs=8 — BASELINE config 1).
 
 Tolerances (stated, per SURVEY §7 "hard parts"): the reference CPU path is fp32; the HIP path multiplies in bf16 with
-fp32 accumulation and an fp32 residual stream.  We require  max|logits - ref| / max|ref| <= 1e-2  and
-|loss - ref| <= 5e-3 in that mode, gradients within 3e-2 relative L2.  Index selection is bit-exact (CPU test)."""
+fp32 accumulation and an fp32 residual stream.  Against the oracle on small synthetic models we require
+max|logits - ref| / max|ref| <= 1e-2, |loss - ref| <= 5e-3 and gradients within 3e-2 relative L2; against the REFERENCE's
+golden output on BASELINE config 1 the bounds are what is measured: logits <= 8e-3, gradients <= 2e-2 (the north-star
+1e-3 is met by the fp16 build, tests/test_fp16_gpu.py; bf16 operand rounding alone is 7.3e-3 on this model).  Index
+selection is bit-exact (CPU test)."""
 import os
 
 import numpy as np
@@ -17,6 +20,10 @@ pytestmark = pytest.mark.gpu
 
 LOGIT_TOL = 1e-2
 GRAD_TOL = 3e-2
+# BASELINE config 1 against the reference's own CPU output: what is measured (6.4e-3 logits, <1.3e-2 gradients; bench.py prints the
+# live figure as `parity`) with little slack — bf16 operand rounding alone gives 7.3e-3 on this model
+CFG1_LOGIT_TOL = 8e-3
+CFG1_GRAD_TOL = 2e-2
 
 
 def rel_l2(a, b):
@@ -198,13 +205,13 @@ def test_engine_cfg1_matches_reference_golden():
     torch.cuda.synchronize()
     e_logits = rel_err(eng.logits.cpu(), g["logits"])
     print(f"cfg1 logits rel err {e_logits:.3e}; loss {float(eng.loss):.6f} vs ref {float(g['loss']):.6f}")
-    assert e_logits < LOGIT_TOL
+    assert e_logits < CFG1_LOGIT_TOL
     assert abs(float(eng.loss) - float(g["loss"])) < 5e-3
     for i in (0, 5, 11):
         for nm in ("proj_weight1", "proj_bias1"):
             e = rel_l2(eng.grads()[f"backbone.blocks.{i}.attn.{nm}"].cpu(), g[f"g.blocks.{i}.attn.{nm}"])
-            assert e < GRAD_TOL, (i, nm, e)
-    assert rel_l2(eng.grads()["fc.weight"].cpu(), g["g.fc.weight"]) < GRAD_TOL
+            assert e < CFG1_GRAD_TOL, (i, nm, e)
+    assert rel_l2(eng.grads()["fc.weight"].cpu(), g["g.fc.weight"]) < CFG1_GRAD_TOL
     eng.optimizer_step()
     torch.cuda.synchronize()
     assert abs(float(eng.grad_norm) - float(g["gnorm"])) < 2e-2 * float(g["gnorm"])
@@ -406,3 +413,42 @@ def test_main_evaluation_and_knn(tmp_path):
     main.main(main.update_params_from_args(main.load_parameters(path), args), args)
     m2 = main.main.last_metrics
     assert abs(m2["test_loss"] - m1["val_loss"]) < 1e-5 and m2["test_accuracy"] == m1["val_accuracy"]
+
+
+def test_nonfinite_gradient_skips_the_update_and_is_counted():
+    """on the static loss-scale path a non-finite gradient norm skips the update (GradScaler.step semantics); the
+    skip is counted on the device, the bias corrections use the number of updates actually applied, and a checkpoint stores
+    that number — so the next finite step equals the first step of an untouched engine."""
+    from apla_amd.engine import AplaTrainEngine, OptimConfig
+    from apla_amd import checkpoint as ckpt
+    g = torch.Generator().manual_seed(0)
+    images, labels = torch.randn(4, 3, 32, 32, generator=g).cuda(), torch.randint(0, 10, (4,), generator=g).cuda()
+    oc = OptimConfig(lr=1e-3, weight_decay=1e-2, grad_clipping=1.0)
+    eng = AplaTrainEngine(small_vit(depth=2), 4, 32, optim=oc, use_graphs=False)
+    ref = AplaTrainEngine(small_vit(depth=2), 4, 32, optim=oc, use_graphs=False)
+    eng.set_batch(images, labels)
+    eng.forward_backward()
+    before = eng.flat_params.clone()
+    eng.flat_grads[5] = float("nan")
+    eng.optimizer_step()
+    torch.cuda.synchronize()
+    assert torch.equal(eng.flat_params, before) and eng.skipped_steps == 1 and eng.applied_steps == 0
+    assert float(ckpt.optimizer_state_dict(eng)["state"][0]["step"]) == 0.0
+    eng.forward_backward()
+    eng.optimizer_step()                       # host step count 2, applied update number 1
+    ref.train_step(images, labels)
+    torch.cuda.synchronize()
+    assert eng.skipped_steps == 1 and eng.applied_steps == 1
+    assert torch.allclose(eng.flat_params, ref.flat_params, rtol=1e-5, atol=1e-7)
+
+
+def test_cross_entropy_rejects_out_of_range_labels():
+    """a class id outside [0, C) must not read out of bounds: that row gets a zero gradient and a NaN loss."""
+    from apla_amd import ops
+    logits = torch.randn(4, 10, device="cuda")
+    labels = torch.tensor([1, 10, -1, 3], device="cuda", dtype=torch.int32)
+    dl, rl, loss = torch.empty_like(logits), torch.empty(4, device="cuda"), torch.empty(1, device="cuda")
+    ops.cross_entropy(logits, labels, dlogits=dl, row_loss=rl, loss=loss)
+    torch.cuda.synchronize()
+    assert torch.isnan(rl[1]) and torch.isnan(rl[2]) and torch.isfinite(rl[0]) and torch.isfinite(rl[3]) and torch.isnan(loss[0])
+    assert float(dl[1].abs().max()) == 0.0 and float(dl[2].abs().max()) == 0.0 and float(dl[0].abs().max()) > 0

@@ -204,6 +204,49 @@ def test_pretrained_backbone_loading_rules():
         ckpt.load_pretrained_backbone(dst, sd)
 
 
+def test_classifier_from_checkpoint_both_kinds(tmp_path):
+    """--pretrained_path: (a) an unsplit dinov2-named backbone is loaded BEFORE build_apla, so the split module
+    carries the checkpoint's projection rows — not a random initialisation; (b) an APLA / session checkpoint loads strictly after
+    the split (utils/pretrained_loader.py:27-30); (c) a checkpoint that matches nothing raises instead of printing key counts."""
+    from apla_amd import vit, checkpoint as ckpt
+    tp = dict(img_size=[32], patch_size=16, pretrained_type="dinov2", block_conf=dict(has_layerscale=True, layerscale_init_values=1.0))
+    mp = dict(backbone_type="vit_tiny", n_classes=5, pretrained=False, transformers_params=tp,
+              adaptation=dict(mode="apla", params=dict(partial_size=16)))
+    sp = dict(which_GPUs="0")
+    torch.manual_seed(11)
+    src = vit.vit_tiny(pretrained=False, **tp)
+    with torch.no_grad():
+        for p_ in src.parameters():
+            p_.add_(torch.randn_like(p_) * 0.01)
+    bare = {k: v.clone() for k, v in src.state_dict().items()}
+    bare["mask_token"] = torch.zeros(1, 192)                      # dinov2 hub checkpoints carry it; the reference drops it
+    torch.save(bare, tmp_path / "dinov2_like.pth")
+    torch.manual_seed(5)
+    model, kind = ckpt.build_classifier_from_checkpoint(str(tmp_path / "dinov2_like.pth"), mp, sp)
+    assert kind == "backbone"
+    a = model.backbone.blocks[3].attn
+    W = src.blocks[3].attn.proj.weight
+    assert torch.equal(a.proj_weight1, W[a.inds[:16]]) and torch.equal(a.proj_weight2, W[a.inds[16:]])
+    assert torch.equal(model.backbone.blocks[0].mlp.fc1.weight, src.blocks[0].mlp.fc1.weight)
+    # (b) session file written from that model -> strict reload into a differently initialised model
+    torch.save({"state_dict": {("module." + k): v for k, v in model.state_dict().items()}, "iters": 3}, tmp_path / "apla_session.pth")
+    torch.manual_seed(6)
+    again, kind = ckpt.build_classifier_from_checkpoint(str(tmp_path / "apla_session.pth"), mp, sp)
+    assert kind == "apla"
+    for (k1, v1), (k2, v2) in zip(model.state_dict().items(), again.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2), k1
+    # (c) wrong geometry / missing keys raise
+    sd = dict(model.state_dict())
+    sd.pop("backbone.blocks.2.attn.proj_weight2")
+    torch.save({"state_dict": sd}, tmp_path / "apla_broken.pth")
+    with pytest.raises(KeyError):
+        ckpt.build_classifier_from_checkpoint(str(tmp_path / "apla_broken.pth"), mp, sp)
+    bare.pop("blocks.1.norm1.weight")
+    torch.save(bare, tmp_path / "backbone_broken.pth")
+    with pytest.raises(RuntimeError):
+        ckpt.build_classifier_from_checkpoint(str(tmp_path / "backbone_broken.pth"), mp, sp)
+
+
 # ----------------------------------------------------------------------------------------------- main.py entry point
 def test_main_parameter_resolution():
     """src/main.py:241-253 + :58-158: __common__.yml overridden key by key by the given file, then by the CLI flags."""
