@@ -15,10 +15,26 @@
 // bitwise reproducible.  delta = rowsum(dO*O) is produced by the dQ kernel and consumed by the dKdV kernel.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 #define ATT_LDSP(p) ((__attribute__((address_space(3))) void*)(p))
 #define ATT_GLBP(p) ((const __attribute__((address_space(1))) void*)(p))
+
+#if defined(APLA_ATT_STAMPS)   // diagnostic build (tools/attn_stamps.py): per-wave cycle sums of the fused backward's segments
+__device__ unsigned long long apla_att_dbg[4096 * 4 * 16];
+extern "C" int apla_attn_debug_dump(unsigned long long* host_out, int n) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(apla_att_dbg), (size_t)n * 8, 0, hipMemcpyDeviceToHost);
+}
+#define STAMP_DECL unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_t = clock64(), st_n;
+#define STAMP(k) do { __builtin_amdgcn_sched_barrier(0); st_n = clock64(); st_acc[k] += st_n - st_t; st_t = st_n; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define STAMP_FLUSH() do { if (lane == 0) { const int wg = blockIdx.y * gridDim.x + blockIdx.x; if (wg < 4096) for (int k_ = 0; k_ < 16; ++k_) apla_att_dbg[(wg * 4 + wave) * 16 + k_] = st_acc[k_]; } } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(k)
+#define STAMP_FLUSH()
+#endif
 
 namespace {
 
@@ -110,6 +126,39 @@ __device__ __forceinline__ bf16x8 tr_join(const TrPair& f) {
   return out;
 }
 
+// Lane-constant parts of the fragment addresses.  tile_off's swizzle looks at bits 1-3 of the row only, so for a fragment whose
+// first row is a multiple of 16 the byte offset is (first row) * 128 + a value that depends on the lane alone: one VGPR per
+// k-step (row fragments) or per (column half, row half) (transposed fragments) for the whole kernel, a single v_add per tile and
+// instruction immediates for everything else.  Left to hipcc the swizzle arithmetic was redone for every fragment of every tile
+// (18 / 30 of the 76 / 112 VALU instructions per tile in the two bodies of the fused backward).
+struct FragOffs { unsigned rf[4], tr[4]; };
+__device__ __forceinline__ FragOffs frag_offs(int lane) {
+  FragOffs f;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) f.rf[ks] = (unsigned)tile_off(lane & 31, 2 * ks + (lane >> 5));
+  const int g = lane >> 4, i = lane & 15;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int col = 32 * dt + 16 * (g & 1) + 4 * (i & 3);
+      const int r = 4 * (g >> 1) + (i >> 2) + 8 * half;
+      f.tr[2 * dt + half] = (unsigned)(tile_off(r, col >> 3) + ((col & 4) << 1));
+    }
+  return f;
+}
+__device__ __forceinline__ unsigned lds_addr(const char* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p; }
+// transposed fragment pair (rows rbase .. rbase+15 of the tile at LDS byte address `tile`, columns 32*dt ..): base + immediate
+template <int OFF>
+__device__ __forceinline__ void tr_issue_at(TrPair& f, unsigned a_lo, unsigned a_hi) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.lo) : "v"(a_lo), "n"(OFF));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.hi) : "v"(a_hi), "n"(OFF));
+}
+template <int OFF>
+__device__ __forceinline__ bf16x8 row_frag_at(unsigned a) {
+  return *(const bf16x8*)((__attribute__((address_space(3))) const char*)(size_t)(a + OFF));
+}
+
 __device__ __forceinline__ bf16x8 acc_to_operand(const f32x16& a, int s) {
   bf16x8 o;
 #pragma unroll
@@ -137,6 +186,32 @@ __device__ __forceinline__ void store_acc_T(const f32x16 (&acc)[2], bf16* rowptr
       bf16x4 v = pack4(acc[dt][4 * g] * mul, acc[dt][4 * g + 1] * mul, acc[dt][4 * g + 2] * mul, acc[dt][4 * g + 3] * mul);
       *(bf16x4*)(rowptr + 32 * dt + 8 * g + 4 * h) = v;
     }
+}
+
+// The same store through a per-wave 4 KB LDS buffer [32 rows][64 columns], 16-byte chunk c of row r at chunk c ^ (r & 7): every
+// global store instruction then writes 8 rows x 128 B (whole lines) with 16 bytes per lane — 4 instructions per 32 x 64 tile
+// instead of 8 that touch 32-64 lines each.  In-kernel stamps showed the direct form costing 8-11k cycles per head in the fused
+// backward (all waves of a workgroup reach their stores together and queue behind each other: store-issue bound).
+// `row0` = sequence row of the tile's first row, rows >= N are not stored; dst points at row 0 of the sequence (+ head column).
+__device__ __forceinline__ void store_acc_T_staged(const f32x16 (&acc)[2], char* buf, bf16* dst, long ld, int row0, int N, int lane, float mul) {
+  // the addresses below derive from this opaque copy of the lane id: hipcc cannot hoist them out of the caller's loops, where
+  // they would stay live across the product loops and push other lane constants to scratch (reloaded next to in-flight LDS-DMA)
+  asm volatile("" : "+v"(lane));
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const bf16x4 v = pack4(acc[dt][4 * g] * mul, acc[dt][4 * g + 1] * mul, acc[dt][4 * g + 2] * mul, acc[dt][4 * g + 3] * mul);
+      *(bf16x4*)(buf + r * 128 + (((4 * dt + g) ^ (r & 7)) << 4) + 8 * h) = v;   // columns 32dt + 8g + 4h .. +3 of row r
+    }
+  const int c = lane & 7;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int rr = (lane >> 3) + 8 * j;
+    const bf16x8 v = *(const bf16x8*)(buf + rr * 128 + ((c ^ (rr & 7)) << 4));
+    if (row0 + rr < N) *(bf16x8*)(dst + (long)(row0 + rr) * ld + c * 8) = v;
+  }
 }
 
 // Sequence geometry.  Uniform batch (cu == nullptr): sequence b holds tokens [b*N, (b+1)*N) and lse/delta are [B, H, N].
@@ -261,10 +336,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
 // swizzle of tile_off is applied on the source column since the LDS side of a DMA is lane-linear), one barrier, and then
 // every wave walks the keys on its own — no per-block staging through registers, no further barriers.  Two workgroups
 // per CU (56 KB of LDS each at N = 197).
-constexpr int SMALL_MAX_ROWS = 256;
+constexpr int SMALL_MAX_ROWS = 288;   // up to nine 32-row blocks: also the 257-token sequences of ViT-*/14 at 224 px
 constexpr int SMALL_MAX_ROWS_BWD = 288;  // the fused backward also takes the 257-token sequences of ViT-*/14 at 224 px (9 blocks of 32 rows)
 
-__global__ __launch_bounds__(512, 4) void attn_fwd_small_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
+__global__ __launch_bounds__(576, 4) void attn_fwd_small_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
                                                                 float* __restrict__ lse, int Nmax, int H, float scale,
     const int32_t* __restrict__ cu, int total) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // K rows [NP][64] then V rows [NP][64], NP = 32 * waves
@@ -311,9 +386,12 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_small_kernel(const bf16* __re
   __syncthreads();
   if (wave * 32 >= N) return;  // packed batches: waves past this sequence's end only helped loading
 
-  const int nkb = (N + 63) / 64;
-  for (int kb = 0; kb < nkb; ++kb) {
-    const bool two = kb * 64 + 32 < N;  // second 32-key tile of this block has at least one valid key
+  // One block = 64 keys = two 32-key tiles.  Only the sequence's LAST block can hold keys >= N: the full blocks run a body
+  // without masking (as one predicated loop hipcc emitted compare + select for every score of every block: 64 of the ~300
+  // VALU instructions per block).
+  auto block = [&](int kb, auto MASKED) {
+    constexpr bool masked = decltype(MASKED)::value;
+    const bool two = !masked || kb * 64 + 32 < N;  // second 32-key tile of this block has at least one valid key
     f32x16 s[2];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
@@ -328,7 +406,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_small_kernel(const bf16* __re
       for (int ks = 1; ks < 4; ++ks)
         s[kt] = MFMA_F32_32x32x16_H16(row_frag(Ks, kb * 64 + kt * 32, ks, lane), qf[ks], s[kt]);
     }
-    if (kb * 64 + 64 > N) {
+    if constexpr (masked) {
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -367,7 +445,11 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_small_kernel(const bf16* __re
           acc_o[dt] = MFMA_F32_32x32x16_H16(tr_frag(Vs, kb * 64 + kt * 32 + 16 * sk, 32 * dt, lane), pb, acc_o[dt]);
       }
     }
-  }
+  };
+  const int nfull = N >> 6;   // blocks without a key >= N
+#pragma unroll 1
+  for (int kb = 0; kb < nfull; ++kb) block(kb, std::false_type{});
+  if (N & 63) block(nfull, std::true_type{});
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   if (qvalid) {
     store_acc_T(acc_o, o + ((long)sq.start + q) * D + h * 64, h2, 1.0f / l_tot);
@@ -671,25 +753,33 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_small_kernel(const bf16* __re
                                                                 float* __restrict__ delta, bf16* __restrict__ dqkv, int Nmax,
                                                                 int H, float scale, const int32_t* __restrict__ cu, int total,
                                                                 int NP) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // two tiles [NP][64] (K,V then Q,dO), lse [NP -> 64], delta [NP]
+  // two tiles at a FIXED distance (so that the second tile is an instruction immediate away from the first), then
+  // lse * log2(e) and delta of the head's rows, both written by phase 1
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, h2 = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.y, h = blockIdx.x;
   const Seq sq = seq_of(cu, b, Nmax, H, total);
   const int N = sq.n;
   if (N <= 0) return;
+#if defined(APLA_ATT_PRIO)
+  if (((blockIdx.y * gridDim.x + blockIdx.x) >> 8) & 1) __builtin_amdgcn_s_setprio(APLA_ATT_PRIO);
+#endif
   const int D = H * 64;
   const long ld = 3L * D;
   const bf16* base = qkv + (long)sq.start * ld + h * 64;
   const bf16* dobase = dout + (long)sq.start * D + h * 64;
   const float c = scale * LOG2E;
-  char* TA = smem;             // K, later Q
-  char* TB = smem + NP * 128;  // V, later dO
-  float* lses = (float*)(TB + NP * 128);  // filled in whole 64-float pieces (one 4-byte LDS-DMA per wave): rounded up to 64
-  float* dls = lses + ((NP + 63) & ~63);
-  const float* lsebase = lse + sq.stat + (long)h * sq.stat_h;
+  constexpr int TB_OFF = SMALL_MAX_ROWS_BWD * 128;   // byte distance TA -> TB
+  char* TA = smem;            // K, later Q
+  char* TB = smem + TB_OFF;   // V, later dO
+  float* lses2 = (float*)(smem + 2 * TB_OFF);
+  float* dls = lses2 + SMALL_MAX_ROWS_BWD;
   const int nt = (N + 31) / 32;   // 32-row blocks of this sequence
   const int npc = NP / 8;         // 1 KB pieces (8 rows x 128 B) per tile
+  const FragOffs fo = frag_offs(lane);
+  const unsigned ta0 = lds_addr(TA);
+  STAMP_DECL
 
   // both tiles of a phase: 2 * npc pieces, dealt round-robin to the four waves; swizzle on the source column (the LDS side
   // of a DMA is lane-linear)
@@ -708,11 +798,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_small_kernel(const bf16* __re
 
   // ================================================================ phase 1: K, V resident; delta and dQ per query block
   stage(base + D, ld, base + 2 * D, ld);
-  for (int pc = wave; pc * 64 < NP; pc += 4) {   // 64-float pieces of lse
-    int qq = pc * 64 + lane;
-    qq = qq < N ? qq : N - 1;
-    __builtin_amdgcn_global_load_lds(ATT_GLBP(lsebase + qq), ATT_LDSP((char*)lses + pc * 256), 4, 0, 0);
-  }
   for (int blk = wave, first = 1; blk < SMALL_MAX_ROWS_BWD / 32 + 3; blk += 4, first = 0) {   // the barrier below is reached by every wave exactly once
     const bool active = blk < nt;
     int r = blk * 32 + (lane & 31);
@@ -732,31 +817,38 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_small_kernel(const bf16* __re
       dl += __shfl_xor(dl, 32, 64);
       const long statidx = sq.stat + (long)h * sq.stat_h + r;
       if (rvalid && h2 == 0) delta[statidx] = dl;
-      if (h2 == 0) dls[blk * 32 + (lane & 31)] = dl;
       lse2 = lse[statidx] * LOG2E;
+      if (h2 == 0) { dls[blk * 32 + (lane & 31)] = dl; lses2[blk * 32 + (lane & 31)] = lse2; }   // for phase 2 (every row < NP)
     }
+    STAMP(0);   // block start: row loads issued, delta
     if (first) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();   // K, V and lse have landed
+      __syncthreads();   // K and V have landed
     }
+    STAMP(1);   // wait for K, V (first block) / row loads
     if (!active) continue;
     f32x16 acc_dq[2];
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc_dq[0][i] = 0.f; acc_dq[1][i] = 0.f; }
     for (int t = 0; t < nt; ++t) {
+      const unsigned tb = ta0 + t * 4096;            // tile row 32t (uniform)
+      unsigned ar[4], at[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { ar[k] = tb + fo.rf[k]; at[k] = tb + fo.tr[k]; }
       const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      f32x16 s = MFMA_F32_32x32x16_H16(row_frag(TA, t * 32, 0, lane), qf[0], zero);
-      f32x16 dp = MFMA_F32_32x32x16_H16(row_frag(TB, t * 32, 0, lane), dof[0], zero);
+      f32x16 s = MFMA_F32_32x32x16_H16(row_frag_at<0>(ar[0]), qf[0], zero);
+      f32x16 dp = MFMA_F32_32x32x16_H16(row_frag_at<TB_OFF>(ar[0]), dof[0], zero);
 #pragma unroll
       for (int ks = 1; ks < 4; ++ks) {
-        s = MFMA_F32_32x32x16_H16(row_frag(TA, t * 32, ks, lane), qf[ks], s);
-        dp = MFMA_F32_32x32x16_H16(row_frag(TB, t * 32, ks, lane), dof[ks], dp);
+        s = MFMA_F32_32x32x16_H16(row_frag_at<0>(ar[ks]), qf[ks], s);
+        dp = MFMA_F32_32x32x16_H16(row_frag_at<TB_OFF>(ar[ks]), dof[ks], dp);
       }
-      TrPair kt_[4];
-#pragma unroll
-      for (int sk = 0; sk < 2; ++sk)
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) tr_issue(kt_[2 * sk + dt], TA, t * 32 + 16 * sk, 32 * dt, lane);
+      TrPair kt_[4];   // K^T fragments [sk][dt]: rows 32t + 16sk .., columns 32dt ..
+      tr_issue_at<0>(kt_[0], at[0], at[1]);
+      tr_issue_at<0>(kt_[1], at[2], at[3]);
+      tr_issue_at<2048>(kt_[2], at[0], at[1]);
+      tr_issue_at<2048>(kt_[3], at[2], at[3]);
+      STAMP(2);   // P1: fragment reads + first-stage products issued
       if (t * 32 + 32 <= N) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) s[i] = ATT_EXP2(fmaf(s[i], c, -lse2)) * (dp[i] - dl);
@@ -768,6 +860,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_small_kernel(const bf16* __re
           s[i] = p * (dp[i] - dl);
         }
       }
+      asm volatile("" :: "v"(s[0]), "v"(s[15]));
+      STAMP(3);   // P1: softmax arithmetic (starts with the wait for the products)
       lds_landed(kt_);
 #pragma unroll
       for (int sk = 0; sk < 2; ++sk) {
@@ -776,10 +870,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_small_kernel(const bf16* __re
         for (int dt = 0; dt < 2; ++dt)
           acc_dq[dt] = MFMA_F32_32x32x16_H16(tr_join(kt_[2 * sk + dt]), dsb, acc_dq[dt]);
       }
+      STAMP(4);   // P1: second-stage products issued
     }
     if (rvalid) store_acc_T(acc_dq, dqkv + ((long)sq.start + r) * ld + h * 64, h2, scale);
+    STAMP(5);     // P1: dQ stores issued
   }
-  __syncthreads();   // every wave is done with K, V; all delta rows are in LDS
+  __syncthreads();   // every wave is done with K, V; all delta / lse rows are in LDS
+  STAMP(6);       // barrier at the end of phase 1
 
   // ================================================================ phase 2: Q, dO resident; dK and dV per key block
   stage(base, ld, dobase, D);
@@ -793,38 +890,46 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_small_kernel(const bf16* __re
       load_row_frags(kf, base + D + (long)r * ld, lane);
       load_row_frags(vf, base + 2 * D + (long)r * ld, lane);
     }
+    STAMP(7);   // P2 block start: stage issue (first) + own k / v row loads issued
     if (first) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();   // Q, dO have landed
     }
+    STAMP(8);   // wait for Q, dO
     if (!active) continue;
     f32x16 acc_dk[2], acc_dv[2];
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc_dk[0][i] = 0.f; acc_dk[1][i] = 0.f; acc_dv[0][i] = 0.f; acc_dv[1][i] = 0.f; }
     for (int t = 0; t < nt; ++t) {
+      const unsigned tb = ta0 + t * 4096;
+      unsigned ar[4], at[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { ar[k] = tb + fo.rf[k]; at[k] = tb + fo.tr[k]; }
       f32x16 s, dp;
 #pragma unroll
       for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        s = MFMA_F32_32x32x16_H16(row_frag(TA, t * 32, ks, lane), kf[ks], s);
-        dp = MFMA_F32_32x32x16_H16(row_frag(TB, t * 32, ks, lane), vf[ks], dp);
+        s = MFMA_F32_32x32x16_H16(row_frag_at<0>(ar[ks]), kf[ks], s);
+        dp = MFMA_F32_32x32x16_H16(row_frag_at<TB_OFF>(ar[ks]), vf[ks], dp);
       }
-      TrPair tf[8];
-#pragma unroll
-      for (int sk = 0; sk < 2; ++sk)
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          tr_issue(tf[4 * sk + dt], TB, t * 32 + 16 * sk, 32 * dt, lane);
-          tr_issue(tf[4 * sk + 2 + dt], TA, t * 32 + 16 * sk, 32 * dt, lane);
-        }
+      TrPair tf[8];   // [4 sk + dt] = dO^T, [4 sk + 2 + dt] = Q^T
+      tr_issue_at<TB_OFF>(tf[0], at[0], at[1]);
+      tr_issue_at<0>(tf[2], at[0], at[1]);
+      tr_issue_at<TB_OFF>(tf[1], at[2], at[3]);
+      tr_issue_at<0>(tf[3], at[2], at[3]);
+      tr_issue_at<TB_OFF + 2048>(tf[4], at[0], at[1]);
+      tr_issue_at<2048>(tf[6], at[0], at[1]);
+      tr_issue_at<TB_OFF + 2048>(tf[5], at[2], at[3]);
+      tr_issue_at<2048>(tf[7], at[2], at[3]);
+      STAMP(9);   // P2: fragment reads + first-stage products issued
       // P and dS (in place of dP).  Only the sequence's last query tile needs the per-row mask: as one predicated loop hipcc emits
       // the compare/select pair for every element of every tile.
       if (t * 32 + 32 <= N) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int r0 = t * 32 + 8 * g + 4 * h2;
-          const f32x4 l4 = *(const f32x4*)(lses + r0) * LOG2E, d4 = *(const f32x4*)(dls + r0);
+          const f32x4 l4 = *(const f32x4*)(lses2 + r0), d4 = *(const f32x4*)(dls + r0);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int i = 4 * g + e;
@@ -837,7 +942,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_small_kernel(const bf16* __re
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int r0 = t * 32 + 8 * g + 4 * h2;
-          const f32x4 l4 = *(const f32x4*)(lses + r0) * LOG2E, d4 = *(const f32x4*)(dls + r0);
+          const f32x4 l4 = *(const f32x4*)(lses2 + r0), d4 = *(const f32x4*)(dls + r0);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int i = 4 * g + e;
@@ -848,6 +953,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_small_kernel(const bf16* __re
           }
         }
       }
+      asm volatile("" :: "v"(s[0]), "v"(dp[15]));
+      STAMP(10);  // P2: softmax arithmetic
       lds_landed(tf);
 #pragma unroll
       for (int sk = 0; sk < 2; ++sk) {
@@ -858,13 +965,324 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_small_kernel(const bf16* __re
           acc_dk[dt] = MFMA_F32_32x32x16_H16(tr_join(tf[4 * sk + 2 + dt]), dsb, acc_dk[dt]);
         }
       }
+      STAMP(11);  // P2: second-stage products issued
     }
     if (rvalid) {
       bf16* orow = dqkv + ((long)sq.start + r) * ld + h * 64;
       store_acc_T(acc_dk, orow + D, h2, scale);
       store_acc_T(acc_dv, orow + 2 * D, h2, 1.0f);
     }
+    STAMP(12);    // P2: dK / dV stores issued
   }
+  STAMP_FLUSH();
+}
+
+// ------------------------------------------------------------------------------------------------ backward, persistent
+// Uniform batches of short sequences (N <= 256: at most eight 32-row blocks).  In-kernel stamps of the kernel above
+// (tools/attn_stamps.py, -DAPLA_ATT_STAMPS) show that only half of a wave's time is spent in the two product loops: a quarter
+// goes to the start of each query block (its q / dO / o rows come straight from HBM and are waited for on the spot), the rest to
+// the two load phases and the stores — and a wave that waits leaves its SIMD to ONE other wave, which alone keeps it ~55 % busy.
+// Here ONE 8-wave workgroup per CU walks its heads (b*H + h = blockIdx.x, + gridDim.x, ...) and every byte is requested one phase
+// before it is needed:
+//   LDS   set A = (K, V) tiles of head i, set B = (Q, dO) tiles of head i, lse * log2(e) and delta of head i.
+//   P1(i) dQ:     A(i) resident; the LDS-DMA of B(i) runs under it.  Wave w owns query block w: its q / dO / o rows and lse are in
+//                 registers already (inline-asm loads issued at the end of P2(i-1) and waited for, behind the dK / dV stores, before
+//                 the loop's back edge: hipcc treats an asm load's destination as written at once and may copy it, so the wait sits in
+//                 the same straight-line code); delta = rowsum(dO * o) and lse * log2(e) go to LDS for P2.
+//   P2(i) dK/dV:  B(i) resident.  Wave w owns key block w: its k / v row fragments are READ FROM SET A (the A and B operand of
+//                 v_mfma_f32_32x32x16 have the same lane layout) before the barrier that frees the set; the LDS-DMA of A(i+1) runs
+//                 under the products; then the row loads of head i+1, then the dK / dV stores.
+// Two barriers per head, each preceded by a counted vmcnt (never a drain of the stores).  Products, their order and the
+// arithmetic between them are those of attn_bwd_small_kernel (and of the split kernels): the results are bitwise the same.
+struct RowRegs { f32x4 q[4], d[4], o[4]; float lse; };   // 16-byte pieces = 8 packed 16-bit values each
+
+__device__ __forceinline__ void rows_prefetch(RowRegs& r, const bf16* qp, const bf16* dp, const bf16* op, const float* lp) {
+  asm volatile(
+      "global_load_dwordx4 %0, %13, off\n\tglobal_load_dwordx4 %1, %13, off offset:32\n\t"
+      "global_load_dwordx4 %2, %13, off offset:64\n\tglobal_load_dwordx4 %3, %13, off offset:96\n\t"
+      "global_load_dwordx4 %4, %14, off\n\tglobal_load_dwordx4 %5, %14, off offset:32\n\t"
+      "global_load_dwordx4 %6, %14, off offset:64\n\tglobal_load_dwordx4 %7, %14, off offset:96\n\t"
+      "global_load_dwordx4 %8, %15, off\n\tglobal_load_dwordx4 %9, %15, off offset:32\n\t"
+      "global_load_dwordx4 %10, %15, off offset:64\n\tglobal_load_dwordx4 %11, %15, off offset:96\n\t"
+      "global_load_dword %12, %16, off"
+      : "=&v"(r.q[0]), "=&v"(r.q[1]), "=&v"(r.q[2]), "=&v"(r.q[3]), "=&v"(r.d[0]), "=&v"(r.d[1]), "=&v"(r.d[2]), "=&v"(r.d[3]),
+        "=&v"(r.o[0]), "=&v"(r.o[1]), "=&v"(r.o[2]), "=&v"(r.o[3]), "=&v"(r.lse)
+      : "v"(qp), "v"(dp), "v"(op), "v"(lp)
+      : "memory");
+}
+// wait until at most YOUNGER vector-memory operations of this wave are outstanding, then pin the prefetched registers behind the wait
+template <int YOUNGER>
+__device__ __forceinline__ void rows_landed(RowRegs& r) {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER) : "memory");
+  asm volatile("" : "+v"(r.q[0]), "+v"(r.q[1]), "+v"(r.q[2]), "+v"(r.q[3]), "+v"(r.d[0]), "+v"(r.d[1]), "+v"(r.d[2]), "+v"(r.d[3]),
+               "+v"(r.o[0]), "+v"(r.o[1]), "+v"(r.o[2]), "+v"(r.o[3]), "+v"(r.lse));
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+constexpr int PERSIST_MAX_ROWS = 256;
+
+// NT = 32-row blocks per sequence (compile time: the four tiles then sit at instruction-immediate distances of NT * 4 KB).
+// STAGED: the dQ / dK / dV tiles leave through a per-wave 4 KB LDS buffer as whole lines (store_acc_T_staged); the eight buffers
+// fit beside the four tiles up to seven blocks (N <= 224), the eight-block case stores directly.
+template <int NT, bool STAGED>
+__global__ __launch_bounds__(512, 2) void attn_bwd_persist_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
+                                                                  const bf16* __restrict__ dout, const float* __restrict__ lse,
+                                                                  float* __restrict__ delta, bf16* __restrict__ dqkv, int N,
+                                                                  int H, float scale, int BH) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // K, V, Q, dO tiles [32 NT][64]; lse*log2e [256]; delta [256]; store buffers
+  const int tid = threadIdx.x, lane = tid & 63, h2 = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int D = H * 64;
+  const long ld = 3L * D;
+  const float c = scale * LOG2E;
+  constexpr int T_OFF = NT * 4096;   // byte distance between consecutive tiles
+  char* KA = smem;
+  char* VA = smem + T_OFF;
+  char* QB = smem + 2 * T_OFF;
+  char* DB = smem + 3 * T_OFF;
+  float* lses2 = (float*)(smem + 4 * T_OFF);
+  float* dls = lses2 + PERSIST_MAX_ROWS;
+  constexpr int DQ_STORES = STAGED ? 4 : 8, DKV_STORES = STAGED ? 8 : 16;   // store instructions per wave: dQ; dK + dV
+  constexpr int nt = NT;             // wave w owns block w in both phases
+  const bool active = wave < nt;
+  int r = wave * 32 + (lane & 31);
+  const bool rvalid = active && r < N;
+  if (r >= N) r = N - 1;
+  const FragOffs fo = frag_offs(lane);
+  const unsigned ka0 = lds_addr(KA);
+  char* wbuf = smem + 4 * T_OFF + 2 * PERSIST_MAX_ROWS * 4 + wave * 4096;   // STAGED: this wave's store buffer
+  STAMP_DECL
+
+  // A set of two tiles is 8 * nt pieces of 1 KB (8 rows x 128 B): wave w issues pieces [(w & 3) * nt, +nt) of the first (w < 4) or
+  // second tile; the XOR swizzle of tile_off goes on the source column (the LDS side of a DMA is lane-linear)
+  // (inside the product loops ONE piece is issued per tile iteration — nt iterations, nt pieces per wave —, so that the issue cost
+  // of a set, 1.3-1.9k cycles per wave when issued in one go, disappears into the loop's stall slots)
+  auto stage_piece = [&](int it, const bf16* srcA, long ldA, const bf16* srcB, long ldB, char* TA, char* TB) {
+    const bool isb = wave >= 4;
+    const bf16* src = isb ? srcB : srcA;
+    const long lds_ = isb ? ldB : ldA;
+    char* dst = isb ? TB : TA;
+    const int pr = (wave & 3) * nt + it;
+    const int row = pr * 8 + (lane >> 3);
+    const int f = (((row >> 1) & 1) << 2) | ((row >> 2) & 3);
+    const int ch = (lane & 7) ^ f;
+    const int gr = row < N ? row : N - 1;
+    __builtin_amdgcn_global_load_lds(ATT_GLBP(src + (long)gr * lds_ + ch * 8), ATT_LDSP(dst + pr * 1024), 16, 0, 0);
+  };
+  auto stage = [&](const bf16* srcA, long ldA, const bf16* srcB, long ldB, char* TA, char* TB) {
+#pragma unroll 1
+    for (int it = 0; it < nt; ++it) stage_piece(it, srcA, ldA, srcB, ldB, TA, TB);
+  };
+  struct Head { const bf16* base; const bf16* dobase; const bf16* obase; const float* lsebase; float* dlbase; bf16* outbase; };
+  auto head_of = [&](int idx) {
+    const int b = idx / H, h = idx - b * H;
+    Head hd;
+    hd.base = qkv + (long)b * N * ld + h * 64;
+    hd.dobase = dout + (long)b * N * D + h * 64;
+    hd.obase = o + (long)b * N * D + h * 64;
+    hd.lsebase = lse + (long)idx * N;
+    hd.dlbase = delta + (long)idx * N;
+    hd.outbase = dqkv + (long)b * N * ld + h * 64;
+    return hd;
+  };
+  auto prefetch_rows = [&](RowRegs& rr, const Head& hd) {
+    const int e = 8 * h2;
+    rows_prefetch(rr, hd.base + (long)r * ld + e, hd.dobase + (long)r * D + e, hd.obase + (long)r * D + e, hd.lsebase + r);
+  };
+
+  int idx = blockIdx.x;
+  if (idx >= BH) return;
+  Head hd = head_of(idx);
+  RowRegs rr;
+  if (active) { prefetch_rows(rr, hd); rows_landed<0>(rr); }   // first head only: the rows are waited for on the spot
+  stage(hd.base + D, ld, hd.base + 2 * D, ld, KA, VA);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  STAMP(0);   // first head: rows + set A
+  while (true) {
+    // ================================================================ X: set A (and, before the back edge, this wave's rows) landed
+    __builtin_amdgcn_s_barrier();   // every wave is done with set B, lse and delta of the previous head
+    asm volatile("" ::: "memory");
+    STAMP(1);   // barrier X
+    if (!active) stage(hd.base, ld, hd.dobase, D, QB, DB);   // a wave without a block issues its share of set B in one go
+    if (active) {   // ---------------------------------------------- P1: delta and dQ of query block `wave`
+      bf16x8 qf[4], dof[4];
+      float dl = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        qf[ks] = __builtin_bit_cast(bf16x8, rr.q[ks]);
+        dof[ks] = __builtin_bit_cast(bf16x8, rr.d[ks]);
+        const bf16x8 of = __builtin_bit_cast(bf16x8, rr.o[ks]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dl += (float)dof[ks][j] * (float)of[j];
+      }
+      dl += __shfl_xor(dl, 32, 64);
+      if (rvalid && h2 == 0) hd.dlbase[r] = dl;
+      const float lse2 = rr.lse * LOG2E;
+      if (h2 == 0) { dls[wave * 32 + (lane & 31)] = dl; lses2[wave * 32 + (lane & 31)] = lse2; }
+      f32x16 acc_dq[2];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { acc_dq[0][i] = 0.f; acc_dq[1][i] = 0.f; }
+      STAMP(2);   // P1 start: delta
+#pragma unroll 1
+      for (int t = 0; t < nt; ++t) {
+        stage_piece(t, hd.base, ld, hd.dobase, D, QB, DB);   // set B, one piece per iteration
+        const unsigned tb = ka0 + t * 4096;
+        unsigned ar[4], at[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { ar[k] = tb + fo.rf[k]; at[k] = tb + fo.tr[k]; }
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        f32x16 s = MFMA_F32_32x32x16_H16(row_frag_at<0>(ar[0]), qf[0], zero);
+        f32x16 dp = MFMA_F32_32x32x16_H16(row_frag_at<T_OFF>(ar[0]), dof[0], zero);
+#pragma unroll
+        for (int ks = 1; ks < 4; ++ks) {
+          s = MFMA_F32_32x32x16_H16(row_frag_at<0>(ar[ks]), qf[ks], s);
+          dp = MFMA_F32_32x32x16_H16(row_frag_at<T_OFF>(ar[ks]), dof[ks], dp);
+        }
+        TrPair kt_[4];
+        tr_issue_at<0>(kt_[0], at[0], at[1]);
+        tr_issue_at<0>(kt_[1], at[2], at[3]);
+        tr_issue_at<2048>(kt_[2], at[0], at[1]);
+        tr_issue_at<2048>(kt_[3], at[2], at[3]);
+        if (t * 32 + 32 <= N) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) s[i] = ATT_EXP2(fmaf(s[i], c, -lse2)) * (dp[i] - dl);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            float p = ATT_EXP2(fmaf(s[i], c, -lse2));
+            if (t * 32 + acc_row(i, h2) >= N) p = 0.f;
+            s[i] = p * (dp[i] - dl);
+          }
+        }
+        lds_landed(kt_);
+#pragma unroll
+        for (int sk = 0; sk < 2; ++sk) {
+          const bf16x8 dsb = acc_to_operand(s, sk);
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt)
+            acc_dq[dt] = MFMA_F32_32x32x16_H16(tr_join(kt_[2 * sk + dt]), dsb, acc_dq[dt]);
+        }
+      }
+      STAMP(3);   // P1 loop
+      if constexpr (STAGED) store_acc_T_staged(acc_dq, wbuf, hd.outbase, ld, wave * 32, N, lane, scale);
+      else if (rvalid) store_acc_T(acc_dq, hd.outbase + (long)r * ld, h2, scale);
+      STAMP(4);   // dQ stores
+    }
+    // ================================================================ Y: own k / v rows out of set A, set B has landed
+    bf16x8 kf[4], vf[4];
+    if (active) {
+      const unsigned a0 = ka0 + wave * 4096;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) { kf[ks] = row_frag_at<0>(a0 + fo.rf[ks]); vf[ks] = row_frag_at<T_OFF>(a0 + fo.rf[ks]); }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(kf[ks]), "+v"(vf[ks]));
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DQ_STORES) : "memory");   // the DMA of set B is older than the dQ stores
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    STAMP(5);   // wait for set B
+    __builtin_amdgcn_s_barrier();   // every wave is done with set A; set B, lse and delta are complete
+    asm volatile("" ::: "memory");
+    STAMP(6);   // barrier Y
+    const int next = idx + gridDim.x;
+    const bool has_next = next < BH;
+    Head hn = hd;
+    if (has_next) {
+      hn = head_of(next);
+      if (!active) stage(hn.base + D, ld, hn.base + 2 * D, ld, KA, VA);
+    }
+    if (active) {   // ---------------------------------------------- P2: dK and dV of key block `wave`
+      f32x16 acc_dk[2], acc_dv[2];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { acc_dk[0][i] = 0.f; acc_dk[1][i] = 0.f; acc_dv[0][i] = 0.f; acc_dv[1][i] = 0.f; }
+      STAMP(7);   // P2 start
+#pragma unroll 1
+      for (int t = 0; t < nt; ++t) {
+        if (has_next) stage_piece(t, hn.base + D, ld, hn.base + 2 * D, ld, KA, VA);   // set A of the next head, one piece per iteration
+        const unsigned tb = ka0 + 2 * T_OFF + t * 4096;   // Q tile, row 32t; the dO tile is T_OFF further
+        unsigned ar[4], at[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { ar[k] = tb + fo.rf[k]; at[k] = tb + fo.tr[k]; }
+        f32x16 s, dp;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          s = MFMA_F32_32x32x16_H16(row_frag_at<0>(ar[ks]), kf[ks], s);
+          dp = MFMA_F32_32x32x16_H16(row_frag_at<T_OFF>(ar[ks]), vf[ks], dp);
+        }
+        TrPair tf[8];   // [4 sk + dt] = dO^T, [4 sk + 2 + dt] = Q^T
+        tr_issue_at<T_OFF>(tf[0], at[0], at[1]);
+        tr_issue_at<0>(tf[2], at[0], at[1]);
+        tr_issue_at<T_OFF>(tf[1], at[2], at[3]);
+        tr_issue_at<0>(tf[3], at[2], at[3]);
+        tr_issue_at<T_OFF + 2048>(tf[4], at[0], at[1]);
+        tr_issue_at<2048>(tf[6], at[0], at[1]);
+        tr_issue_at<T_OFF + 2048>(tf[5], at[2], at[3]);
+        tr_issue_at<2048>(tf[7], at[2], at[3]);
+        if (t * 32 + 32 <= N) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int r0 = t * 32 + 8 * g + 4 * h2;
+            const f32x4 l4 = *(const f32x4*)(lses2 + r0), d4 = *(const f32x4*)(dls + r0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int i = 4 * g + e;
+              const float p = ATT_EXP2(fmaf(s[i], c, -l4[e]));
+              s[i] = p;
+              dp[i] = p * (dp[i] - d4[e]);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int r0 = t * 32 + 8 * g + 4 * h2;
+            const f32x4 l4 = *(const f32x4*)(lses2 + r0), d4 = *(const f32x4*)(dls + r0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int i = 4 * g + e;
+              float p = ATT_EXP2(fmaf(s[i], c, -l4[e]));
+              if (r0 + e >= N) p = 0.f;
+              s[i] = p;
+              dp[i] = p * (dp[i] - d4[e]);
+            }
+          }
+        }
+        lds_landed(tf);
+#pragma unroll
+        for (int sk = 0; sk < 2; ++sk) {
+          const bf16x8 pb = acc_to_operand(s, sk), dsb = acc_to_operand(dp, sk);
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            acc_dv[dt] = MFMA_F32_32x32x16_H16(tr_join(tf[4 * sk + dt]), pb, acc_dv[dt]);
+            acc_dk[dt] = MFMA_F32_32x32x16_H16(tr_join(tf[4 * sk + 2 + dt]), dsb, acc_dk[dt]);
+          }
+        }
+      }
+      STAMP(8);   // P2 loop
+      // rows of the next head: older than the stores below in the vmcnt queue.  Unconditional (the last head re-reads its own
+      // rows, never used): a conditional definition would keep the previous head's 49 registers alive through P2
+      // (the row loads sit between the dK and the dV stores: once dK has left, its 32 accumulator registers are free for them)
+      if constexpr (STAGED) store_acc_T_staged(acc_dk, wbuf, hd.outbase + D, ld, wave * 32, N, lane, scale);
+      else if (rvalid) store_acc_T(acc_dk, hd.outbase + (long)r * ld + D, h2, scale);
+      asm volatile("" ::: "memory");
+      prefetch_rows(rr, hn);
+      if constexpr (STAGED) store_acc_T_staged(acc_dv, wbuf, hd.outbase + 2 * D, ld, wave * 32, N, lane, 1.0f);
+      else if (rvalid) store_acc_T(acc_dv, hd.outbase + (long)r * ld + 2 * D, h2, 1.0f);
+      STAMP(9);   // row prefetch + dK / dV stores issued
+      rows_landed<DKV_STORES / 2>(rr);   // set A of the next head (older still) and the rows: landed; the dV stores stay in flight
+      STAMP(10);  // wait for rows / set A
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (!has_next) break;
+    idx = next;
+    hd = hn;
+  }
+#if defined(APLA_ATT_STAMPS)
+  if (lane == 0 && blockIdx.x < 512) for (int k_ = 0; k_ < 16; ++k_) apla_att_dbg[(blockIdx.x * 8 + wave) * 16 + k_] = st_acc[k_];
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ attention matrix on demand
@@ -972,7 +1390,19 @@ __global__ __launch_bounds__(256) void attn_bwd_cls_kernel(const bf16* __restric
 
 }  // namespace
 
-// 0 = auto (short-sequence kernels when N <= 256), 1 = always the blocked kernels (tests; APLA_ATTN_VARIANT=1 for A/B timing)
+// number of CUs of the current device (persistent kernels launch one workgroup per CU); queried once
+static int apla_num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+    else n = 256;
+  }
+  return n;
+}
+
+// 0 = auto (short-sequence kernels when N <= 256), 1 = always the blocked kernels, 2 = the one-workgroup-per-head short-sequence
+// kernels (never the persistent ones), 3 = the persistent kernels wherever they apply (tests; APLA_ATTN_VARIANT for A/B timing)
 static int g_attn_variant = [] { const char* e = getenv("APLA_ATTN_VARIANT"); return e ? atoi(e) : 0; }();
 extern "C" int apla_attn_set_variant(int v) { const int old = g_attn_variant; g_attn_variant = v; return old; }
 
@@ -981,6 +1411,11 @@ static int launch_attn_fwd(const void* qkv, void* o, float* lse, const int32_t* 
                            float scale, hipStream_t stream, const char* who) {
   if (N <= SMALL_MAX_ROWS && g_attn_variant != 1) {
     const int nw = (N + 31) / 32;
+    static bool attr_set_f = false;
+    if (!attr_set_f) {   // 72 KB of dynamic LDS at nine blocks
+      (void)hipFuncSetAttribute((const void*)attn_fwd_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMALL_MAX_ROWS * 256);
+      attr_set_f = true;
+    }
     hipLaunchKernelGGL(attn_fwd_small_kernel, dim3(H, B), dim3(64 * nw), (size_t)nw * 32 * 256, stream, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, cu, total);
   } else {
     hipLaunchKernelGGL(attn_fwd_kernel, dim3((N + 127) / 128, H, B), dim3(256), 0, stream, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, cu, total);
@@ -992,12 +1427,37 @@ static int launch_attn_fwd(const void* qkv, void* o, float* lse, const int32_t* 
 static int launch_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv,
                            const int32_t* cu, int total, int B, int N, int H, float scale, hipStream_t stream,
                            const char* who) {
+  // uniform batch of short sequences with at least one head per CU: the persistent kernel (every load one phase ahead of its use);
+  // variant 2 pins the one-workgroup-per-head kernel below, variant 3 the persistent one wherever it applies (tests, A/B timing)
+  if (cu == nullptr && N <= PERSIST_MAX_ROWS && g_attn_variant != 1 && g_attn_variant != 2 &&
+      (g_attn_variant == 3 || (long)B * H >= apla_num_cus())) {
+    const int NP = (N + 31) / 32 * 32, BH = B * H;
+    const int nt = NP / 32;
+    const bool staged = nt <= 7;       // 4 tiles + 2 KB + 8 x 4 KB of store buffers: 162 KB at eight blocks, one CU has 160
+    const size_t lds = (size_t)nt * 4096 * 4 + 2 * PERSIST_MAX_ROWS * 4 + (staged ? 8 * 4096 : 0);
+    const int G = BH < apla_num_cus() ? BH : apla_num_cus();
+#define APLA_PERSIST_CASE(NTV)                                                                                                       \
+    case NTV: {                                                                                                                      \
+      auto kern = attn_bwd_persist_kernel<NTV, (NTV <= 7)>;                                                                          \
+      static bool attr_set_p = false;                                                                                                \
+      if (!attr_set_p) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set_p = true; } \
+      hipLaunchKernelGGL(kern, dim3(G), dim3(512), lds, stream, (const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse, delta, (bf16*)dqkv, N, H, scale, BH); \
+    } break;
+    switch (nt) {
+      APLA_PERSIST_CASE(1) APLA_PERSIST_CASE(2) APLA_PERSIST_CASE(3) APLA_PERSIST_CASE(4)
+      APLA_PERSIST_CASE(5) APLA_PERSIST_CASE(6) APLA_PERSIST_CASE(7) APLA_PERSIST_CASE(8)
+      default: apla_set_error("%s: bad block count %d", who, nt); return APLA_EINVAL;
+    }
+#undef APLA_PERSIST_CASE
+    APLA_CHECK_LAUNCH(who);
+    return APLA_OK;
+  }
   if (N <= SMALL_MAX_ROWS_BWD && g_attn_variant != 1) {  // one workgroup per head, operands read from HBM once (see the kernel)
     const int NP = (N + 31) / 32 * 32;
-    const size_t lds = (size_t)NP * (2 * 128 + 4) + (size_t)((NP + 63) & ~63) * 4;  // two tiles + delta + lse (64-float pieces)
+    const size_t lds = (size_t)SMALL_MAX_ROWS_BWD * (2 * 128 + 8);   // two tiles at a fixed distance + lse*log2e + delta
     static bool attr_set = false;
-    if (!attr_set) {   // > 64 KB of dynamic LDS at N > 224
-      hipFuncSetAttribute((const void*)attn_bwd_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMALL_MAX_ROWS_BWD * (2 * 128 + 8) + 256);
+    if (!attr_set) {   // > 64 KB of dynamic LDS
+      (void)hipFuncSetAttribute((const void*)attn_bwd_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       attr_set = true;
     }
     hipLaunchKernelGGL(attn_bwd_small_kernel, dim3(H, B), dim3(256), lds, stream, (const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse, delta, (bf16*)dqkv, N, H, scale, cu, total, NP);

@@ -183,16 +183,17 @@ def test_layernorm_cls_rows_strided(ops):
 # ------------------------------------------------------------------------------------------- attention
 @pytest.fixture
 def attn_variant(request):
-    """0 = auto (one-workgroup-per-head kernels for N <= 256), 1 = always the key-blocked kernels."""
+    """0 = auto, 1 = always the key-blocked kernels, 2 = the one-workgroup-per-head short-sequence kernels, 3 = the persistent
+    kernels (one workgroup per CU walking its heads) wherever they apply."""
     from apla_amd._lib import lib
     old = lib().apla_attn_set_variant(request.param)
     yield request.param
     lib().apla_attn_set_variant(old)
 
 
-@pytest.mark.parametrize("attn_variant", [0, 1], indirect=True)
+@pytest.mark.parametrize("attn_variant", [0, 1, 2, 3], indirect=True)
 @pytest.mark.parametrize("B,N,H", [(2, 197, 2), (1, 64, 1), (3, 300, 3), (1, 1, 1), (2, 129, 2), (1, 1370, 1), (2, 256, 3),
-                                   (1, 33, 2), (2, 224, 1)])
+                                   (1, 33, 2), (2, 224, 1), (2, 257, 2), (3, 288, 1), (5, 225, 2)])
 def test_attention_fwd_bwd(ops, attn_variant, B, N, H):
     D = 64 * H
     scale = 64 ** -0.5
@@ -516,12 +517,13 @@ def test_cross_entropy_soft_targets(ops):
     assert abs(float(l1) - float(l2)) < 1e-6 * float(l2) and rel_err(d1.cpu(), d2.cpu().double()) < 1e-6
 
 
-@pytest.mark.parametrize("B,N", [(128, 197), (96, 50), (40, 256), (64, 257), (48, 288)])
+@pytest.mark.parametrize("B,N", [(128, 197), (96, 50), (40, 256), (64, 257), (48, 288), (30, 225), (23, 32)])
 def test_attn_bwd_fused_short_sequence_kernel_equals_split_kernels_at_full_occupancy(ops, B, N):
-    """The one-workgroup-per-head backward (N <= 256) against the query-/key-blocked kernels on identical inputs, with enough
-    heads to fill the chip several times over: bitwise equal (same products in the same order) and reproducible.  (A first
-    version let the 64-float lse DMA pieces spill into the delta rows next to them: invisible at the small batches of the
-    parity tests above, a race at full occupancy.)"""
+    """The one-workgroup-per-head backward (N <= 288) and the persistent backward (N <= 256: one workgroup per CU walking its
+    heads, every load one phase ahead of its use) against the query-/key-blocked kernels on identical inputs, with enough
+    heads to fill the chip several times over: bitwise equal (same products in the same order), delta included, and
+    reproducible.  (A first version of the fused kernel let the 64-float lse DMA pieces spill into the delta rows next to them:
+    invisible at the small batches of the parity tests above, a race at full occupancy.)"""
     from apla_amd._lib import lib
     H = 12
     g = torch.Generator(device="cuda").manual_seed(N)
@@ -531,13 +533,18 @@ def test_attn_bwd_fused_short_sequence_kernel_equals_split_kernels_at_full_occup
     o, lse = ops.attn_fwd(qkv, B, N, H, scale)
     old = lib().apla_attn_set_variant(0)
     try:
-        a1 = ops.attn_bwd(qkv, o, do, lse, B, N, H, scale).clone()
-        a2 = ops.attn_bwd(qkv, o, do, lse, B, N, H, scale).clone()
-        lib().apla_attn_set_variant(1)
-        b1 = ops.attn_bwd(qkv, o, do, lse, B, N, H, scale).clone()
+        res = {}
+        for v in (2, 3, 0, 1):
+            lib().apla_attn_set_variant(v)
+            d1, d2 = torch.zeros(B, H, N, device="cuda"), torch.zeros(B, H, N, device="cuda")
+            a1 = ops.attn_bwd(qkv, o, do, lse, B, N, H, scale, delta=d1).clone()
+            a2 = ops.attn_bwd(qkv, o, do, lse, B, N, H, scale, delta=d2).clone()
+            assert torch.equal(a1, a2) and torch.equal(d1, d2), v
+            res[v] = (a1, d1.clone())
     finally:
         lib().apla_attn_set_variant(old)
-    assert torch.equal(a1, a2) and torch.equal(a1, b1)
+    for v in (2, 3, 0):
+        assert torch.equal(res[v][0], res[1][0]) and torch.equal(res[v][1], res[1][1]), v
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 768, 768), (128, 768, 3072), (128, 3072, 768), (37, 128, 256), (300, 192, 1536)])

@@ -32,7 +32,7 @@ def timeit(fn, iters=20):
 
 
 res = {}
-for v in (1, 0):
+for v in (1, 2, 3, 0):
     lib().apla_attn_set_variant(v)
     o, lse = ops.attn_fwd(qkv, B, N, H, scale)
     dqkv = ops.attn_bwd(qkv, o, do, lse, B, N, H, scale)
@@ -40,5 +40,6 @@ for v in (1, 0):
     tf = timeit(lambda: ops.attn_fwd(qkv, B, N, H, scale))
     tb = timeit(lambda: ops.attn_bwd(qkv, o, do, lse, B, N, H, scale))
     print(f"variant {v}: fwd {tf:7.1f} us   bwd {tb:7.1f} us", flush=True)
-print("fwd max diff", float((res[0][0].float() - res[1][0].float()).abs().max()),
-      "bwd max diff", float((res[0][1].float() - res[1][1].float()).abs().max()))
+for v in (2, 3, 0):
+    print(f"variant {v} vs 1: fwd max diff", float((res[v][0].float() - res[1][0].float()).abs().max()),
+          "bwd max diff", float((res[v][1].float() - res[1][1].float()).abs().max()))
