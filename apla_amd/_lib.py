@@ -22,11 +22,17 @@ SIGNATURES = {
     "apla_operand_dtype": (c_int, []),
     "apla_gemm_nt": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                              c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
-    "apla_gemm_set_variant": (c_int, [c_int]),
+    "apla_gemm_nt_ex": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     "apla_gemm_small_workspace_bytes": (c_long, [c_int, c_int, c_int]),
     "apla_gemm_nt_small": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                    c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_long, c_void_p]),
-    "apla_attn_set_variant": (c_int, [c_int]),
+    "apla_attn_fwd_ex": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p]),
+    "apla_attn_bwd_ex": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
+                                 c_int, c_void_p]),
+    "apla_attn_varlen_fwd_ex": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
+    "apla_attn_varlen_bwd_ex": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                        c_int, c_float, c_int, c_void_p]),
     "apla_layernorm_fwd": (c_int, [c_void_p, c_int, c_long, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                    c_void_p, c_int, c_int, c_float, c_void_p, c_long, c_void_p, c_long, c_void_p]),
     "apla_layernorm_bwd": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_long, c_void_p, c_void_p, c_void_p,

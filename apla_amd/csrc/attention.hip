@@ -1401,14 +1401,13 @@ static int apla_num_cus() {
   return n;
 }
 
-// 0 = auto (short-sequence kernels when N <= 256), 1 = always the blocked kernels, 2 = the one-workgroup-per-head short-sequence
-// kernels (never the persistent ones), 3 = the persistent kernels wherever they apply (tests; APLA_ATTN_VARIANT for A/B timing)
-static int g_attn_variant = [] { const char* e = getenv("APLA_ATTN_VARIANT"); return e ? atoi(e) : 0; }();
-extern "C" int apla_attn_set_variant(int v) { const int old = g_attn_variant; g_attn_variant = v; return old; }
+// kernel choice, a per-call argument of the *_ex entry points: 0 = auto, 1 = always the blocked kernels, 2 = the
+// one-workgroup-per-head short-sequence kernels (never the persistent one), 3 = the persistent backward wherever it applies
 
 // B sequences of (at most) N tokens; cu == nullptr: uniform batch, else packed with cu[B+1] token offsets and `total` tokens
 static int launch_attn_fwd(const void* qkv, void* o, float* lse, const int32_t* cu, int total, int B, int N, int H,
-                           float scale, hipStream_t stream, const char* who) {
+                           float scale, int g_attn_variant, hipStream_t stream, const char* who) {
+  APLA_REQUIRE(g_attn_variant >= 0 && g_attn_variant <= 3, "%s: unknown kernel variant %d", who, g_attn_variant);
   if (N <= SMALL_MAX_ROWS && g_attn_variant != 1) {
     const int nw = (N + 31) / 32;
     static bool attr_set_f = false;
@@ -1425,8 +1424,9 @@ static int launch_attn_fwd(const void* qkv, void* o, float* lse, const int32_t* 
 }
 
 static int launch_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv,
-                           const int32_t* cu, int total, int B, int N, int H, float scale, hipStream_t stream,
-                           const char* who) {
+                           const int32_t* cu, int total, int B, int N, int H, float scale, int g_attn_variant,
+                           hipStream_t stream, const char* who) {
+  APLA_REQUIRE(g_attn_variant >= 0 && g_attn_variant <= 3, "%s: unknown kernel variant %d", who, g_attn_variant);
   // uniform batch of short sequences with at least one head per CU: the persistent kernel (every load one phase ahead of its use);
   // variant 2 pins the one-workgroup-per-head kernel below, variant 3 the persistent one wherever it applies (tests, A/B timing)
   if (cu == nullptr && N <= PERSIST_MAX_ROWS && g_attn_variant != 1 && g_attn_variant != 2 &&
@@ -1472,37 +1472,53 @@ static int launch_attn_bwd(const void* qkv, const void* o, const void* d_o, cons
   return APLA_OK;
 }
 
-extern "C" int apla_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, float scale,
-                             hipStream_t stream) {
+extern "C" int apla_attn_fwd_ex(const void* qkv, void* o, float* lse, int B, int N, int H, float scale, int variant,
+                                hipStream_t stream) {
   APLA_REQUIRE(qkv && o && lse && B > 0 && N > 0 && H > 0, "apla_attn_fwd: bad arguments");
   APLA_REQUIRE(apla_aligned16(qkv) && apla_aligned16(o), "apla_attn_fwd: pointers must be 16-byte aligned");
   APLA_REQUIRE(B <= 65535 && H <= 65535, "apla_attn_fwd: B/H exceed grid limits");
-  return launch_attn_fwd(qkv, o, lse, nullptr, B * N, B, N, H, scale, stream, "apla_attn_fwd");
+  return launch_attn_fwd(qkv, o, lse, nullptr, B * N, B, N, H, scale, variant, stream, "apla_attn_fwd");
+}
+extern "C" int apla_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, float scale, hipStream_t stream) {
+  return apla_attn_fwd_ex(qkv, o, lse, B, N, H, scale, 0, stream);
 }
 
-extern "C" int apla_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta,
-                             void* dqkv, int B, int N, int H, float scale, hipStream_t stream) {
+extern "C" int apla_attn_bwd_ex(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta,
+                                void* dqkv, int B, int N, int H, float scale, int variant, hipStream_t stream) {
   APLA_REQUIRE(qkv && o && d_o && lse && delta && dqkv && B > 0 && N > 0 && H > 0, "apla_attn_bwd: bad arguments");
   APLA_REQUIRE(apla_aligned16(qkv) && apla_aligned16(o) && apla_aligned16(d_o) && apla_aligned16(dqkv), "apla_attn_bwd: pointers must be 16-byte aligned");
   APLA_REQUIRE(B <= 65535 && H <= 65535, "apla_attn_bwd: B/H exceed grid limits");
-  return launch_attn_bwd(qkv, o, d_o, lse, delta, dqkv, nullptr, B * N, B, N, H, scale, stream, "apla_attn_bwd");
+  return launch_attn_bwd(qkv, o, d_o, lse, delta, dqkv, nullptr, B * N, B, N, H, scale, variant, stream, "apla_attn_bwd");
+}
+extern "C" int apla_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta,
+                             void* dqkv, int B, int N, int H, float scale, hipStream_t stream) {
+  return apla_attn_bwd_ex(qkv, o, d_o, lse, delta, dqkv, B, N, H, scale, 0, stream);
 }
 
-extern "C" int apla_attn_varlen_fwd(const void* qkv, void* o, float* lse, const int32_t* cu_seqlens, int S, int total,
-                                    int max_n, int H, float scale, hipStream_t stream) {
+extern "C" int apla_attn_varlen_fwd_ex(const void* qkv, void* o, float* lse, const int32_t* cu_seqlens, int S, int total,
+                                       int max_n, int H, float scale, int variant, hipStream_t stream) {
   APLA_REQUIRE(qkv && o && lse && cu_seqlens && S > 0 && total > 0 && max_n > 0 && H > 0, "apla_attn_varlen_fwd: bad arguments");
   APLA_REQUIRE(apla_aligned16(qkv) && apla_aligned16(o), "apla_attn_varlen_fwd: pointers must be 16-byte aligned");
   APLA_REQUIRE(S <= 65535 && H <= 65535, "apla_attn_varlen_fwd: S/H exceed grid limits");
-  return launch_attn_fwd(qkv, o, lse, cu_seqlens, total, S, max_n, H, scale, stream, "apla_attn_varlen_fwd");
+  return launch_attn_fwd(qkv, o, lse, cu_seqlens, total, S, max_n, H, scale, variant, stream, "apla_attn_varlen_fwd");
+}
+extern "C" int apla_attn_varlen_fwd(const void* qkv, void* o, float* lse, const int32_t* cu_seqlens, int S, int total,
+                                    int max_n, int H, float scale, hipStream_t stream) {
+  return apla_attn_varlen_fwd_ex(qkv, o, lse, cu_seqlens, S, total, max_n, H, scale, 0, stream);
 }
 
-extern "C" int apla_attn_varlen_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta,
-                                    void* dqkv, const int32_t* cu_seqlens, int S, int total, int max_n, int H,
-                                    float scale, hipStream_t stream) {
+extern "C" int apla_attn_varlen_bwd_ex(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta,
+                                       void* dqkv, const int32_t* cu_seqlens, int S, int total, int max_n, int H,
+                                       float scale, int variant, hipStream_t stream) {
   APLA_REQUIRE(qkv && o && d_o && lse && delta && dqkv && cu_seqlens && S > 0 && total > 0 && max_n > 0 && H > 0, "apla_attn_varlen_bwd: bad arguments");
   APLA_REQUIRE(apla_aligned16(qkv) && apla_aligned16(o) && apla_aligned16(d_o) && apla_aligned16(dqkv), "apla_attn_varlen_bwd: pointers must be 16-byte aligned");
   APLA_REQUIRE(S <= 65535 && H <= 65535, "apla_attn_varlen_bwd: S/H exceed grid limits");
-  return launch_attn_bwd(qkv, o, d_o, lse, delta, dqkv, cu_seqlens, total, S, max_n, H, scale, stream, "apla_attn_varlen_bwd");
+  return launch_attn_bwd(qkv, o, d_o, lse, delta, dqkv, cu_seqlens, total, S, max_n, H, scale, variant, stream, "apla_attn_varlen_bwd");
+}
+extern "C" int apla_attn_varlen_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta,
+                                    void* dqkv, const int32_t* cu_seqlens, int S, int total, int max_n, int H,
+                                    float scale, hipStream_t stream) {
+  return apla_attn_varlen_bwd_ex(qkv, o, d_o, lse, delta, dqkv, cu_seqlens, S, total, max_n, H, scale, 0, stream);
 }
 
 extern "C" int apla_attn_fwd_cls(const void* qkv, void* o, float* lse, int B, int N, int H, float scale,

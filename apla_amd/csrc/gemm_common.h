@@ -14,7 +14,10 @@ struct GemmParams {
   void* aux_out; int ld_aux_out;
   int M, N, K, tiles_n;
   int ngrp;  // n-tiles per column group of the tile walk (0 = plain row-major walk); see tile_coords
+  int tag;   // profiling tag (apla_gemm_nt_tagged): selects one of several identical kernel instantiations so that a rocprofv3
+             // kernel trace tells the call sites of the step apart (qkv / proj / fc2 / dfc1 / dproj / dqkv …); 0 = untagged
 };
+constexpr int APLA_GEMM_TAGS = 8;   // tags 0 .. 7
 
 // 8-wave ping-pong kernel (gemm_pp2.hip); returns APLA_ENOSYS when the shape / (epilogue, dtype) is not covered there
 int apla_gemm_pp2_launch(const GemmParams& p, int epilogue, int out_dtype, hipStream_t stream);

@@ -270,7 +270,8 @@ __global__ __launch_bounds__(256, 2) void gemm_persist_kernel(GemmParams p, int 
   }
 }
 
-int g_variant = 4;  // tuning knob (apla_gemm_set_variant): 4 = auto, 9 = ping-pong, 14/15 = 128-wide persistent MI 4/5, 0 = simple non-persistent kernel
+// kernel schedule, a per-call argument (apla_gemm_nt_ex): 4 = auto, 9 = ping-pong, 14/15 = 128-wide persistent MI 4/5,
+// 1 = the simple non-persistent kernel
 constexpr int RESIDENT_WGS = 512;  // 256 CUs x 2 workgroups (64-80 KB LDS, <=256 VGPR)
 
 template <int EPI, typename OutT, int MI>
@@ -299,7 +300,7 @@ inline int pick_mi(int M, int tiles_n) {
 }
 
 template <int EPI, typename OutT>
-int launch(const GemmParams& p, hipStream_t stream) {
+int launch(const GemmParams& p, int g_variant, hipStream_t stream) {
   // auto (4): the 8-wave ping-pong kernel for large problems whose epilogue it handles well, else the 128-wide persistent
   // kernel; 9 forces ping-pong wherever it is instantiated; 14/15 force the 128-wide persistent kernel with MI 4/5.
   if (g_variant == 9 || (g_variant == 4 && p.M >= 2048)) {
@@ -320,51 +321,62 @@ int launch(const GemmParams& p, hipStream_t stream) {
 
 }  // namespace
 
-extern "C" int apla_gemm_set_variant(int v) {
-  const int old = g_variant;
-  g_variant = v;
-  return old;
-}
-
-extern "C" int apla_gemm_nt(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int M,
-                            int N, int K, int epilogue, int out_dtype, const void* aux_in, int ld_aux_in,
-                            void* aux_out, int ld_aux_out, hipStream_t stream) {
+static int gemm_nt_impl(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int M,
+                        int N, int K, int epilogue, int out_dtype, const void* aux_in, int ld_aux_in,
+                        void* aux_out, int ld_aux_out, int tag, int variant, hipStream_t stream) {
   APLA_REQUIRE(M > 0 && N > 0 && K > 0, "apla_gemm_nt: empty problem M=%d N=%d K=%d", M, N, K);
   APLA_REQUIRE(N % BN == 0 && K % BK == 0, "apla_gemm_nt: need N%%128==0 and K%%64==0 (N=%d K=%d)", N, K);
   APLA_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && lda >= K && ldw >= K, "apla_gemm_nt: bad lda/ldw (%d,%d) K=%d", lda, ldw, K);
   APLA_REQUIRE(apla_aligned16(A) && apla_aligned16(W) && apla_aligned16(C) && A && W && C, "apla_gemm_nt: pointers must be 16-byte aligned");
   APLA_REQUIRE(bias == nullptr || apla_aligned16(bias), "apla_gemm_nt: bias must be 16-byte aligned");
   APLA_REQUIRE(ldc % 4 == 0, "apla_gemm_nt: ldc %% 4 != 0");
-  GemmParams p{(const bf16*)A, lda, (const bf16*)W, ldw, bias, C, ldc, aux_in, ld_aux_in, aux_out, ld_aux_out, M, N, K, N / BN, 0};
+  GemmParams p{(const bf16*)A, lda, (const bf16*)W, ldw, bias, C, ldc, aux_in, ld_aux_in, aux_out, ld_aux_out, M, N, K, N / BN, 0,
+               (tag >= 0 && tag < APLA_GEMM_TAGS) ? tag : 0};
   switch (epilogue) {
     case APLA_EPI_STORE:
       APLA_REQUIRE(ldc >= N, "apla_gemm_nt: ldc < N");
-      if (out_dtype == APLA_H16) return launch<APLA_EPI_STORE, bf16>(p, stream);
-      if (out_dtype == APLA_F32) return launch<APLA_EPI_STORE, float>(p, stream);
+      if (out_dtype == APLA_H16) return launch<APLA_EPI_STORE, bf16>(p, variant, stream);
+      if (out_dtype == APLA_F32) return launch<APLA_EPI_STORE, float>(p, variant, stream);
       break;
     case APLA_EPI_GELU:
       APLA_REQUIRE(aux_out && apla_aligned16(aux_out) && ld_aux_out % 4 == 0 && ld_aux_out >= N && ldc >= N, "apla_gemm_nt[gelu]: aux_out [M,N] bf16 required");
-      return launch<APLA_EPI_GELU, bf16>(p, stream);
+      return launch<APLA_EPI_GELU, bf16>(p, variant, stream);
     case APLA_EPI_GELU_FWD:
       APLA_REQUIRE(ldc >= N && out_dtype == APLA_H16, "apla_gemm_nt[gelu_fwd]: 16-bit output [M,N]");
-      return launch<APLA_EPI_GELU_FWD, bf16>(p, stream);
+      return launch<APLA_EPI_GELU_FWD, bf16>(p, variant, stream);
     case APLA_EPI_RESIDUAL:
       APLA_REQUIRE(aux_in && apla_aligned16(aux_in) && ld_aux_in % 4 == 0 && ld_aux_in >= N && ldc >= N, "apla_gemm_nt[residual]: aux_in [M,N] required");
-      if (out_dtype == APLA_H16) return launch<APLA_EPI_RESIDUAL, bf16>(p, stream);
-      if (out_dtype == APLA_F32) return launch<APLA_EPI_RESIDUAL, float>(p, stream);
+      if (out_dtype == APLA_H16) return launch<APLA_EPI_RESIDUAL, bf16>(p, variant, stream);
+      if (out_dtype == APLA_F32) return launch<APLA_EPI_RESIDUAL, float>(p, variant, stream);
       break;
     case APLA_EPI_MUL:
       APLA_REQUIRE(aux_in && apla_aligned16(aux_in) && ld_aux_in % 4 == 0 && ld_aux_in >= N && ldc >= N, "apla_gemm_nt[mul]: aux_in [M,N] bf16 required");
-      return launch<APLA_EPI_MUL, bf16>(p, stream);
+      return launch<APLA_EPI_MUL, bf16>(p, variant, stream);
     case APLA_EPI_SWIGLU:
       APLA_REQUIRE(aux_out && apla_aligned16(aux_out) && ld_aux_out % 4 == 0 && ld_aux_out >= N && ldc % 2 == 0 && ldc >= N / 2, "apla_gemm_nt[swiglu]: aux_out [M,N] bf16 required");
-      return launch<APLA_EPI_SWIGLU, bf16>(p, stream);
+      return launch<APLA_EPI_SWIGLU, bf16>(p, variant, stream);
     case APLA_EPI_SWIGLU_BWD:
       APLA_REQUIRE(aux_in && apla_aligned16(aux_in) && ld_aux_in % 8 == 0 && ld_aux_in >= 2 * N && ldc % 8 == 0 && ldc >= 2 * N, "apla_gemm_nt[swiglu_bwd]: aux_in [M,2N] bf16 required");
-      return launch<APLA_EPI_SWIGLU_BWD, bf16>(p, stream);
+      return launch<APLA_EPI_SWIGLU_BWD, bf16>(p, variant, stream);
     default:
       break;
   }
   apla_set_error("apla_gemm_nt: unsupported epilogue %d / out_dtype %d", epilogue, out_dtype);
   return APLA_ENOSYS;
+}
+
+extern "C" int apla_gemm_nt(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int M,
+                            int N, int K, int epilogue, int out_dtype, const void* aux_in, int ld_aux_in,
+                            void* aux_out, int ld_aux_out, hipStream_t stream) {
+  return gemm_nt_impl(A, lda, W, ldw, bias, C, ldc, M, N, K, epilogue, out_dtype, aux_in, ld_aux_in, aux_out, ld_aux_out, 0, 4, stream);
+}
+
+// flags: bits 0-7 = profiling tag (GemmParams::tag), bits 8-15 = kernel schedule (0 = auto; see `launch`)
+extern "C" int apla_gemm_nt_ex(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int M,
+                               int N, int K, int epilogue, int out_dtype, const void* aux_in, int ld_aux_in,
+                               void* aux_out, int ld_aux_out, int flags, hipStream_t stream) {
+  const int tag = flags & 0xff, v = (flags >> 8) & 0xff;
+  APLA_REQUIRE(v == 0 || v == 1 || v == 4 || v == 9 || v == 14 || v == 15, "apla_gemm_nt_ex: unknown schedule %d", v);
+  return gemm_nt_impl(A, lda, W, ldw, bias, C, ldc, M, N, K, epilogue, out_dtype, aux_in, ld_aux_in, aux_out, ld_aux_out, tag,
+                      v == 0 ? 4 : (v == 1 ? 0 : v), stream);
 }

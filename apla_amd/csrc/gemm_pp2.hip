@@ -26,7 +26,8 @@ constexpr int QNS = 4;
 constexpr int QGRP = 5;  // LDS-DMA pieces per wave per K-step: 36 real (20 A + 16 W) + 4 duplicates over 8 waves
 constexpr int QAHEAD = 3;
 
-template <int EPI, typename OutT>
+// TAG: profiling tag only (see GemmParams::tag) — the instantiations of one (EPI, OutT) are the same code under different names
+template <int EPI, typename OutT, int TAG = 0>
 __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmParams p, int tiles_m) {
   using E = WideEpi<EPI, OutT>;
   __shared__ __attribute__((aligned(16))) char smem[QNS * QSTG + 2048 + 4 * 2048];  // + two bias pieces (256 floats each) + four 2 KB epilogue line buffers
@@ -258,7 +259,22 @@ int apla_gemm_pp2_launch(const GemmParams& p_in, int epilogue, int out_dtype, hi
   } while (0)
   switch (epilogue) {
     case APLA_EPI_STORE:
-      if (out_dtype == APLA_F32) PP2_LAUNCH(APLA_EPI_STORE, float); else PP2_LAUNCH(APLA_EPI_STORE, bf16);
+      if (out_dtype == APLA_F32) PP2_LAUNCH(APLA_EPI_STORE, float);
+      switch (p.tag) {   // bf16 STORE: the step's six call-site shapes run through this one kernel
+#define PP2_TAGGED(T)                                                                                                 \
+        case T:                                                                                                        \
+          hipLaunchKernelGGL((gemm_pp2_kernel<APLA_EPI_STORE, bf16, T>), dim3(G), dim3(512), 0, stream, p, tiles_m);  \
+          break;
+        PP2_TAGGED(1) PP2_TAGGED(2) PP2_TAGGED(3) PP2_TAGGED(4) PP2_TAGGED(5) PP2_TAGGED(6) PP2_TAGGED(7)
+#undef PP2_TAGGED
+        default:
+          hipLaunchKernelGGL((gemm_pp2_kernel<APLA_EPI_STORE, bf16, 0>), dim3(G), dim3(512), 0, stream, p, tiles_m);
+      }
+      {
+        hipError_t e__ = hipGetLastError();
+        if (e__ != hipSuccess) { apla_set_error("apla_gemm_nt[pp2]: launch failed: %s", hipGetErrorString(e__)); return APLA_EIO; }
+        return APLA_OK;
+      }
     case APLA_EPI_GELU:
       PP2_LAUNCH(APLA_EPI_GELU, bf16);
     case APLA_EPI_GELU_FWD:

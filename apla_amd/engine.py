@@ -362,7 +362,7 @@ class AplaTrainEngine:
         computed nor stored); everything else is the training forward."""
         B, N, H, D = self.B, self.N, self.H, self.D
         ops.patchify(self.images, self.patch, self.Kp, out=self.cols)
-        ops.gemm_nt(self.cols, self.Wpe, self.bpe, out=self.patches)
+        ops.gemm_nt(self.cols, self.Wpe, self.bpe, out=self.patches, tag=ops.TAG_PATCH)
         ops.assemble_tokens(self.patches, self.cls, self.pos, B, self.Np, out=self.x[0])
         # The residual updates x += branch (vit.py:284-285) are fused into the NEXT LayerNorm: the projection / fc2 GEMMs store
         # their (LayerScale-folded) branch output in bf16 — as the reference's fp16-autocast Linear does before the fp32
@@ -376,14 +376,14 @@ class AplaTrainEngine:
                                   rstd=self.rstd1[i], add=self.branch, x_out=self.x[i])
             if i == self.L - 1 and self.cls_only_tail:
                 # last block: K and V for every token, Q for the CLS rows only (the only query that is ever used)
-                ops.gemm_nt(self.ln_out, st.Wqkv[D:], None if st.bqkv is None else st.bqkv[D:], out=self.qkv[i][:, D:])
+                ops.gemm_nt(self.ln_out, st.Wqkv[D:], None if st.bqkv is None else st.bqkv[D:], out=self.qkv[i][:, D:], tag=ops.TAG_QKV)
                 self._gemm_rows(self.ln_out.view(B, N * D)[:, :D], st.Wqkv[:D], None if st.bqkv is None else st.bqkv[:D],
                             out=self.qkv[i].view(B, N * 3 * D)[:, :D])
                 self._forward_last_block_tail(st, i)
                 break
-            ops.gemm_nt(self.ln_out, st.Wqkv, st.bqkv, out=self.qkv[i])
+            ops.gemm_nt(self.ln_out, st.Wqkv, st.bqkv, out=self.qkv[i], tag=ops.TAG_QKV)
             ops.attn_fwd(self.qkv[i], B, N, H, self.scale, o=self.o[i], lse=self.lse[i])
-            ops.gemm_nt(self.o[i], st.Wnat, st.bnat, out=self.branch)
+            ops.gemm_nt(self.o[i], st.Wnat, st.bnat, out=self.branch, tag=ops.TAG_PROJ)
             ops.layernorm_fwd(self.x[i], st.g2, st.b2, self.eps, out=self.ln_out, mean=self.mean2[i], rstd=self.rstd2[i],
                               add=self.branch, x_out=self.xmid[i])
             ev = self._fc1_events
@@ -399,7 +399,7 @@ class AplaTrainEngine:
             if ev is not None:
                 e1.record()
                 ev.append((e0, e1))
-            ops.gemm_nt(self.h, st.Wout, st.bout, out=self.branch)
+            ops.gemm_nt(self.h, st.Wout, st.bout, out=self.branch, tag=ops.TAG_FC2)
         # final norm on the CLS rows only (vit.py:416-419) with the last residual add fused, fp32 head + mean CE
         ops.layernorm_fwd(self.xmid[self.L - 1], self.gf, self.bf_, self.eps, out=self.xn, mean=self.meanf, rstd=self.rstdf,
                           rows=B, row_stride=N * D, add=self.branch_cls if self.cls_only_tail else self.branch,
@@ -472,19 +472,19 @@ class AplaTrainEngine:
         copy = None if self.Gb is self.G else self.Gb
         if self.swiglu:
             ops.gemm_nt(self.Gb, st.WoutT, None, epilogue=ops.EPI_SWIGLU_BWD, aux_in=self.act_saved[i], out=self.dact)
-            ops.gemm_nt(self.dact, st.W12T, None, out=self.dln)
+            ops.gemm_nt(self.dact, st.W12T, None, out=self.dln, tag=ops.TAG_DFC1)
         else:
             ops.gemm_nt(self.Gb, st.WoutT, None, epilogue=ops.EPI_MUL, aux_in=self.act_saved[i], out=self.dact)
-            ops.gemm_nt(self.dact, st.Wfc1T, None, out=self.dln)
+            ops.gemm_nt(self.dact, st.Wfc1T, None, out=self.dln, tag=ops.TAG_DFC1)
         dyg = self.dyg[:M * st.r_pad].view(M, st.r_pad)
         ops.layernorm_bwd(self.dln, self.xmid[i], st.g2, self.mean2[i], self.rstd2[i], dres=self.G, out=self.G,
                           out_bf16=copy, inds=st.inds, r=st.r_pad, gathered=dyg)
         self._proj_dw(st, dyg, self.o[i])
         if i == 0:
             return  # nothing upstream of block 0's projection is trainable
-        ops.gemm_nt(self.Gb, st.WnatT, None, out=self.dO)
+        ops.gemm_nt(self.Gb, st.WnatT, None, out=self.dO, tag=ops.TAG_DPROJ)
         ops.attn_bwd(self.qkv[i], self.o[i], self.dO, self.lse[i], B, N, H, self.scale, dqkv=self.dqkv, delta=self.delta)
-        ops.gemm_nt(self.dqkv, st.WqkvT, None, out=self.dln)
+        ops.gemm_nt(self.dqkv, st.WqkvT, None, out=self.dln, tag=ops.TAG_DQKV)
         ops.layernorm_bwd(self.dln, self.x[i], st.g1, self.mean1[i], self.rstd1[i], dres=self.G, out=self.G, out_bf16=copy)
 
     def _backward_last_block(self):
@@ -513,7 +513,7 @@ class AplaTrainEngine:
             return
         self._gemm_rows(cls(self.Gb), st.WnatT, None, out=self.dO_cls)
         ops.attn_bwd_cls(self.qkv[i], self.o[i], self.dO_cls, self.lse[i], B, N, H, self.scale, dqkv=self.dqkv)
-        ops.gemm_nt(self.dqkv, st.WqkvT, None, out=self.dln)
+        ops.gemm_nt(self.dqkv, st.WqkvT, None, out=self.dln, tag=ops.TAG_DQKV)
         ops.layernorm_bwd(self.dln, self.x[i], st.g1, self.mean1[i], self.rstd1[i], dres=self.G, out=self.G, out_bf16=copy)
 
     def _segment(self, k):

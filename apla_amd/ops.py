@@ -4,6 +4,7 @@ PyTorch is used here for device memory and streams only: every function checks i
 dtype, contiguity, shapes — a mis-shaped launch can fault the GPU), passes raw pointers and the current HIP stream to
 libapla_hip.so and raises on a non-zero return code.  No function has a CPU path.
 """
+import os
 from typing import Optional
 
 import torch
@@ -72,10 +73,33 @@ def _rows2d(t: torch.Tensor, name: str):
     return t.shape[0], t.shape[1], t.stride(0)
 
 
+# Kernel-schedule choice of the GEMM / attention wrappers: test and benchmark hooks kept HERE, in Python (the C-ABI itself is
+# stateless: the choice travels as a per-call argument of the *_ex entry points).  0 = auto.
+_GEMM_VARIANT = 0
+_ATTN_VARIANT = int(os.environ.get("APLA_ATTN_VARIANT", "0"))
+# profiling tags of apla_gemm_nt_ex (kernel names in a rocprofv3 trace): call sites of the training step
+TAG_QKV, TAG_PROJ, TAG_FC2, TAG_DFC1, TAG_DPROJ, TAG_DQKV, TAG_PATCH = 1, 2, 3, 4, 5, 6, 7
+
+
+def set_gemm_variant(v: int) -> int:
+    """Pin the GEMM kernel schedule for subsequent ops.gemm_nt calls (include/apla_hip.h:apla_gemm_nt_ex); returns the old value."""
+    global _GEMM_VARIANT
+    old, _GEMM_VARIANT = _GEMM_VARIANT, int(v)
+    return old
+
+
+def set_attn_variant(v: int) -> int:
+    """Pin the attention kernel choice for subsequent ops.attn_* calls (apla_attn_*_ex); returns the old value."""
+    global _ATTN_VARIANT
+    old, _ATTN_VARIANT = _ATTN_VARIANT, int(v)
+    return old
+
+
 def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, epilogue: int = EPI_STORE,
             out: Optional[torch.Tensor] = None, out_dtype=None, aux_in: Optional[torch.Tensor] = None,
-            aux_out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out[M,Nout] = epilogue(a[M,K] @ w[N,K]^T + bias).  See include/apla_hip.h:apla_gemm_nt."""
+            aux_out: Optional[torch.Tensor] = None, tag: int = 0) -> torch.Tensor:
+    """out[M,Nout] = epilogue(a[M,K] @ w[N,K]^T + bias).  See include/apla_hip.h:apla_gemm_nt / apla_gemm_nt_ex (`tag`: profiling
+    tag of the call site, TAG_*)."""
     _req(a, half(), "a", 2), _req(w, half(), "w", 2)
     M, K, lda = _rows2d(a, "a")
     N, Kw, ldw = _rows2d(w, "w")
@@ -115,8 +139,9 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = Non
         raise TypeError("gemm_nt: this epilogue writes bf16")
     if epilogue == EPI_GELU_FWD and aux_out is not None:
         raise ValueError("gemm_nt: EPI_GELU_FWD saves nothing (use EPI_GELU to get gelu')")
-    rc = lib().apla_gemm_nt(a.data_ptr(), lda, w.data_ptr(), ldw, _ptr(bias), out.data_ptr(), out.stride(0), M, N, K,
-                            epilogue, _DT[out.dtype], _ptr(aux_in), ld_in, _ptr(aux_out), ld_out, _stream())
+    rc = lib().apla_gemm_nt_ex(a.data_ptr(), lda, w.data_ptr(), ldw, _ptr(bias), out.data_ptr(), out.stride(0), M, N, K,
+                               epilogue, _DT[out.dtype], _ptr(aux_in), ld_in, _ptr(aux_out), ld_out,
+                               (int(tag) & 0xff) | (_GEMM_VARIANT << 8), _stream())
     check(rc, "apla_gemm_nt")
     return out
 
@@ -278,7 +303,7 @@ def attn_fwd(qkv: torch.Tensor, B: int, N: int, H: int, scale: float, *, o: Opti
     _req(o, half(), "o", 2), _req(lse, torch.float32, "lse", 3)
     if tuple(o.shape) != (B * N, H * 64) or tuple(lse.shape) != (B, H, N) or not (o.is_contiguous() and lse.is_contiguous()):
         raise ValueError("attn_fwd: bad output buffers")
-    check(lib().apla_attn_fwd(qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), B, N, H, float(scale), _stream()),
+    check(lib().apla_attn_fwd_ex(qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), B, N, H, float(scale), _ATTN_VARIANT, _stream()),
           "apla_attn_fwd")
     return o, lse
 
@@ -298,8 +323,8 @@ def attn_bwd(qkv: torch.Tensor, o: torch.Tensor, do: torch.Tensor, lse: torch.Te
         delta = torch.empty(B, H, N, device=qkv.device, dtype=torch.float32)
     if dqkv.shape != qkv.shape or not dqkv.is_contiguous() or delta.numel() < B * H * N:
         raise ValueError("attn_bwd: bad dqkv/delta buffers")
-    check(lib().apla_attn_bwd(qkv.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(), delta.data_ptr(),
-                              dqkv.data_ptr(), B, N, H, float(scale), _stream()), "apla_attn_bwd")
+    check(lib().apla_attn_bwd_ex(qkv.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(), delta.data_ptr(),
+                                 dqkv.data_ptr(), B, N, H, float(scale), _ATTN_VARIANT, _stream()), "apla_attn_bwd")
     return dqkv
 
 
@@ -327,8 +352,8 @@ def attn_varlen_fwd(qkv: torch.Tensor, cu_seqlens: torch.Tensor, max_n: int, H: 
     _req(o, half(), "o", 2), _req(lse, torch.float32, "lse", 2)
     if tuple(o.shape) != (total, H * 64) or tuple(lse.shape) != (H, total) or not (o.is_contiguous() and lse.is_contiguous()):
         raise ValueError("attn_varlen_fwd: bad output buffers")
-    check(lib().apla_attn_varlen_fwd(qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), cu_seqlens.data_ptr(), S, total,
-                                     int(max_n), H, float(scale), _stream()), "apla_attn_varlen_fwd")
+    check(lib().apla_attn_varlen_fwd_ex(qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), cu_seqlens.data_ptr(), S, total,
+                                        int(max_n), H, float(scale), _ATTN_VARIANT, _stream()), "apla_attn_varlen_fwd")
     return o, lse
 
 
@@ -350,9 +375,9 @@ def attn_varlen_bwd(qkv: torch.Tensor, o: torch.Tensor, do: torch.Tensor, lse: t
         delta = torch.empty(H, total, device=qkv.device, dtype=torch.float32)
     if dqkv.shape != qkv.shape or not dqkv.is_contiguous() or delta.numel() < H * total:
         raise ValueError("attn_varlen_bwd: bad dqkv/delta buffers")
-    check(lib().apla_attn_varlen_bwd(qkv.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(), delta.data_ptr(),
-                                     dqkv.data_ptr(), cu_seqlens.data_ptr(), S, total, int(max_n), H, float(scale),
-                                     _stream()), "apla_attn_varlen_bwd")
+    check(lib().apla_attn_varlen_bwd_ex(qkv.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(), delta.data_ptr(),
+                                        dqkv.data_ptr(), cu_seqlens.data_ptr(), S, total, int(max_n), H, float(scale),
+                                        _ATTN_VARIANT, _stream()), "apla_attn_varlen_bwd")
     return dqkv
 
 

@@ -4,8 +4,10 @@
  *   - every entry point is `extern "C" int fn(..., hipStream_t stream)`; 0 = OK, negative = error
  *     (APLA_EINVAL shape/alignment, APLA_ENOSYS unsupported configuration, APLA_EIO HIP launch error);
  *     a human-readable message for the calling thread is available from apla_last_error().
- *   - stateless and re-entrant: no allocation, no synchronisation, no global state; all buffers (including
- *     workspaces) are owned by the caller; kernels are enqueued on `stream` only (hipGraph-capturable).
+ *   - stateless and re-entrant: no allocation, no synchronisation, no global state (kernel-schedule choices used by the
+ *     tests and the A/B benchmarks are per-call arguments of the *_ex entry points; the only process-wide datum is the
+ *     cached CU count of the device); all buffers (including workspaces) are owned by the caller; kernels are enqueued on
+ *     `stream` only (hipGraph-capturable).
  *   - activations / frozen weights are bf16 (raw uint16 storage), trainable masters / statistics / gradients fp32,
  *     index vectors int32 on device.  "res" buffers (the residual stream and its gradient) are fp32 or bf16,
  *     selected by `res_dtype` (APLA_F32 / APLA_BF16).
@@ -61,13 +63,18 @@ int apla_gemm_nt(const void* A, int lda, const void* W, int ldw, const float* bi
                  int K, int epilogue, int out_dtype, const void* aux_in, int ld_aux_in, void* aux_out,
                  int ld_aux_out, hipStream_t stream);
 
-/* Tuning/diagnostic knob: selects the kernel schedule of apla_gemm_nt for subsequent launches (process-wide):
- *   4  = auto (default): 8-wave ping-pong kernel (320x256x32 tile, gemm_pp2.hip) for M >= 2048, N % 256 == 0 and the
- *        STORE / GELU epilogues; otherwise the 4-wave persistent kernel (128/160 x 128 x 64 tile, gemm_nt.hip)
- *   9  = ping-pong wherever instantiated; 14 / 15 = 4-wave persistent kernel with BM 128 / 160
- *   0  = simple non-persistent 2-stage kernel (the round-1 starting point; kept as an in-tree A/B baseline)
- * Returns the previous value.  All variants compute the same results (tests/test_kernels_gpu.py). */
-int apla_gemm_set_variant(int variant);
+/* apla_gemm_nt with two extra choices packed into `flags`:
+ *   bits 0-7   profiling tag 0..7: picks one of several identical instantiations of the bf16 STORE kernel, so that a
+ *              rocprofv3 kernel trace names the call sites of the step (1 qkv, 2 proj, 3 fc2, 4 dfc1, 5 dproj, 6 dqkv,
+ *              7 patch embedding; 0 = untagged).  No effect on results or speed.
+ *   bits 8-15  kernel schedule: 0 = auto (what apla_gemm_nt does): 8-wave ping-pong kernel (320x256x32 tile, gemm_pp2.hip)
+ *              for M >= 2048, N % 256 == 0 and the STORE / GELU epilogues, else the 4-wave persistent kernel (128/160 x 128 x
+ *              64 tile, gemm_nt.hip); 9 = ping-pong wherever instantiated; 14 / 15 = 4-wave persistent kernel with BM 128 /
+ *              160; 1 = the simple non-persistent 2-stage kernel (the round-1 starting point; an in-tree A/B baseline).
+ *              All schedules compute the same results (tests/test_kernels_gpu.py). */
+int apla_gemm_nt_ex(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int M, int N,
+                    int K, int epilogue, int out_dtype, const void* aux_in, int ld_aux_in, void* aux_out,
+                    int ld_aux_out, int flags, hipStream_t stream);
 
 /* apla_gemm_nt for FEW rows (the CLS-only tail of the last block: projection / MLP / Q of Block.forward on the B rows that
  * reach x[:, 0], vit.py:279-288,416-419): the K axis is split over K/64 (K <= 1536) or K/128 slices so that a few hundred
@@ -120,10 +127,21 @@ int apla_attn_varlen_fwd(const void* qkv, void* o, float* lse, const int32_t* cu
 int apla_attn_varlen_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv,
                          const int32_t* cu_seqlens, int S, int total, int max_n, int H, float scale, hipStream_t stream);
 
-/* Tuning/diagnostic knob for apla_attn_fwd (process-wide): 0 = auto (default): sequences of up to 256 tokens use the
- * one-workgroup-per-head forward kernel that keeps the whole K/V of a head in LDS; 1 = always the key-blocked kernel.
- * Returns the previous value.  Both compute the same results (tests/test_kernels_gpu.py). */
-int apla_attn_set_variant(int variant);
+/* The attention entry points with an explicit kernel choice (`variant`; the plain entry points pass 0):
+ *   0 = auto: uniform batches of up to 288 tokens use the one-workgroup-per-head forward (whole K / V of a head in LDS) and,
+ *       up to 256 tokens with at least one head per CU, the persistent backward (one 8-wave workgroup per CU walking its heads,
+ *       every load one phase ahead of its use); packed batches and 257..288 tokens the one-workgroup-per-head backward;
+ *       longer sequences the key-/query-blocked kernels;
+ *   1 = always the blocked kernels; 2 = the one-workgroup-per-head kernels (never the persistent one); 3 = the persistent
+ *       backward wherever it applies.  All compute bitwise the same results (tests/test_kernels_gpu.py). */
+int apla_attn_fwd_ex(const void* qkv, void* o, float* lse, int B, int N, int H, float scale, int variant, hipStream_t stream);
+int apla_attn_bwd_ex(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv, int B, int N,
+                     int H, float scale, int variant, hipStream_t stream);
+int apla_attn_varlen_fwd_ex(const void* qkv, void* o, float* lse, const int32_t* cu_seqlens, int S, int total, int max_n,
+                            int H, float scale, int variant, hipStream_t stream);
+int apla_attn_varlen_bwd_ex(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv,
+                            const int32_t* cu_seqlens, int S, int total, int max_n, int H, float scale, int variant,
+                            hipStream_t stream);
 
 /* Attention backward from (qkv, o, do, lse): dqkv[B*N, 3*H*64].  `delta` is a caller workspace of B*H*N floats.
  * Deterministic (no atomics).  Autograd of appla_attn.py:53-60. */

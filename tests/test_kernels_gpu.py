@@ -185,10 +185,10 @@ def test_layernorm_cls_rows_strided(ops):
 def attn_variant(request):
     """0 = auto, 1 = always the key-blocked kernels, 2 = the one-workgroup-per-head short-sequence kernels, 3 = the persistent
     kernels (one workgroup per CU walking its heads) wherever they apply."""
-    from apla_amd._lib import lib
-    old = lib().apla_attn_set_variant(request.param)
+    from apla_amd import ops
+    old = ops.set_attn_variant(request.param)
     yield request.param
-    lib().apla_attn_set_variant(old)
+    ops.set_attn_variant(old)
 
 
 @pytest.mark.parametrize("attn_variant", [0, 1, 2, 3], indirect=True)
@@ -368,10 +368,10 @@ def test_head_and_cross_entropy(ops):
 
 
 # ------------------------------------------------------------------------------------------- GEMM schedule variants
-@pytest.mark.parametrize("variant", [4, 9, 14, 15, 0])
+@pytest.mark.parametrize("variant", [4, 9, 14, 15, 1])
 @pytest.mark.parametrize("M,N,K", [(25216, 768, 768), (1000, 512, 256), (333, 256, 128), (161, 256, 192)])
 def test_gemm_variants_all_epilogues(ops, variant, M, N, K):
-    """Every main-loop schedule (apla_gemm_set_variant) must give the same results for every epilogue, including the
+    """Every main-loop schedule (apla_gemm_nt_ex flags, pinned through ops.set_gemm_variant) must give the same results for every epilogue, including the
     persistent multi-tile-per-workgroup case (M = 25216) and row tails."""
     from apla_amd._lib import lib
     a, ad = bf(rnd(M, K, seed=81))
@@ -380,7 +380,7 @@ def test_gemm_variants_all_epilogues(ops, variant, M, N, K):
     base = ad @ wd.t() + bias.double()
     res32 = rnd(M, N, seed=84)
     g, gd = bf(rnd(M, N, seed=85))
-    old = lib().apla_gemm_set_variant(variant)
+    old = ops.set_gemm_variant(variant)
     try:
         A, W, Bv = dev(a), dev(w), dev(bias)
         assert rel_err(ops.gemm_nt(A, W, Bv).cpu(), base) < BF16_OUT
@@ -395,7 +395,7 @@ def test_gemm_variants_all_epilogues(ops, variant, M, N, K):
         mlt = ops.gemm_nt(A, W, None, epilogue=ops.EPI_MUL, aux_in=dev(g))
         assert rel_err(mlt.cpu(), (ad @ wd.t()) * gd) < BF16_OUT
     finally:
-        lib().apla_gemm_set_variant(old)
+        ops.set_gemm_variant(old)
 
 
 @pytest.mark.parametrize("B,N,H", [(3, 197, 2), (2, 5, 1), (1, 300, 3)])
@@ -531,18 +531,18 @@ def test_attn_bwd_fused_short_sequence_kernel_equals_split_kernels_at_full_occup
     do = torch.randn(B * N, 64 * H, device="cuda", generator=g).to(torch.bfloat16)
     scale = 64 ** -0.5
     o, lse = ops.attn_fwd(qkv, B, N, H, scale)
-    old = lib().apla_attn_set_variant(0)
+    old = ops.set_attn_variant(0)
     try:
         res = {}
         for v in (2, 3, 0, 1):
-            lib().apla_attn_set_variant(v)
+            ops.set_attn_variant(v)
             d1, d2 = torch.zeros(B, H, N, device="cuda"), torch.zeros(B, H, N, device="cuda")
             a1 = ops.attn_bwd(qkv, o, do, lse, B, N, H, scale, delta=d1).clone()
             a2 = ops.attn_bwd(qkv, o, do, lse, B, N, H, scale, delta=d2).clone()
             assert torch.equal(a1, a2) and torch.equal(d1, d2), v
             res[v] = (a1, d1.clone())
     finally:
-        lib().apla_attn_set_variant(old)
+        ops.set_attn_variant(old)
     for v in (2, 3, 0):
         assert torch.equal(res[v][0], res[1][0]) and torch.equal(res[v][1], res[1][1]), v
 
@@ -631,7 +631,7 @@ def test_apla_proj_fwd_bwd_operators(ops, M, D, r):
                                ws.data_ptr(), 16, M, D, r, 0, s) == -22      # workspace too small: -EINVAL, nothing launched
 
 
-@pytest.mark.parametrize("M,N,K,variant", [(2500, 512, 256, 4), (300, 256, 128, 4), (300, 256, 128, 0), (128, 768, 768, -1)])
+@pytest.mark.parametrize("M,N,K,variant", [(2500, 512, 256, 4), (300, 256, 128, 4), (300, 256, 128, 1), (128, 768, 768, -1)])
 def test_gemm_gelu_forward_only_epilogue(ops, M, N, K, variant):
     """APLA_EPI_GELU_FWD (the no-grad forward: evaluation, EMA teacher) writes the same h as APLA_EPI_GELU bit for bit and saves
     nothing: ping-pong (M >= 2048), persistent, simple and few-row kernels."""
@@ -646,12 +646,12 @@ def test_gemm_gelu_forward_only_epilogue(ops, M, N, K, variant):
         h_ref = ops.gemm_nt_small(a, w, bias, workspace=ws, epilogue=ops.EPI_GELU, aux_out=gp)
         h = ops.gemm_nt_small(a, w, bias, workspace=ws, epilogue=ops.EPI_GELU_FWD)
     else:
-        old = lib().apla_gemm_set_variant(variant)
+        old = ops.set_gemm_variant(variant)
         try:
             h_ref = ops.gemm_nt(a, w, bias, epilogue=ops.EPI_GELU, aux_out=gp)
             h = ops.gemm_nt(a, w, bias, epilogue=ops.EPI_GELU_FWD)
         finally:
-            lib().apla_gemm_set_variant(old)
+            ops.set_gemm_variant(old)
         with pytest.raises(ValueError):
             ops.gemm_nt(a, w, bias, epilogue=ops.EPI_GELU_FWD, aux_out=gp)
     assert torch.equal(h, h_ref)

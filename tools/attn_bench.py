@@ -33,7 +33,7 @@ def timeit(fn, iters=20):
 
 res = {}
 for v in (1, 2, 3, 0):
-    lib().apla_attn_set_variant(v)
+    ops.set_attn_variant(v)
     o, lse = ops.attn_fwd(qkv, B, N, H, scale)
     dqkv = ops.attn_bwd(qkv, o, do, lse, B, N, H, scale)
     res[v] = (o.clone(), dqkv.clone())

@@ -11,12 +11,12 @@ g = torch.Generator(device="cuda").manual_seed(0)
 qkv = (torch.randn(B * N, 3 * D, device="cuda", generator=g) * float(os.environ.get("ATT_STD", 1.0))).to(torch.bfloat16)
 do = torch.randn(B * N, D, device="cuda", generator=g).to(torch.bfloat16)
 o, lse = ops.attn_fwd(qkv, B, N, H, scale)
-lib().apla_attn_set_variant(0)
+ops.set_attn_variant(0)
 a1 = ops.attn_bwd(qkv, o, do, lse, B, N, H, scale).clone()
 a2 = ops.attn_bwd(qkv, o, do, lse, B, N, H, scale).clone()
-lib().apla_attn_set_variant(1)
+ops.set_attn_variant(1)
 b1 = ops.attn_bwd(qkv, o, do, lse, B, N, H, scale).clone()
-lib().apla_attn_set_variant(0)
+ops.set_attn_variant(0)
 print("fused deterministic:", torch.equal(a1, a2))
 d = (a1.float() - b1.float()).abs()
 nz = d > 0

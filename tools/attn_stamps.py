@@ -42,7 +42,7 @@ for w in (0, 3):
               f"   P2 = {a[:, w, 9].mean() / blocks / nt:6.0f} + {a[:, w, 10].mean() / blocks / nt:6.0f} + {a[:, w, 11].mean() / blocks / nt:6.0f}")
 
 # persistent kernel (variant 3): 8 waves per workgroup, one workgroup per CU, stamps of blockIdx < 512
-lib().apla_attn_set_variant(3)
+ops.set_attn_variant(3)
 for _ in range(3):
     ops.attn_bwd(qkv, o, do, lse, B, N, H, scale)
 torch.cuda.synchronize()

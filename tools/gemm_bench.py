@@ -38,7 +38,7 @@ def main():
         out = torch.empty(M, N, device=dev, dtype=kw.get("out_dtype", torch.bfloat16))
         ref = None
         for v in VARIANTS:
-            lib().apla_gemm_set_variant(v)
+            ops.set_gemm_variant(v)
             o = ops.gemm_nt(a, w, bias, epilogue=epi, out=out, **{k: x for k, x in kw.items() if k != "out_dtype"}).clone()
             if ref is None:
                 ref = o
@@ -47,7 +47,7 @@ def main():
         times = {v: [] for v in VARIANTS}
         for _ in range(ROUNDS):
             for v in VARIANTS:
-                lib().apla_gemm_set_variant(v)
+                ops.set_gemm_variant(v)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(ITERS):

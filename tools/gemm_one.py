@@ -22,7 +22,7 @@ elif epi == ops.EPI_GELU:
 elif epi == ops.EPI_MUL:
     kw = dict(aux_in=torch.randn(M, N, device=dev).to(torch.bfloat16))
 out = torch.empty(M, N, device=dev, dtype=out_dtype)
-lib().apla_gemm_set_variant(variant)
+ops.set_gemm_variant(variant)
 for _ in range(iters):
     ops.gemm_nt(a, w, bias, epilogue=epi, out=out, **kw)
 torch.cuda.synchronize()

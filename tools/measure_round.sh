@@ -8,9 +8,10 @@ cd "$R"
 O=gpurun_out/round
 rm -rf $O && mkdir -p $O
 python -m pytest tests -m gpu -q -p no:cacheprovider > $O/pytest_gpu.txt 2>&1; tail -3 $O/pytest_gpu.txt
-python bench.py --steps 30 --warmup 5 > $O/bench.json 2> $O/bench.err; tail -c 1500 $O/bench.json
+tools/mfma_peak 1.0 > $O/mfma_peak.json 2>&1
+python bench.py > $O/bench.json 2> $O/bench.err; tail -c 1500 $O/bench.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline > $O/trace_bench.log 2>&1
-python3 tools/summarize_prof.py $(find $O/trace -name "*kernel_stats.csv") 14 > $O/kernel_stats.md
+python3 tools/summarize_prof.py $(find $O/trace -name "*kernel_stats.csv") 14 --cfg2 > $O/kernel_stats.md
 cp $(find $O/trace -name "*kernel_stats.csv") $O/kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -- python3 tools/gemm_one.py 3072 768 1 4 6 > /dev/null 2>&1
@@ -24,7 +25,7 @@ def val(path, name):
     for l in open(path):
         if name in l:
             return float(l.split("avg=")[1])
-d = {"kernel": "gemm_pp2_kernel<GELU,bf16> M=25216 N=3072 K=768 (fc1+GELU launch)",
+d = {"kernel": "gemm_pp2_kernel<GELU,bf16> M=25216 N=3072 K=768 (fc1+GELU launch)", "taken_at": "${APLA_ROUND_TAG:-round 2}",
      "FETCH_SIZE_KiB": val("$O/pmc_FETCH_SIZE.txt", "FETCH_SIZE"), "WRITE_SIZE_KiB": val("$O/pmc_WRITE_SIZE.txt", "WRITE_SIZE"),
      "note": "rocprofv3 --pmc, one counter per pass, averaged over 6 launches; FETCH_SIZE must be doubled on gfx950 (MI355X_MICROARCH.md HBM section)"}
 json.dump(d, open("$O/pmc_dominant_kernel.json", "w"), indent=1)

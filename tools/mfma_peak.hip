@@ -161,7 +161,7 @@ int main(int argc, char** argv) {
          "\"bf16_16x16x32_1wave_per_simd\": %.1f, \"bf16_16x16x32_2waves_per_simd\": %.1f, "
          "\"bf16_32x32x16_1wave_per_simd\": %.1f, \"bf16_32x32x16_2waves_per_simd\": %.1f, \"f16_16x16x32_1wave_per_simd\": %.1f, "
          "\"clock_ghz\": {\"bf16_16x16x32\": %.3f, \"bf16_16x16x32_x2\": %.3f, \"bf16_32x32x16\": %.3f, \"bf16_32x32x16_x2\": %.3f, \"f16_16x16x32\": %.3f}}\n",
-         prop.name, cus, a1.tflops, a2.tflops, b1.tflops, b2.tflops, c1.tflops, a1.clock_ghz, a2.clock_ghz, b1.clock_ghz,
+         prop.gcnArchName, cus, a1.tflops, a2.tflops, b1.tflops, b2.tflops, c1.tflops, a1.clock_ghz, a2.clock_ghz, b1.clock_ghz,
          b2.clock_ghz, c1.clock_ghz);
   return 0;
 }

@@ -1,12 +1,19 @@
 #!/usr/bin/env python3
 """Condense a rocprofv3 `*_kernel_stats.csv` into a short markdown table (kernel names shortened).
-usage: tools/summarize_prof.py <kernel_stats.csv> [steps]  > profiles/<name>.md"""
+usage: tools/summarize_prof.py <kernel_stats.csv> [steps] [--cfg2]  > profiles/<name>.md
+--cfg2: the run was bench.py's default workload (ViT-B/16, bs 128: M = 25216 tokens, D = 768, F = 3072); the GEMM rows then
+carry their call site (the kernel's profiling tag, include/apla_hip.h:apla_gemm_nt_ex) and the TFLOP/s of that shape."""
 import csv
 import re
 import sys
 
 
-EPI = {"0": "STORE", "1": "GELU", "2": "RESIDUAL", "3": "MUL", "4": "SWIGLU", "5": "SWIGLU_BWD"}
+EPI = {"0": "STORE", "1": "GELU", "2": "RESIDUAL", "3": "MUL", "4": "SWIGLU", "5": "SWIGLU_BWD", "6": "GELU_FWD"}
+TAGS = {"1": "qkv", "2": "proj", "3": "fc2", "4": "dfc1", "5": "dproj", "6": "dqkv", "7": "patch"}
+# (N, K) of the call sites at BASELINE config 2; M = 25216 (patch embedding: 25088 rows).  The CLS-only last block runs its
+# K/V-only qkv (N = 1536) under the qkv tag: 1 of 12 launches, the average TFLOP/s of that row is read with that in mind.
+CFG2 = {"qkv": (2304, 768), "proj": (768, 768), "fc2": (768, 3072), "dfc1": (768, 3072), "dproj": (768, 768), "dqkv": (768, 2304),
+        "patch": (768, 768), "GELU": (3072, 768), "MUL": (3072, 768)}
 
 
 def demangle(name):
@@ -53,7 +60,12 @@ def short(name):
     name = name.replace("__bf16", "bf16")
     m = re.match(r"(?:void )?(gemm_\w+_kernel|gemm_nt_kernel)<(\d), (\w+)(.*)>", name)
     if m:
-        return f"{m.group(1)}<{EPI.get(m.group(2), m.group(2))},{m.group(3)}{m.group(4)}>"
+        rest = m.group(4)
+        if m.group(1) == "gemm_pp2_kernel":
+            t = re.match(r",\s*(\d+)$", rest)
+            if t:
+                rest = f" [{TAGS[t.group(1)]}]" if t.group(1) in TAGS else ""
+        return f"{m.group(1)}<{EPI.get(m.group(2), m.group(2))},{m.group(3)}{rest}>"
     name = re.sub(r"^void ", "", name)
     name = re.sub(r"\(.*$", "", name)
     if name.startswith("at::native"):
@@ -61,14 +73,27 @@ def short(name):
     return name[:70]
 
 
+def shape_tf(label, avg_us):
+    """TFLOP/s of a GEMM row at config 2, from its call-site tag or epilogue; None for other kernels."""
+    m = re.search(r"\[(\w+)\]", label)
+    key = m.group(1) if m else ("GELU" if label.startswith("gemm_pp2_kernel<GELU,") else "MUL" if "<MUL," in label else None)
+    if key not in CFG2:
+        return None
+    n, k = CFG2[key]
+    return 2.0 * (25088 if key == "patch" else 25216) * n * k / (avg_us * 1e-6) / 1e12
+
+
 def main():
+    cfg2 = "--cfg2" in sys.argv
+    if cfg2:
+        sys.argv.remove("--cfg2")
     path = sys.argv[1]
     steps = float(sys.argv[2]) if len(sys.argv) > 2 else None
     rows = list(csv.DictReader(open(path)))
     total = sum(float(r["TotalDurationNs"]) for r in rows)
     print(f"source: {path}\n")
-    print("| kernel | calls | avg us | total ms | % |" + (" ms/step |" if steps else ""))
-    print("|---|---:|---:|---:|---:|" + ("---:|" if steps else ""))
+    print("| kernel | calls | avg us | total ms | % |" + (" ms/step |" if steps else "") + (" TFLOP/s (cfg 2 shape) |" if cfg2 else ""))
+    print("|---|---:|---:|---:|---:|" + ("---:|" if steps else "") + ("---:|" if cfg2 else ""))
     for r in rows:
         t = float(r["TotalDurationNs"])
         if t / total < 0.0005:
@@ -76,6 +101,9 @@ def main():
         line = f"| {short(r['Name'])} | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {t / 1e6:.2f} | {100 * t / total:.1f} |"
         if steps:
             line += f" {t / 1e6 / steps:.3f} |"
+        if cfg2:
+            tf = shape_tf(short(r["Name"]), float(r["AverageNs"]) / 1e3)
+            line += f" {tf:.0f} |" if tf else " |"
         print(line)
     print(f"\ntotal kernel time {total / 1e6:.2f} ms" + (f" = {total / 1e6 / steps:.2f} ms/step over {steps:g} steps" if steps else ""))
 
