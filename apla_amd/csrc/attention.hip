@@ -214,6 +214,16 @@ __device__ __forceinline__ void store_acc_T_staged(const f32x16 (&acc)[2], char*
   }
 }
 
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n in 0..4 (the counter is an instruction immediate)
+__device__ __forceinline__ void wait_vmcnt_upto4(int n) {
+  n = __builtin_amdgcn_readfirstlane(n);
+  if (n >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if (n == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if (n == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // Sequence geometry.  Uniform batch (cu == nullptr): sequence b holds tokens [b*N, (b+1)*N) and lse/delta are [B, H, N].
 // Packed variable-length batch (block-diagonal attention, appla_attn_mem_eff.py:40-42 with a BlockDiagonalMask): sequence b
 // holds tokens [cu[b], cu[b+1]) of one [total, ...] activation and lse/delta are [H, total].
@@ -1011,6 +1021,11 @@ __device__ __forceinline__ void rows_prefetch(RowRegs& r, const bf16* qp, const 
       : "memory");
 }
 // wait until at most YOUNGER vector-memory operations of this wave are outstanding, then pin the prefetched registers behind the wait
+__device__ __forceinline__ void rows_pin(RowRegs& r) {
+  asm volatile("" : "+v"(r.q[0]), "+v"(r.q[1]), "+v"(r.q[2]), "+v"(r.q[3]), "+v"(r.d[0]), "+v"(r.d[1]), "+v"(r.d[2]), "+v"(r.d[3]),
+               "+v"(r.o[0]), "+v"(r.o[1]), "+v"(r.o[2]), "+v"(r.o[3]), "+v"(r.lse));
+  __builtin_amdgcn_sched_barrier(0);
+}
 template <int YOUNGER>
 __device__ __forceinline__ void rows_landed(RowRegs& r) {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER) : "memory");
@@ -1042,7 +1057,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_persist_kernel(const bf16* __
   char* DB = smem + 3 * T_OFF;
   float* lses2 = (float*)(smem + 4 * T_OFF);
   float* dls = lses2 + PERSIST_MAX_ROWS;
-  constexpr int DQ_STORES = STAGED ? 4 : 8, DKV_STORES = STAGED ? 8 : 16;   // store instructions per wave: dQ; dK + dV
+  // store instructions per wave and 32 x 64 tile: 8 direct stores (all issued whenever the block has a valid row), or — staged —
+  // one per 8 rows that hold a valid row (hipcc branches around a store no lane executes): the counted waits below must leave
+  // exactly the stores that WERE issued in flight, or they return before older loads / LDS-DMA have landed
+  const int tile_stores = STAGED ? ((N - wave * 32 + 7) >> 3 < 4 ? (N - wave * 32 + 7) >> 3 : 4) : 8;
   constexpr int nt = NT;             // wave w owns block w in both phases
   const bool active = wave < nt;
   int r = wave * 32 + (lane & 31);
@@ -1177,7 +1195,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_persist_kernel(const bf16* __
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(kf[ks]), "+v"(vf[ks]));
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DQ_STORES) : "memory");   // the DMA of set B is older than the dQ stores
+      // the DMA of set B is older than the dQ stores
+      if constexpr (STAGED) wait_vmcnt_upto4(tile_stores); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -1271,7 +1290,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_persist_kernel(const bf16* __
       if constexpr (STAGED) store_acc_T_staged(acc_dv, wbuf, hd.outbase + 2 * D, ld, wave * 32, N, lane, 1.0f);
       else if (rvalid) store_acc_T(acc_dv, hd.outbase + (long)r * ld + 2 * D, h2, 1.0f);
       STAMP(9);   // row prefetch + dK / dV stores issued
-      rows_landed<DKV_STORES / 2>(rr);   // set A of the next head (older still) and the rows: landed; the dV stores stay in flight
+      // set A of the next head (older still) and the rows: landed; the dV stores stay in flight
+      if constexpr (STAGED) { wait_vmcnt_upto4(tile_stores); rows_pin(rr); } else rows_landed<8>(rr);
       STAMP(10);  // wait for rows / set A
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

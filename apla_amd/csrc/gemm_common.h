@@ -17,7 +17,7 @@ struct GemmParams {
   int tag;   // profiling tag (apla_gemm_nt_tagged): selects one of several identical kernel instantiations so that a rocprofv3
              // kernel trace tells the call sites of the step apart (qkv / proj / fc2 / dfc1 / dproj / dqkv …); 0 = untagged
 };
-constexpr int APLA_GEMM_TAGS = 8;   // tags 0 .. 7
+constexpr int APLA_GEMM_TAGS = 9;   // tags 0 .. 8 (1 is not used: the profiler's demangler garbles that instantiation's name)
 
 // 8-wave ping-pong kernel (gemm_pp2.hip); returns APLA_ENOSYS when the shape / (epilogue, dtype) is not covered there
 int apla_gemm_pp2_launch(const GemmParams& p, int epilogue, int out_dtype, hipStream_t stream);

@@ -265,7 +265,7 @@ int apla_gemm_pp2_launch(const GemmParams& p_in, int epilogue, int out_dtype, hi
         case T:                                                                                                        \
           hipLaunchKernelGGL((gemm_pp2_kernel<APLA_EPI_STORE, bf16, T>), dim3(G), dim3(512), 0, stream, p, tiles_m);  \
           break;
-        PP2_TAGGED(1) PP2_TAGGED(2) PP2_TAGGED(3) PP2_TAGGED(4) PP2_TAGGED(5) PP2_TAGGED(6) PP2_TAGGED(7)
+        PP2_TAGGED(2) PP2_TAGGED(3) PP2_TAGGED(4) PP2_TAGGED(5) PP2_TAGGED(6) PP2_TAGGED(7) PP2_TAGGED(8)
 #undef PP2_TAGGED
         default:
           hipLaunchKernelGGL((gemm_pp2_kernel<APLA_EPI_STORE, bf16, 0>), dim3(G), dim3(512), 0, stream, p, tiles_m);

@@ -78,7 +78,7 @@ def _rows2d(t: torch.Tensor, name: str):
 _GEMM_VARIANT = 0
 _ATTN_VARIANT = int(os.environ.get("APLA_ATTN_VARIANT", "0"))
 # profiling tags of apla_gemm_nt_ex (kernel names in a rocprofv3 trace): call sites of the training step
-TAG_QKV, TAG_PROJ, TAG_FC2, TAG_DFC1, TAG_DPROJ, TAG_DQKV, TAG_PATCH = 1, 2, 3, 4, 5, 6, 7
+TAG_QKV, TAG_PROJ, TAG_FC2, TAG_DFC1, TAG_DPROJ, TAG_DQKV, TAG_PATCH = 2, 3, 4, 5, 6, 7, 8
 
 
 def set_gemm_variant(v: int) -> int:

@@ -64,9 +64,9 @@ int apla_gemm_nt(const void* A, int lda, const void* W, int ldw, const float* bi
                  int ld_aux_out, hipStream_t stream);
 
 /* apla_gemm_nt with two extra choices packed into `flags`:
- *   bits 0-7   profiling tag 0..7: picks one of several identical instantiations of the bf16 STORE kernel, so that a
- *              rocprofv3 kernel trace names the call sites of the step (1 qkv, 2 proj, 3 fc2, 4 dfc1, 5 dproj, 6 dqkv,
- *              7 patch embedding; 0 = untagged).  No effect on results or speed.
+ *   bits 0-7   profiling tag: picks one of several identical instantiations of the bf16 STORE kernel, so that a
+ *              rocprofv3 kernel trace names the call sites of the step (2 qkv, 3 proj, 4 fc2, 5 dfc1, 6 dproj, 7 dqkv,
+ *              8 patch embedding; 0 = untagged).  No effect on results or speed.
  *   bits 8-15  kernel schedule: 0 = auto (what apla_gemm_nt does): 8-wave ping-pong kernel (320x256x32 tile, gemm_pp2.hip)
  *              for M >= 2048, N % 256 == 0 and the STORE / GELU epilogues, else the 4-wave persistent kernel (128/160 x 128 x
  *              64 tile, gemm_nt.hip); 9 = ping-pong wherever instantiated; 14 / 15 = 4-wave persistent kernel with BM 128 /

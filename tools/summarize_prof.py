@@ -9,7 +9,7 @@ import sys
 
 
 EPI = {"0": "STORE", "1": "GELU", "2": "RESIDUAL", "3": "MUL", "4": "SWIGLU", "5": "SWIGLU_BWD", "6": "GELU_FWD"}
-TAGS = {"1": "qkv", "2": "proj", "3": "fc2", "4": "dfc1", "5": "dproj", "6": "dqkv", "7": "patch"}
+TAGS = {"2": "qkv", "3": "proj", "4": "fc2", "5": "dfc1", "6": "dproj", "7": "dqkv", "8": "patch"}
 # (N, K) of the call sites at BASELINE config 2; M = 25216 (patch embedding: 25088 rows).  The CLS-only last block runs its
 # K/V-only qkv (N = 1536) under the qkv tag: 1 of 12 launches, the average TFLOP/s of that row is read with that in mind.
 CFG2 = {"qkv": (2304, 768), "proj": (768, 768), "fc2": (768, 3072), "dfc1": (768, 3072), "dproj": (768, 768), "dqkv": (768, 2304),
