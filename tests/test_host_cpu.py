@@ -9,7 +9,7 @@ import os
 import pytest
 import torch
 
-from conftest import GOLDEN, load_golden, rel_err, t
+from conftest import GOLDEN, ROOT, load_golden, rel_err, t
 from oracle import apla_oracle as O
 
 TP = dict(img_size=[224], patch_size=16, pretrained_type="dinov2", is_memory_efficient=True,
@@ -312,3 +312,40 @@ def test_knn_predict_matches_bruteforce_vote():
         order = sim[b].argsort(descending=True)[:k]
         w = torch.exp(sim[b, order] / temp)
         assert torch.allclose(got[b], (multi[:, order] * (w / w.sum())).sum(1), atol=1e-6)
+
+
+@pytest.mark.parametrize("name,dinov2,expect", [
+    ("cfg1_vit_s16_cifar10_bs8", False, dict(img=224, batch=8, n_classes=10, backbone="vit_small", patch=16, r=64, gpus=1)),
+    ("cfg2_vit_b16_bs128", False, dict(img=224, batch=128, n_classes=1000, backbone="vit_base", patch=16, r=192, gpus=1)),
+    ("cfg3_vit_l14_bs256_8gpu", False, dict(img=224, batch=256, n_classes=1000, backbone="vit_large", patch=14, r=256, gpus=8, dim=1024, depth=24)),
+    ("cfg5_vit_g14_518_bs32_8gpu_fp16", False, dict(img=518, batch=32, n_classes=1000, backbone="vit_giant", patch=14, r=512, gpus=8, dim=1536, depth=40)),
+    ("cfg4_dinov2_ssl_vit_b14_8gpu", True, dict(batch=64, backbone="vit_base", patch=14, r=192, gpus=8, dim=768, depth=12)),
+])
+def test_baseline_params_files_resolve(name, dinov2, expect):
+    """params/baseline/*: one parameter file pair per BASELINE config (schema: reference params/**/__common__.yml +
+    apla.yml).  They must load through main.py's own merge / resolution and describe the configuration's geometry; the multi-GPU
+    ones carry the shared index file the reference demands (apla_vit.py:77), resolved next to the parameter file."""
+    import json
+    import os
+    import main
+    path = os.path.join(ROOT, "params", "baseline", name, "apla.yml")
+    argv = ["--params_path", path] + (["--dinov2"] if dinov2 else [])
+    args = main.parse_arguments(argv)
+    params = main.update_params_from_args(main.load_parameters(path), args)
+    mp = params["model_params"]
+    assert mp["backbone_type"] == expect["backbone"] and mp["adaptation"]["params"]["partial_size"] == expect["r"]
+    if dinov2:
+        run = main.resolve_dinov2_run(params, args)
+        assert run["patch"] == expect["patch"] and mp["dinov2"]["dino"]["head_n_prototypes"] == 65536
+    else:
+        run = main.resolve_run(params, args)
+        assert (run["img"], run["n_classes"]) == (expect["img"], expect["n_classes"])
+        assert mp["transformers_params"]["patch_size"] == expect["patch"]
+    assert run["batch"] == expect["batch"] and len(run["gpus"]) == expect["gpus"]
+    if expect["gpus"] > 1:
+        ip = mp["adaptation"]["params"]["inds_path"]
+        assert os.path.exists(ip), ip
+        inds = json.load(open(ip))
+        assert sorted(inds) == sorted(f"block_{i}" for i in range(expect["depth"]))
+        for v in inds.values():
+            assert len(v) == expect["r"] and len(set(v)) == expect["r"] and 0 <= min(v) and max(v) < expect["dim"]
