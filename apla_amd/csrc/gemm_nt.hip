@@ -301,9 +301,14 @@ inline int pick_mi(int M, int tiles_n) {
 
 template <int EPI, typename OutT>
 int launch(const GemmParams& p, int g_variant, hipStream_t stream) {
-  // auto (4): the 8-wave ping-pong kernel for large problems whose epilogue it handles well, else the 128-wide persistent
+  // auto (4): the 8-wave ping-pong kernel for large problems with the plain STORE epilogue, else the 128-wide persistent
   // kernel; 9 forces ping-pong wherever it is instantiated; 14/15 force the 128-wide persistent kernel with MI 4/5.
-  if (g_variant == 9 || (g_variant == 4 && p.M >= 2048)) {
+  // The GELU epilogues go to the persistent kernel although its main loop is the slower one (qkv shape: 786 vs 962 TFLOP/s):
+  // its two workgroups per CU run one's epilogue under the other's main loop, and the GELU / GELU' arithmetic — a third of the
+  // fc1 launch on the ping-pong kernel, whose eight waves reach their epilogues together — disappears: fc1 + GELU at
+  // M = 25216: 185 -> 148 us, the forward-only GELU 147 -> 135 us (tools/gemm_bench.py, GEMM_VARIANTS=4,9,15, one process).
+  constexpr bool pp2_auto = (EPI == APLA_EPI_STORE);
+  if (g_variant == 9 || (g_variant == 4 && pp2_auto && p.M >= 2048)) {
     const int rc = apla_gemm_pp2_launch(p, EPI, std::is_same<OutT, float>::value ? APLA_F32 : APLA_H16, stream);
     if (rc != APLA_ENOSYS) return rc;
   }

@@ -380,7 +380,7 @@ def main():
                        "hip_graphs": not args.no_graphs},
             "images_per_sec_per_gpu": round(img_s / world, 1), "peak_mem_gib": round(peak_mem, 2),
             "final_loss": round(loss, 4),
-            "roofline": {"bound": "mfma", "kernel": f"gemm_pp2_kernel<GELU> (apla_gemm_nt, fc1+GELU launch) M={M} N={eng.blocks[0].F} K={bb.embed_dim}",
+            "roofline": {"bound": "mfma", "kernel": f"gemm_persist_kernel<GELU> (apla_gemm_nt, fc1+GELU launch) M={M} N={eng.blocks[0].F} K={bb.embed_dim}",
                          "achieved": round(k_tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(k_tf / PEAK_BF16_TFLOPS, 4),
                          # register-only MFMA loop on random data on THIS GPU (tools/mfma_peak.hip): what the matrix pipes deliver

@@ -12,7 +12,8 @@ from apla_amd._lib import lib
 
 M = int(os.environ.get("GEMM_M", 25216))
 ONLY = os.environ.get("GEMM_ONLY")
-SHAPES = [("qkv", 2304, 768, ops.EPI_STORE), ("proj+res", 768, 768, ops.EPI_RESIDUAL), ("fc1+gelu", 3072, 768, ops.EPI_GELU),
+SHAPES = [("qkv", 2304, 768, ops.EPI_STORE), ("proj", 768, 768, ops.EPI_STORE), ("fc2", 768, 3072, ops.EPI_STORE),
+          ("fc1+gelu_fwd", 3072, 768, ops.EPI_GELU_FWD), ("proj+res", 768, 768, ops.EPI_RESIDUAL), ("fc1+gelu", 3072, 768, ops.EPI_GELU),
           ("fc2+res", 768, 3072, ops.EPI_RESIDUAL), ("dfc2*g", 3072, 768, ops.EPI_MUL), ("dfc1", 768, 3072, ops.EPI_STORE),
           ("dproj", 768, 768, ops.EPI_STORE), ("dqkv", 768, 2304, ops.EPI_STORE)]
 VARIANTS = [int(v) for v in os.environ.get("GEMM_VARIANTS", "0,2,3").split(",")]
