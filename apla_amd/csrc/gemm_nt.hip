@@ -307,13 +307,20 @@ int launch(const GemmParams& p, int g_variant, hipStream_t stream) {
   // its two workgroups per CU run one's epilogue under the other's main loop, and the GELU / GELU' arithmetic — a third of the
   // fc1 launch on the ping-pong kernel, whose eight waves reach their epilogues together — disappears: fc1 + GELU at
   // M = 25216: 185 -> 148 us, the forward-only GELU 147 -> 135 us (tools/gemm_bench.py, GEMM_VARIANTS=4,9,15, one process).
-  constexpr bool pp2_auto = (EPI == APLA_EPI_STORE);
+  // (measured limit of that rule: the two-output GELU epilogue at M = 58 496, the packed student batch of the self-supervised
+  // step — 719 MB of stores per launch — runs 480 us on the persistent kernel against 423 us on the ping-pong kernel, while the
+  // one-output GELU_FWD and MUL do not care: above 40 000 rows GELU goes back to the ping-pong kernel)
+  const bool pp2_auto = (EPI == APLA_EPI_STORE) || (EPI == APLA_EPI_GELU && p.M > 40000);
   if (g_variant == 9 || (g_variant == 4 && pp2_auto && p.M >= 2048)) {
     const int rc = apla_gemm_pp2_launch(p, EPI, std::is_same<OutT, float>::value ? APLA_F32 : APLA_H16, stream);
     if (rc != APLA_ENOSYS) return rc;
   }
   if (g_variant >= 4) {
-    const int mi = (g_variant == 4 || g_variant == 9) ? pick_mi(p.M, p.tiles_n) : g_variant - 10;
+    // tile height: fewest (rounds x rows) over the resident workgroups — except for large problems with an epilogue that does
+    // arithmetic or reads a second operand, where the taller tile is worth more than a few per cent of quantisation (the
+    // self-supervised step's student fc1, M = 58 496: 128-row tiles win the round count by 2 % and ran 494 us against 368 us)
+    constexpr bool heavy = (EPI == APLA_EPI_GELU || EPI == APLA_EPI_GELU_FWD || EPI == APLA_EPI_MUL);
+    const int mi = (g_variant == 4 || g_variant == 9) ? ((heavy && p.M >= 8192) ? 5 : pick_mi(p.M, p.tiles_n)) : g_variant - 10;
     if (mi == 5) return launch_persist<EPI, OutT, 5>(p, stream);
     return launch_persist<EPI, OutT, 4>(p, stream);
   }
