@@ -51,6 +51,9 @@ SIGNATURES = {
     "apla_dw_workspace_bytes": (c_long, [c_int, c_int, c_int]),
     "apla_proj_dw": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                              c_int, c_void_p]),
+    "apla_dw_workspace_bytes_batched": (c_long, [c_int, c_int, c_int, c_int]),
+    "apla_proj_dw_batched": (c_int, [c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                     c_int, c_void_p]),
     "apla_proj_workspace_bytes": (c_long, [c_int, c_int, c_int]),
     "apla_proj_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "apla_proj_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int,

@@ -70,25 +70,34 @@ constexpr int TJ = 64, TK = 128, TM = 64;  // j granule 64; output tile (64*NJ) 
 // Operands stream global -> LDS by LDS-DMA (16 B per lane, 1 KB pieces of 8 rows x 128 B; the XOR swizzle of tile_off is
 // applied on the SOURCE column because the LDS side of a DMA is lane-linear) through a 3-stage ring: two 64-token steps
 // are in flight while one is multiplied, one s_barrier per step, counted vmcnt (never 0 inside the loop).
-// grid = 8 * ceil(S/8) * tiles_k * j_groups (1-D).  partial layout: [S][r][D] fp32, then [S][r] fp32 for the bias sums.
+// Several layers' gradients can share ONE launch (apla_proj_dw_batched): a unit = (layer, token slab), U = nb * S units.  With
+// nb layers the token axis is cut into 1/nb as many slabs for the same number of workgroups, so a workgroup's pipeline is nb
+// times longer (prologue, the r x 128 partial tile it writes and the reduce pass are paid once per unit, not once per layer
+// and slab) and the slab partials shrink from S x r x D to S/nb x r x D per layer.
+// grid = 8 * ceil(U/8) * tiles_k * j_groups (1-D).  partial layout: [U][r][D] fp32, then [U][r] fp32 for the bias sums.
 #define DW_LDSP(p) ((__attribute__((address_space(3))) void*)(p))
 #define DW_GLBP(p) ((const __attribute__((address_space(1))) void*)(p))
+constexpr int DW_MAX_BATCH = 8;
+struct DwIn { const bf16* dyg[DW_MAX_BATCH]; const bf16* x[DW_MAX_BATCH]; };
+struct DwOut { float* dW[DW_MAX_BATCH]; float* db[DW_MAX_BATCH]; const float* row_scale[DW_MAX_BATCH]; };
 template <int N> __device__ __forceinline__ void dw_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <int NJ>
-__global__ __launch_bounds__(256) void proj_dw_partial_kernel(const bf16* __restrict__ dyg, const bf16* __restrict__ x,
-                                                              int ldx, float* __restrict__ partial, int M, int r,
+__global__ __launch_bounds__(256) void proj_dw_partial_kernel(DwIn in, int nb, int ldx, float* __restrict__ partial, int M, int r,
                                                               int D, int rows_per_slab, int S) {
   constexpr int STG = (NJ + 2) * 8192, NS = 3, PW = (NJ + 2) * 2;  // stage bytes; ring depth; pieces per wave per step
   __shared__ __attribute__((aligned(16))) char smem[NS * STG];
   const int tid = threadIdx.x, lane = tid & 63, h2 = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // Workgroup ids are dealt round-robin to the 8 XCDs: all (tj, tk) tiles of one token slab get ids of the same residue
-  // mod 8, so the slab's dyg and x rows are fetched from HBM once and shared through that XCD's L2.
+  // Workgroup ids are dealt round-robin to the 8 XCDs: all (tj, tk) tiles of one unit (layer, token slab) get ids of the same
+  // residue mod 8, so the slab's dyg and x rows are fetched from HBM once and shared through that XCD's L2.
   const int tiles_k = D / TK, tiles = tiles_k * (r / (TJ * NJ));
   const int xcd = blockIdx.x & 7, n = blockIdx.x >> 3;
-  const int tile = n % tiles, slab = (n / tiles) * 8 + xcd;
-  if (slab >= S) return;
+  const int tile = n % tiles, unit = (n / tiles) * 8 + xcd, U = nb * S;
+  if (unit >= U) return;
+  const int layer = unit / S, slab = unit - layer * S;
+  const bf16* __restrict__ dyg = in.dyg[layer];
+  const bf16* __restrict__ x = in.x[layer];
   const int tj = tile / tiles_k, tk = tile - tj * tiles_k;
   const int j0 = tj * (TJ * NJ), k0 = tk * TK;
   const int m_begin = slab * rows_per_slab;
@@ -134,49 +143,75 @@ __global__ __launch_bounds__(256) void proj_dw_partial_kernel(const bf16* __rest
   }
   if (nsteps > 0) issue(0);
   if (nsteps > 1) issue(1);
-  for (int s = 0; s < nsteps; ++s) {
+  // One 64-token step.  TAIL: token rows past the end exist in this step (only the last step of the last slab of a layer);
+  // BIAS: this workgroup also sums dyg's columns (the tk == 0 tiles).  Both are compile-time so that the six products of a
+  // 16-row step are issued back to back (as run-time tests they put two branches between every two MFMAs).
+  auto step = [&](int s, auto TAILC, auto BIASC) {
+    constexpr bool TAIL = TAILC.value != 0, BIAS = BIASC.value != 0;
     if (s + 1 < nsteps) dw_wait_vmcnt<PW>(); else dw_wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();  // stage s has landed for every wave; everyone is done reading stage s-1
     if (s + 2 < nsteps) issue(s + 2);
-    char* Ys = smem + (s % NS) * STG;  // NJ x [64 m][64 j]
-    char* Xs = Ys + NJ * 8192;         // 2 x [64 m][64 k]
     const int valid = m_end - (m_begin + s * TM);  // token rows of this step that exist (< 64 only at the very end of M)
     // Rows past the end were fetched from a clamped address: their dyg fragment elements are forced to zero (element e
     // of a transposed fragment is token row 16*ks + 8*(e>>2) + 4*(lane>>5) + (e&3)).  No LDS writes here: a plain LDS
     // store next to in-flight LDS-DMA makes hipcc drain vmcnt(0) in front of the fragment reads of every step.
-    const unsigned so = (unsigned)((s % NS) * STG);
+    const unsigned so = (unsigned)((s % NS) * STG);   // Ys = NJ x [64 m][64 j] at so, Xs = 2 x [64 m][64 k] behind it
     const unsigned xa0 = xb[0] + so, xa1 = xb[1] + so;
     const unsigned ya00 = yb[0][0] + so, ya01 = yb[0][1] + so, ya10 = yb[1][0] + so, ya11 = yb[1][1] + so;
-    static_for<0, 4>([&](auto KS) {
-      constexpr int ks = KS.value;
-      bf16x4 blo, bhi, alo[2 * NJ], ahi[2 * NJ];
-      blo = tr_read<2048 * ks>(xa0);  // B[k' = m][col = k]
-      bhi = tr_read<2048 * ks>(xa1);
+    // The transposed fragment reads of 16-row step ks+1 are issued before the products of step ks (two register sets): with
+    // one wave per SIMD nothing else hides the LDS latency.  LDS reads return in order, so lgkmcnt(2 + 4*NJ) = "all but the
+    // reads just issued" retires exactly the set about to be multiplied.
+    bf16x4 blo[2], bhi[2], alo[2][2 * NJ], ahi[2][2 * NJ];
+    auto frags = [&](auto KS) {
+      constexpr int ks = KS.value, st = ks & 1;
+      blo[st] = tr_read<2048 * ks>(xa0);  // B[k' = m][col = k]
+      bhi[st] = tr_read<2048 * ks>(xa1);
       static_for<0, 2 * NJ>([&](auto T) {  // A[row = j][k' = m]
         constexpr int t = T.value;
-        alo[t] = tr_read<2048 * ks + 8192 * (t >> 1)>((t & 1) ? ya10 : ya00);
-        ahi[t] = tr_read<2048 * ks + 8192 * (t >> 1)>((t & 1) ? ya11 : ya01);
+        alo[st][t] = tr_read<2048 * ks + 8192 * (t >> 1)>((t & 1) ? ya10 : ya00);
+        ahi[st][t] = tr_read<2048 * ks + 8192 * (t >> 1)>((t & 1) ? ya11 : ya01);
       });
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    frags(IntC<0>{});
+    static_for<0, 4>([&](auto KS) {
+      constexpr int ks = KS.value, st = ks & 1;
+      if constexpr (ks + 1 < 4) {
+        frags(IntC<ks + 1>{});
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 + 4 * NJ) : "memory");
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
       __builtin_amdgcn_sched_barrier(0);
-      const bf16x8 b = join8(blo, bhi);
+      const bf16x8 b = join8(blo[st], bhi[st]);
 #pragma unroll
       for (int t = 0; t < 2 * NJ; ++t) {
-        bf16x8 a = join8(alo[t], ahi[t]);
-        if (valid < TM) {
+        bf16x8 a = join8(alo[st][t], ahi[st][t]);
+        if constexpr (TAIL) {
 #pragma unroll
           for (int e = 0; e < 8; ++e)
             if (16 * ks + 8 * (e >> 2) + 4 * h2 + (e & 3) >= valid) a[e] = (bf16)0.f;
         }
         acc[t] = MFMA_F32_32x32x16_H16(a, b, acc[t]);
-        if (tk == 0 && ks == wave) {  // lane holds dyg[8 token rows][j = 32t + (lane&31)]
-          float sm = 0.f;
+        if constexpr (BIAS) {
+          if (ks == wave) {  // lane holds dyg[8 token rows][j = 32t + (lane&31)]
+            float sm = 0.f;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) sm += (float)a[e];
-          bsum[t] += sm;
+            for (int e = 0; e < 8; ++e) sm += (float)a[e];
+            bsum[t] += sm;
+          }
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
     });
+  };
+  const bool ragged = nsteps > 0 && m_end - (m_begin + (nsteps - 1) * TM) < TM;  // the last step holds fewer than 64 rows
+  const int nfull = ragged ? nsteps - 1 : nsteps;
+  if (tk == 0) {
+    for (int s = 0; s < nfull; ++s) step(s, IntC<0>{}, IntC<1>{});
+    if (ragged) step(nsteps - 1, IntC<1>{}, IntC<1>{});
+  } else {
+    for (int s = 0; s < nfull; ++s) step(s, IntC<0>{}, IntC<0>{});
+    if (ragged) step(nsteps - 1, IntC<1>{}, IntC<0>{});
   }
   // D[j][k]: lane col = k (lane&31), rows j = acc_row(reg, h2).  The tile goes through LDS (the ring is idle now) so that
   // the partial slab is written with 16-byte stores of whole 512-byte rows instead of 32*NJ dword stores per wave.
@@ -190,7 +225,7 @@ __global__ __launch_bounds__(256) void proj_dw_partial_kernel(const bf16* __rest
       Ts[j * 132 + wk + (lane & 31)] = acc[t][reg];
     }
   __syncthreads();
-  float* P = partial + (size_t)slab * r * D;
+  float* P = partial + (size_t)unit * r * D;
   for (int e = tid; e < 64 * NJ * 32; e += 256) {
     const int j = e >> 5, c4 = (e & 31) * 4;
     *(f32x4*)(P + (size_t)(j0 + j) * D + k0 + c4) = *(const f32x4*)(Ts + j * 132 + c4);
@@ -205,17 +240,20 @@ __global__ __launch_bounds__(256) void proj_dw_partial_kernel(const bf16* __rest
     }
     __syncthreads();
     if (tid < 64 * NJ)
-      partial[(size_t)S * r * D + (size_t)slab * r + j0 + tid] =
+      partial[(size_t)U * r * D + (size_t)unit * r + j0 + tid] =
           (Bs[tid] + Bs[64 * NJ + tid]) + (Bs[2 * 64 * NJ + tid] + Bs[3 * 64 * NJ + tid]);
   }
 }
 
 // Slab sum in a fixed order (bitwise reproducible).  Four lanes share one float4 of the output: lane q of the quad sums
 // slabs q, q+4, q+8, ... (eight loads in flight), then the quad is folded 0+2, 1+3, (0+2)+(1+3).
-__global__ __launch_bounds__(256) void proj_dw_reduce_kernel(const float* __restrict__ partial,
-                                                             const float* __restrict__ row_scale,
-                                                             float* __restrict__ dW1, float* __restrict__ db1, int r,
+__global__ __launch_bounds__(256) void proj_dw_reduce_kernel(const float* __restrict__ partial_all, DwOut out, int nb, int r,
                                                              int D, int S, int accumulate) {
+  const int layer = blockIdx.y;  // this layer's S slabs are units layer*S .. layer*S + S-1
+  const float* __restrict__ partial = partial_all + (size_t)layer * S * r * D;
+  const float* __restrict__ row_scale = out.row_scale[layer];
+  float* __restrict__ dW1 = out.dW[layer];
+  float* __restrict__ db1 = out.db[layer];
   const long n4 = (long)r * D / 4;
   const long t = (long)blockIdx.x * 256 + threadIdx.x;
   const long i = t >> 2;
@@ -247,7 +285,7 @@ __global__ __launch_bounds__(256) void proj_dw_reduce_kernel(const float* __rest
     *(f32x4*)(dW1 + i * 4) = s;
   }
   if (t < r) {
-    const float* pb = partial + (size_t)S * stride;
+    const float* pb = partial_all + (size_t)nb * S * stride + (size_t)layer * S * r;
     float b = 0.f;
     for (int sl = 0; sl < S; ++sl) b += pb[(size_t)sl * r + t];
     if (row_scale != nullptr) b *= row_scale[t];
@@ -258,9 +296,14 @@ __global__ __launch_bounds__(256) void proj_dw_reduce_kernel(const float* __rest
 
 inline int dw_group(int r) { return r % 192 == 0 ? 3 : (r % 128 == 0 ? 2 : 1); }  // 64-row granules per workgroup
 
-inline int dw_slabs(int M, int r, int D) {
+inline int dw_slabs(int M, int r, int D, int nb = 1) {
   const int tiles = (r / (TJ * dw_group(r))) * (D / TK);
   int S = 256 / tiles / 8 * 8;  // a multiple of 8 (one slab set per XCD), at most one workgroup per CU
+  if (nb > 1) {                 // units = nb * S are dealt to the XCDs one by one: any S, still at most one workgroup per CU
+    S = 256 / (tiles * nb);
+    const int max_s = (M + TM - 1) / TM;
+    return S < 1 ? 1 : (S > max_s ? max_s : S);
+  }
 #if defined(APLA_ABL_DWSLABS)  // diagnostic build: slab count from the environment
   if (const char* e = getenv("APLA_DW_SLABS")) S = atoi(e);
 #endif
@@ -316,23 +359,47 @@ extern "C" long apla_dw_workspace_bytes(int M, int r, int D) {
   return S * ((long)r * D + r) * (long)sizeof(float);
 }
 
-extern "C" int apla_proj_dw(const void* dyg, const void* x, int ldx, const float* row_scale, float* dW1, float* db1,
-                            void* partial, int M, int r, int D, int accumulate, hipStream_t stream) {
+extern "C" long apla_dw_workspace_bytes_batched(int M, int r, int D, int nb) {
+  if (M <= 0 || r <= 0 || D <= 0 || r % TJ != 0 || D % TK != 0 || nb < 1 || nb > DW_MAX_BATCH) return -1;
+  const long U = (long)nb * dw_slabs(M, r, D, nb);
+  return U * ((long)r * D + r) * (long)sizeof(float);
+}
+
+extern "C" int apla_proj_dw_batched(int nb, const void* const* dyg, const void* const* x, int ldx, const float* const* row_scale,
+                                    float* const* dW1, float* const* db1, void* partial, int M, int r, int D, int accumulate,
+                                    hipStream_t stream) {
+  APLA_REQUIRE(nb >= 1 && nb <= DW_MAX_BATCH, "apla_proj_dw_batched: 1..%d layers per call (got %d)", DW_MAX_BATCH, nb);
   APLA_REQUIRE(dyg && x && dW1 && db1 && partial, "apla_proj_dw: null pointer");
   APLA_REQUIRE(M > 0 && r > 0 && r % TJ == 0 && D % TK == 0, "apla_proj_dw: need r%%64==0 and D%%128==0 (r=%d D=%d)", r, D);
-  APLA_REQUIRE(ldx % 8 == 0 && ldx >= D && apla_aligned16(dyg) && apla_aligned16(x) && apla_aligned16(dW1) && apla_aligned16(partial), "apla_proj_dw: alignment");
-  const int S = dw_slabs(M, r, D);
+  APLA_REQUIRE(ldx % 8 == 0 && ldx >= D && apla_aligned16(partial), "apla_proj_dw: alignment");
+  DwIn in{};
+  DwOut out{};
+  for (int l = 0; l < nb; ++l) {
+    APLA_REQUIRE(dyg[l] && x[l] && dW1[l] && db1[l], "apla_proj_dw: null pointer (layer %d of the batch)", l);
+    APLA_REQUIRE(apla_aligned16(dyg[l]) && apla_aligned16(x[l]) && apla_aligned16(dW1[l]), "apla_proj_dw: alignment");
+    in.dyg[l] = (const bf16*)dyg[l];
+    in.x[l] = (const bf16*)x[l];
+    out.dW[l] = dW1[l];
+    out.db[l] = db1[l];
+    out.row_scale[l] = row_scale ? row_scale[l] : nullptr;
+  }
+  const int S = dw_slabs(M, r, D, nb), U = nb * S;
   int rows_per_slab = ((M + S - 1) / S + TM - 1) / TM * TM;
   const int nj = dw_group(r);
-  const dim3 grid(8 * ((S + 7) / 8) * (r / (TJ * nj)) * (D / TK));
-  if (nj == 3) hipLaunchKernelGGL(proj_dw_partial_kernel<3>, grid, dim3(256), 0, stream, (const bf16*)dyg, (const bf16*)x, ldx, (float*)partial, M, r, D, rows_per_slab, S);
-  else if (nj == 2) hipLaunchKernelGGL(proj_dw_partial_kernel<2>, grid, dim3(256), 0, stream, (const bf16*)dyg, (const bf16*)x, ldx, (float*)partial, M, r, D, rows_per_slab, S);
-  else hipLaunchKernelGGL(proj_dw_partial_kernel<1>, grid, dim3(256), 0, stream, (const bf16*)dyg, (const bf16*)x, ldx, (float*)partial, M, r, D, rows_per_slab, S);
+  const dim3 grid(8 * ((U + 7) / 8) * (r / (TJ * nj)) * (D / TK));
+  if (nj == 3) hipLaunchKernelGGL(proj_dw_partial_kernel<3>, grid, dim3(256), 0, stream, in, nb, ldx, (float*)partial, M, r, D, rows_per_slab, S);
+  else if (nj == 2) hipLaunchKernelGGL(proj_dw_partial_kernel<2>, grid, dim3(256), 0, stream, in, nb, ldx, (float*)partial, M, r, D, rows_per_slab, S);
+  else hipLaunchKernelGGL(proj_dw_partial_kernel<1>, grid, dim3(256), 0, stream, in, nb, ldx, (float*)partial, M, r, D, rows_per_slab, S);
   APLA_CHECK_LAUNCH("apla_proj_dw[partial]");
   const long n4 = (long)r * D / 4;
-  hipLaunchKernelGGL(proj_dw_reduce_kernel, dim3((unsigned)((4 * n4 + 255) / 256)), dim3(256), 0, stream, (const float*)partial, row_scale, dW1, db1, r, D, S, accumulate);
+  hipLaunchKernelGGL(proj_dw_reduce_kernel, dim3((unsigned)((4 * n4 + 255) / 256), nb), dim3(256), 0, stream, (const float*)partial, out, nb, r, D, S, accumulate);
   APLA_CHECK_LAUNCH("apla_proj_dw[reduce]");
   return APLA_OK;
+}
+
+extern "C" int apla_proj_dw(const void* dyg, const void* x, int ldx, const float* row_scale, float* dW1, float* db1,
+                            void* partial, int M, int r, int D, int accumulate, hipStream_t stream) {
+  return apla_proj_dw_batched(1, &dyg, &x, ldx, &row_scale, &dW1, &db1, partial, M, r, D, accumulate, stream);
 }
 
 extern "C" int apla_pack_proj_rows(const float* W1, const float* b1, const int32_t* inds, const float* gamma,

@@ -315,6 +315,17 @@ class AplaTrainEngine:
         # CLS-only backward of the last block (compact [B, .] operands)
         self.dact_cls, self.dln_cls, self.dO_cls = e(B, Fsave), e(B, D), e(B, D)
         self.dyg_cls = e(B * rmax)
+        # dW1 / db1 of several blocks in one launch pair (apla_proj_dw_batched): the gathered gradient columns of a block are
+        # kept (one [M, r] buffer per block instead of one for all) and the blocks of a backward segment are flushed
+        # together, at most DW_BATCH at a time.  Needs one r for all blocks and no row padding; else block by block.
+        self.dw_batch = 0
+        if os.environ.get("APLA_DW_BATCH", "1") != "0" and len({st.r for st in self.blocks}) == 1 and \
+                all(st.r_pad == st.r for st in self.blocks) and self.L > 2:
+            self.dw_batch = min(int(os.environ.get("APLA_DW_BATCH_MAX", "6")), ops.DW_MAX_BATCH)
+        self._dw_pending = []
+        if self.dw_batch > 1:
+            self.dyg_all = e(self.L - 1, M * rmax)
+            self.dw_ws_batched = {}   # layers in the batch -> workspace (sized by the C-ABI for that count)
         self.dyg = e(M * rmax)
         self.dw_ws = ops.dw_workspace(M, rmax, D, dev)
         for st in self.blocks:
@@ -466,6 +477,20 @@ class AplaTrainEngine:
         self._grad_view(st.W1_name).copy_(dW[:st.r])
         self._grad_view(st.b1_name).copy_(db[:st.r])
 
+    def _flush_dw(self):
+        """The pending blocks' dW1 / db1 in one launch pair (end of a backward segment, or DW_BATCH blocks collected)."""
+        pend, self._dw_pending = self._dw_pending, []
+        if not pend:
+            return
+        if len(pend) == 1:
+            return self._proj_dw(*pend[0])
+        nb, st0 = len(pend), pend[0][0]
+        if nb not in self.dw_ws_batched:
+            self.dw_ws_batched[nb] = ops.dw_workspace_batched(self.M, st0.r_pad, self.D, nb, self.device)
+        ops.proj_dw_batched([p[1] for p in pend], [p[2] for p in pend], [self._grad_view(p[0].W1_name) for p in pend],
+                            [self._grad_view(p[0].b1_name) for p in pend], row_scale=[p[0].row_scale for p in pend],
+                            workspace=self.dw_ws_batched[nb])
+
     def _backward_block(self, i):
         st = self.blocks[i]
         B, N, H, M, D = self.B, self.N, self.H, self.M, self.D
@@ -476,10 +501,15 @@ class AplaTrainEngine:
         else:
             ops.gemm_nt(self.Gb, st.WoutT, None, epilogue=ops.EPI_MUL, aux_in=self.act_saved[i], out=self.dact)
             ops.gemm_nt(self.dact, st.Wfc1T, None, out=self.dln, tag=ops.TAG_DFC1)
-        dyg = self.dyg[:M * st.r_pad].view(M, st.r_pad)
+        dyg = (self.dyg_all[i] if self.dw_batch > 1 else self.dyg)[:M * st.r_pad].view(M, st.r_pad)
         ops.layernorm_bwd(self.dln, self.xmid[i], st.g2, self.mean2[i], self.rstd2[i], dres=self.G, out=self.G,
                           out_bf16=copy, inds=st.inds, r=st.r_pad, gathered=dyg)
-        self._proj_dw(st, dyg, self.o[i])
+        if self.dw_batch > 1:
+            self._dw_pending.append((st, dyg, self.o[i]))
+            if len(self._dw_pending) == self.dw_batch:
+                self._flush_dw()
+        else:
+            self._proj_dw(st, dyg, self.o[i])
         if i == 0:
             return  # nothing upstream of block 0's projection is trainable
         ops.gemm_nt(self.Gb, st.WnatT, None, out=self.dO, tag=ops.TAG_DPROJ)
@@ -529,6 +559,8 @@ class AplaTrainEngine:
             hi = self.seg_cuts[k - 1]
         for i in range(hi - 1, self.seg_cuts[k] - 1, -1):
             self._backward_block(i)
+        if self.dw_batch > 1:
+            self._flush_dw()   # a segment's gradients are complete when it ends (its all-reduce chunk is launched next)
 
     def _capture(self):
         n = len(self.seg_cuts)

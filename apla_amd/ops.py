@@ -426,6 +426,46 @@ def dw_workspace(M: int, r: int, D: int, device) -> torch.Tensor:
     return torch.empty(nbytes // 4, device=device, dtype=torch.float32)
 
 
+DW_MAX_BATCH = 8
+
+
+def dw_workspace_batched(M: int, r: int, D: int, nb: int, device) -> torch.Tensor:
+    nbytes = lib().apla_dw_workspace_bytes_batched(M, r, D, nb)
+    if nbytes < 0:
+        raise ValueError(f"apla_proj_dw_batched needs r%64==0, D%128==0 and 1..{DW_MAX_BATCH} layers (r={r}, D={D}, nb={nb})")
+    return torch.empty(nbytes // 4, device=device, dtype=torch.float32)
+
+
+def proj_dw_batched(dyg, x, dW1, db1, *, row_scale=None, workspace: Optional[torch.Tensor] = None, accumulate: bool = False):
+    """proj_dw for several projections of equal shape in one launch pair: lists of tensors (row_scale: list with None entries,
+    or None).  All layers share M, r, D and the row stride of x."""
+    import ctypes
+    nb = len(dyg)
+    if not (1 <= nb <= DW_MAX_BATCH) or len(x) != nb or len(dW1) != nb or len(db1) != nb or (row_scale is not None and len(row_scale) != nb):
+        raise ValueError(f"proj_dw_batched: 1..{DW_MAX_BATCH} layers, lists of equal length")
+    M, r = dyg[0].shape
+    _, D, ldx = _rows2d(x[0], "x")
+    for l in range(nb):
+        _req(dyg[l], half(), "dyg", 2), _req(x[l], half(), "x", 2)
+        _req(dW1[l], torch.float32, "dW1", 2), _req(db1[l], torch.float32, "db1", 1)
+        Mx, Dx, ldl = _rows2d(x[l], "x")
+        if tuple(dyg[l].shape) != (M, r) or (Mx, Dx, ldl) != (M, D, ldx) or tuple(dW1[l].shape) != (r, D) or db1[l].numel() != r \
+                or not dyg[l].is_contiguous() or not dW1[l].is_contiguous():
+            raise ValueError("proj_dw_batched: shape mismatch")
+        if row_scale is not None and row_scale[l] is not None:
+            _req(row_scale[l], torch.float32, "row_scale", 1)
+            if row_scale[l].numel() != r:
+                raise ValueError("proj_dw_batched: row_scale length != r")
+    if workspace is None:
+        workspace = dw_workspace_batched(M, r, D, nb, x[0].device)
+    if workspace.numel() * 4 < lib().apla_dw_workspace_bytes_batched(M, r, D, nb):
+        raise ValueError("proj_dw_batched: workspace too small")
+    arr = lambda ts: (ctypes.c_void_p * nb)(*[None if t is None else t.data_ptr() for t in ts])
+    rs = arr(row_scale) if row_scale is not None else None
+    check(lib().apla_proj_dw_batched(nb, arr(dyg), arr(x), ldx, rs, arr(dW1), arr(db1), workspace.data_ptr(), M, r, D,
+                                     int(accumulate), _stream()), "apla_proj_dw_batched")
+
+
 def proj_dw(dyg: torch.Tensor, x: torch.Tensor, dW1: torch.Tensor, db1: torch.Tensor, *,
             row_scale: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None,
             accumulate: bool = False):

@@ -190,6 +190,16 @@ int apla_proj_bwd(const void* dy, const void* x, const void* WnatT, const int32_
 long apla_dw_workspace_bytes(int M, int r, int D);
 int apla_proj_dw(const void* dyg, const void* x, int ldx, const float* row_scale, float* dW1, float* db1,
                  void* partial, int M, int r, int D, int accumulate, hipStream_t stream);
+/* The same gradient for nb (1..8) projections of equal shape in ONE launch pair — e.g. the blocks of one backward segment,
+ * whose dyg / x the caller kept: the arrays are HOST arrays of nb device pointers (row_scale, or single entries of it, may be
+ * NULL).  The token axis is cut into 1/nb as many slabs per layer, so each workgroup's pipeline is nb times longer and the
+ * slab partials per layer shrink by nb (config 2, 11 blocks in batches of 6 + 5: 42 -> 22 us per block).  The result of a
+ * layer differs from apla_proj_dw's only by the fp32 summation order over the token slabs (deterministic for a given nb).
+ * `partial`: apla_dw_workspace_bytes_batched(M, r, D, nb) bytes. */
+long apla_dw_workspace_bytes_batched(int M, int r, int D, int nb);
+int apla_proj_dw_batched(int nb, const void* const* dyg, const void* const* x, int ldx, const float* const* row_scale,
+                         float* const* dW1, float* const* db1, void* partial, int M, int r, int D, int accumulate,
+                         hipStream_t stream);
 
 /* Refresh the engine-layout copies of the projection after W1/b1 changed:
  *   Wnat[inds[j], :]  = bf16(gamma[inds[j]] * W1[j, :])         natural-order forward weight  [D,D]

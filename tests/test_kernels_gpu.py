@@ -278,6 +278,37 @@ def test_proj_dw(ops, M, r, D):
     assert torch.equal(dW2, dW3) and torch.equal(db2, db3)
 
 
+@pytest.mark.parametrize("M,r,D,nb", [(1000, 64, 128, 2), (3001, 192, 768, 5), (700, 128, 256, 8), (130, 64, 128, 3)])
+def test_proj_dw_batched(ops, M, r, D, nb):
+    """Several projections' weight gradients in one launch pair (apla_proj_dw_batched): every layer against the fp64 oracle,
+    with a row scale on some layers only, accumulate, and bitwise reproducibility."""
+    dygs, xs, refs_w, refs_b, scales = [], [], [], [], []
+    for l in range(nb):
+        dyg, dygd = bf(rnd(M, r, seed=300 + l))
+        x, xd = bf(rnd(M, D, seed=400 + l))
+        sc = None if l % 2 else 0.5 + torch.rand(r, generator=torch.Generator().manual_seed(500 + l))
+        scd = torch.ones(r, dtype=torch.float64) if sc is None else sc.double()
+        dygs.append(dev(dyg)), xs.append(dev(x)), scales.append(None if sc is None else dev(sc))
+        refs_w.append(scd[:, None] * (dygd.t() @ xd)), refs_b.append(scd * dygd.sum(0))
+    dWs = [torch.full((r, D), 3.0, device="cuda") for _ in range(nb)]
+    dbs = [torch.full((r,), 3.0, device="cuda") for _ in range(nb)]
+    ops.proj_dw_batched(dygs, xs, dWs, dbs, row_scale=scales)
+    for l in range(nb):
+        assert rel_err(dWs[l].cpu(), refs_w[l]) < 5e-5 and rel_err(dbs[l].cpu(), refs_b[l]) < 5e-5, l
+    ops.proj_dw_batched(dygs, xs, dWs, dbs, row_scale=scales, accumulate=True)
+    for l in range(nb):
+        assert rel_err(dWs[l].cpu(), 2 * refs_w[l]) < 5e-5 and rel_err(dbs[l].cpu(), 2 * refs_b[l]) < 5e-5, l
+    dW2 = [torch.empty_like(t) for t in dWs]
+    db2 = [torch.empty_like(t) for t in dbs]
+    dW3 = [torch.empty_like(t) for t in dWs]
+    db3 = [torch.empty_like(t) for t in dbs]
+    ops.proj_dw_batched(dygs, xs, dW2, db2, row_scale=scales)
+    ops.proj_dw_batched(dygs, xs, dW3, db3, row_scale=scales)
+    assert all(torch.equal(a, b) for a, b in zip(dW2, dW3)) and all(torch.equal(a, b) for a, b in zip(db2, db3))
+    with pytest.raises(ValueError):
+        ops.proj_dw_batched(dygs * 9, xs * 9, dWs * 9, dbs * 9)
+
+
 def test_pack_proj_rows_equals_reference_scatter(ops):
     """Weight-side scatter == the reference's activation-side scatter (appla_attn.py:64-79)."""
     D, r, M = 128, 32, 50

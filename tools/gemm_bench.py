@@ -16,14 +16,19 @@ SHAPES = [("qkv", 2304, 768, ops.EPI_STORE), ("proj", 768, 768, ops.EPI_STORE), 
           ("fc1+gelu_fwd", 3072, 768, ops.EPI_GELU_FWD), ("proj+res", 768, 768, ops.EPI_RESIDUAL), ("fc1+gelu", 3072, 768, ops.EPI_GELU),
           ("fc2+res", 768, 3072, ops.EPI_RESIDUAL), ("dfc2*g", 3072, 768, ops.EPI_MUL), ("dfc1", 768, 3072, ops.EPI_STORE),
           ("dproj", 768, 768, ops.EPI_STORE), ("dqkv", 768, 2304, ops.EPI_STORE)]
+if os.environ.get("GEMM_SQ"):  # square problems (e.g. GEMM_SQ=4096,8192) to compare with published figures for other kernels
+    SHAPES = [(f"sq{v}", int(v), int(v), ops.EPI_STORE, int(v)) for v in os.environ["GEMM_SQ"].split(",")]
 VARIANTS = [int(v) for v in os.environ.get("GEMM_VARIANTS", "0,2,3").split(",")]
 ROUNDS, ITERS = 5, 10
+ROTATE = int(os.environ.get("GEMM_ROTATE", 1))   # distinct output (and second-operand) buffers walked round-robin, as the step does
+                                                 # with its per-layer saved activations (cold pages / cache state instead of a warm loop)
 
 
 def main():
     dev = "cuda"
     res = {}
-    for name, N, K, epi in SHAPES:
+    for name, N, K, epi, *rest in SHAPES:
+        M = rest[0] if rest else globals()["M"]
         if ONLY and name not in ONLY.split(','):
             continue
         a = torch.randn(M, K, device=dev).to(torch.bfloat16)
@@ -37,6 +42,10 @@ def main():
         elif epi == ops.EPI_MUL:
             kw = dict(aux_in=torch.randn(M, N, device=dev).to(torch.bfloat16))
         out = torch.empty(M, N, device=dev, dtype=kw.get("out_dtype", torch.bfloat16))
+        rot = [(out, kw)]
+        for _ in range(ROTATE - 1):
+            rot.append((torch.empty_like(out), {k: (torch.empty_like(x) if k == "aux_out" else x.clone() if torch.is_tensor(x) else x)
+                                                for k, x in kw.items()}))
         ref = None
         for v in VARIANTS:
             ops.set_gemm_variant(v)
@@ -51,8 +60,9 @@ def main():
                 ops.set_gemm_variant(v)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                for _ in range(ITERS):
-                    ops.gemm_nt(a, w, bias, epilogue=epi, out=out, **{k: x for k, x in kw.items() if k != "out_dtype"})
+                for it in range(ITERS):
+                    o_, kw_ = rot[it % ROTATE]
+                    ops.gemm_nt(a, w, bias, epilogue=epi, out=o_, **{k: x for k, x in kw_.items() if k != "out_dtype"})
                 e1.record()
                 torch.cuda.synchronize()
                 times[v].append(e0.elapsed_time(e1) / ITERS)

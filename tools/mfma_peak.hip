@@ -5,7 +5,8 @@
 //
 // Each workgroup is four waves (one per SIMD; "x2" variants launch two workgroups per CU = two waves per SIMD).  A wave keeps
 // 4 A and 4 B fragments in registers and issues the 16 independent products of them back to back; nothing touches LDS or
-// memory inside the loop, so the figure is the matrix pipes at the clock the chip holds under that load (it lowers its
+// memory inside the loop (the MFMAs are inline asm on pinned registers: with the builtins hipcc moved the 16x16x32 accumulators
+// through AGPR copies and s_nops and that loop reached 57 % of its issue rate), so the figure is the matrix pipes at the clock the chip holds under that load (it lowers its
 // clock under a dense MFMA stream: MI355X_MICROARCH.md "DVFS give-back").  Prints ONE JSON line; bench.py embeds it as
 // roofline.peak_measured.  `clock_ghz` is the in-kernel clock (s_memtime ticks / s_memrealtime at 100 MHz) of the median
 // workgroup.
@@ -19,6 +20,7 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
@@ -29,9 +31,12 @@ template <int SHAPE, bool F16>
 __global__ __launch_bounds__(256) void mfma_loop(const uint4* __restrict__ src, float* __restrict__ sink, int iters,
                                                  unsigned long long* __restrict__ stamps) {
   const int lane_id = blockIdx.x * 256 + threadIdx.x;
-  uint4 ra[4], rb[4];
+  u32x4 ra[4], rb[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { ra[i] = src[(lane_id * 8 + i) & 0xFFFFF]; rb[i] = src[(lane_id * 8 + 4 + i) & 0xFFFFF]; }
+  for (int i = 0; i < 4; ++i) {
+    ra[i] = __builtin_bit_cast(u32x4, src[(lane_id * 8 + i) & 0xFFFFF]);
+    rb[i] = __builtin_bit_cast(u32x4, src[(lane_id * 8 + 4 + i) & 0xFFFFF]);
+  }
   const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
   float total = 0.f;
   if constexpr (SHAPE == 0) {
@@ -46,9 +51,9 @@ __global__ __launch_bounds__(256) void mfma_loop(const uint4* __restrict__ src, 
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           if constexpr (F16)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ra[i]), __builtin_bit_cast(f16x8, rb[j]), acc[i][j], 0, 0, 0);
+            asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(ra[i]), "v"(rb[j]));
           else
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ra[i]), __builtin_bit_cast(bf16x8, rb[j]), acc[i][j], 0, 0, 0);
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(ra[i]), "v"(rb[j]));
         }
     }
 #pragma unroll
@@ -69,9 +74,9 @@ __global__ __launch_bounds__(256) void mfma_loop(const uint4* __restrict__ src, 
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           if constexpr (F16)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ra[i]), __builtin_bit_cast(f16x8, rb[j]), acc[i][j], 0, 0, 0);
+            asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(ra[i]), "v"(rb[j]));
           else
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ra[i]), __builtin_bit_cast(bf16x8, rb[j]), acc[i][j], 0, 0, 0);
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(ra[i]), "v"(rb[j]));
         }
     }
 #pragma unroll
