@@ -51,6 +51,10 @@ SIGNATURES = {
     "apla_dw_workspace_bytes": (c_long, [c_int, c_int, c_int]),
     "apla_proj_dw": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                              c_int, c_void_p]),
+    "apla_gemm_nt_panel_ok": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "apla_pack_k_panels": (c_int, [c_void_p, c_long, c_void_p, c_int, c_int, c_void_p]),
+    "apla_pack_proj_rows_batched_ex": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                               c_int, c_int, c_int, c_void_p]),
     "apla_dw_workspace_bytes_batched": (c_long, [c_int, c_int, c_int, c_int]),
     "apla_proj_dw_batched": (c_int, [c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                      c_int, c_void_p]),

@@ -335,7 +335,8 @@ __global__ __launch_bounds__(256) void pack_proj_rows_batched_kernel(const float
                                                                      const int32_t* __restrict__ inds_all,
                                                                      const float* __restrict__ gamma_all,
                                                                      bf16* __restrict__ Wnat_all, bf16* __restrict__ WnatT_all,
-                                                                     float* __restrict__ bnat_all, int r, int D) {
+                                                                     float* __restrict__ bnat_all, bf16* __restrict__ Wp_all,
+                                                                     bf16* __restrict__ WTp_all, int r, int D) {
   const int j = blockIdx.x, l = blockIdx.y;
   const float* W1 = flat + (long)l * block_stride;
   const float* b1 = W1 + (long)r * D;
@@ -343,10 +344,14 @@ __global__ __launch_bounds__(256) void pack_proj_rows_batched_kernel(const float
   const float g = gamma_all != nullptr ? gamma_all[(long)l * D + row] : 1.0f;
   bf16* Wnat = Wnat_all + (long)l * D * D;
   bf16* WnatT = WnatT_all + (long)l * D * D;
+  bf16* Wp = Wp_all ? Wp_all + (long)l * D * D : nullptr;     // K-panel images of the two copies (apla_pack_k_panels layout)
+  bf16* WTp = WTp_all ? WTp_all + (long)l * D * D : nullptr;
   for (int k = threadIdx.x; k < D; k += 256) {
     const bf16 v = (bf16)(g * W1[(size_t)j * D + k]);
     Wnat[(size_t)row * D + k] = v;
     WnatT[(size_t)k * D + row] = v;
+    if (Wp) Wp[((size_t)(k >> 5) * D + row) * 32 + (k & 31)] = v;
+    if (WTp) WTp[((size_t)(row >> 5) * D + k) * 32 + (row & 31)] = v;
   }
   if (threadIdx.x == 0) bnat_all[(long)l * D + row] = g * b1[j];
 }
@@ -411,14 +416,21 @@ extern "C" int apla_pack_proj_rows(const float* W1, const float* b1, const int32
   return APLA_OK;
 }
 
+extern "C" int apla_pack_proj_rows_batched_ex(const float* flat, long block_stride, const int32_t* inds_all,
+                                              const float* gamma_all, void* Wnat_all, void* WnatT_all, float* bnat_all,
+                                              void* Wnat_panels, void* WnatT_panels, int L, int r, int D, hipStream_t stream) {
+  APLA_REQUIRE(flat && inds_all && Wnat_all && WnatT_all && bnat_all && L > 0 && L <= 65535 && r > 0 && r <= D &&
+               block_stride >= (long)r * D + r, "apla_pack_proj_rows_batched: bad arguments");
+  APLA_REQUIRE((!Wnat_panels && !WnatT_panels) || D % 32 == 0, "apla_pack_proj_rows_batched_ex: K-panel images need D %% 32 == 0");
+  hipLaunchKernelGGL(pack_proj_rows_batched_kernel, dim3(r, L), dim3(256), 0, stream, flat, block_stride, inds_all, gamma_all, (bf16*)Wnat_all, (bf16*)WnatT_all, bnat_all, (bf16*)Wnat_panels, (bf16*)WnatT_panels, r, D);
+  APLA_CHECK_LAUNCH("apla_pack_proj_rows_batched");
+  return APLA_OK;
+}
+
 extern "C" int apla_pack_proj_rows_batched(const float* flat, long block_stride, const int32_t* inds_all,
                                            const float* gamma_all, void* Wnat_all, void* WnatT_all, float* bnat_all,
                                            int L, int r, int D, hipStream_t stream) {
-  APLA_REQUIRE(flat && inds_all && Wnat_all && WnatT_all && bnat_all && L > 0 && L <= 65535 && r > 0 && r <= D &&
-               block_stride >= (long)r * D + r, "apla_pack_proj_rows_batched: bad arguments");
-  hipLaunchKernelGGL(pack_proj_rows_batched_kernel, dim3(r, L), dim3(256), 0, stream, flat, block_stride, inds_all, gamma_all, (bf16*)Wnat_all, (bf16*)WnatT_all, bnat_all, r, D);
-  APLA_CHECK_LAUNCH("apla_pack_proj_rows_batched");
-  return APLA_OK;
+  return apla_pack_proj_rows_batched_ex(flat, block_stride, inds_all, gamma_all, Wnat_all, WnatT_all, bnat_all, nullptr, nullptr, L, r, D, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ composite operator entry points

@@ -14,6 +14,9 @@ struct GemmParams {
   void* aux_out; int ld_aux_out;
   int M, N, K, tiles_n;
   int ngrp;  // n-tiles per column group of the tile walk (0 = plain row-major walk); see tile_coords
+  int w_panel;  // operand images (apla_gemm_nt_ex flags bits 16 / 17): bit 0 = W is K-panel-major [K/32][N][32], bit 1 = A is
+                // [K/32][M][32].  In that image the 64 bytes a row gives to a 32-wide K-step sit next to its neighbours' (whole
+                // 128-byte lines per LDS-DMA instruction: tools/dma_probe.hip); ping-pong kernel only.
   int tag;   // profiling tag (apla_gemm_nt_tagged): selects one of several identical kernel instantiations so that a rocprofv3
              // kernel trace tells the call sites of the step apart (qkv / proj / fc2 / dfc1 / dproj / dqkv …); 0 = untagged
 };
@@ -21,6 +24,7 @@ constexpr int APLA_GEMM_TAGS = 9;   // tags 0 .. 8 (1 is not used: the profiler'
 
 // 8-wave ping-pong kernel (gemm_pp2.hip); returns APLA_ENOSYS when the shape / (epilogue, dtype) is not covered there
 int apla_gemm_pp2_launch(const GemmParams& p, int epilogue, int out_dtype, hipStream_t stream);
+bool apla_gemm_pp2_covers(int M, int N, int K, long lda, long ldw, int epilogue, int out_dtype);
 
 // Tile walk.  Linear tile ids are dealt to XCDs in contiguous runs (each XCD has its own 4 MB L2).  With n fastest, a run
 // touches ALL column tiles, i.e. the whole weight matrix: fine while W fits next to the streaming A panels (N = 768:

@@ -56,8 +56,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmParams p, int tile
   const int koff = ((lane & 3) ^ ((-(srow >> 2)) & 3)) * 8;
   // waves 0-3 stream the 20 A pieces (c = 5*wave + it), waves 4-7 the 16 W pieces (+ 4 duplicates of the last one)
   const bool a_wave = wave < 4;
-  const unsigned lane_off = a_wave ? ((unsigned)srow * (unsigned)p.lda + koff) * 2u
-                                   : ((unsigned)(8 * (srow >> 2) + (srow & 3)) * (unsigned)p.ldw + koff) * 2u;
+  const unsigned wrow = (p.w_panel & 1) ? 32u : (unsigned)p.ldw;   // elements between consecutive W rows
+  const size_t wkstep = (p.w_panel & 1) ? (size_t)p.N * 64 : (size_t)QBK * 2;  // bytes between consecutive K-steps of W
+  const unsigned arow = (p.w_panel & 2) ? 32u : (unsigned)p.lda;   // experiment: A K-panel-major too ([K/32][M][32])
+  const size_t akstep = (p.w_panel & 2) ? (size_t)p.M * 64 : (size_t)QBK * 2;
+  const unsigned lane_off = a_wave ? ((unsigned)srow * arow + koff) * 2u
+                                   : ((unsigned)(8 * (srow >> 2) + (srow & 3)) * wrow + koff) * 2u;
   int d_step = 0, d_k = 0, d_tile = 0, d_tm = 0, d_tn = 0, d_slot = 0;
   bool d_edge = false;
   // wave-uniform addressing: one operand base per tile (SGPR pair) + this wave's five piece offsets (fixed for the kernel)
@@ -69,8 +73,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmParams p, int tile
     // W piece pw = c-20 fills LDS rows 16*pw + srow = (wn'=pw>>3)*128 + (j=pw&7)*16 + srow, which hold W row
     //   wn'*128 + 32*(j>>1) + 8*(srow>>2) + 4*(j&1) + (srow&3)     (MFMA order, see gemm_common.h)
     const int pw = c - 20, j = pw & 7;
-    poff[it] = a_wave ? (unsigned)(c * 16) * (unsigned)p.lda * 2u
-                      : (unsigned)((pw >> 3) * 128 + 32 * (j >> 1) + 4 * (j & 1)) * (unsigned)p.ldw * 2u;
+    poff[it] = a_wave ? (unsigned)(c * 16) * arow * 2u
+                      : (unsigned)((pw >> 3) * 128 + 32 * (j >> 1) + 4 * (j & 1)) * wrow * 2u;
   }
   const char* tbase = nullptr;
   auto dma_issue = [&]() {
@@ -81,13 +85,13 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmParams p, int tile
     if (d_k == 0) {
       tile_coords(xbeg + slot + d_tile * slots, tiles_m, tiles_n, p.ngrp, d_tm, d_tn);
       d_edge = a_wave && d_tm * QBM + QBM > p.M;
-      tbase = a_wave ? (const char*)(p.A + (size_t)(d_tm * QBM) * p.lda) : (const char*)(p.W + (size_t)(d_tn * QBN) * p.ldw);
+      tbase = a_wave ? (const char*)(p.A + (size_t)(d_tm * QBM) * arow) : (const char*)(p.W + (size_t)(d_tn * QBN) * wrow);
     }
     char* base = smem + d_slot * QSTG + (a_wave ? wave * QGRP * 1024 : 0);
 #if defined(APLA_ABL_SAMEK)  // diagnostic build: every K-step streams the k = 0 slice again (cache-resident source)
-    const int kb = 0;
+    const size_t kb = 0;
 #else
-    const int kb = d_k * QBK * 2;  // byte offset of this K-step inside a row
+    const size_t kb = a_wave ? (size_t)d_k * akstep : (size_t)d_k * wkstep;  // byte offset of this K-step
 #endif
     if (!d_edge) {
 #pragma unroll
@@ -103,7 +107,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmParams p, int tile
         const int c = wave * QGRP + it;
         int gr = d_tm * QBM + c * 16 + srow;
         gr = gr < p.M ? gr : p.M - 1;
-        const unsigned off = ((unsigned)gr * (unsigned)p.lda + koff) * 2u;
+        const unsigned off = ((unsigned)gr * arow + koff) * 2u;
         __builtin_amdgcn_global_load_lds(GLBP((const char*)p.A + kb + off), LDSP(base + it * 1024), 16, 0, 0);
       }
     }
@@ -242,9 +246,17 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmParams p, int tile
 
 }  // namespace
 
+bool apla_gemm_pp2_covers(int M, int N, int K, long lda, long ldw, int epilogue, int out_dtype) {
+  if (N % QBN != 0 || K % QBK != 0 || K < 4 * QBK) return false;
+  if ((size_t)M * lda >= (1ull << 30) || (size_t)N * ldw >= (1ull << 30)) return false;  // 32-bit operand offsets
+  if (epilogue == APLA_EPI_STORE) return out_dtype == APLA_H16 || out_dtype == APLA_F32;
+  return (epilogue == APLA_EPI_GELU || epilogue == APLA_EPI_GELU_FWD) && out_dtype == APLA_H16;
+}
+
 int apla_gemm_pp2_launch(const GemmParams& p_in, int epilogue, int out_dtype, hipStream_t stream) {
-  if (p_in.N % QBN != 0 || p_in.K % QBK != 0 || p_in.K < 4 * QBK) return APLA_ENOSYS;
-  if ((size_t)p_in.M * p_in.lda >= (1ull << 30) || (size_t)p_in.N * p_in.ldw >= (1ull << 30)) return APLA_ENOSYS;  // 32-bit operand offsets
+  // (operands given as K-panel images are addressed with a row pitch of 32 elements: the offset limit applies to that pitch)
+  if (!apla_gemm_pp2_covers(p_in.M, p_in.N, p_in.K, (p_in.w_panel & 2) ? 32 : p_in.lda, (p_in.w_panel & 1) ? 32 : p_in.ldw, epilogue, out_dtype))
+    return APLA_ENOSYS;
   GemmParams p = p_in;
   p.ngrp = pick_ngrp(p.N / QBN, QBN, p.K);
   const int tiles_m = (p.M + QBM - 1) / QBM;

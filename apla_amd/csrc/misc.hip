@@ -405,3 +405,24 @@ extern "C" int apla_colsum(const float* X, long ld, float* out, int M, int N, hi
   APLA_CHECK_LAUNCH("apla_colsum");
   return APLA_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ K-panel operand image
+// dst[(k / 32) * rows + r][k % 32] = src[r][k]: the image apla_gemm_nt_ex reads with flags bit 16 (W) / bit 17 (A).  One thread
+// moves 16 bytes; a frozen weight is converted once, a trainable one by its own pack kernel.
+__global__ __launch_bounds__(256) void pack_k_panels_kernel(const bf16* __restrict__ src, long ld, bf16* __restrict__ dst, int rows, int K) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const int cpr = K / 8;  // 16-byte chunks per row
+  if (t >= (long)rows * cpr) return;
+  const int r = (int)(t / cpr), c = (int)(t - (long)r * cpr);
+  const bf16x8 v = *(const bf16x8*)(src + (long)r * ld + c * 8);
+  *(bf16x8*)(dst + ((long)(c >> 2) * rows + r) * 32 + (c & 3) * 8) = v;
+}
+
+extern "C" int apla_pack_k_panels(const void* src, long ld, void* dst, int rows, int K, hipStream_t stream) {
+  APLA_REQUIRE(src && dst && rows > 0 && K > 0 && K % 32 == 0 && ld % 8 == 0 && ld >= K && apla_aligned16(src) && apla_aligned16(dst),
+               "apla_pack_k_panels: [rows, K] 16-bit matrix with K %% 32 == 0, 16-byte aligned rows");
+  const long n = (long)rows * (K / 8);
+  hipLaunchKernelGGL(pack_k_panels_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const bf16*)src, ld, (bf16*)dst, rows, K);
+  APLA_CHECK_LAUNCH("apla_pack_k_panels");
+  return APLA_OK;
+}

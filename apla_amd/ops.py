@@ -81,6 +81,22 @@ _ATTN_VARIANT = int(os.environ.get("APLA_ATTN_VARIANT", "0"))
 TAG_QKV, TAG_PROJ, TAG_FC2, TAG_DFC1, TAG_DPROJ, TAG_DQKV, TAG_PATCH = 2, 3, 4, 5, 6, 7, 8
 
 
+def k_panels(m: torch.Tensor) -> torch.Tensor:
+    """The K-panel image [K/32, rows, 32] of a 16-bit [rows, K] matrix (include/apla_hip.h:apla_pack_k_panels)."""
+    _req(m, half(), "m", 2)
+    rows, K, ld = _rows2d(m, "m")
+    if K % 32:
+        raise ValueError("k_panels: K % 32 != 0")
+    out = torch.empty(K // 32, rows, 32, device=m.device, dtype=m.dtype)
+    check(lib().apla_pack_k_panels(m.data_ptr(), ld, out.data_ptr(), rows, K, _stream()), "apla_pack_k_panels")
+    return out
+
+
+def gemm_panel_ok(M: int, N: int, K: int, epilogue: int = 0, out_dtype=None) -> bool:
+    """May this problem take K-panel operand images? (apla_gemm_nt_panel_ok)"""
+    return bool(lib().apla_gemm_nt_panel_ok(M, N, K, epilogue, _DT[out_dtype or half()]))
+
+
 def set_gemm_variant(v: int) -> int:
     """Pin the GEMM kernel schedule for subsequent ops.gemm_nt calls (include/apla_hip.h:apla_gemm_nt_ex); returns the old value."""
     global _GEMM_VARIANT
@@ -99,10 +115,23 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = Non
             out: Optional[torch.Tensor] = None, out_dtype=None, aux_in: Optional[torch.Tensor] = None,
             aux_out: Optional[torch.Tensor] = None, tag: int = 0) -> torch.Tensor:
     """out[M,Nout] = epilogue(a[M,K] @ w[N,K]^T + bias).  See include/apla_hip.h:apla_gemm_nt / apla_gemm_nt_ex (`tag`: profiling
-    tag of the call site, TAG_*)."""
-    _req(a, half(), "a", 2), _req(w, half(), "w", 2)
-    M, K, lda = _rows2d(a, "a")
-    N, Kw, ldw = _rows2d(w, "w")
+    tag of the call site, TAG_*).  A 3-D contiguous operand [K/32, rows, 32] is taken as its K-panel image (k_panels())."""
+    _req(a, half(), "a", None), _req(w, half(), "w", None)
+    panel = 0
+    if w.ndim == 3:
+        if w.shape[2] != 32 or not w.is_contiguous():
+            raise ValueError("gemm_nt: a K-panel image is a contiguous [K/32, N, 32] tensor")
+        N, Kw, ldw, panel = w.shape[1], w.shape[0] * 32, 32, 1
+    else:
+        _req(w, half(), "w", 2)
+        N, Kw, ldw = _rows2d(w, "w")
+    if a.ndim == 3:
+        if a.shape[2] != 32 or not a.is_contiguous():
+            raise ValueError("gemm_nt: a K-panel image is a contiguous [K/32, M, 32] tensor")
+        M, K, lda, panel = a.shape[1], a.shape[0] * 32, 32, panel | 2
+    else:
+        _req(a, half(), "a", 2)
+        M, K, lda = _rows2d(a, "a")
     if K != Kw:
         raise ValueError(f"gemm_nt: K mismatch {K} vs {Kw}")
     if bias is not None:
@@ -141,7 +170,7 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = Non
         raise ValueError("gemm_nt: EPI_GELU_FWD saves nothing (use EPI_GELU to get gelu')")
     rc = lib().apla_gemm_nt_ex(a.data_ptr(), lda, w.data_ptr(), ldw, _ptr(bias), out.data_ptr(), out.stride(0), M, N, K,
                                epilogue, _DT[out.dtype], _ptr(aux_in), ld_in, _ptr(aux_out), ld_out,
-                               (int(tag) & 0xff) | (_GEMM_VARIANT << 8), _stream())
+                               (int(tag) & 0xff) | (_GEMM_VARIANT << 8) | (panel << 16), _stream())
     check(rc, "apla_gemm_nt")
     return out
 
@@ -505,8 +534,10 @@ def pack_proj_rows(W1: torch.Tensor, b1: Optional[torch.Tensor], inds: torch.Ten
 
 
 def pack_proj_rows_batched(flat: torch.Tensor, block_stride: int, inds_all: torch.Tensor, gamma_all: Optional[torch.Tensor],
-                           Wnat_all: torch.Tensor, WnatT_all: torch.Tensor, bnat_all: torch.Tensor, r: int):
-    """pack_proj_rows for all L blocks in one launch; see include/apla_hip.h:apla_pack_proj_rows_batched."""
+                           Wnat_all: torch.Tensor, WnatT_all: torch.Tensor, bnat_all: torch.Tensor, r: int,
+                           Wnat_panels: Optional[torch.Tensor] = None, WnatT_panels: Optional[torch.Tensor] = None):
+    """pack_proj_rows for all L blocks in one launch; see include/apla_hip.h:apla_pack_proj_rows_batched(_ex).  The optional
+    K-panel images are [L, D/32, D, 32]."""
     _req(flat, torch.float32, "flat", 1), _req(inds_all, torch.int32, "inds_all", 2)
     _req(Wnat_all, half(), "Wnat_all", 3), _req(WnatT_all, half(), "WnatT_all", 3), _req(bnat_all, torch.float32, "bnat_all", 2)
     L, D = inds_all.shape
@@ -518,9 +549,15 @@ def pack_proj_rows_batched(flat: torch.Tensor, block_stride: int, inds_all: torc
         _req(gamma_all, torch.float32, "gamma_all", 2)
         if tuple(gamma_all.shape) != (L, D) or not gamma_all.is_contiguous():
             raise ValueError("pack_proj_rows_batched: gamma_all shape")
-    check(lib().apla_pack_proj_rows_batched(flat.data_ptr(), int(block_stride), inds_all.data_ptr(), _ptr(gamma_all),
-                                            Wnat_all.data_ptr(), WnatT_all.data_ptr(), bnat_all.data_ptr(), L, r, D,
-                                            _stream()), "apla_pack_proj_rows_batched")
+    for t_ in (Wnat_panels, WnatT_panels):
+        if t_ is not None:
+            _req(t_, half(), "panels", 4)
+            if tuple(t_.shape) != (L, D // 32, D, 32) or not t_.is_contiguous():
+                raise ValueError("pack_proj_rows_batched: K-panel images are [L, D/32, D, 32]")
+    check(lib().apla_pack_proj_rows_batched_ex(flat.data_ptr(), int(block_stride), inds_all.data_ptr(), _ptr(gamma_all),
+                                               Wnat_all.data_ptr(), WnatT_all.data_ptr(), bnat_all.data_ptr(),
+                                               _ptr(Wnat_panels), _ptr(WnatT_panels), L, r, D, _stream()),
+          "apla_pack_proj_rows_batched")
 
 
 def adamw_step(params, grads, exp_avg, exp_avg_sq, decay_mask, *, lr, weight_decay, betas=(0.9, 0.999), eps=1e-8,

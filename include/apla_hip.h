@@ -71,7 +71,17 @@ int apla_gemm_nt(const void* A, int lda, const void* W, int ldw, const float* bi
  *              for M >= 2048, N % 256 == 0 and the STORE / GELU epilogues, else the 4-wave persistent kernel (128/160 x 128 x
  *              64 tile, gemm_nt.hip); 9 = ping-pong wherever instantiated; 14 / 15 = 4-wave persistent kernel with BM 128 /
  *              160; 1 = the simple non-persistent 2-stage kernel (the round-1 starting point; an in-tree A/B baseline).
- *              All schedules compute the same results (tests/test_kernels_gpu.py). */
+ *              All schedules compute the same results (tests/test_kernels_gpu.py).
+ *   bit 16     W is given as its K-PANEL IMAGE [K/32][N][32] (apla_pack_k_panels; `ldw` is not read), bit 17 the same for A
+ *              ([K/32][M][32], `lda` not read).  The fill path of a CU works in 128-byte lines: an LDS-DMA instruction that
+ *              takes 64 bytes (a 32-wide K-step) from each of 16 rows of a row-major operand moves half of what one reading
+ *              whole lines does (64 vs 115-129 GB/s per CU, tools/dma_probe.hip); in the panel image the 16 rows' 64 bytes are
+ *              1 KB contiguous.  Same results bit for bit; the six STORE shapes of config 2 run 2-9 % faster with W as an
+ *              image and 2-9 % more with A too.  Ping-pong kernel only: apla_gemm_nt_panel_ok(M, N, K, epilogue, out_dtype)
+ *              tells whether a problem is covered (it is an error to pass an image otherwise). */
+int apla_gemm_nt_panel_ok(int M, int N, int K, int epilogue, int out_dtype);
+/* dst[(k / 32) * rows + r][k % 32] = src[r][k] for a 16-bit [rows, K] matrix with row pitch ld (K % 32 == 0): the K-panel image */
+int apla_pack_k_panels(const void* src, long ld, void* dst, int rows, int K, hipStream_t stream);
 int apla_gemm_nt_ex(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int M, int N,
                     int K, int epilogue, int out_dtype, const void* aux_in, int ld_aux_in, void* aux_out,
                     int ld_aux_out, int flags, hipStream_t stream);
@@ -216,6 +226,11 @@ int apla_pack_proj_rows(const float* W1, const float* b1, const int32_t* inds, c
 int apla_pack_proj_rows_batched(const float* flat, long block_stride, const int32_t* inds_all, const float* gamma_all,
                                 void* Wnat_all, void* WnatT_all, float* bnat_all, int L, int r, int D,
                                 hipStream_t stream);
+/* ... and, when the pointers are not NULL, the same r rows into the K-panel images of the two copies ([L][D/32][D][32] each;
+ * the frozen rows of the images are the caller's, as they are for Wnat_all / WnatT_all) */
+int apla_pack_proj_rows_batched_ex(const float* flat, long block_stride, const int32_t* inds_all, const float* gamma_all,
+                                   void* Wnat_all, void* WnatT_all, float* bnat_all, void* Wnat_panels, void* WnatT_panels,
+                                   int L, int r, int D, hipStream_t stream);
 
 /* Fused global-norm clip + AdamW over the flat trainable buffer (defaults/trainer.py:127-138,
  * defaults/wrappers.py:205-221): grads are first multiplied by grad_scale (1/world for DDP mean), the global L2

@@ -429,6 +429,37 @@ def test_gemm_variants_all_epilogues(ops, variant, M, N, K):
         ops.set_gemm_variant(old)
 
 
+@pytest.mark.parametrize("M,N,K", [(25216, 768, 768), (2500, 512, 256), (4001, 256, 128)])
+def test_gemm_k_panel_images(ops, M, N, K):
+    """Operands given as K-panel images (apla_gemm_nt_ex flags bits 16 / 17, ops.k_panels) give the row-major results bit for bit;
+    the image itself is the documented permutation; a problem the ping-pong kernel does not cover refuses an image."""
+    from apla_amd._lib import AplaHipError
+    a, _ = bf(rnd(M, K, seed=91))
+    w, _ = bf(rnd(N, K, scale=K ** -0.5, seed=92))
+    bias = dev(rnd(N, seed=93))
+    A, W = dev(a), dev(w)
+    Wi, Ai = ops.k_panels(W), ops.k_panels(A)
+    assert torch.equal(Wi.cpu(), w.view(N, K // 32, 32).permute(1, 0, 2).contiguous())
+    assert torch.equal(ops.k_panels(A[:, : K]).cpu(), a.view(M, K // 32, 32).permute(1, 0, 2).contiguous())
+    assert ops.gemm_panel_ok(M, N, K)
+    ref = ops.gemm_nt(A, W, bias)
+    assert torch.equal(ops.gemm_nt(A, Wi, bias), ref)
+    assert torch.equal(ops.gemm_nt(Ai, Wi, bias), ref)
+    assert torch.equal(ops.gemm_nt(Ai, W, bias), ref)
+    ref32 = ops.gemm_nt(A, W, bias, out_dtype=torch.float32)
+    assert torch.equal(ops.gemm_nt(A, Wi, bias, out_dtype=torch.float32), ref32)
+    g0, g1 = torch.empty(M, N, device="cuda", dtype=torch.bfloat16), torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    h0 = ops.gemm_nt(A, W, bias, epilogue=ops.EPI_GELU, aux_out=g0)
+    h1 = ops.gemm_nt(A, Wi, bias, epilogue=ops.EPI_GELU, aux_out=g1)
+    assert torch.equal(h0, h1) and torch.equal(g0, g1)
+    # not covered: an operand epilogue, N not a multiple of 256, fewer than four 32-wide K-steps
+    assert not ops.gemm_panel_ok(M, 128, K) and not ops.gemm_panel_ok(M, N, K, ops.EPI_MUL)
+    with pytest.raises(AplaHipError):
+        ops.gemm_nt(A, Wi, None, epilogue=ops.EPI_MUL, aux_in=g0)
+    with pytest.raises(AplaHipError):
+        ops.gemm_nt(dev(a[:, :64].contiguous()), ops.k_panels(dev(w[:, :64].contiguous())), bias)   # K = 64 < 128
+
+
 @pytest.mark.parametrize("B,N,H", [(3, 197, 2), (2, 5, 1), (1, 300, 3)])
 def test_attention_bwd_cls_only(ops, B, N, H):
     """dO non-zero only at token 0 (last ViT block): the rank-1 kernel equals the general backward."""

@@ -47,17 +47,23 @@ def main():
             rot.append((torch.empty_like(out), {k: (torch.empty_like(x) if k == "aux_out" else x.clone() if torch.is_tensor(x) else x)
                                                 for k, x in kw.items()}))
         ref = None
+        w_rm, a_rm = w, a
         for v in VARIANTS:
-            ops.set_gemm_variant(v)
+            ops.set_gemm_variant(v % 100)
+            # v = 100 + schedule: W passed as its K-panel image; 300 + schedule: A too (ping-pong kernel only)
+            w = ops.k_panels(w_rm) if v >= 100 else w_rm
+            a = ops.k_panels(a_rm) if v >= 300 else a_rm
             o = ops.gemm_nt(a, w, bias, epilogue=epi, out=out, **{k: x for k, x in kw.items() if k != "out_dtype"}).clone()
             if ref is None:
                 ref = o
-            elif v < 100:
+            else:
                 assert torch.equal(o, ref), f"variant {v} differs on {name}: {(o.float() - ref.float()).abs().max()}"
         times = {v: [] for v in VARIANTS}
         for _ in range(ROUNDS):
             for v in VARIANTS:
-                ops.set_gemm_variant(v)
+                ops.set_gemm_variant(v % 100)
+                w = ops.k_panels(w_rm) if v >= 100 else w_rm
+                a = ops.k_panels(a_rm) if v >= 300 else a_rm
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for it in range(ITERS):
