@@ -52,6 +52,7 @@ SIGNATURES = {
     "apla_proj_dw": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                              c_int, c_void_p]),
     "apla_gemm_nt_panel_ok": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "apla_gemm_nt_out_image_ok": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "apla_pack_k_panels": (c_int, [c_void_p, c_long, c_void_p, c_int, c_int, c_void_p]),
     "apla_pack_proj_rows_batched_ex": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                c_int, c_int, c_int, c_void_p]),

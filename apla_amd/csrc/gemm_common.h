@@ -16,7 +16,9 @@ struct GemmParams {
   int ngrp;  // n-tiles per column group of the tile walk (0 = plain row-major walk); see tile_coords
   int w_panel;  // operand images (apla_gemm_nt_ex flags bits 16 / 17): bit 0 = W is K-panel-major [K/32][N][32], bit 1 = A is
                 // [K/32][M][32].  In that image the 64 bytes a row gives to a 32-wide K-step sit next to its neighbours' (whole
-                // 128-byte lines per LDS-DMA instruction: tools/dma_probe.hip); ping-pong kernel only.
+                // 128-byte lines per LDS-DMA instruction: tools/dma_probe.hip); ping-pong kernel only.  Bit 2 = the OUTPUT C is
+                // written as its K-panel image [N/32][M][32] (16-bit, 4-wave persistent kernel: GELU / GELU_FWD / MUL), ready to be
+                // the A operand of the next GEMM.
   int tag;   // profiling tag (apla_gemm_nt_tagged): selects one of several identical kernel instantiations so that a rocprofv3
              // kernel trace tells the call sites of the step apart (qkv / proj / fc2 / dfc1 / dproj / dqkv …); 0 = untagged
 };
@@ -169,6 +171,12 @@ __device__ __forceinline__ void persist_epilogue(const GemmParams& p, f32x4 (&ac
                                                  int m0, int n0, int wm, int wn, int lane) {
   const int frow = lane & 15, fq = lane >> 4;
   const int ncol = wn * 64 + fq * 8;  // + 32*u : first of the 8 columns this lane owns in pair u (tile-local)
+  // element (m, n) of the 16-bit output C: row-major, or its K-panel image (the 8 columns a lane owns never straddle a panel,
+  // and the 16 rows of a fragment are 1 KB contiguous there)
+  const bool c_img = (p.w_panel & 4) != 0;
+  auto c_at = [&](int m, int n) -> bf16* {
+    return (bf16*)p.C + (c_img ? ((size_t)(n >> 5) * p.M + m) * 32 + (n & 31) : (size_t)m * p.ldc + n);
+  };
   int mrow[MI];
 #pragma unroll
   for (int i = 0; i < MI; ++i) mrow[i] = m0 + wm * (MI * 16) + i * 16 + frow;
@@ -215,7 +223,7 @@ __device__ __forceinline__ void persist_epilogue(const GemmParams& p, f32x4 (&ac
       if constexpr (EPI == APLA_EPI_STORE || EPI == APLA_EPI_RESIDUAL) {
         Vec8IO<OutT>::store((OutT*)p.C + (size_t)m * p.ldc + n, lo, hi);
       } else if constexpr (EPI == APLA_EPI_MUL) {
-        Vec8IO<bf16>::store((bf16*)p.C + (size_t)m * p.ldc + n, lo, hi);
+        Vec8IO<bf16>::store(c_at(m, n), lo, hi);
       } else if constexpr (EPI == APLA_EPI_GELU) {
         f32x4 hl, hh, gl, gh;
 #pragma unroll
@@ -224,13 +232,13 @@ __device__ __forceinline__ void persist_epilogue(const GemmParams& p, f32x4 (&ac
           gelu_and_grad(lo[e], a, b); hl[e] = a; gl[e] = b;
           gelu_and_grad(hi[e], a, b); hh[e] = a; gh[e] = b;
         }
-        Vec8IO<bf16>::store((bf16*)p.C + (size_t)m * p.ldc + n, hl, hh);
+        Vec8IO<bf16>::store(c_at(m, n), hl, hh);
         Vec8IO<bf16>::store((bf16*)p.aux_out + (size_t)m * p.ld_aux_out + n, gl, gh);
       } else if constexpr (EPI == APLA_EPI_GELU_FWD) {
         f32x4 hl, hh;
 #pragma unroll
         for (int e = 0; e < 4; ++e) { hl[e] = gelu_only(lo[e]); hh[e] = gelu_only(hi[e]); }
-        Vec8IO<bf16>::store((bf16*)p.C + (size_t)m * p.ldc + n, hl, hh);
+        Vec8IO<bf16>::store(c_at(m, n), hl, hh);
       } else if constexpr (EPI == APLA_EPI_SWIGLU) {
         // columns come in (x1_i, x2_i) pairs: 8 columns = 4 hidden units
         Vec8IO<bf16>::store((bf16*)p.aux_out + (size_t)m * p.ld_aux_out + n, lo, hi);

@@ -314,6 +314,11 @@ class AplaTrainEngine:
         self.ln_out = e(M, D)
         self.branch = e(M, D)  # bf16 branch output (projection / fc2) awaiting the fused residual add
         self.h = e(M, self.blocks[0].F)
+        # fc1's output h and dfc2's product go straight to a plain-store GEMM (fc2, dfc1): where both sides allow it they are
+        # written as K-panel images by the producing epilogue (ops.gemm_nt with a 3-D `out`) and read as such
+        F, use = self.blocks[0].F, os.environ.get("APLA_W_PANELS", "1") != "0" and not self.swiglu
+        self.h_img = use and ops.gemm_out_image_ok(M, F, D, ops.EPI_GELU) and ops.gemm_panel_ok(M, D, F)
+        self.h_out = self.h.view(F // 32, M, 32) if self.h_img else self.h
         # last block, forward: only the CLS row of every sequence is used downstream (final norm + x[:, 0])
         self.branch_cls = e(B, D)
         self.ln_cls = e(B, D)
@@ -330,6 +335,8 @@ class AplaTrainEngine:
         self.G = torch.zeros(M, D, device=dev, dtype=self.grad_dtype)               # residual-gradient stream
         self.Gb = self.G if self.grad_dtype == ops.half() else torch.zeros(M, D, device=dev, dtype=ops.half())
         self.dact = e(M, Fsave)
+        self.dact_img = use and ops.gemm_out_image_ok(M, F, D, ops.EPI_MUL) and ops.gemm_panel_ok(M, D, F) and Fsave == F
+        self.dact_out = self.dact.view(F // 32, M, 32) if self.dact_img else self.dact
         self.dln = e(M, D)
         self.dO = e(M, D)
         self.dqkv = e(M, 3 * D)
@@ -431,13 +438,13 @@ class AplaTrainEngine:
             if self.swiglu:
                 ops.gemm_nt(self.ln_out, st.W12, st.b12, epilogue=ops.EPI_SWIGLU, aux_out=self.act_saved[i], out=self.h)
             elif inference:
-                ops.gemm_nt(self.ln_out, st.Wfc1, st.bfc1, epilogue=ops.EPI_GELU_FWD, out=self.h)
+                ops.gemm_nt(self.ln_out, st.Wfc1, st.bfc1, epilogue=ops.EPI_GELU_FWD, out=self.h_out)
             else:
-                ops.gemm_nt(self.ln_out, st.Wfc1, st.bfc1, epilogue=ops.EPI_GELU, aux_out=self.act_saved[i], out=self.h)
+                ops.gemm_nt(self.ln_out, st.Wfc1, st.bfc1, epilogue=ops.EPI_GELU, aux_out=self.act_saved[i], out=self.h_out)
             if ev is not None:
                 e1.record()
                 ev.append((e0, e1))
-            ops.gemm_nt(self.h, st.Wout_i, st.bout, out=self.branch, tag=ops.TAG_FC2)
+            ops.gemm_nt(self.h_out, st.Wout_i, st.bout, out=self.branch, tag=ops.TAG_FC2)
         # final norm on the CLS rows only (vit.py:416-419) with the last residual add fused, fp32 head + mean CE
         ops.layernorm_fwd(self.xmid[self.L - 1], self.gf, self.bf_, self.eps, out=self.xn, mean=self.meanf, rstd=self.rstdf,
                           rows=B, row_stride=N * D, add=self.branch_cls if self.cls_only_tail else self.branch,
@@ -526,8 +533,8 @@ class AplaTrainEngine:
             ops.gemm_nt(self.Gb, st.WoutT, None, epilogue=ops.EPI_SWIGLU_BWD, aux_in=self.act_saved[i], out=self.dact)
             ops.gemm_nt(self.dact, st.Wdfc1_i, None, out=self.dln, tag=ops.TAG_DFC1)
         else:
-            ops.gemm_nt(self.Gb, st.WoutT, None, epilogue=ops.EPI_MUL, aux_in=self.act_saved[i], out=self.dact)
-            ops.gemm_nt(self.dact, st.Wdfc1_i, None, out=self.dln, tag=ops.TAG_DFC1)
+            ops.gemm_nt(self.Gb, st.WoutT, None, epilogue=ops.EPI_MUL, aux_in=self.act_saved[i], out=self.dact_out)
+            ops.gemm_nt(self.dact_out, st.Wdfc1_i, None, out=self.dln, tag=ops.TAG_DFC1)
         dyg = (self.dyg_all[i] if self.dw_batch > 1 else self.dyg)[:M * st.r_pad].view(M, st.r_pad)
         ops.layernorm_bwd(self.dln, self.xmid[i], st.g2, self.mean2[i], self.rstd2[i], dres=self.G, out=self.G,
                           out_bf16=copy, inds=st.inds, r=st.r_pad, gathered=dyg)

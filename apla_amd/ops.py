@@ -92,6 +92,11 @@ def k_panels(m: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def gemm_out_image_ok(M: int, N: int, K: int, epilogue: int, out_dtype=None) -> bool:
+    """May this problem write its output as a K-panel image? (apla_gemm_nt_out_image_ok)"""
+    return bool(lib().apla_gemm_nt_out_image_ok(M, N, K, epilogue, _DT[out_dtype or half()]))
+
+
 def gemm_panel_ok(M: int, N: int, K: int, epilogue: int = 0, out_dtype=None) -> bool:
     """May this problem take K-panel operand images? (apla_gemm_nt_panel_ok)"""
     return bool(lib().apla_gemm_nt_panel_ok(M, N, K, epilogue, _DT[out_dtype or half()]))
@@ -115,7 +120,8 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = Non
             out: Optional[torch.Tensor] = None, out_dtype=None, aux_in: Optional[torch.Tensor] = None,
             aux_out: Optional[torch.Tensor] = None, tag: int = 0) -> torch.Tensor:
     """out[M,Nout] = epilogue(a[M,K] @ w[N,K]^T + bias).  See include/apla_hip.h:apla_gemm_nt / apla_gemm_nt_ex (`tag`: profiling
-    tag of the call site, TAG_*).  A 3-D contiguous operand [K/32, rows, 32] is taken as its K-panel image (k_panels())."""
+    tag of the call site, TAG_*).  A 3-D contiguous operand [K/32, rows, 32] is taken as its K-panel image (k_panels()); a 3-D `out`
+    [N/32, M, 32] is written as one (GELU / GELU_FWD / MUL epilogues)."""
     _req(a, half(), "a", None), _req(w, half(), "w", None)
     panel = 0
     if w.ndim == 3:
@@ -141,9 +147,17 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = Non
     n_out = {EPI_SWIGLU: N // 2, EPI_SWIGLU_BWD: 2 * N}.get(epilogue, N)
     if out is None:
         out = torch.empty(M, n_out, device=a.device, dtype=out_dtype or half())
-    _req(out, None, "out", 2)
-    if out.shape != (M, n_out):
-        raise ValueError(f"gemm_nt: out shape {tuple(out.shape)} != {(M, n_out)}")
+    ldc = None
+    if out.ndim == 3:   # the output as a K-panel image [n_out/32, M, 32]: the A operand of the next GEMM
+        _req(out, half(), "out", 3)
+        if tuple(out.shape) != (n_out // 32, M, 32) or n_out % 32 or not out.is_contiguous():
+            raise ValueError(f"gemm_nt: an output image is a contiguous [{n_out // 32}, {M}, 32] tensor")
+        panel, ldc = panel | 4, n_out
+    else:
+        _req(out, None, "out", 2)
+        if out.shape != (M, n_out):
+            raise ValueError(f"gemm_nt: out shape {tuple(out.shape)} != {(M, n_out)}")
+        ldc = out.stride(0)
     ld_in = ld_out = 0
     if aux_in is not None:
         _req(aux_in, None, "aux_in", 2)
@@ -168,7 +182,7 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = Non
         raise TypeError("gemm_nt: this epilogue writes bf16")
     if epilogue == EPI_GELU_FWD and aux_out is not None:
         raise ValueError("gemm_nt: EPI_GELU_FWD saves nothing (use EPI_GELU to get gelu')")
-    rc = lib().apla_gemm_nt_ex(a.data_ptr(), lda, w.data_ptr(), ldw, _ptr(bias), out.data_ptr(), out.stride(0), M, N, K,
+    rc = lib().apla_gemm_nt_ex(a.data_ptr(), lda, w.data_ptr(), ldw, _ptr(bias), out.data_ptr(), ldc, M, N, K,
                                epilogue, _DT[out.dtype], _ptr(aux_in), ld_in, _ptr(aux_out), ld_out,
                                (int(tag) & 0xff) | (_GEMM_VARIANT << 8) | (panel << 16), _stream())
     check(rc, "apla_gemm_nt")

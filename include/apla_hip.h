@@ -78,8 +78,12 @@ int apla_gemm_nt(const void* A, int lda, const void* W, int ldw, const float* bi
  *              whole lines does (64 vs 115-129 GB/s per CU, tools/dma_probe.hip); in the panel image the 16 rows' 64 bytes are
  *              1 KB contiguous.  Same results bit for bit; the six STORE shapes of config 2 run 2-9 % faster with W as an
  *              image and 2-9 % more with A too.  Ping-pong kernel only: apla_gemm_nt_panel_ok(M, N, K, epilogue, out_dtype)
- *              tells whether a problem is covered (it is an error to pass an image otherwise). */
+ *              tells whether a problem is covered (it is an error to pass an image otherwise).
+ *   bit 18     the OUTPUT C [M, N] is written as its K-panel image [N/32][M][32] (`ldc` not read): 16-bit GELU / GELU_FWD / MUL
+ *              epilogues with row-major operands (they run on the 4-wave persistent kernel), so that fc1's h and dfc2's
+ *              product reach the next GEMM (fc2, dfc1) as images without a conversion pass. */
 int apla_gemm_nt_panel_ok(int M, int N, int K, int epilogue, int out_dtype);
+int apla_gemm_nt_out_image_ok(int M, int N, int K, int epilogue, int out_dtype);   /* bit 18: is the image store available AND on the kernel the automatic schedule picks? */
 /* dst[(k / 32) * rows + r][k % 32] = src[r][k] for a 16-bit [rows, K] matrix with row pitch ld (K % 32 == 0): the K-panel image */
 int apla_pack_k_panels(const void* src, long ld, void* dst, int rows, int K, hipStream_t stream);
 int apla_gemm_nt_ex(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int M, int N,

@@ -452,6 +452,22 @@ def test_gemm_k_panel_images(ops, M, N, K):
     h0 = ops.gemm_nt(A, W, bias, epilogue=ops.EPI_GELU, aux_out=g0)
     h1 = ops.gemm_nt(A, Wi, bias, epilogue=ops.EPI_GELU, aux_out=g1)
     assert torch.equal(h0, h1) and torch.equal(g0, g1)
+    # the output written as an image (GELU / MUL epilogues of the 4-wave kernel) = k_panels of the row-major output, also when it
+    # feeds the next GEMM as its A operand
+    hi_ = torch.empty(N // 32, M, 32, device="cuda", dtype=torch.bfloat16)
+    g2 = torch.empty_like(g0)
+    ops.gemm_nt(A, W, bias, epilogue=ops.EPI_GELU, aux_out=g2, out=hi_)
+    assert torch.equal(hi_, ops.k_panels(h0)) and torch.equal(g2, g0)
+    ops.gemm_nt(A, W, bias, epilogue=ops.EPI_GELU_FWD, out=hi_.zero_())
+    assert torch.equal(hi_, ops.k_panels(h0))
+    mref = ops.gemm_nt(A, W, None, epilogue=ops.EPI_MUL, aux_in=g0)
+    ops.gemm_nt(A, W, None, epilogue=ops.EPI_MUL, aux_in=g0, out=hi_.zero_())
+    assert torch.equal(hi_, ops.k_panels(mref))
+    w2, _ = bf(rnd(256, N, scale=N ** -0.5, seed=94))
+    W2 = dev(w2)
+    assert torch.equal(ops.gemm_nt(hi_, ops.k_panels(W2)), ops.gemm_nt(mref, W2))
+    with pytest.raises(AplaHipError):
+        ops.gemm_nt(A, W, bias, out=hi_)          # plain STORE has no output image
     # not covered: an operand epilogue, N not a multiple of 256, fewer than four 32-wide K-steps
     assert not ops.gemm_panel_ok(M, 128, K) and not ops.gemm_panel_ok(M, N, K, ops.EPI_MUL)
     with pytest.raises(AplaHipError):
