@@ -18,7 +18,9 @@ struct GemmParams {
                 // [K/32][M][32].  In that image the 64 bytes a row gives to a 32-wide K-step sit next to its neighbours' (whole
                 // 128-byte lines per LDS-DMA instruction: tools/dma_probe.hip); ping-pong kernel only.  Bit 2 = the OUTPUT C is
                 // written as its K-panel image [N/32][M][32] (16-bit, 4-wave persistent kernel: GELU / GELU_FWD / MUL), ready to be
-                // the A operand of the next GEMM.
+                // the A operand of the next GEMM.  Bit 3 = the second operand of the epilogue (aux_out of GELU, aux_in of MUL: gelu'
+                // saved by the forward for the backward) is an image [N/32][M][32] too: a tensor private to those two epilogues,
+                // stored and loaded in whole lines instead of 64-byte row pieces.
   int tag;   // profiling tag (apla_gemm_nt_tagged): selects one of several identical kernel instantiations so that a rocprofv3
              // kernel trace tells the call sites of the step apart (qkv / proj / fc2 / dfc1 / dproj / dqkv …); 0 = untagged
 };
@@ -162,6 +164,11 @@ __device__ __forceinline__ void asm_load_row2(AuxRegs<float>& a0, AuxRegs<float>
                "global_load_dwordx4 %2, %4, off offset:128\n\tglobal_load_dwordx4 %3, %4, off offset:144"
                : "=&v"(a0.lo), "=&v"(a0.hi), "=&v"(a1.lo), "=&v"(a1.hi) : "v"(p) : "memory");
 }
+__device__ __forceinline__ void asm_load_2ptr(AuxRegs<bf16>& a0, AuxRegs<bf16>& a1, const bf16* p0, const bf16* p1) {
+  asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %3, off"
+               : "=&v"(a0.lo), "=&v"(a1.lo) : "v"(p0), "v"(p1) : "memory");
+}
+__device__ __forceinline__ void asm_load_2ptr(AuxRegs<float>&, AuxRegs<float>&, const float*, const float*) {}  // (no fp32 image)
 __device__ __forceinline__ void asm_load_row2(AuxRegs<bf16>& a0, AuxRegs<bf16>& a1, const bf16* p) {
   asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:64"
                : "=&v"(a0.lo), "=&v"(a1.lo) : "v"(p) : "memory");
@@ -197,7 +204,12 @@ __device__ __forceinline__ void persist_epilogue(const GemmParams& p, f32x4 (&ac
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       const int mr = mrow[i] < p.M ? mrow[i] : p.M - 1;
-      asm_load_row2(aux[i][0], aux[i][1], (const AuxT*)p.aux_in + (size_t)mr * p.ld_aux_in + n0 + ncol);
+      if (EPI == APLA_EPI_MUL && (p.w_panel & 8)) {   // image: the two 8-column pieces of a row sit in consecutive panels
+        const AuxT* q = (const AuxT*)p.aux_in + ((size_t)((n0 + ncol) >> 5) * p.M + mr) * 32 + ((n0 + ncol) & 31);
+        asm_load_2ptr(aux[i][0], aux[i][1], q, q + (size_t)p.M * 32);
+      } else {
+        asm_load_row2(aux[i][0], aux[i][1], (const AuxT*)p.aux_in + (size_t)mr * p.ld_aux_in + n0 + ncol);
+      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
@@ -233,7 +245,7 @@ __device__ __forceinline__ void persist_epilogue(const GemmParams& p, f32x4 (&ac
           gelu_and_grad(hi[e], a, b); hh[e] = a; gh[e] = b;
         }
         Vec8IO<bf16>::store(c_at(m, n), hl, hh);
-        Vec8IO<bf16>::store((bf16*)p.aux_out + (size_t)m * p.ld_aux_out + n, gl, gh);
+        Vec8IO<bf16>::store((bf16*)p.aux_out + ((p.w_panel & 8) ? ((size_t)(n >> 5) * p.M + m) * 32 + (n & 31) : (size_t)m * p.ld_aux_out + n), gl, gh);
       } else if constexpr (EPI == APLA_EPI_GELU_FWD) {
         f32x4 hl, hh;
 #pragma unroll

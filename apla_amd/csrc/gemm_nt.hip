@@ -310,7 +310,7 @@ int launch(const GemmParams& p, int g_variant, hipStream_t stream) {
   // (measured limit of that rule: the two-output GELU epilogue at M = 58 496, the packed student batch of the self-supervised
   // step — 719 MB of stores per launch — runs 480 us on the persistent kernel against 423 us on the ping-pong kernel, while the
   // one-output GELU_FWD and MUL do not care: above 40 000 rows GELU goes back to the ping-pong kernel)
-  if (p.w_panel & 4) {  // output image: the 4-wave persistent kernel's GELU / GELU_FWD / MUL epilogues (checked by gemm_nt_impl)
+  if (p.w_panel & 12) {  // output / second-operand image: the 4-wave persistent kernel's GELU / GELU_FWD / MUL epilogues (checked by gemm_nt_impl)
     return launch_persist<EPI, OutT, 5>(p, stream);
   }
   if (p.w_panel) {  // K-panel operand images exist on the ping-pong kernel only (gemm_nt_impl checked that it covers the problem)
@@ -345,10 +345,11 @@ static int gemm_nt_impl(const void* A, int lda, const void* W, int ldw, const fl
   APLA_REQUIRE(M > 0 && N > 0 && K > 0, "apla_gemm_nt: empty problem M=%d N=%d K=%d", M, N, K);
   APLA_REQUIRE(N % BN == 0 && K % BK == 0, "apla_gemm_nt: need N%%128==0 and K%%64==0 (N=%d K=%d)", N, K);
   APLA_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && ((w_panel & 2) || lda >= K) && ((w_panel & 1) || ldw >= K), "apla_gemm_nt: bad lda/ldw (%d,%d) K=%d", lda, ldw, K);
-  if (w_panel & 4) {
+  if (w_panel & 12) {
     APLA_REQUIRE((w_panel & 3) == 0 && out_dtype == APLA_H16 && N % 32 == 0 &&
                  (epilogue == APLA_EPI_GELU || epilogue == APLA_EPI_GELU_FWD || epilogue == APLA_EPI_MUL),
-                 "apla_gemm_nt_ex: an output image needs a 16-bit GELU / GELU_FWD / MUL epilogue and row-major operands");
+                 "apla_gemm_nt_ex: an output / second-operand image needs a 16-bit GELU / GELU_FWD / MUL epilogue and row-major operands");
+    APLA_REQUIRE(!(w_panel & 8) || epilogue != APLA_EPI_GELU_FWD, "apla_gemm_nt_ex: GELU_FWD has no second operand");
   } else if (w_panel) {
     APLA_REQUIRE(apla_gemm_pp2_covers(M, N, K, (w_panel & 2) ? 32 : lda, (w_panel & 1) ? 32 : ldw, epilogue, out_dtype),
                  "apla_gemm_nt_ex: K-panel operand images need the ping-pong kernel (STORE / GELU, N %% 256 == 0, K %% 32 == 0, K >= 128): ask apla_gemm_nt_panel_ok first");
@@ -356,6 +357,7 @@ static int gemm_nt_impl(const void* A, int lda, const void* W, int ldw, const fl
   APLA_REQUIRE(apla_aligned16(A) && apla_aligned16(W) && apla_aligned16(C) && A && W && C, "apla_gemm_nt: pointers must be 16-byte aligned");
   APLA_REQUIRE(bias == nullptr || apla_aligned16(bias), "apla_gemm_nt: bias must be 16-byte aligned");
   APLA_REQUIRE((w_panel & 4) || ldc % 4 == 0, "apla_gemm_nt: ldc %% 4 != 0");
+  if (w_panel & 8) { ld_aux_in = ld_aux_in ? N : 0; ld_aux_out = ld_aux_out ? N : 0; }   // not read for an image; keeps the row-major checks quiet
   GemmParams p{(const bf16*)A, lda, (const bf16*)W, ldw, bias, C, ldc, aux_in, ld_aux_in, aux_out, ld_aux_out, M, N, K, N / BN, 0, w_panel,
                (tag >= 0 && tag < APLA_GEMM_TAGS) ? tag : 0};
   switch (epilogue) {
@@ -418,5 +420,5 @@ extern "C" int apla_gemm_nt_ex(const void* A, int lda, const void* W, int ldw, c
   const int tag = flags & 0xff, v = (flags >> 8) & 0xff;
   APLA_REQUIRE(v == 0 || v == 1 || v == 4 || v == 9 || v == 14 || v == 15, "apla_gemm_nt_ex: unknown schedule %d", v);
   return gemm_nt_impl(A, lda, W, ldw, bias, C, ldc, M, N, K, epilogue, out_dtype, aux_in, ld_aux_in, aux_out, ld_aux_out, tag,
-                      v == 0 ? 4 : (v == 1 ? 0 : v), stream, (flags >> 16) & 7);
+                      v == 0 ? 4 : (v == 1 ? 0 : v), stream, (flags >> 16) & 15);
 }

@@ -319,6 +319,10 @@ class AplaTrainEngine:
         F, use = self.blocks[0].F, os.environ.get("APLA_W_PANELS", "1") != "0" and not self.swiglu
         self.h_img = use and ops.gemm_out_image_ok(M, F, D, ops.EPI_GELU) and ops.gemm_panel_ok(M, D, F)
         self.h_out = self.h.view(F // 32, M, 32) if self.h_img else self.h
+        # gelu' (saved by fc1's epilogue for dfc2's) is private to those two epilogues: an image too, except in the last block,
+        # whose CLS-only backward picks rows b*N out of the row-major buffer
+        act_img = self.h_img and os.environ.get("APLA_ACT_IMG", "1") != "0"
+        self.act_io = [a.view(F // 32, M, 32) if act_img and i < L - 1 else a for i, a in enumerate(self.act_saved)]
         # last block, forward: only the CLS row of every sequence is used downstream (final norm + x[:, 0])
         self.branch_cls = e(B, D)
         self.ln_cls = e(B, D)
@@ -440,7 +444,7 @@ class AplaTrainEngine:
             elif inference:
                 ops.gemm_nt(self.ln_out, st.Wfc1, st.bfc1, epilogue=ops.EPI_GELU_FWD, out=self.h_out)
             else:
-                ops.gemm_nt(self.ln_out, st.Wfc1, st.bfc1, epilogue=ops.EPI_GELU, aux_out=self.act_saved[i], out=self.h_out)
+                ops.gemm_nt(self.ln_out, st.Wfc1, st.bfc1, epilogue=ops.EPI_GELU, aux_out=self.act_io[i], out=self.h_out)
             if ev is not None:
                 e1.record()
                 ev.append((e0, e1))
@@ -533,7 +537,7 @@ class AplaTrainEngine:
             ops.gemm_nt(self.Gb, st.WoutT, None, epilogue=ops.EPI_SWIGLU_BWD, aux_in=self.act_saved[i], out=self.dact)
             ops.gemm_nt(self.dact, st.Wdfc1_i, None, out=self.dln, tag=ops.TAG_DFC1)
         else:
-            ops.gemm_nt(self.Gb, st.WoutT, None, epilogue=ops.EPI_MUL, aux_in=self.act_saved[i], out=self.dact_out)
+            ops.gemm_nt(self.Gb, st.WoutT, None, epilogue=ops.EPI_MUL, aux_in=self.act_io[i], out=self.dact_out)
             ops.gemm_nt(self.dact_out, st.Wdfc1_i, None, out=self.dln, tag=ops.TAG_DFC1)
         dyg = (self.dyg_all[i] if self.dw_batch > 1 else self.dyg)[:M * st.r_pad].view(M, st.r_pad)
         ops.layernorm_bwd(self.dln, self.xmid[i], st.g2, self.mean2[i], self.rstd2[i], dres=self.G, out=self.G,

@@ -159,6 +159,15 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = Non
             raise ValueError(f"gemm_nt: out shape {tuple(out.shape)} != {(M, n_out)}")
         ldc = out.stride(0)
     ld_in = ld_out = 0
+    aux = aux_in if aux_in is not None else aux_out
+    if aux is not None and aux.ndim == 3:   # gelu' kept as a K-panel image [N/32, M, 32] between the GELU and MUL epilogues
+        _req(aux, half(), "aux", 3)
+        if epilogue not in (EPI_GELU, EPI_MUL) or tuple(aux.shape) != (N // 32, M, 32) or N % 32 or not aux.is_contiguous():
+            raise ValueError(f"gemm_nt: a second-operand image is a contiguous [{N // 32}, {M}, 32] tensor (GELU / MUL epilogues)")
+        panel |= 8
+        ld_in, ld_out = (N, 0) if aux_in is not None else (0, N)
+        aux_view = aux.view(M, N)       # shape bookkeeping below only
+        aux_in, aux_out = (aux_view, None) if aux_in is not None else (None, aux_view)
     if aux_in is not None:
         _req(aux_in, None, "aux_in", 2)
         need = {EPI_RESIDUAL: (M, N), EPI_MUL: (M, N), EPI_SWIGLU_BWD: (M, 2 * N)}.get(epilogue)

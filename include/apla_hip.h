@@ -81,7 +81,9 @@ int apla_gemm_nt(const void* A, int lda, const void* W, int ldw, const float* bi
  *              tells whether a problem is covered (it is an error to pass an image otherwise).
  *   bit 18     the OUTPUT C [M, N] is written as its K-panel image [N/32][M][32] (`ldc` not read): 16-bit GELU / GELU_FWD / MUL
  *              epilogues with row-major operands (they run on the 4-wave persistent kernel), so that fc1's h and dfc2's
- *              product reach the next GEMM (fc2, dfc1) as images without a conversion pass. */
+ *              product reach the next GEMM (fc2, dfc1) as images without a conversion pass.
+ *   bit 19     the epilogue's second operand (aux_out of GELU = gelu', aux_in of MUL) is an image [N/32][M][32] (`ld_aux_*` not
+ *              read): private to those two epilogues, stored and loaded in whole lines.  Same kernels and conditions as bit 18. */
 int apla_gemm_nt_panel_ok(int M, int N, int K, int epilogue, int out_dtype);
 int apla_gemm_nt_out_image_ok(int M, int N, int K, int epilogue, int out_dtype);   /* bit 18: is the image store available AND on the kernel the automatic schedule picks? */
 /* dst[(k / 32) * rows + r][k % 32] = src[r][k] for a 16-bit [rows, K] matrix with row pitch ld (K % 32 == 0): the K-panel image */

@@ -463,6 +463,13 @@ def test_gemm_k_panel_images(ops, M, N, K):
     mref = ops.gemm_nt(A, W, None, epilogue=ops.EPI_MUL, aux_in=g0)
     ops.gemm_nt(A, W, None, epilogue=ops.EPI_MUL, aux_in=g0, out=hi_.zero_())
     assert torch.equal(hi_, ops.k_panels(mref))
+    # gelu' as an image between the two epilogues that own it
+    gi = torch.empty(N // 32, M, 32, device="cuda", dtype=torch.bfloat16)
+    h3 = ops.gemm_nt(A, W, bias, epilogue=ops.EPI_GELU, aux_out=gi)
+    assert torch.equal(h3, h0) and torch.equal(gi, ops.k_panels(g0))
+    assert torch.equal(ops.gemm_nt(A, W, None, epilogue=ops.EPI_MUL, aux_in=gi), mref)
+    ops.gemm_nt(A, W, None, epilogue=ops.EPI_MUL, aux_in=gi, out=hi_.zero_())
+    assert torch.equal(hi_, ops.k_panels(mref))
     w2, _ = bf(rnd(256, N, scale=N ** -0.5, seed=94))
     W2 = dev(w2)
     assert torch.equal(ops.gemm_nt(hi_, ops.k_panels(W2)), ops.gemm_nt(mref, W2))
