@@ -9,6 +9,7 @@ O=gpurun_out/round
 rm -rf $O && mkdir -p $O
 python -m pytest tests -m gpu -q -p no:cacheprovider > $O/pytest_gpu.txt 2>&1; tail -3 $O/pytest_gpu.txt
 tools/mfma_peak 1.0 > $O/mfma_peak.json 2>&1
+[ -x tools/dma_probe ] && tools/dma_probe > $O/dma_probe.txt 2>&1
 python bench.py > $O/bench.json 2> $O/bench.err; tail -c 1500 $O/bench.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-parity --no-peak-probe > $O/trace_bench.log 2>&1
 python3 tools/summarize_prof.py $(find $O/trace -name "*kernel_stats.csv") 14 --cfg2 > $O/kernel_stats.md
