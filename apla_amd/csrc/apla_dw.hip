@@ -93,8 +93,12 @@ __global__ __launch_bounds__(256) void proj_dw_partial_kernel(DwIn in, int nb, i
   // residue mod 8, so the slab's dyg and x rows are fetched from HBM once and shared through that XCD's L2.
   const int tiles_k = D / TK, tiles = tiles_k * (r / (TJ * NJ));
   const int xcd = blockIdx.x & 7, n = blockIdx.x >> 3;
-  const int tile = n % tiles, unit = (n / tiles) * 8 + xcd, U = nb * S;
-  if (unit >= U) return;
+  const int U = nb * S;
+  // (a problem with hundreds of output tiles and a single slab — r = 65 536 prototypes x a few thousand token rows — has nothing to
+  // share through an L2: its tiles are dealt to the XCDs one by one; grid = tiles then)
+  const bool flat = U == 1;
+  const int tile = flat ? blockIdx.x : n % tiles, unit = flat ? 0 : (n / tiles) * 8 + xcd;
+  if (unit >= U || tile >= tiles) return;
   const int layer = unit / S, slab = unit - layer * S;
   const bf16* __restrict__ dyg = in.dyg[layer];
   const bf16* __restrict__ x = in.x[layer];
@@ -299,6 +303,7 @@ inline int dw_group(int r) { return r % 192 == 0 ? 3 : (r % 128 == 0 ? 2 : 1); }
 inline int dw_slabs(int M, int r, int D, int nb = 1) {
   const int tiles = (r / (TJ * dw_group(r))) * (D / TK);
   int S = 256 / tiles / 8 * 8;  // a multiple of 8 (one slab set per XCD), at most one workgroup per CU
+  if (tiles >= 256) return 1;   // more output tiles than CUs: no token split (every slab would cost an r x D fp32 partial)
   if (nb > 1) {                 // units = nb * S are dealt to the XCDs one by one: any S, still at most one workgroup per CU
     S = 256 / (tiles * nb);
     const int max_s = (M + TM - 1) / TM;
@@ -391,7 +396,7 @@ extern "C" int apla_proj_dw_batched(int nb, const void* const* dyg, const void* 
   const int S = dw_slabs(M, r, D, nb), U = nb * S;
   int rows_per_slab = ((M + S - 1) / S + TM - 1) / TM * TM;
   const int nj = dw_group(r);
-  const dim3 grid(8 * ((U + 7) / 8) * (r / (TJ * nj)) * (D / TK));
+  const dim3 grid(U == 1 ? (r / (TJ * nj)) * (D / TK) : 8 * ((U + 7) / 8) * (r / (TJ * nj)) * (D / TK));
   if (nj == 3) hipLaunchKernelGGL(proj_dw_partial_kernel<3>, grid, dim3(256), 0, stream, in, nb, ldx, (float*)partial, M, r, D, rows_per_slab, S);
   else if (nj == 2) hipLaunchKernelGGL(proj_dw_partial_kernel<2>, grid, dim3(256), 0, stream, in, nb, ldx, (float*)partial, M, r, D, rows_per_slab, S);
   else hipLaunchKernelGGL(proj_dw_partial_kernel<1>, grid, dim3(256), 0, stream, in, nb, ldx, (float*)partial, M, r, D, rows_per_slab, S);

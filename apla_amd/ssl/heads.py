@@ -3,8 +3,9 @@
 * ``DINOHead`` — self_supervised/dinov2/layers/dino_head.py:12-40: 3-layer MLP (GELU), L2-normalised bottleneck,
   weight-normalised prototype layer with the norm frozen at 1.  Same parameter names (``mlp.{0,2,4}.{weight,bias}``,
   ``last_layer.weight_g / weight_v``).  The products run on the HIP GEMM (`apla_gemm_nt`); the weight gradients of the
-  three MLP layers on the TN MFMA kernel (`apla_proj_dw`), and the [K, 256] prototype gradient — a plain GEMM with the few
-  hundred token rows as its reduction axis — on the vendor library (fp32), as plain library GEMMs may.
+  three MLP layers and the [K, 256] prototype gradient (the few thousand token rows are its reduction axis) on the TN MFMA kernel
+  (`apla_proj_dw`: dW = dy^T x with fp32 accumulation; round 1 ran the prototype gradient as an fp32 vendor GEMM, 1.3 ms per
+  iteration).
 * ``KoLeoLoss`` — dinov2/loss/koleo_loss.py:17-45 (a [B, B] nearest-neighbour search on the CLS tokens: torch ops, fp32).
 * ``update_teacher`` — dinov2/models.py:443-453: teacher = m * teacher + (1 - m) * student over the trainable tensors.
 """
@@ -17,7 +18,7 @@ from .. import ops
 
 
 class _ProtoLinear(torch.autograd.Function):
-    """y = x @ W^T for the [K, 256] prototype matrix: forward and dX on the MFMA GEMM, dW = dy^T x on the vendor GEMM."""
+    """y = x @ W^T for the [K, 256] prototype matrix: forward and dX on the MFMA GEMM, dW = dy^T x on the TN MFMA kernel."""
 
     @staticmethod
     def forward(ctx, x, W):
@@ -33,7 +34,14 @@ class _ProtoLinear(torch.autograd.Function):
         x2, Wh = ctx.saved_tensors
         dy2 = AF._as2d_bf16(dy)
         dx = ops.gemm_nt(dy2, Wh.t().contiguous()).reshape(ctx.shape) if ctx.needs_input_grad[0] else None
-        dW = torch.mm(dy2.float().t(), x2.float()) if ctx.needs_input_grad[1] else None
+        dW = None
+        if ctx.needs_input_grad[1]:
+            K, Din = Wh.shape
+            if K % 64 == 0 and Din % 128 == 0:
+                dW = torch.empty(K, Din, device=dy2.device, dtype=torch.float32)
+                ops.proj_dw(dy2, x2, dW, torch.empty(K, device=dy2.device, dtype=torch.float32))
+            else:   # shapes the TN kernel does not take
+                dW = torch.mm(dy2.float().t(), x2.float())
         return dx, dW
 
 

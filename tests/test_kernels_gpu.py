@@ -257,7 +257,7 @@ def test_attention_online_softmax_rescale_branch(ops, attn_variant):
 
 
 # ------------------------------------------------------------------------------------------- APLA dW / pack
-@pytest.mark.parametrize("M,r,D", [(1000, 64, 128), (197 * 8, 64, 384), (64, 128, 256), (25216, 192, 768)])
+@pytest.mark.parametrize("M,r,D", [(1000, 64, 128), (197 * 8, 64, 384), (64, 128, 256), (25216, 192, 768), (300, 16384, 256)])
 def test_proj_dw(ops, M, r, D):
     dyg, dygd = bf(rnd(M, r, seed=41))
     x, xd = bf(rnd(M, D, seed=42))
