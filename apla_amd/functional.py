@@ -8,6 +8,7 @@ the parameter's version counter.  No function has a CPU path: CPU tensors raise 
 
 The fused whole-step path (apla_amd/engine.py) does not use autograd at all.
 """
+import os
 import weakref
 
 import torch
@@ -64,6 +65,18 @@ def w_bf16_t(p):
 
 def b_f32(p):
     return None if p is None else CACHE.get(p, "f32", lambda: p.detach().float().contiguous())
+
+
+_IMAGES = os.environ.get("APLA_W_PANELS", "1") != "0"
+
+
+def _img(p, kind: str, make, M: int):
+    """The K-panel image (ops.k_panels) of a cached 16-bit weight copy for a plain-store GEMM with M rows, where the ping-pong
+    kernel covers the problem; else the row-major copy.  Cached like the copy itself (a frozen weight is converted once)."""
+    w = CACHE.get(p, kind, make)
+    if not (_IMAGES and ops.gemm_panel_ok(M, w.shape[0], w.shape[1])):
+        return w
+    return CACHE.get(p, kind + "_img", lambda: ops.k_panels(w))
 
 
 def _as2d_bf16(x):
@@ -142,7 +155,7 @@ class _LinearFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         _require_cuda(x, "linear")
         x2 = _as2d_bf16(x)
-        y = ops.gemm_nt(x2, w_bf16(weight), b_f32(bias))
+        y = ops.gemm_nt(x2, _img(weight, "bf16", lambda: weight.detach().to(_BF).contiguous(), x2.shape[0]), b_f32(bias))
         ctx.save_for_backward(x2, weight, bias if bias is not None else torch.empty(0))
         ctx.has_bias = bias is not None
         ctx.shape = x.shape
@@ -152,7 +165,9 @@ class _LinearFn(torch.autograd.Function):
     def backward(ctx, dy):
         x2, weight, bias = ctx.saved_tensors
         dy2 = _as2d_bf16(dy)
-        dx = ops.gemm_nt(dy2, w_bf16_t(weight)).reshape(ctx.shape) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.gemm_nt(dy2, _img(weight, "bf16_t", lambda: weight.detach().t().to(_BF).contiguous(), dy2.shape[0])).reshape(ctx.shape)
         dW = db = None
         if weight.requires_grad:
             dW = torch.empty(weight.shape, device=dy.device, dtype=torch.float32)
@@ -321,14 +336,31 @@ def _scaled_b(b, gamma):
     return None if b is None else CACHE.get(b, f"f32_g{id(gamma)}_{gamma._version}", lambda: (b.detach().float() * gamma.detach().float()).contiguous())
 
 
+def _hidden_buffer(M, F, n_next, epilogue, device):
+    """Output buffer of the MLP's first GEMM of a pass ([M, F], epilogue GELU / GELU_FWD / MUL) whose only reader is a plain-store
+    GEMM with n_next outputs: a K-panel image [F/32, M, 32] where the producing epilogue can write one and the consumer reads one."""
+    if _IMAGES and ops.gemm_out_image_ok(M, F, n_next, epilogue) and ops.gemm_panel_ok(M, n_next, F):
+        return torch.empty(F // 32, M, 32, device=device, dtype=_BF)
+    return torch.empty(M, F, device=device, dtype=_BF)
+
+
+def _fc2_weight(w2, gamma, M):
+    if gamma is None:
+        return _img(w2, "bf16", lambda: w2.detach().to(_BF).contiguous(), M)
+    return _img(w2, f"bf16_g{id(gamma)}_{gamma._version}",
+                lambda: (w2.detach().float() * gamma.detach().float()[:, None]).to(_BF).contiguous(), M)
+
+
 class _MlpGeluFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, gamma):
         _require_cuda(x, "mlp")
         x2 = _as2d_bf16(x)
-        gp = torch.empty(x2.shape[0], w1.shape[0], device=x.device, dtype=_BF)
-        h = ops.gemm_nt(x2, w_bf16(w1), b_f32(b1), epilogue=ops.EPI_GELU, aux_out=gp)
-        y = ops.gemm_nt(h, w_bf16(w2), b_f32(b2)) if gamma is None else ops.gemm_nt(h, _scaled_w(w2, gamma), _scaled_b(b2, gamma))
+        M, F = x2.shape[0], w1.shape[0]
+        gp = torch.empty(M, F, device=x.device, dtype=_BF)
+        h = _hidden_buffer(M, F, w2.shape[0], ops.EPI_GELU, x.device)   # a K-panel image where fc1's epilogue can write one
+        ops.gemm_nt(x2, w_bf16(w1), b_f32(b1), epilogue=ops.EPI_GELU, aux_out=gp, out=h)
+        y = ops.gemm_nt(h, _fc2_weight(w2, gamma, M), b_f32(b2) if gamma is None else _scaled_b(b2, gamma))
         ctx.save_for_backward(gp, w1, w2, gamma if gamma is not None else torch.empty(0))
         ctx.shape, ctx.has_gamma = x.shape, gamma is not None
         return y.reshape(x.shape[:-1] + (w2.shape[0],))
@@ -339,8 +371,10 @@ class _MlpGeluFn(torch.autograd.Function):
         if w1.requires_grad or w2.requires_grad or (ctx.has_gamma and gamma.requires_grad):
             raise NotImplementedError("trainable MLP weights / LayerScale are outside the APLA path")
         w2t = _scaled_w_t(w2, gamma) if ctx.has_gamma else w_bf16_t(w2)
-        da = ops.gemm_nt(_as2d_bf16(dy), w2t, epilogue=ops.EPI_MUL, aux_in=gp)
-        dx = ops.gemm_nt(da, w_bf16_t(w1))
+        M, F = gp.shape
+        da = _hidden_buffer(M, F, w1.shape[1], ops.EPI_MUL, dy.device)
+        ops.gemm_nt(_as2d_bf16(dy), w2t, epilogue=ops.EPI_MUL, aux_in=gp, out=da)
+        dx = ops.gemm_nt(da, _img(w1, "bf16_t", lambda: w1.detach().t().to(_BF).contiguous(), M))
         return dx.reshape(ctx.shape), None, None, None, None, None
 
 
@@ -349,8 +383,11 @@ def mlp_gelu(x, w1, b1, w2, b2, gamma=None):
     autograd (evaluation, the EMA teacher) fc1 runs the forward-only GELU epilogue: GELU' is neither computed nor stored."""
     if not torch.is_grad_enabled():
         _require_cuda(x, "mlp")
-        h = ops.gemm_nt(_as2d_bf16(x), w_bf16(w1), b_f32(b1), epilogue=ops.EPI_GELU_FWD)
-        y = ops.gemm_nt(h, w_bf16(w2), b_f32(b2)) if gamma is None else ops.gemm_nt(h, _scaled_w(w2, gamma), _scaled_b(b2, gamma))
+        x2 = _as2d_bf16(x)
+        M, F = x2.shape[0], w1.shape[0]
+        h = _hidden_buffer(M, F, w2.shape[0], ops.EPI_GELU_FWD, x.device)
+        ops.gemm_nt(x2, w_bf16(w1), b_f32(b1), epilogue=ops.EPI_GELU_FWD, out=h)
+        y = ops.gemm_nt(h, _fc2_weight(w2, gamma, M), b_f32(b2) if gamma is None else _scaled_b(b2, gamma))
         return y.reshape(x.shape[:-1] + (w2.shape[0],)).to(x.dtype)
     return _MlpGeluFn.apply(x, w1, b1, w2, b2, gamma).to(x.dtype)
 
