@@ -399,8 +399,13 @@ extern "C" int apla_gemm_nt(const void* A, int lda, const void* W, int ldw, cons
   return gemm_nt_impl(A, lda, W, ldw, bias, C, ldc, M, N, K, epilogue, out_dtype, aux_in, ld_aux_in, aux_out, ld_aux_out, 0, 4, stream);
 }
 
+// Should this problem be given K-panel operand images?  Yes where the ping-pong kernel covers it AND is what the automatic
+// schedule runs it on (plain STORE from 2048 rows, the two-output GELU above 40 000 rows: see `launch`); an image passed anyway is
+// accepted wherever the kernel covers the problem, and forces it.
 extern "C" int apla_gemm_nt_panel_ok(int M, int N, int K, int epilogue, int out_dtype) {
-  return (M > 0 && apla_gemm_pp2_covers(M, N, K, 32, 32, epilogue, out_dtype)) ? 1 : 0;
+  if (M <= 0 || !apla_gemm_pp2_covers(M, N, K, 32, 32, epilogue, out_dtype)) return 0;
+  if (epilogue == APLA_EPI_STORE) return M >= 2048 ? 1 : 0;
+  return (epilogue == APLA_EPI_GELU && M > 40000) ? 1 : 0;
 }
 
 // May (and should) this problem write its output as a K-panel image?  Yes where the automatic schedule runs it on the 4-wave

@@ -359,7 +359,10 @@ class _MlpGeluFn(torch.autograd.Function):
         M, F = x2.shape[0], w1.shape[0]
         gp = torch.empty(M, F, device=x.device, dtype=_BF)
         h = _hidden_buffer(M, F, w2.shape[0], ops.EPI_GELU, x.device)   # a K-panel image where fc1's epilogue can write one
-        ops.gemm_nt(x2, w_bf16(w1), b_f32(b1), epilogue=ops.EPI_GELU, aux_out=gp, out=h)
+        w1h = w_bf16(w1)
+        if _IMAGES and ops.gemm_panel_ok(M, F, w1.shape[1], ops.EPI_GELU):   # the two-output GELU above 40 000 rows: ping-pong kernel
+            w1h = CACHE.get(w1, "bf16_img", lambda: ops.k_panels(w1h))
+        ops.gemm_nt(x2, w1h, b_f32(b1), epilogue=ops.EPI_GELU, aux_out=gp, out=h)
         y = ops.gemm_nt(h, _fc2_weight(w2, gamma, M), b_f32(b2) if gamma is None else _scaled_b(b2, gamma))
         ctx.save_for_backward(gp, w1, w2, gamma if gamma is not None else torch.empty(0))
         ctx.shape, ctx.has_gamma = x.shape, gamma is not None

@@ -78,7 +78,8 @@ int apla_gemm_nt(const void* A, int lda, const void* W, int ldw, const float* bi
  *              whole lines does (64 vs 115-129 GB/s per CU, tools/dma_probe.hip); in the panel image the 16 rows' 64 bytes are
  *              1 KB contiguous.  Same results bit for bit; the six STORE shapes of config 2 run 2-9 % faster with W as an
  *              image and 2-9 % more with A too.  Ping-pong kernel only: apla_gemm_nt_panel_ok(M, N, K, epilogue, out_dtype)
- *              tells whether a problem is covered (it is an error to pass an image otherwise).
+ *              tells whether a problem is covered AND runs on that kernel under the automatic schedule (an image passed anyway
+ *              forces the kernel where it covers the problem and is an error where it does not).
  *   bit 18     the OUTPUT C [M, N] is written as its K-panel image [N/32][M][32] (`ldc` not read): 16-bit GELU / GELU_FWD / MUL
  *              epilogues with row-major operands (they run on the 4-wave persistent kernel), so that fc1's h and dfc2's
  *              product reach the next GEMM (fc2, dfc1) as images without a conversion pass.

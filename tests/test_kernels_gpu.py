@@ -476,7 +476,8 @@ def test_gemm_k_panel_images(ops, M, N, K):
     with pytest.raises(AplaHipError):
         ops.gemm_nt(A, W, bias, out=hi_)          # plain STORE has no output image
     # not covered: an operand epilogue, N not a multiple of 256, fewer than four 32-wide K-steps
-    assert not ops.gemm_panel_ok(M, 128, K) and not ops.gemm_panel_ok(M, N, K, ops.EPI_MUL)
+    assert not ops.gemm_panel_ok(M, 128, K) and not ops.gemm_panel_ok(M, N, K, ops.EPI_MUL) and not ops.gemm_panel_ok(1000, N, K)
+    assert ops.gemm_panel_ok(50000, N, K, ops.EPI_GELU) and not ops.gemm_panel_ok(M, N, K, ops.EPI_GELU)
     with pytest.raises(AplaHipError):
         ops.gemm_nt(A, Wi, None, epilogue=ops.EPI_MUL, aux_in=g0)
     with pytest.raises(AplaHipError):
