@@ -29,6 +29,34 @@ def test_header_symbols_are_exported_and_bound():
     assert handle.apla_version() >= 100
 
 
+def test_host_side_queries_answer_without_a_gpu():
+    """The ABI's pure host queries (sizes, coverage of the operand-image paths) need no device: they mirror the dispatch rules
+    documented in include/apla_hip.h."""
+    from apla_amd import _lib
+    h = _lib.lib()
+    from apla_amd import ops
+    STORE, GELU, GELU_FWD, MUL = ops.EPI_STORE, ops.EPI_GELU, ops.EPI_GELU_FWD, ops.EPI_MUL
+    H16 = ops._DT[ops.half()]
+    # K-panel operand images: ping-pong kernel coverage AND the automatic schedule's rule
+    assert h.apla_gemm_nt_panel_ok(25216, 768, 3072, STORE, H16) == 1
+    assert h.apla_gemm_nt_panel_ok(1000, 768, 3072, STORE, H16) == 0          # few rows: the 4-wave kernel runs it
+    assert h.apla_gemm_nt_panel_ok(25216, 384, 384, STORE, H16) == 0          # N % 256 != 0
+    assert h.apla_gemm_nt_panel_ok(25216, 768, 64, STORE, H16) == 0           # fewer than four 32-wide K-steps
+    assert h.apla_gemm_nt_panel_ok(25216, 3072, 768, GELU, H16) == 0 and h.apla_gemm_nt_panel_ok(58496, 3072, 768, GELU, H16) == 1
+    assert h.apla_gemm_nt_panel_ok(25216, 3072, 768, MUL, H16) == 0
+    # output images: the epilogues of the 4-wave kernel, where the automatic schedule uses it
+    assert h.apla_gemm_nt_out_image_ok(25216, 3072, 768, GELU, H16) == 1 and h.apla_gemm_nt_out_image_ok(58496, 3072, 768, GELU, H16) == 0
+    assert h.apla_gemm_nt_out_image_ok(58496, 3072, 768, MUL, H16) == 1 and h.apla_gemm_nt_out_image_ok(58496, 3072, 768, GELU_FWD, H16) == 1
+    assert h.apla_gemm_nt_out_image_ok(25216, 3072, 768, STORE, H16) == 0
+    # workspaces
+    one = h.apla_dw_workspace_bytes(25216, 192, 768)
+    assert one == 40 * (192 * 768 + 192) * 4
+    six = h.apla_dw_workspace_bytes_batched(25216, 192, 768, 6)
+    assert six == 6 * 7 * (192 * 768 + 192) * 4 and h.apla_dw_workspace_bytes_batched(25216, 192, 768, 1) == one
+    assert h.apla_dw_workspace_bytes_batched(25216, 192, 768, 9) == -1 and h.apla_dw_workspace_bytes(25216, 100, 768) == -1
+    assert h.apla_dw_workspace_bytes(5519, 65536, 256) == (65536 * 256 + 65536) * 4   # more tiles than CUs: one slab
+
+
 def test_no_cpu_fallback():
     """The product path must fail loudly on CPU tensors instead of computing something else."""
     import torch
