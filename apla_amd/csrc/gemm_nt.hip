@@ -42,14 +42,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
         Vec4IO<OutT>::store((OutT*)p.C + (size_t)m * p.ldc + n, v);
       } else if constexpr (EPI == APLA_EPI_GELU) {
         f32x4 h, g;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { float hh, gg; gelu_and_grad(v[e], hh, gg); h[e] = hh; g[e] = gg; }
+        gelu_and_grad4(v, h, g);
         Vec4IO<bf16>::store((bf16*)p.C + (size_t)m * p.ldc + n, h);
         Vec4IO<bf16>::store((bf16*)p.aux_out + (size_t)m * p.ld_aux_out + n, g);
       } else if constexpr (EPI == APLA_EPI_GELU_FWD) {
         f32x4 h;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) h[e] = gelu_only(v[e]);
+        h = gelu_only4(v);
         Vec4IO<bf16>::store((bf16*)p.C + (size_t)m * p.ldc + n, h);
       } else if constexpr (EPI == APLA_EPI_RESIDUAL) {
         f32x4 r = Vec4IO<OutT>::load((const OutT*)p.aux_in + (size_t)m * p.ld_aux_in + n);

@@ -88,13 +88,11 @@ __global__ __launch_bounds__(256) void gemm_small_reduce_kernel(const float* __r
     Vec4IO<OutT>::store(C + (size_t)m * ldc + n, v);
   } else if constexpr (EPI == APLA_EPI_GELU_FWD) {
     f32x4 h;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) h[e] = gelu_only(v[e]);
+    h = gelu_only4(v);
     Vec4IO<OutT>::store(C + (size_t)m * ldc + n, h);
   } else {  // GELU: h and gelu'
     f32x4 h, g;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { float a, b; gelu_and_grad(v[e], a, b); h[e] = a; g[e] = b; }
+    gelu_and_grad4(v, h, g);
     Vec4IO<OutT>::store(C + (size_t)m * ldc + n, h);
     Vec4IO<bf16>::store(aux_out + (size_t)m * ld_out + n, g);
   }
