@@ -1,4 +1,5 @@
-// Shared pieces of the bf16 MFMA GEMM kernels (gemm_nt.hip: 128-wide tiles, gemm_wide.hip: 256-wide tiles).
+// Shared pieces of the bf16 MFMA GEMM kernels (gemm_nt.hip: 4-wave kernels, 128-wide tiles; gemm_pp2.hip: 8-wave ping-pong kernel,
+// 320 x 256 tiles; gemm_small.hip: few-row split-K).
 #pragma once
 #include <cstdlib>
 #include <type_traits>

@@ -4,7 +4,8 @@
 // linears use the frozen weight as stored by nn.Linear ([out,in]); the dX backward uses a transposed bf16 copy of the
 // same frozen weight that the engine prepares once (288 GB of HBM makes the duplicate free), so no "NN" kernel exists.
 //
-// Three schedules share the data layout, swizzles and epilogue code (gemm_common.h); apla_gemm_set_variant picks one:
+// Three schedules share the data layout, swizzles and epilogue code (gemm_common.h); the schedule is a per-call argument
+// (apla_gemm_nt_ex flags, 0 = the automatic rule in `launch` below):
 //   * gemm_pp2.hip — 8-wave ping-pong kernel, 320x256x32 tile, one workgroup per CU (STORE / GELU epilogues, large M);
 //   * gemm_persist_kernel (here) — 4 waves, (128|160)x128x64 tile, 2 persistent workgroups per CU whose LDS ring runs
 //     across tiles (no load prologue, epilogue overlapped with the next tile's LDS-DMA and with the co-resident

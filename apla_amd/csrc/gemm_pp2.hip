@@ -1,6 +1,6 @@
 // Ping-pong persistent bf16 MFMA GEMM, second generation: tile 320(M) x 256(N) x 32(K), 8 waves, one workgroup per CU.
 //
-// Same role alternation as gemm_pp.hip (two groups of four waves, one wave of each group on every SIMD; while one group
+// Role alternation of a ping-pong kernel (two groups of four waves, one wave of each group on every SIMD; while one group
 // issues its 40 MFMAs the other issues LDS-DMA and reads fragments; one s_barrier per phase), with the tile reshaped so
 // that the NON-compute phase gets cheaper than the compute phase (measured on gemm_pp: 7 LDS-DMA pieces + 18
 // ds_read_b128 per prepare phase took ~1100 cycles against 640 cycles of MFMA):
