@@ -38,7 +38,10 @@ def _strip_prefix(sd, prefix):
 def read_state_dict(path: str) -> Dict[str, torch.Tensor]:
     """A checkpoint file's weights: the ``state_dict`` entry of a session file (defaults/bases.py:456-467) or the file itself
     (a bare dinov2 / timm state dict); DDP's ``module.`` prefix removed."""
-    sd = torch.load(path, map_location="cpu", weights_only=False)
+    try:   # plain tensors first; session files that carry pickled objects (parameters / original_state) need the full loader
+        sd = torch.load(path, map_location="cpu", weights_only=True)
+    except Exception:  # noqa: BLE001  (pickle.UnpicklingError and friends)
+        sd = torch.load(path, map_location="cpu", weights_only=False)
     if isinstance(sd, dict) and "state_dict" in sd and isinstance(sd["state_dict"], dict):
         sd = sd["state_dict"]
     return _strip_prefix(sd, "module.")
@@ -74,10 +77,21 @@ def build_classifier_from_checkpoint(path: str, model_params, system_params):
         model = Classifier(model_params, system_params)
         load_apla_state_dict(model, sd)
         return model, "apla"
+    head = {k: v for k, v in sd.items() if k.startswith("fc.")}
     if any(k.startswith("backbone.") for k in sd):
         sd = {k[len("backbone."):]: v for k, v in sd.items() if k.startswith("backbone.")}
+    dropped = sorted(k for k in sd if k.startswith("fc.") or k.startswith("head."))
     sd = {k: v for k, v in sd.items() if not (k.startswith("fc.") or k.startswith("head."))}
-    return Classifier(model_params, system_params, backbone_state_dict=sd), "backbone"
+    model = Classifier(model_params, system_params, backbone_state_dict=sd)
+    # a full unsplit Classifier (``backbone.`` + ``fc.``): the reference's non-APLA branch loads the head too
+    # (utils/pretrained_loader.py:33, strict=True); a head of another shape (other class count) cannot be taken over
+    own = {"fc." + k: v for k, v in model.fc.state_dict().items()}
+    if head and set(head) == set(own) and all(tuple(head[k].shape) == tuple(own[k].shape) for k in own):
+        model.fc.load_state_dict({k[len("fc."):]: v for k, v in head.items()})
+    elif head or dropped:
+        from .dist import print_ddp
+        print_ddp(f"checkpoint: classification head keys not loaded (shape / name mismatch): {(sorted(head) or dropped)[:4]}")
+    return model, "backbone"
 
 
 def _group_order(model: torch.nn.Module):
@@ -170,4 +184,5 @@ def load_session(engine, session: dict, load_optimizer: bool = True):
         steps = float(engine.step_count)
         engine.scaler.copy_(torch.tensor([scale, tracker, steps, scale, tracker, steps, scale, 0.0]))
         engine._scaler_calls = 0
+        engine._scaler_step0 = steps   # skipped_steps counts from here (engine.skipped_steps)
     return session.get("iters", 0), session.get("epoch", 0)

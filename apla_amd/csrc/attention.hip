@@ -17,6 +17,8 @@
 
 #include <type_traits>
 
+#include <atomic>
+
 #include "common.h"
 
 #define ATT_LDSP(p) ((__attribute__((address_space(3))) void*)(p))
@@ -1410,15 +1412,31 @@ __global__ __launch_bounds__(256) void attn_bwd_cls_kernel(const bf16* __restric
 
 }  // namespace
 
-// number of CUs of the current device (persistent kernels launch one workgroup per CU); queried once
+// Per-device facts.  A process may drive several devices (one engine per device): the CU count and the "dynamic LDS limit raised"
+// marks are kept per device ordinal (hipFuncSetAttribute acts on the current device only), never process-wide.
+constexpr int APLA_MAX_DEVICES = 64;
+static int apla_current_device() {
+  int dev = 0;
+  return (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < APLA_MAX_DEVICES) ? dev : -1;
+}
+// number of CUs of the current device (persistent kernels launch one workgroup per CU); queried once per device
 static int apla_num_cus() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
-    else n = 256;
+  static std::atomic<int> n[APLA_MAX_DEVICES];
+  const int dev = apla_current_device();
+  int v = dev >= 0 ? n[dev].load(std::memory_order_relaxed) : 0;
+  if (v == 0) {
+    int q = 0;
+    v = (dev >= 0 && hipDeviceGetAttribute(&q, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && q > 0) ? q : 256;
+    if (dev >= 0) n[dev].store(v, std::memory_order_relaxed);
   }
-  return n;
+  return v;
+}
+// raise a kernel's dynamic-LDS limit once per device (`mask`: one bit per device ordinal, one mask per kernel)
+static void apla_allow_lds(std::atomic<unsigned long long>& mask, const void* kern, int bytes) {
+  const int dev = apla_current_device();
+  if (dev >= 0 && (mask.load(std::memory_order_relaxed) >> dev) & 1ull) return;
+  (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (dev >= 0) mask.fetch_or(1ull << dev, std::memory_order_relaxed);
 }
 
 // kernel choice, a per-call argument of the *_ex entry points: 0 = auto, 1 = always the blocked kernels, 2 = the
@@ -1430,11 +1448,8 @@ static int launch_attn_fwd(const void* qkv, void* o, float* lse, const int32_t* 
   APLA_REQUIRE(g_attn_variant >= 0 && g_attn_variant <= 3, "%s: unknown kernel variant %d", who, g_attn_variant);
   if (N <= SMALL_MAX_ROWS && g_attn_variant != 1) {
     const int nw = (N + 31) / 32;
-    static bool attr_set_f = false;
-    if (!attr_set_f) {   // 72 KB of dynamic LDS at nine blocks
-      (void)hipFuncSetAttribute((const void*)attn_fwd_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMALL_MAX_ROWS * 256);
-      attr_set_f = true;
-    }
+    static std::atomic<unsigned long long> lds_ok{0};   // 72 KB of dynamic LDS at nine blocks
+    apla_allow_lds(lds_ok, (const void*)attn_fwd_small_kernel, SMALL_MAX_ROWS * 256);
     hipLaunchKernelGGL(attn_fwd_small_kernel, dim3(H, B), dim3(64 * nw), (size_t)nw * 32 * 256, stream, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, cu, total);
   } else {
     hipLaunchKernelGGL(attn_fwd_kernel, dim3((N + 127) / 128, H, B), dim3(256), 0, stream, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, cu, total);
@@ -1459,8 +1474,8 @@ static int launch_attn_bwd(const void* qkv, const void* o, const void* d_o, cons
 #define APLA_PERSIST_CASE(NTV)                                                                                                       \
     case NTV: {                                                                                                                      \
       auto kern = attn_bwd_persist_kernel<NTV, (NTV <= 7)>;                                                                          \
-      static bool attr_set_p = false;                                                                                                \
-      if (!attr_set_p) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set_p = true; } \
+      static std::atomic<unsigned long long> lds_ok{0};                                                                              \
+      apla_allow_lds(lds_ok, (const void*)kern, (int)lds);                                                                           \
       hipLaunchKernelGGL(kern, dim3(G), dim3(512), lds, stream, (const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse, delta, (bf16*)dqkv, N, H, scale, BH); \
     } break;
     switch (nt) {
@@ -1475,11 +1490,8 @@ static int launch_attn_bwd(const void* qkv, const void* o, const void* d_o, cons
   if (N <= SMALL_MAX_ROWS_BWD && g_attn_variant != 1) {  // one workgroup per head, operands read from HBM once (see the kernel)
     const int NP = (N + 31) / 32 * 32;
     const size_t lds = (size_t)SMALL_MAX_ROWS_BWD * (2 * 128 + 8);   // two tiles at a fixed distance + lse*log2e + delta
-    static bool attr_set = false;
-    if (!attr_set) {   // > 64 KB of dynamic LDS
-      (void)hipFuncSetAttribute((const void*)attn_bwd_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr_set = true;
-    }
+    static std::atomic<unsigned long long> lds_ok{0};   // > 64 KB of dynamic LDS
+    apla_allow_lds(lds_ok, (const void*)attn_bwd_small_kernel, (int)lds);
     hipLaunchKernelGGL(attn_bwd_small_kernel, dim3(H, B), dim3(256), lds, stream, (const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse, delta, (bf16*)dqkv, N, H, scale, cu, total, NP);
     APLA_CHECK_LAUNCH(who);
     return APLA_OK;

@@ -54,10 +54,12 @@ __device__ __forceinline__ void tile_coords(int t, int tiles_m, int tiles_n, int
 }
 // host: n-tiles per group so that a group's weight slice (bn x K bf16 per tile) stays around 2 MB, groups equalised
 static inline int pick_ngrp(int tiles_n, int bn, int K) {
-  if (const char* e = getenv("APLA_NGRP")) {  // diagnostic override (tools/gemm_bench.py): n-tiles per column group
+#if defined(APLA_ABL_NGRP)  // diagnostic build (tools/build_ablations.sh): n-tiles per column group from the environment
+  if (const char* e = getenv("APLA_NGRP")) {
     const int v = atoi(e);
     if (v >= 0) return v >= tiles_n ? 0 : v;
   }
+#endif
   const long tile_bytes = (long)bn * K * 2;
   if ((long)tiles_n * tile_bytes <= (5L << 19)) return 0;  // <= 2.5 MB: plain walk
   long per = (2L << 20) / tile_bytes;

@@ -148,7 +148,12 @@ __global__ __launch_bounds__(LN_THREADS) void gather_cols_kernel(const ResT* __r
 
 inline int ln_grid(int M) {
   int g = (M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
-  static const int cap = [] { const char* e = getenv("APLA_LN_GRID"); return e ? atoi(e) : 4096; }();   // diagnostic override
+#if defined(APLA_ABL_LNGRID)  // diagnostic build (tools/build_ablations.sh): grid cap from the environment
+  const char* e = getenv("APLA_LN_GRID");
+  const int cap = e ? atoi(e) : 4096;
+#else
+  constexpr int cap = 4096;
+#endif
   return g < cap ? g : cap;
 }
 

@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
                                                     float* __restrict__ v, const uint8_t* __restrict__ decay, long n,
                                                     float lr, float wd, float b1, float b2, float eps, float bc1,
                                                     float bc2_sqrt, float max_norm, float grad_scale,
-                                                    float* __restrict__ ws, int track_step) {
+                                                    float* __restrict__ ws, int track_step, float log_b1, float log_b2) {
   // track_step > 0 (apla_adamw_step): ws[260 + (step & 1)] holds the number of updates SKIPPED so far (non-finite gradient
   // norm); this call reads that slot and block 0 writes the new count into the other slot, which the next call (step + 1)
   // reads — no workgroup reads what another writes in the same launch.  The bias corrections then use the count of updates
@@ -47,8 +47,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
         const float skipped = ws[260 + (track_step & 1)];
         if (skipped > 0.f) {
           const float t = fmaxf((float)track_step - skipped, 1.0f);
-          c1 = 1.0f - powf(b1, t);
-          c2s = sqrtf(1.0f - powf(b2, t));
+          // 1 - b^t as -expm1(t log b) with log b from the host in double: `1 - powf(b, t)` cancels (1 - 0.999^t loses ~2e-5
+          // at small t), and the host path of the unskipped case uses double pow
+          c1 = -expm1f(t * log_b1);
+          c2s = sqrtf(-expm1f(t * log_b2));
         }
         if (blockIdx.x == 0) ws[260 + ((track_step + 1) & 1)] = skipped + (ok ? 0.f : 1.f);
       }
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(256) void adamw_dyn_kernel(float* __restrict__ p, f
                                                         float lr, float wd, float b1, float b2, float eps, float max_norm,
                                                         float grad_scale, float* __restrict__ scaler, int parity,
                                                         float growth, float backoff, int interval,
-                                                        float* __restrict__ ws) {
+                                                        float* __restrict__ ws, float log_b1, float log_b2) {
   __shared__ float coef_s, bc1_s, bc2s_s;
   if (threadIdx.x < 64) {
     float s = 0.f;
@@ -112,8 +114,8 @@ __global__ __launch_bounds__(256) void adamw_dyn_kernel(float* __restrict__ p, f
       if (max_norm > 0.f) { coef = max_norm / (norm + 1e-6f); coef = coef < 1.0f ? coef : 1.0f; }
       coef_s = ok ? coef * grad_scale / scale : __builtin_nanf("");
       const float t = steps + 1.0f;  // torch AdamW bias corrections with the count of steps actually taken
-      bc1_s = 1.0f - powf(b1, t);
-      bc2s_s = sqrtf(1.0f - powf(b2, t));
+      bc1_s = -expm1f(t * log_b1);            // 1 - b^t without the cancellation of 1 - powf(b, t)
+      bc2s_s = sqrtf(-expm1f(t * log_b2));
       if (blockIdx.x == 0) {
         float* nxt = scaler + 3 * (parity ^ 1);
         float nscale = scale, ntr = tracker + 1.0f;
@@ -155,7 +157,7 @@ extern "C" int apla_adamw_step_dynamic(float* params, float* grads, float* exp_a
   APLA_CHECK_LAUNCH("apla_adamw_step_dynamic[sumsq]");
   long blocks = (n + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(adamw_dyn_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, params, grads, exp_avg, exp_avg_sq, decay_mask, n, lr, weight_decay, beta1, beta2, eps, max_norm, grad_scale, scaler, parity, growth_factor, backoff_factor, growth_interval, norm_ws);
+  hipLaunchKernelGGL(adamw_dyn_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, params, grads, exp_avg, exp_avg_sq, decay_mask, n, lr, weight_decay, beta1, beta2, eps, max_norm, grad_scale, scaler, parity, growth_factor, backoff_factor, growth_interval, norm_ws, (float)log((double)beta1), (float)log((double)beta2));
   APLA_CHECK_LAUNCH("apla_adamw_step_dynamic[update]");
   return APLA_OK;
 }
@@ -179,7 +181,7 @@ extern "C" int apla_adamw_apply(float* params, float* grads, float* exp_avg, flo
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   long blocks = (n + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, params, grads, exp_avg, exp_avg_sq, decay_mask, n, lr, weight_decay, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), max_norm, grad_scale, norm_ws, 0);
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, params, grads, exp_avg, exp_avg_sq, decay_mask, n, lr, weight_decay, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), max_norm, grad_scale, norm_ws, 0, 0.f, 0.f);
   APLA_CHECK_LAUNCH("apla_adamw_apply");
   return APLA_OK;
 }
@@ -195,7 +197,7 @@ extern "C" int apla_adamw_step(float* params, float* grads, float* exp_avg, floa
   APLA_CHECK_LAUNCH("apla_adamw_step[sumsq]");
   long blocks = (n + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, params, grads, exp_avg, exp_avg_sq, decay_mask, n, lr, weight_decay, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), max_norm, grad_scale, norm_ws, step);
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, params, grads, exp_avg, exp_avg_sq, decay_mask, n, lr, weight_decay, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), max_norm, grad_scale, norm_ws, step, (float)log((double)beta1), (float)log((double)beta2));
   APLA_CHECK_LAUNCH("apla_adamw_step[update]");
   return APLA_OK;
 }

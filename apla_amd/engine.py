@@ -102,6 +102,7 @@ class AplaTrainEngine:
         self.loss_scale = 1.0 if self.dynamic_scale else float(loss_scale)
         self.scaler = None   # device float32[8], see ops.adamw_step_dynamic
         self._scaler_calls = 0
+        self._scaler_step0 = 0.0   # the scaler's "steps taken" slot when _scaler_calls was last reset (checkpoint.load_session)
         self.res_dtype, self.grad_dtype = res_dtype, (grad_dtype or compute_dtype)
         self.optim = optim or OptimConfig()
         self.pg = process_group
@@ -713,12 +714,17 @@ class AplaTrainEngine:
         """Optimizer steps skipped so far because the gradient norm was not finite (static loss-scale / bf16 path; the dynamic
         scaler keeps its own count).  Reads device memory: call it at logging cadence, not every step."""
         if self.dynamic_scale:
-            return int(self._scaler_calls - float(self.scaler[3 * (self._scaler_calls & 1) + 2])) if self._scaler_calls else 0
+            # calls since the last (re)start minus the steps the scaler counted since then (a resumed session starts its step
+            # slot at the restored count: checkpoint.load_session)
+            taken = float(self.scaler[3 * (self._scaler_calls & 1) + 2]) - self._scaler_step0
+            return int(self._scaler_calls - taken) if self._scaler_calls else 0
         return int(float(self.norm_ws[260 + ((self.step_count + 1) & 1)]))
 
     @property
     def applied_steps(self) -> int:
         """Updates actually applied = what torch.optim.AdamW would report as ``step`` (skipped steps do not count)."""
+        if self.dynamic_scale:   # the scaler's own count (includes the steps of a resumed session)
+            return int(float(self.scaler[3 * (self._scaler_calls & 1) + 2]))
         return self.step_count - self.skipped_steps
 
     def grads(self):

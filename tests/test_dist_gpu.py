@@ -1,6 +1,7 @@
 """The data-parallel TRAINING STEP end to end on the GPU (SURVEY §8e / golden G7 semantics): two processes share cuda:0,
 each owns half of the global batch and runs the fused engine with a process group; their updated parameters must equal
-those of ONE process stepping on the whole batch (DDP mean = SUM all-reduce, 1/world folded into the optimizer).
+those of ONE process stepping on the whole batch (DDP mean = SUM all-reduce, 1/world folded into the optimizer) AND the CPU
+oracle's step on the whole batch (exchanged gradients, gradient norm, parameters after three updates).
 
 The collective here is gloo on CUDA tensors — RCCL cannot put two ranks on one device, and the test boxes have a single
 GPU — so this covers everything of the N > 1 path except the RCCL transport itself: chunked exchange on the side stream
@@ -32,7 +33,13 @@ def _worker(outdir, use_graphs):
     eng = AplaTrainEngine(small_vit(depth=4, r=64), 4, 32, optim=OptimConfig(lr=1e-3, weight_decay=1e-2, grad_clipping=1.0),
                           process_group=dist.group.WORLD, use_graphs=use_graphs)
     assert eng.world == 2 and len(eng.chunks) == 4 and len(eng.seg_cuts) == 4
-    for _ in range(3):
+    # step 1 in two halves, so that the exchanged gradient (SUM over ranks; the optimizer applies 1/world) can be stored
+    eng.set_batch(images[sl].cuda(), labels[sl].cuda())
+    eng.forward_backward()
+    torch.cuda.synchronize()
+    np.save(os.path.join(outdir, f"grads_{rank}.npy"), (eng.flat_grads / world).cpu().numpy())
+    eng.optimizer_step()
+    for _ in range(2):
         eng.train_step(images[sl].cuda(), labels[sl].cuda())
     torch.cuda.synchronize()
     np.save(os.path.join(outdir, f"params_{rank}.npy"), eng.flat_params.cpu().numpy())
@@ -61,6 +68,36 @@ def test_two_rank_step_equals_full_batch_step(tmp_path, use_graphs):
     # three accumulated AdamW updates (lr 1e-3)
     assert float(np.abs(p0 - ref).max()) < 3e-4, float(np.abs(p0 - ref).max())
     assert abs(float(np.load(tmp_path / "gnorm_0.npy")[0]) - float(eng.grad_norm)) < 2e-2 * float(eng.grad_norm)
+    # ... and against the ORACLE's step on the whole batch (the reference's DDP semantics, defaults/wrappers.py:182-183: the
+    # mean over the global batch of the per-sample gradients; golden G7 pins that the two-half-batch average equals it):
+    # gradients after the exchange, global gradient norm of the third step, parameters after three clip + AdamW updates.
+    from oracle import apla_oracle as O
+    from test_engine_gpu import oracle_params, rel_l2
+    model = small_vit(depth=4, r=64)
+    p = oracle_params(model)
+    p_init = {k: v.clone() for k, v in p.items()}
+    cfg = dict(patch=16, depth=4, heads=2, r=64)
+    state = {}
+    for _ in range(3):
+        _, _, _, gnorm = O.train_step(images.double(), labels, p, cfg, state, lr=1e-3, wd=1e-2, clip=1.0)
+    g0 = np.load(tmp_path / "grads_0.npy")
+    assert np.array_equal(g0, np.load(tmp_path / "grads_1.npy"))     # both ranks hold the same exchanged buffer
+    lf, cf = O.vit_forward(images.double(), oracle_params(model), cfg)
+    _, dlf = O.cross_entropy_fwd_bwd(lf, labels)
+    gref = O.vit_backward(dlf, cf, oracle_params(model), cfg)        # first-step gradients before the clip (train_step clips in place)
+    strip = lambda n: n[len("backbone."):] if n.startswith("backbone.") else n  # noqa: E731
+    for n in eng.names:
+        off, k, shape = eng.slices[n]
+        assert rel_l2(g0[off:off + k], gref[strip(n)].reshape(-1)) < 3e-2, n
+    assert abs(float(np.load(tmp_path / "gnorm_0.npy")[0]) - float(gnorm)) < 3e-2 * float(gnorm)
+    upd, upd_ref = [], []
+    for n in eng.names:
+        off, k, shape = eng.slices[n]
+        upd.append(torch.from_numpy(p0[off:off + k]).double() - p_init[strip(n)].reshape(-1))
+        upd_ref.append(p[strip(n)].reshape(-1) - p_init[strip(n)].reshape(-1))
+    # AdamW normalises every element's update to ~lr, so elements whose gradient is at the bf16 noise floor move differently;
+    # the update as a whole must agree
+    assert rel_l2(torch.cat(upd), torch.cat(upd_ref)) < 0.15
 
 
 def _rccl_worker(outdir):

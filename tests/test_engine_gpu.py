@@ -477,6 +477,34 @@ def test_nonfinite_gradient_skips_the_update_and_is_counted():
     assert torch.allclose(eng.flat_params, ref.flat_params, rtol=1e-5, atol=1e-7)
 
 
+def test_skipped_steps_after_resume_under_dynamic_scale():
+    """a session resumed at step 100 under the dynamic loss scale starts its skip count at zero (the scaler's step
+    slot starts at the restored count), and applied_steps continues from the restored count."""
+    from apla_amd.engine import AplaTrainEngine, OptimConfig
+    from apla_amd import checkpoint as ckpt
+    g = torch.Generator().manual_seed(0)
+    images, labels = torch.randn(4, 3, 32, 32, generator=g).cuda(), torch.randint(0, 10, (4,), generator=g).cuda()
+    oc = OptimConfig(lr=1e-3, weight_decay=1e-2, grad_clipping=1.0)
+    mk = lambda: AplaTrainEngine(small_vit(depth=2), 4, 32, optim=oc, use_graphs=False, compute_dtype=torch.float16, loss_scale="dynamic")  # noqa: E731
+    a = mk()
+    a.train_step(images, labels)
+    sess = ckpt.session_dict(a)
+    for st in sess["optimizer"]["state"].values():
+        st["step"] = torch.tensor(100.0)
+    b = mk()
+    ckpt.load_session(b, sess)
+    assert b.skipped_steps == 0 and b.applied_steps == 100
+    b.train_step(images, labels)
+    torch.cuda.synchronize()
+    assert b.skipped_steps == 0 and b.applied_steps == 101
+    b.set_batch(images, labels)
+    b.forward_backward()
+    b.flat_grads[3] = float("inf")
+    b.optimizer_step()
+    torch.cuda.synchronize()
+    assert b.skipped_steps == 1 and b.applied_steps == 101
+
+
 def test_cross_entropy_rejects_out_of_range_labels():
     """a class id outside [0, C) must not read out of bounds: that row gets a zero gradient and a NaN loss."""
     from apla_amd import ops

@@ -247,6 +247,29 @@ def test_classifier_from_checkpoint_both_kinds(tmp_path):
         ckpt.build_classifier_from_checkpoint(str(tmp_path / "backbone_broken.pth"), mp, sp)
 
 
+def test_unsplit_classifier_checkpoint_keeps_its_head(tmp_path):
+    """a full unsplit Classifier file (``backbone.`` + ``fc.``) must bring its head along, as the reference's
+    non-APLA branch does (utils/pretrained_loader.py:33, strict=True); a head of another class count is reported, not loaded."""
+    from apla_amd import vit, checkpoint as ckpt
+    tp = dict(img_size=[32], patch_size=16, pretrained_type="dinov2", block_conf=dict(has_layerscale=True, layerscale_init_values=1.0))
+    mp = dict(backbone_type="vit_tiny", n_classes=5, pretrained=False, transformers_params=tp,
+              adaptation=dict(mode="apla", params=dict(partial_size=16)))
+    sp = dict(which_GPUs="0")
+    torch.manual_seed(3)
+    src = vit.vit_tiny(pretrained=False, **tp)
+    full = {"backbone." + k: v.clone() for k, v in src.state_dict().items()}
+    full["fc.weight"], full["fc.bias"] = torch.randn(5, 192), torch.randn(5)
+    torch.save({"state_dict": full}, tmp_path / "full.pth")
+    torch.manual_seed(4)
+    model, kind = ckpt.build_classifier_from_checkpoint(str(tmp_path / "full.pth"), mp, sp)
+    assert kind == "backbone"
+    assert torch.equal(model.fc.weight, full["fc.weight"]) and torch.equal(model.fc.bias, full["fc.bias"])
+    full["fc.weight"], full["fc.bias"] = torch.randn(7, 192), torch.randn(7)        # other class count: head stays as built
+    torch.save({"state_dict": full}, tmp_path / "full7.pth")
+    model, _ = ckpt.build_classifier_from_checkpoint(str(tmp_path / "full7.pth"), mp, sp)
+    assert tuple(model.fc.weight.shape) == (5, 192)
+
+
 # ----------------------------------------------------------------------------------------------- main.py entry point
 def test_main_parameter_resolution():
     """src/main.py:241-253 + :58-158: __common__.yml overridden key by key by the given file, then by the CLI flags."""

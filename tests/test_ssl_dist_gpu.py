@@ -1,7 +1,8 @@
 """Data-parallel DINOv2-APLA iteration: two processes share cuda:0 (gloo on CUDA tensors, as in tests/test_dist_gpu.py —
 everything of the N > 1 path except the RCCL transport).  (a) Both ranks fed the SAME batch must reproduce the
 single-process iteration: the flat-gradient all-reduce is a SUM with 1/world folded into the optimizer, the centre
-all-reduces divide by rows * world (dino_clstoken_loss.py:90-101).  (b) Fed DIFFERENT batches, the replicas' students,
+all-reduces divide by rows * world (dino_clstoken_loss.py:90-101) — and the reference's own two iterations (golden G12).
+(b) Fed DIFFERENT batches, the replicas' students,
 teachers and centres stay bit-identical."""
 import os
 import sys
@@ -53,6 +54,9 @@ def _worker(outdir, same_data):
     np.save(os.path.join(outdir, f"student_{rank}.npy"), tr.optimizer.flat.cpu().numpy())
     np.save(os.path.join(outdir, f"teacher_{rank}.npy"), teacher.cpu().numpy())
     np.save(os.path.join(outdir, f"center_{rank}.npy"), tr.model.dino_loss.center.cpu().numpy())
+    if rank == 0:
+        np.savez(os.path.join(outdir, "student_named.npz"),
+                 **{n: p.detach().cpu().numpy() for n, p in tr.model.student.named_parameters() if p.requires_grad})
     dist.barrier()
 
 
@@ -76,3 +80,13 @@ def test_two_rank_ssl_iteration(tmp_path, same_data):
     # same batch on both ranks: the summed gradient is exactly twice the local one and 1/world halves it again
     assert float(np.abs(got - ref).max()) < 1e-6, float(np.abs(got - ref).max())
     assert np.allclose(np.load(tmp_path / "center_0.npy"), tr.model.dino_loss.center.cpu().numpy(), rtol=1e-5, atol=1e-7)
+    # ... and the two-rank result against what the REFERENCE's own classes produced for these two iterations (golden G12:
+    # tests/golden/make_golden.py): the student's accumulated update of every trainable tensor and the DINO centre
+    from conftest import rel_err, t
+    named = np.load(tmp_path / "student_named.npz")
+    assert sorted(named.files) == sorted(str(n) for n in g["trainable"])
+    for n in named.files:
+        ref_upd = t(g[f"it2.student.{n}"]) - t(g["init." + n])
+        upd = torch.from_numpy(named[n]) - t(g["init." + n])
+        assert float((upd - ref_upd).abs().mean() / (ref_upd.abs().mean() + 1e-12)) < 0.2, n
+    assert rel_err(torch.from_numpy(np.load(tmp_path / "center_0.npy")), g["dino.center"]) < 2e-2

@@ -27,3 +27,5 @@ build DWSLABS apla_dw "-DAPLA_ABL_DWSLABS"           # dW slab count from APLA_D
 build ATT_NOEXP attention "-DAPLA_ABL_ATT_NOEXP"     # no transcendental in the softmax recompute
 build ATT_NOS attention "-DAPLA_ABL_ATT_NOS"         # split kernels without the S / dP products
 build ATT_NOTR attention "-DAPLA_ABL_ATT_NOTR"       # split kernels without the transposed reads and second-stage products
+build LNGRID layernorm "-DAPLA_ABL_LNGRID"           # LayerNorm grid cap from APLA_LN_GRID
+build NGRP gemm_pp2 "-DAPLA_ABL_NGRP"                # n-tiles per column group of the tile walk from APLA_NGRP (ping-pong kernel)
