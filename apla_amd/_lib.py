@@ -38,6 +38,11 @@ SIGNATURES = {
     "apla_layernorm_bwd": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_long, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_int, c_long, c_void_p, c_long, c_void_p, c_int, c_void_p,
                                    c_int, c_int, c_void_p]),
+    "apla_layernorm_bwd_ex": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_long, c_void_p, c_void_p, c_void_p,
+                                      c_void_p, c_int, c_void_p, c_int, c_long, c_void_p, c_long, c_void_p, c_int, c_void_p,
+                                      c_int, c_int, c_void_p]),
+    "apla_gemm_nt_kernel_name": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_char_p, c_int]),
+    "apla_probe_occupy": (c_int, [c_int, c_int, c_int, c_int, c_void_p]),
     "apla_gather_cols": (c_int, [c_void_p, c_int, c_long, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     "apla_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "apla_attn_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,

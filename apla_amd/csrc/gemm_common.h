@@ -22,6 +22,8 @@ struct GemmParams {
                 // the A operand of the next GEMM.  Bit 3 = the second operand of the epilogue (aux_out of GELU, aux_in of MUL: gelu'
                 // saved by the forward for the backward) is an image [N/32][M][32] too: a tensor private to those two epilogues,
                 // stored and loaded in whole lines instead of 64-byte row pieces.
+  int reserve;  // CUs this launch leaves free (apla_gemm_nt_ex flags bits 20-27): the persistent kernels start 256 - reserve (ping-pong)
+                // or 2 * (256 - reserve) (4-wave) workgroups, so that the kernels of a concurrent collective find CUs of their own
   int tag;   // profiling tag (apla_gemm_nt_tagged): selects one of several identical kernel instantiations so that a rocprofv3
              // kernel trace tells the call sites of the step apart (qkv / proj / fc2 / dfc1 / dproj / dqkv …); 0 = untagged
 };

@@ -16,6 +16,8 @@
 // ds_read_b128; v_mfma_f32_16x16x32_bf16 with the WEIGHT fragment as the A operand, i.e. C^T tiles, so that a lane owns
 // consecutive output columns of one output row and the epilogue is a vector op on 16-byte global accesses; XCD-aware
 // tile walk (gemm_common.h:tile_coords).
+#include <cstdio>
+
 #include "gemm_common.h"
 
 namespace {
@@ -279,7 +281,8 @@ int launch_persist(const GemmParams& p_in, hipStream_t stream) {
   p.ngrp = pick_ngrp(p.tiles_n, BN, p.K);
   const int tiles_m = (p.M + 32 * MI - 1) / (32 * MI);
   const int total = tiles_m * p.tiles_n;
-  int G = total < RESIDENT_WGS ? total : RESIDENT_WGS;
+  const int resident = RESIDENT_WGS - 2 * (p.reserve > 0 && p.reserve < 192 ? p.reserve : 0);
+  int G = total < resident ? total : resident;
   hipLaunchKernelGGL((gemm_persist_kernel<EPI, OutT, MI>), dim3(G), dim3(256), 0, stream, p, tiles_m);
   APLA_CHECK_LAUNCH("apla_gemm_nt");
   return APLA_OK;
@@ -298,8 +301,11 @@ inline int pick_mi(int M, int tiles_n) {
   return best;
 }
 
-template <int EPI, typename OutT>
-int launch(const GemmParams& p, int g_variant, hipStream_t stream) {
+// The schedule decision, separate from the launch so that apla_gemm_nt_kernel_name can report it (bench.py names the dominant
+// kernel from the dispatch, not from a literal).  kind: 0 = simple non-persistent kernel, 1 = 4-wave persistent kernel with
+// BM = 32 * mi, 2 = 8-wave ping-pong kernel.
+struct Sched { int kind, mi; };
+inline Sched pick_schedule(int epi, int out_dtype, int M, int N, int K, int lda, int ldw, int w_panel, int g_variant) {
   // auto (4): the 8-wave ping-pong kernel for large problems with the plain STORE epilogue, else the 128-wide persistent
   // kernel; 9 forces ping-pong wherever it is instantiated; 14/15 force the 128-wide persistent kernel with MI 4/5.
   // The GELU epilogues go to the persistent kernel although its main loop is the slower one (qkv shape: 786 vs 962 TFLOP/s):
@@ -309,24 +315,28 @@ int launch(const GemmParams& p, int g_variant, hipStream_t stream) {
   // (measured limit of that rule: the two-output GELU epilogue at M = 58 496, the packed student batch of the self-supervised
   // step — 719 MB of stores per launch — runs 480 us on the persistent kernel against 423 us on the ping-pong kernel, while the
   // one-output GELU_FWD and MUL do not care: above 40 000 rows GELU goes back to the ping-pong kernel)
-  if (p.w_panel & 12) {  // output / second-operand image: the 4-wave persistent kernel's GELU / GELU_FWD / MUL epilogues (checked by gemm_nt_impl)
-    return launch_persist<EPI, OutT, 5>(p, stream);
-  }
-  if (p.w_panel) {  // K-panel operand images exist on the ping-pong kernel only (gemm_nt_impl checked that it covers the problem)
-    return apla_gemm_pp2_launch(p, EPI, std::is_same<OutT, float>::value ? APLA_F32 : APLA_H16, stream);
-  }
-  const bool pp2_auto = (EPI == APLA_EPI_STORE) || (EPI == APLA_EPI_GELU && p.M > 40000);
-  if (g_variant == 9 || (g_variant == 4 && pp2_auto && p.M >= 2048)) {
-    const int rc = apla_gemm_pp2_launch(p, EPI, std::is_same<OutT, float>::value ? APLA_F32 : APLA_H16, stream);
-    if (rc != APLA_ENOSYS) return rc;
-  }
+  if (w_panel & 12) return {1, 5};  // output / second-operand image: the 4-wave persistent kernel's GELU / GELU_FWD / MUL epilogues (checked by gemm_nt_impl)
+  if (w_panel) return {2, 0};       // K-panel operand images exist on the ping-pong kernel only (gemm_nt_impl checked that it covers the problem)
+  const bool pp2_auto = (epi == APLA_EPI_STORE) || (epi == APLA_EPI_GELU && M > 40000);
+  if ((g_variant == 9 || (g_variant == 4 && pp2_auto && M >= 2048)) && apla_gemm_pp2_covers(M, N, K, lda, ldw, epi, out_dtype)) return {2, 0};
   if (g_variant >= 4) {
     // tile height: fewest (rounds x rows) over the resident workgroups — except for large problems with an epilogue that does
     // arithmetic or reads a second operand, where the taller tile is worth more than a few per cent of quantisation (the
     // self-supervised step's student fc1, M = 58 496: 128-row tiles win the round count by 2 % and ran 494 us against 368 us)
-    constexpr bool heavy = (EPI == APLA_EPI_GELU || EPI == APLA_EPI_GELU_FWD || EPI == APLA_EPI_MUL);
-    const int mi = (g_variant == 4 || g_variant == 9) ? ((heavy && p.M >= 8192) ? 5 : pick_mi(p.M, p.tiles_n)) : g_variant - 10;
-    if (mi == 5) return launch_persist<EPI, OutT, 5>(p, stream);
+    const bool heavy = (epi == APLA_EPI_GELU || epi == APLA_EPI_GELU_FWD || epi == APLA_EPI_MUL);
+    const int mi = (g_variant == 4 || g_variant == 9) ? ((heavy && M >= 8192) ? 5 : pick_mi(M, N / BN)) : g_variant - 10;
+    return {1, mi == 5 ? 5 : 4};
+  }
+  return {0, 4};
+}
+
+template <int EPI, typename OutT>
+int launch(const GemmParams& p, int g_variant, hipStream_t stream) {
+  const int odt = std::is_same<OutT, float>::value ? APLA_F32 : APLA_H16;
+  const Sched sc = pick_schedule(EPI, odt, p.M, p.N, p.K, (p.w_panel & 2) ? 32 : p.lda, (p.w_panel & 1) ? 32 : p.ldw, p.w_panel, g_variant);
+  if (sc.kind == 2) return apla_gemm_pp2_launch(p, EPI, odt, stream);
+  if (sc.kind == 1) {
+    if (sc.mi == 5) return launch_persist<EPI, OutT, 5>(p, stream);
     return launch_persist<EPI, OutT, 4>(p, stream);
   }
   const int tiles_m = (p.M + BM - 1) / BM;
@@ -340,7 +350,7 @@ int launch(const GemmParams& p, int g_variant, hipStream_t stream) {
 
 static int gemm_nt_impl(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int M,
                         int N, int K, int epilogue, int out_dtype, const void* aux_in, int ld_aux_in,
-                        void* aux_out, int ld_aux_out, int tag, int variant, hipStream_t stream, int w_panel = 0) {
+                        void* aux_out, int ld_aux_out, int tag, int variant, hipStream_t stream, int w_panel = 0, int reserve = 0) {
   APLA_REQUIRE(M > 0 && N > 0 && K > 0, "apla_gemm_nt: empty problem M=%d N=%d K=%d", M, N, K);
   APLA_REQUIRE(N % BN == 0 && K % BK == 0, "apla_gemm_nt: need N%%128==0 and K%%64==0 (N=%d K=%d)", N, K);
   APLA_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && ((w_panel & 2) || lda >= K) && ((w_panel & 1) || ldw >= K), "apla_gemm_nt: bad lda/ldw (%d,%d) K=%d", lda, ldw, K);
@@ -357,7 +367,7 @@ static int gemm_nt_impl(const void* A, int lda, const void* W, int ldw, const fl
   APLA_REQUIRE(bias == nullptr || apla_aligned16(bias), "apla_gemm_nt: bias must be 16-byte aligned");
   APLA_REQUIRE((w_panel & 4) || ldc % 4 == 0, "apla_gemm_nt: ldc %% 4 != 0");
   if (w_panel & 8) { ld_aux_in = ld_aux_in ? N : 0; ld_aux_out = ld_aux_out ? N : 0; }   // not read for an image; keeps the row-major checks quiet
-  GemmParams p{(const bf16*)A, lda, (const bf16*)W, ldw, bias, C, ldc, aux_in, ld_aux_in, aux_out, ld_aux_out, M, N, K, N / BN, 0, w_panel,
+  GemmParams p{(const bf16*)A, lda, (const bf16*)W, ldw, bias, C, ldc, aux_in, ld_aux_in, aux_out, ld_aux_out, M, N, K, N / BN, 0, w_panel, reserve,
                (tag >= 0 && tag < APLA_GEMM_TAGS) ? tag : 0};
   switch (epilogue) {
     case APLA_EPI_STORE:
@@ -417,12 +427,31 @@ extern "C" int apla_gemm_nt_out_image_ok(int M, int N, int K, int epilogue, int 
 }
 
 // flags: bits 0-7 = profiling tag (GemmParams::tag), bits 8-15 = kernel schedule (0 = auto; see `launch`), bit 16 / 17 = W / A
-// given as K-panel images
+// given as K-panel images, bits 18 / 19 output / second-operand image, bits 20-27 = CUs to leave free (GemmParams::reserve)
 extern "C" int apla_gemm_nt_ex(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int M,
                                int N, int K, int epilogue, int out_dtype, const void* aux_in, int ld_aux_in,
                                void* aux_out, int ld_aux_out, int flags, hipStream_t stream) {
   const int tag = flags & 0xff, v = (flags >> 8) & 0xff;
   APLA_REQUIRE(v == 0 || v == 1 || v == 4 || v == 9 || v == 14 || v == 15, "apla_gemm_nt_ex: unknown schedule %d", v);
   return gemm_nt_impl(A, lda, W, ldw, bias, C, ldc, M, N, K, epilogue, out_dtype, aux_in, ld_aux_in, aux_out, ld_aux_out, tag,
-                      v == 0 ? 4 : (v == 1 ? 0 : v), stream, (flags >> 16) & 15);
+                      v == 0 ? 4 : (v == 1 ? 0 : v), stream, (flags >> 16) & 15, (flags >> 20) & 0xff);
+}
+
+// Which kernel does apla_gemm_nt_ex run this problem on?  Writes e.g. "gemm_persist_kernel<GELU,bf16,5>" (the name a rocprofv3
+// kernel trace shows, as tools/summarize_prof.py shortens it) into buf; same decision code as the launch.
+extern "C" int apla_gemm_nt_kernel_name(int M, int N, int K, int epilogue, int out_dtype, int flags, char* buf, int buflen) {
+  APLA_REQUIRE(buf && buflen >= 48 && M > 0 && N > 0 && K > 0, "apla_gemm_nt_kernel_name: bad arguments");
+  static const char* const epi_names[] = {"STORE", "GELU", "RESIDUAL", "MUL", "SWIGLU", "SWIGLU_BWD", "GELU_FWD"};
+  APLA_REQUIRE(epilogue >= 0 && epilogue <= 6, "apla_gemm_nt_kernel_name: unknown epilogue %d", epilogue);
+  const int v = (flags >> 8) & 0xff, w_panel = (flags >> 16) & 15;
+  const Sched sc = pick_schedule(epilogue, out_dtype, M, N, K, (w_panel & 2) ? 32 : K, (w_panel & 1) ? 32 : K, w_panel, v == 0 ? 4 : (v == 1 ? 0 : v));
+#if defined(APLA_FP16)
+  const char* ot = out_dtype == APLA_F32 ? "float" : "f16";
+#else
+  const char* ot = out_dtype == APLA_F32 ? "float" : "bf16";
+#endif
+  if (sc.kind == 2) snprintf(buf, buflen, "gemm_pp2_kernel<%s,%s>", epi_names[epilogue], ot);
+  else if (sc.kind == 1) snprintf(buf, buflen, "gemm_persist_kernel<%s,%s,%d>", epi_names[epilogue], ot, sc.mi);
+  else snprintf(buf, buflen, "gemm_nt_kernel<%s,%s>", epi_names[epilogue], ot);
+  return APLA_OK;
 }

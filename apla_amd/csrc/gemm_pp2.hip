@@ -261,7 +261,8 @@ int apla_gemm_pp2_launch(const GemmParams& p_in, int epilogue, int out_dtype, hi
   p.ngrp = pick_ngrp(p.N / QBN, QBN, p.K);
   const int tiles_m = (p.M + QBM - 1) / QBM;
   const int total = tiles_m * (p.N / QBN);
-  const int G = total < 256 ? total : 256;
+  const int cus = 256 - (p.reserve > 0 && p.reserve < 192 ? p.reserve : 0);
+  const int G = total < cus ? total : cus;
 #define PP2_LAUNCH(E, T)                                                                                 \
   do {                                                                                                   \
     hipLaunchKernelGGL((gemm_pp2_kernel<E, T>), dim3(G), dim3(512), 0, stream, p, tiles_m);              \

@@ -64,10 +64,14 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const ResT* x, long 
     for (int c = 0; c < NC; ++c) {
       const int ch = lane + c * 64;
       if (ch < nchunk) {
-        const f32x4 g = *(const f32x4*)(gamma + ch * 4), b = *(const f32x4*)(beta + ch * 4);
         f32x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (v[c][e] - mean) * rstd * g[e] + b[e];
+        for (int e = 0; e < 4; ++e) o[e] = (v[c][e] - mean) * rstd;
+        if (gamma != nullptr) {   // NULL: y = xhat (gamma / beta folded into the weights of the GEMM that reads y)
+          const f32x4 g = *(const f32x4*)(gamma + ch * 4), b = *(const f32x4*)(beta + ch * 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = o[e] * g[e] + b[e];
+        }
         Vec4IO<YT>::store(yr + ch * 4, o);
       }
     }
@@ -82,7 +86,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const DYT* __restric
                                                      const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                      const GT* dres, GT* dx, long dxs, bf16* __restrict__ dxb, long dbs,
                                                      const int32_t* __restrict__ inds, int r, bf16* __restrict__ gout,
-                                                     int M, int D) {
+                                                     int M, int D, int dres_period) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* rowbuf = (float*)smem_raw;  // [ROWS_PER_BLOCK][D] when GATHER
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -92,7 +96,13 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const DYT* __restric
     if (m < M) {
       const XT* xr = x + (size_t)m * xs;
       const DYT* dyr = dy + (size_t)m * lddy;
-      const float mean = mean_i[m], rstd = rstd_i[m];
+      // mean_i == NULL: x holds the NORMALISED row (what the forward wrote with gamma == NULL), saved in 16 bits: the backward
+      // then reads 2 bytes per element instead of the 4 of the fp32 residual row
+      const float mean = mean_i != nullptr ? mean_i[m] : 0.f, rstd = rstd_i[m];
+      const float xsc = mean_i != nullptr ? rstd : 1.0f;
+      // dres_period > 1: only every dres_period-th row of the incoming residual gradient is non-zero (the CLS rows below the
+      // final norm, vit.py:416-419) and the rest is NOT read — no zero-fill of the stream, no read of zeros
+      const bool has_res = dres != nullptr && (dres_period <= 1 || m % dres_period == 0);
       f32x4 xh[NC], w[NC];
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -101,10 +111,11 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const DYT* __restric
         if (ch < nchunk) {
           const f32x4 xv = Vec4IO<XT>::load(xr + ch * 4);
           const f32x4 dv = Vec4IO<DYT>::load(dyr + ch * 4);
-          const f32x4 g = *(const f32x4*)(gamma + ch * 4);
+          f32x4 g = f32x4{1.f, 1.f, 1.f, 1.f};
+          if (gamma != nullptr) g = *(const f32x4*)(gamma + ch * 4);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            xh[c][e] = (xv[e] - mean) * rstd;
+            xh[c][e] = (xv[e] - mean) * xsc;
             w[c][e] = dv[e] * g[e];
             s1 += w[c][e];
             s2 += w[c][e] * xh[c][e];
@@ -120,7 +131,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const DYT* __restric
           f32x4 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = (w[c][e] - c1 - xh[c][e] * c2) * rstd;
-          if (dres != nullptr) o += Vec4IO<GT>::load(dres + (size_t)m * dxs + ch * 4);
+          if (has_res) o += Vec4IO<GT>::load(dres + (size_t)m * dxs + ch * 4);
           Vec4IO<GT>::store(dxr + ch * 4, o);
           if (dxb != nullptr) Vec4IO<bf16>::store(dxb + (size_t)m * dbs + ch * 4, o);
           if constexpr (GATHER) *(f32x4*)(rowbuf + wave * D + ch * 4) = o;
@@ -164,9 +175,9 @@ extern "C" int apla_layernorm_fwd(const void* x, int res_dtype, long x_row_strid
                                   int D, float eps, const void* add_in, long add_row_stride, void* x_out,
                                   long x_out_row_stride, hipStream_t stream) {
   APLA_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 256 * MAXC, "apla_layernorm_fwd: need D%%4==0 and D<=2048 (D=%d)", D);
-  APLA_REQUIRE(x && y && gamma && beta && mean && rstd, "apla_layernorm_fwd: null pointer");
+  APLA_REQUIRE(x && y && mean && rstd && ((gamma == nullptr) == (beta == nullptr)), "apla_layernorm_fwd: null pointer (gamma and beta are given together or not at all)");
   APLA_REQUIRE(x_row_stride % 4 == 0 && ldy % 4 == 0 && x_row_stride >= D && ldy >= D, "apla_layernorm_fwd: strides must be >= D and multiples of 4");
-  APLA_REQUIRE(apla_aligned16(x) && apla_aligned16(gamma) && apla_aligned16(beta) && (((uintptr_t)y) & 7) == 0, "apla_layernorm_fwd: alignment");
+  APLA_REQUIRE(apla_aligned16(x) && (gamma == nullptr || (apla_aligned16(gamma) && apla_aligned16(beta))) && (((uintptr_t)y) & 7) == 0, "apla_layernorm_fwd: alignment");
   APLA_REQUIRE(add_in == nullptr || (x_out != nullptr && add_row_stride % 4 == 0 && add_row_stride >= D && x_out_row_stride % 4 == 0 && x_out_row_stride >= D),
                "apla_layernorm_fwd: fused residual add needs x_out and valid strides");
 #define LN_FWD_NC(T, Y, NCV) hipLaunchKernelGGL((ln_fwd_kernel<T, Y, NCV>), dim3(ln_grid(M)), dim3(LN_THREADS), 0, stream, (const T*)x, x_row_stride, gamma, beta, (Y*)y, ldy, mean, rstd, M, D, eps, (const bf16*)add_in, add_row_stride, (T*)x_out, x_out_row_stride)
@@ -194,13 +205,13 @@ extern "C" int apla_layernorm_fwd(const void* x, int res_dtype, long x_row_strid
   return APLA_OK;
 }
 
-extern "C" int apla_layernorm_bwd(const void* dy, int dy_dtype, int lddy, const void* x, int x_dtype, long x_row_stride,
-                                  const float* gamma, const float* mean, const float* rstd, const void* dres_in,
-                                  void* dx_out, int grad_dtype, long dx_row_stride, void* dx_bf16_copy,
-                                  long copy_row_stride, const int32_t* inds, int r, void* gather_out, int M, int D,
-                                  hipStream_t stream) {
+extern "C" int apla_layernorm_bwd_ex(const void* dy, int dy_dtype, int lddy, const void* x, int x_dtype, long x_row_stride,
+                                     const float* gamma, const float* mean, const float* rstd, const void* dres_in,
+                                     int dres_row_period, void* dx_out, int grad_dtype, long dx_row_stride, void* dx_bf16_copy,
+                                     long copy_row_stride, const int32_t* inds, int r, void* gather_out, int M, int D,
+                                     hipStream_t stream) {
   APLA_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 256 * MAXC, "apla_layernorm_bwd: need D%%4==0 and D<=2048 (D=%d)", D);
-  APLA_REQUIRE(dy && x && gamma && mean && rstd && dx_out, "apla_layernorm_bwd: null pointer");
+  APLA_REQUIRE(dy && x && rstd && dx_out && dres_row_period >= 0, "apla_layernorm_bwd: null pointer");
   APLA_REQUIRE(lddy % 4 == 0 && x_row_stride % 4 == 0 && dx_row_stride % 4 == 0 && lddy >= D && x_row_stride >= D && dx_row_stride >= D, "apla_layernorm_bwd: bad strides");
   APLA_REQUIRE(dx_bf16_copy == nullptr || (copy_row_stride % 4 == 0 && copy_row_stride >= D), "apla_layernorm_bwd: bad copy stride");
   APLA_REQUIRE(gather_out == nullptr || (inds != nullptr && r > 0 && r <= D), "apla_layernorm_bwd: gather needs inds and 0<r<=D");
@@ -209,7 +220,7 @@ extern "C" int apla_layernorm_bwd(const void* dy, int dy_dtype, int lddy, const 
 #define LN_BWD_NC(X, Y, G, GA, NCV)                                                                                    \
   hipLaunchKernelGGL((ln_bwd_kernel<X, Y, G, GA, NCV>), dim3(ln_grid(M)), dim3(LN_THREADS), lds, stream, (const Y*)dy, lddy,  \
                      (const X*)x, x_row_stride, gamma, mean, rstd, (const G*)dres_in, (G*)dx_out, dx_row_stride,       \
-                     (bf16*)dx_bf16_copy, copy_row_stride, inds, r, (bf16*)gather_out, M, D)
+                     (bf16*)dx_bf16_copy, copy_row_stride, inds, r, (bf16*)gather_out, M, D, dres_row_period)
 #define LN_BWD(X, Y, G, GA)                             \
   do {                                                  \
     const int nc_ = (D + 255) / 256;                    \
@@ -242,6 +253,16 @@ extern "C" int apla_layernorm_bwd(const void* dy, int dy_dtype, int lddy, const 
 #undef LN_BWD_NC
   APLA_CHECK_LAUNCH("apla_layernorm_bwd");
   return APLA_OK;
+}
+
+extern "C" int apla_layernorm_bwd(const void* dy, int dy_dtype, int lddy, const void* x, int x_dtype, long x_row_stride,
+                                  const float* gamma, const float* mean, const float* rstd, const void* dres_in,
+                                  void* dx_out, int grad_dtype, long dx_row_stride, void* dx_bf16_copy,
+                                  long copy_row_stride, const int32_t* inds, int r, void* gather_out, int M, int D,
+                                  hipStream_t stream) {
+  APLA_REQUIRE(gamma && mean, "apla_layernorm_bwd: null pointer (apla_layernorm_bwd_ex takes a normalised row / no gamma)");
+  return apla_layernorm_bwd_ex(dy, dy_dtype, lddy, x, x_dtype, x_row_stride, gamma, mean, rstd, dres_in, 0, dx_out, grad_dtype,
+                               dx_row_stride, dx_bf16_copy, copy_row_stride, inds, r, gather_out, M, D, stream);
 }
 
 extern "C" int apla_gather_cols(const void* src, int res_dtype, long src_row_stride, const int32_t* inds, int r,

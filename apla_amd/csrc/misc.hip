@@ -426,3 +426,21 @@ extern "C" int apla_pack_k_panels(const void* src, long ld, void* dst, int rows,
   APLA_CHECK_LAUNCH("apla_pack_k_panels");
   return APLA_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ CU-occupancy probe (diagnostic)
+// `workgroups` workgroups of `threads` threads holding `lds_bytes` of LDS each spin for `usec` microseconds (constant 100 MHz
+// clock; bounded).  Launched on a side stream next to the fused step it stands in for a collective's kernels: the persistent GEMM /
+// attention kernels of the step launch one (or two) workgroups per CU and want all 256 CUs at once, so what a resident foreign
+// kernel costs them is measured, not assumed (tools/contention_probe.py -> profiles/r03_contention.md).  Not on the product path.
+__global__ void occupy_kernel(long ticks) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  unsigned n = 0;   // every wave leaves after `ticks` of the 100 MHz clock, or after 2^24 polls at the latest
+  while ((long)(__builtin_amdgcn_s_memrealtime() - t0) < ticks && n < (1u << 24)) { ++n; __builtin_amdgcn_s_sleep(8); }
+}
+extern "C" int apla_probe_occupy(int workgroups, int threads, int lds_bytes, int usec, hipStream_t stream) {
+  APLA_REQUIRE(workgroups > 0 && workgroups <= 1024 && threads >= 64 && threads <= 1024 && threads % 64 == 0 && lds_bytes >= 0 &&
+               lds_bytes <= 64 * 1024 && usec > 0 && usec <= 50000, "apla_probe_occupy: bad arguments");
+  hipLaunchKernelGGL(occupy_kernel, dim3(workgroups), dim3(threads), (size_t)lds_bytes, stream, (long)usec * 100);
+  APLA_CHECK_LAUNCH("apla_probe_occupy");
+  return APLA_OK;
+}

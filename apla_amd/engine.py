@@ -183,6 +183,10 @@ class AplaTrainEngine:
             # exchanging: the LAST chunk is the one nothing overlaps, so it is made as small as possible — block 0 alone (its
             # backward is also the shortest: no attention part) — and the other three share the rest: L = 12 -> [8, 4, 1, 0]
             self.seg_cuts = [2 * self.L // 3, self.L // 3, 1, 0]
+        # CUs the step's persistent GEMM launches leave to the RCCL kernels of the overlapped all-reduce (ops.reserved_cus; at
+        # config 2 a reservation of 8 costs the GEMMs nothing — their last round has that many idle CUs anyway);
+        # it matches the channel budget bench.py gives RCCL (NCCL_MAX_NCHANNELS)
+        self.reserve_cus = int(os.environ.get("APLA_RESERVE_CUS", "8")) if (self.world > 1 or force) else 0
         bounds = [self.slices[self.names[2 * c]][0] for c in self.seg_cuts]       # start offset of block cut[s]'s tensors
         his = [n_total] + bounds[:-1]
         self.chunks = [(lo, hi) for lo, hi in zip(bounds, his)]
@@ -222,11 +226,16 @@ class AplaTrainEngine:
             # entries of the block's index permutation (frozen features); their gradient rows are computed and dropped
             st.r_pad = (r + 63) // 64 * 64
             st.inds = inds.to(dev).int().contiguous()
-            st.g1, st.b1 = f32(blk.norm1.weight), f32(blk.norm1.bias)
-            st.g2, st.b2 = f32(blk.norm2.weight), f32(blk.norm2.bias)
+            # gamma / beta of the two (frozen) LayerNorms are folded into the frozen Linear that reads the normalised row:
+            # W' = W diag(gamma), b' = b + W beta.  The LayerNorm kernels then write xhat itself — which is also what the
+            # backward needs, so the 16-bit xhat saved per LayerNorm replaces the fp32 residual rows (apla_layernorm_bwd_ex)
+            g1, b1 = f32(blk.norm1.weight), f32(blk.norm1.bias)
+            g2, b2 = f32(blk.norm2.weight), f32(blk.norm2.bias)
+            fold = lambda w, b, g, be: (w * g[None, :], (b if b is not None else 0.0) + w @ be)  # noqa: E731
             a = blk.attn
-            st.Wqkv, st.WqkvT = _bf(a.qkv.weight), _bf_t(a.qkv.weight)
-            st.bqkv = f32(a.qkv.bias) if a.qkv.bias is not None else None
+            wq, st.bqkv = fold(f32(a.qkv.weight), f32(a.qkv.bias) if a.qkv.bias is not None else None, g1, b1)
+            st.bqkv = st.bqkv.contiguous()
+            st.Wqkv, st.WqkvT = _bf(wq), _bf_t(wq)
             gam1 = f32(blk.ls1.gamma) if hasattr(blk.ls1, "gamma") else None
             gam2 = f32(blk.ls2.gamma) if hasattr(blk.ls2, "gamma") else None
             st.gamma1 = gam1
@@ -253,13 +262,16 @@ class AplaTrainEngine:
             mlp = blk.mlp
             if self.swiglu:
                 st.F = mlp.w3.in_features
-                w12 = _interleave_rows(mlp.w12.weight.detach().float())
+                w12, b12 = fold(f32(mlp.w12.weight), f32(mlp.w12.bias), g2, b2)
+                w12 = _interleave_rows(w12)
                 st.W12, st.W12T = w12.to(ops.half()), w12.t().contiguous().to(ops.half())
-                st.b12 = _interleave_rows(mlp.w12.bias.detach().float()).contiguous()
+                st.b12 = _interleave_rows(b12).contiguous()
                 w3, b3 = mlp.w3.weight.detach().float(), mlp.w3.bias.detach().float()
             else:
                 st.F = mlp.fc1.out_features
-                st.Wfc1, st.Wfc1T, st.bfc1 = _bf(mlp.fc1.weight), _bf_t(mlp.fc1.weight), f32(mlp.fc1.bias)
+                wf, st.bfc1 = fold(f32(mlp.fc1.weight), f32(mlp.fc1.bias), g2, b2)
+                st.bfc1 = st.bfc1.contiguous()
+                st.Wfc1, st.Wfc1T = _bf(wf), _bf_t(wf)
                 w3, b3 = mlp.fc2.weight.detach().float(), mlp.fc2.bias.detach().float()
             if gam2 is not None:
                 w3, b3 = w3 * gam2[:, None], b3 * gam2
@@ -302,17 +314,19 @@ class AplaTrainEngine:
         self.targets = torch.zeros(B, self.C, device=dev, dtype=torch.float32) if self.soft_targets else None
         self.cols = e(B * self.Np, self.Kp)
         self.patches = e(B * self.Np, D)
-        self.x = [e(M, D, dt=self.res_dtype) for _ in range(L + 1)]
-        self.xmid = [e(M, D, dt=self.res_dtype) for _ in range(L)]
+        # ONE residual-stream buffer, updated in place by the LayerNorm kernels (x += branch fused): the backward reads the
+        # normalised rows xh1 / xh2 (16-bit, one per LayerNorm) and rstd instead of the fp32 rows of every block
+        self.res = e(M, D, dt=self.res_dtype)
         stat = lambda: e(M, dt=torch.float32)  # noqa: E731
-        self.mean1, self.rstd1 = [stat() for _ in range(L)], [stat() for _ in range(L)]
-        self.mean2, self.rstd2 = [stat() for _ in range(L)], [stat() for _ in range(L)]
+        self.mean_scratch = stat()                  # the forward kernel's mean output: not needed again
+        self.rstd1, self.rstd2 = [stat() for _ in range(L)], [stat() for _ in range(L)]
+        self.xh1 = [e(M, D) for _ in range(L)]
+        self.xh2 = [e(M, D) if (i < L - 1 or not self.cls_only_tail) else None for i in range(L)]  # last block: ln_cls (CLS rows only)
         self.qkv = [e(M, 3 * D) for _ in range(L)]
         self.o = [e(M, D) for _ in range(L)]
         self.lse = [e(B, H, N, dt=torch.float32) for _ in range(L)]
         Fsave = (2 * self.blocks[0].F) if self.swiglu else self.blocks[0].F
         self.act_saved = [e(M, Fsave) for _ in range(L)]       # gelu'(a) or interleaved x12
-        self.ln_out = e(M, D)
         self.branch = e(M, D)  # bf16 branch output (projection / fc2) awaiting the fused residual add
         self.h = e(M, self.blocks[0].F)
         # fc1's output h and dfc2's product go straight to a plain-store GEMM (fc2, dfc1): where both sides allow it they are
@@ -337,7 +351,7 @@ class AplaTrainEngine:
         self.loss = e(1, dt=torch.float32)
         self.dxn = e(B, D, dt=torch.float32)
         # backward
-        self.G = torch.zeros(M, D, device=dev, dtype=self.grad_dtype)               # residual-gradient stream
+        self.G = torch.zeros(M, D, device=dev, dtype=self.grad_dtype)               # residual-gradient stream (never re-zeroed)
         self.Gb = self.G if self.grad_dtype == ops.half() else torch.zeros(M, D, device=dev, dtype=ops.half())
         self.dact = e(M, Fsave)
         self.dact_img = use and ops.gemm_out_image_ok(M, F, D, ops.EPI_MUL) and ops.gemm_panel_ok(M, D, F) and Fsave == F
@@ -413,47 +427,48 @@ class AplaTrainEngine:
         B, N, H, D = self.B, self.N, self.H, self.D
         ops.patchify(self.images, self.patch, self.Kp, out=self.cols)
         ops.gemm_nt(self.cols, self.Wpe_i, self.bpe, out=self.patches, tag=ops.TAG_PATCH)
-        ops.assemble_tokens(self.patches, self.cls, self.pos, B, self.Np, out=self.x[0])
+        ops.assemble_tokens(self.patches, self.cls, self.pos, B, self.Np, out=self.res)
         # The residual updates x += branch (vit.py:284-285) are fused into the NEXT LayerNorm: the projection / fc2 GEMMs store
         # their (LayerScale-folded) branch output in bf16 — as the reference's fp16-autocast Linear does before the fp32
         # residual add — and the LN kernel forms x_new = x + branch in registers, writes it and normalises it in one pass.
         # The GEMM epilogues stay operand-free (eligible for the ping-pong kernel), the adds cost no kernel of their own.
         for i, st in enumerate(self.blocks):
+            xh1 = self.xh1[i]
             if i == 0:
-                ops.layernorm_fwd(self.x[0], st.g1, st.b1, self.eps, out=self.ln_out, mean=self.mean1[0], rstd=self.rstd1[0])
+                ops.layernorm_fwd(self.res, None, None, self.eps, out=xh1, mean=self.mean_scratch, rstd=self.rstd1[0])
             else:
-                ops.layernorm_fwd(self.xmid[i - 1], st.g1, st.b1, self.eps, out=self.ln_out, mean=self.mean1[i],
-                                  rstd=self.rstd1[i], add=self.branch, x_out=self.x[i])
+                ops.layernorm_fwd(self.res, None, None, self.eps, out=xh1, mean=self.mean_scratch, rstd=self.rstd1[i],
+                                  add=self.branch, x_out=self.res)
             if i == self.L - 1 and self.cls_only_tail:
                 # last block: K and V for every token, Q for the CLS rows only (the only query that is ever used)
-                ops.gemm_nt(self.ln_out, st.Wkv_i, None if st.bqkv is None else st.bqkv[D:], out=self.qkv[i][:, D:], tag=ops.TAG_QKV)
-                self._gemm_rows(self.ln_out.view(B, N * D)[:, :D], st.Wqkv[:D], None if st.bqkv is None else st.bqkv[:D],
-                            out=self.qkv[i].view(B, N * 3 * D)[:, :D])
+                ops.gemm_nt(xh1, st.Wkv_i, st.bqkv[D:], out=self.qkv[i][:, D:], tag=ops.TAG_QKV)
+                self._gemm_rows(xh1.view(B, N * D)[:, :D], st.Wqkv[:D], st.bqkv[:D], out=self.qkv[i].view(B, N * 3 * D)[:, :D])
                 self._forward_last_block_tail(st, i)
                 break
-            ops.gemm_nt(self.ln_out, st.Wqkv_i, st.bqkv, out=self.qkv[i], tag=ops.TAG_QKV)
+            ops.gemm_nt(xh1, st.Wqkv_i, st.bqkv, out=self.qkv[i], tag=ops.TAG_QKV)
             ops.attn_fwd(self.qkv[i], B, N, H, self.scale, o=self.o[i], lse=self.lse[i])
             ops.gemm_nt(self.o[i], st.Wnat_i, st.bnat, out=self.branch, tag=ops.TAG_PROJ)
-            ops.layernorm_fwd(self.x[i], st.g2, st.b2, self.eps, out=self.ln_out, mean=self.mean2[i], rstd=self.rstd2[i],
-                              add=self.branch, x_out=self.xmid[i])
+            xh2 = self.xh2[i]
+            ops.layernorm_fwd(self.res, None, None, self.eps, out=xh2, mean=self.mean_scratch, rstd=self.rstd2[i],
+                              add=self.branch, x_out=self.res)
             ev = self._fc1_events
             if ev is not None:   # bench.py: HIP events around the dominant launch, in its place inside the step (eager replay only)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
             if self.swiglu:
-                ops.gemm_nt(self.ln_out, st.W12, st.b12, epilogue=ops.EPI_SWIGLU, aux_out=self.act_saved[i], out=self.h)
+                ops.gemm_nt(xh2, st.W12, st.b12, epilogue=ops.EPI_SWIGLU, aux_out=self.act_saved[i], out=self.h)
             elif inference:
-                ops.gemm_nt(self.ln_out, st.Wfc1, st.bfc1, epilogue=ops.EPI_GELU_FWD, out=self.h_out)
+                ops.gemm_nt(xh2, st.Wfc1, st.bfc1, epilogue=ops.EPI_GELU_FWD, out=self.h_out)
             else:
-                ops.gemm_nt(self.ln_out, st.Wfc1, st.bfc1, epilogue=ops.EPI_GELU, aux_out=self.act_io[i], out=self.h_out)
+                ops.gemm_nt(xh2, st.Wfc1, st.bfc1, epilogue=ops.EPI_GELU, aux_out=self.act_io[i], out=self.h_out)
             if ev is not None:
                 e1.record()
                 ev.append((e0, e1))
             ops.gemm_nt(self.h_out, st.Wout_i, st.bout, out=self.branch, tag=ops.TAG_FC2)
         # final norm on the CLS rows only (vit.py:416-419) with the last residual add fused, fp32 head + mean CE
-        ops.layernorm_fwd(self.xmid[self.L - 1], self.gf, self.bf_, self.eps, out=self.xn, mean=self.meanf, rstd=self.rstdf,
+        ops.layernorm_fwd(self.res, self.gf, self.bf_, self.eps, out=self.xn, mean=self.meanf, rstd=self.rstdf,
                           rows=B, row_stride=N * D, add=self.branch_cls if self.cls_only_tail else self.branch,
-                          add_row_stride=D if self.cls_only_tail else None, x_out=self.x[self.L])
+                          add_row_stride=D if self.cls_only_tail else None, x_out=self.res)
         ops.sgemm_small(self.xn, self._param_view("fc.weight"), trans_b=True, bias=self._param_view("fc.bias"),
                         out=self.logits)
         ops.cross_entropy(self.logits, self.targets if self.soft_targets else self.labels, dlogits=self.dlogits,
@@ -487,8 +502,8 @@ class AplaTrainEngine:
         cls = lambda t: t.view(B, -1)[:, :t.shape[1]]          # rows b*N of a [B*N, C] buffer as a strided [B, C] view
         ops.attn_fwd_cls(self.qkv[i], B, N, H, self.scale, o=self.o[i], lse=self.lse[i])
         self._gemm_rows(cls(self.o[i]), st.Wnat, st.bnat, out=self.branch_cls)
-        ops.layernorm_fwd(self.x[i], st.g2, st.b2, self.eps, out=self.ln_cls, mean=self.mean2_cls, rstd=self.rstd2_cls,
-                          rows=B, row_stride=N * D, add=self.branch_cls, add_row_stride=D, x_out=self.xmid[i])
+        ops.layernorm_fwd(self.res, None, None, self.eps, out=self.ln_cls, mean=self.mean2_cls, rstd=self.rstd2_cls,
+                          rows=B, row_stride=N * D, add=self.branch_cls, add_row_stride=D, x_out=self.res, D=D)
         if self.swiglu:
             ops.gemm_nt(self.ln_cls, st.W12, st.b12, epilogue=ops.EPI_SWIGLU, aux_out=cls(self.act_saved[i]), out=self.h_cls)
         else:
@@ -500,10 +515,10 @@ class AplaTrainEngine:
         ops.sgemm_small(self.dlogits, self.xn, trans_a=True, out=self._grad_view("fc.weight"))
         ops.colsum(self.dlogits, out=self._grad_view("fc.bias"))
         ops.sgemm_small(self.dlogits, self._param_view("fc.weight"), out=self.dxn)
-        self.G.zero_()
-        if self.Gb is not self.G:
-            self.Gb.zero_()
-        ops.layernorm_bwd(self.dxn, self.x[self.L], self.gf, self.meanf, self.rstdf, out=self.G,
+        # only the CLS rows of the residual gradient exist below the final norm: they are written here, read by the CLS-only
+        # backward of the last block, and the first dense LayerNorm backward takes the other rows as zero (dres_period = N) —
+        # the gradient stream is never zero-filled
+        ops.layernorm_bwd(self.dxn, self.res, self.gf, self.meanf, self.rstdf, out=self.G,
                           out_bf16=None if self.Gb is self.G else self.Gb, rows=B, row_stride=N * D)
 
     def _proj_dw(self, st, dyg, o):
@@ -541,7 +556,7 @@ class AplaTrainEngine:
             ops.gemm_nt(self.Gb, st.WoutT, None, epilogue=ops.EPI_MUL, aux_in=self.act_io[i], out=self.dact_out)
             ops.gemm_nt(self.dact_out, st.Wdfc1_i, None, out=self.dln, tag=ops.TAG_DFC1)
         dyg = (self.dyg_all[i] if self.dw_batch > 1 else self.dyg)[:M * st.r_pad].view(M, st.r_pad)
-        ops.layernorm_bwd(self.dln, self.xmid[i], st.g2, self.mean2[i], self.rstd2[i], dres=self.G, out=self.G,
+        ops.layernorm_bwd(self.dln, self.xh2[i], None, None, self.rstd2[i], dres=self.G, out=self.G,
                           out_bf16=copy, inds=st.inds, r=st.r_pad, gathered=dyg)
         if self.dw_batch > 1:
             self._dw_pending.append((st, dyg, self.o[i]))
@@ -554,7 +569,7 @@ class AplaTrainEngine:
         ops.gemm_nt(self.Gb, st.WnatT_i, None, out=self.dO, tag=ops.TAG_DPROJ)
         ops.attn_bwd(self.qkv[i], self.o[i], self.dO, self.lse[i], B, N, H, self.scale, dqkv=self.dqkv, delta=self.delta)
         ops.gemm_nt(self.dqkv, st.WqkvT_i, None, out=self.dln, tag=ops.TAG_DQKV)
-        ops.layernorm_bwd(self.dln, self.x[i], st.g1, self.mean1[i], self.rstd1[i], dres=self.G, out=self.G, out_bf16=copy)
+        ops.layernorm_bwd(self.dln, self.xh1[i], None, None, self.rstd1[i], dres=self.G, out=self.G, out_bf16=copy)
 
     def _backward_last_block(self):
         """Backward of block L-1 exploiting that only the CLS rows (token 0 of every sequence) of the incoming residual
@@ -573,33 +588,37 @@ class AplaTrainEngine:
             self._gemm_rows(cls(self.Gb), st.WoutT, None, epilogue=ops.EPI_MUL, aux_in=cls(self.act_saved[i]), out=self.dact_cls)
             self._gemm_rows(self.dact_cls, st.Wfc1T, None, out=self.dln_cls)
         dyg = self.dyg_cls[:B * st.r_pad].view(B, st.r_pad)
-        ops.layernorm_bwd(self.dln_cls, self.xmid[i], st.g2,
-                          self.mean2_cls if self.cls_only_tail else self.mean2[i][::N].contiguous(),
-                          self.rstd2_cls if self.cls_only_tail else self.rstd2[i][::N].contiguous(),
-                          dres=self.G, out=self.G, out_bf16=copy, inds=st.inds, r=st.r_pad, gathered=dyg, rows=B, row_stride=N * D)
+        if self.cls_only_tail:    # the forward normalised the CLS rows only: compact [B, D] xhat
+            xh, xh_stride, rstd = self.ln_cls, D, self.rstd2_cls
+        else:                     # (diagnostic full forward) rows b*N of the dense buffers
+            xh, xh_stride, rstd = self.xh2[i], N * D, self.rstd2[i][::N].contiguous()
+        ops.layernorm_bwd(self.dln_cls, xh, None, None, rstd, dres=self.G, out=self.G, out_bf16=copy, inds=st.inds, r=st.r_pad,
+                          gathered=dyg, rows=B, row_stride=N * D, x_row_stride=xh_stride)
         self._proj_dw(st, dyg, cls(self.o[i]))
         if i == 0:
             return
         self._gemm_rows(cls(self.Gb), st.WnatT, None, out=self.dO_cls)
         ops.attn_bwd_cls(self.qkv[i], self.o[i], self.dO_cls, self.lse[i], B, N, H, self.scale, dqkv=self.dqkv)
         ops.gemm_nt(self.dqkv, st.WqkvT_i, None, out=self.dln, tag=ops.TAG_DQKV)
-        ops.layernorm_bwd(self.dln, self.x[i], st.g1, self.mean1[i], self.rstd1[i], dres=self.G, out=self.G, out_bf16=copy)
+        # first dense backward of the step: the incoming stream holds the CLS rows only (see _backward_head)
+        ops.layernorm_bwd(self.dln, self.xh1[i], None, None, self.rstd1[i], dres=self.G, out=self.G, out_bf16=copy, dres_period=N)
 
     def _segment(self, k):
         """Segment k of the step: segment 0 = weight re-scatter + forward + head + the backward down to block seg_cuts[0];
         segment k > 0 = the backward of blocks seg_cuts[k-1]-1 .. seg_cuts[k]."""
-        if k == 0:
-            self.refresh_weights()
-            self._forward()
-            self._backward_head()
-            self._backward_last_block()
-            hi = self.L - 1
-        else:
-            hi = self.seg_cuts[k - 1]
-        for i in range(hi - 1, self.seg_cuts[k] - 1, -1):
-            self._backward_block(i)
-        if self.dw_batch > 1:
-            self._flush_dw()   # a segment's gradients are complete when it ends (its all-reduce chunk is launched next)
+        with ops.reserved_cus(self.reserve_cus):
+            if k == 0:
+                self.refresh_weights()
+                self._forward()
+                self._backward_head()
+                self._backward_last_block()
+                hi = self.L - 1
+            else:
+                hi = self.seg_cuts[k - 1]
+            for i in range(hi - 1, self.seg_cuts[k] - 1, -1):
+                self._backward_block(i)
+            if self.dw_batch > 1:
+                self._flush_dw()   # a segment's gradients are complete when it ends (its all-reduce chunk is launched next)
 
     def _capture(self):
         n = len(self.seg_cuts)

@@ -77,6 +77,7 @@ def _rows2d(t: torch.Tensor, name: str):
 # stateless: the choice travels as a per-call argument of the *_ex entry points).  0 = auto.
 _GEMM_VARIANT = 0
 _ATTN_VARIANT = int(os.environ.get("APLA_ATTN_VARIANT", "0"))
+_RESERVED_CUS = 0   # CUs the persistent GEMM launches leave free (apla_gemm_nt_ex flags bits 20-27): see reserved_cus()
 # profiling tags of apla_gemm_nt_ex (kernel names in a rocprofv3 trace): call sites of the training step
 TAG_QKV, TAG_PROJ, TAG_FC2, TAG_DFC1, TAG_DPROJ, TAG_DQKV, TAG_PATCH = 2, 3, 4, 5, 6, 7, 8
 
@@ -100,6 +101,25 @@ def gemm_out_image_ok(M: int, N: int, K: int, epilogue: int, out_dtype=None) -> 
 def gemm_panel_ok(M: int, N: int, K: int, epilogue: int = 0, out_dtype=None) -> bool:
     """May this problem take K-panel operand images? (apla_gemm_nt_panel_ok)"""
     return bool(lib().apla_gemm_nt_panel_ok(M, N, K, epilogue, _DT[out_dtype or half()]))
+
+
+class reserved_cus:
+    """Context manager: the GEMM launches issued inside leave `n` CUs free for a concurrent collective (data-parallel step)."""
+
+    def __init__(self, n: int):
+        if not 0 <= int(n) < 192:
+            raise ValueError("reserved_cus: 0..191")
+        self.n = int(n)
+
+    def __enter__(self):
+        global _RESERVED_CUS
+        self._old, _RESERVED_CUS = _RESERVED_CUS, self.n
+        return self
+
+    def __exit__(self, *exc):
+        global _RESERVED_CUS
+        _RESERVED_CUS = self._old
+        return False
 
 
 def set_gemm_variant(v: int) -> int:
@@ -193,7 +213,7 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = Non
         raise ValueError("gemm_nt: EPI_GELU_FWD saves nothing (use EPI_GELU to get gelu')")
     rc = lib().apla_gemm_nt_ex(a.data_ptr(), lda, w.data_ptr(), ldw, _ptr(bias), out.data_ptr(), ldc, M, N, K,
                                epilogue, _DT[out.dtype], _ptr(aux_in), ld_in, _ptr(aux_out), ld_out,
-                               (int(tag) & 0xff) | (_GEMM_VARIANT << 8) | (panel << 16), _stream())
+                               (int(tag) & 0xff) | (_GEMM_VARIANT << 8) | (panel << 16) | (_RESERVED_CUS << 20), _stream())
     check(rc, "apla_gemm_nt")
     return out
 
@@ -234,16 +254,30 @@ def gemm_nt_small(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]
     return out
 
 
-def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-6, *,
+def gemm_kernel_name(M: int, N: int, K: int, epilogue: int = EPI_STORE, out_dtype=None, *, out_image: bool = False,
+                     aux_image: bool = False) -> str:
+    """Name of the kernel apla_gemm_nt_ex dispatches this problem to under the current schedule choice (apla_gemm_nt_kernel_name)."""
+    import ctypes
+    buf = ctypes.create_string_buffer(96)
+    panel = (4 if out_image else 0) | (8 if aux_image else 0)
+    check(lib().apla_gemm_nt_kernel_name(M, N, K, epilogue, _DT[out_dtype or half()], (_GEMM_VARIANT << 8) | (panel << 16), buf, 96),
+          "apla_gemm_nt_kernel_name")
+    return buf.value.decode()
+
+
+def layernorm_fwd(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[torch.Tensor], eps: float = 1e-6, *,
                   out_dtype=None, rows: Optional[int] = None, row_stride: Optional[int] = None,
                   out: Optional[torch.Tensor] = None, mean: Optional[torch.Tensor] = None,
                   rstd: Optional[torch.Tensor] = None, add: Optional[torch.Tensor] = None,
-                  x_out: Optional[torch.Tensor] = None, add_row_stride: Optional[int] = None):
+                  x_out: Optional[torch.Tensor] = None, add_row_stride: Optional[int] = None, D: Optional[int] = None):
     """x: [M,D] residual stream (fp32|bf16).  With rows/row_stride given, x (and add / x_out) are flat buffers and row m
     starts at m*row_stride (CLS-row selection).  With ``add`` (bf16 branch output) the residual update x_out = x + add is
-    fused (x_out may alias x).  Returns (y [M,D], mean [M], rstd [M])."""
+    fused (x_out may alias x).  gamma = beta = None: y is the normalised row itself (pass ``D``).
+    Returns (y [M,D], mean [M], rstd [M])."""
     _req(x, None, "x")
-    D = gamma.numel()
+    if (gamma is None) != (beta is None) or (gamma is None and D is None and rows is not None):
+        raise ValueError("layernorm_fwd: gamma and beta go together; without them give D for strided rows")
+    D = gamma.numel() if gamma is not None else (D if D is not None else x.shape[-1])
     if rows is None:
         M, Dx, xs = _rows2d(x, "x")
         if Dx != D:
@@ -252,7 +286,10 @@ def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps:
         M, xs = rows, row_stride
         if (M - 1) * xs + D > x.numel():
             raise ValueError("layernorm_fwd: strided rows exceed the buffer")
-    _req(gamma, torch.float32, "gamma", 1), _req(beta, torch.float32, "beta", 1)
+    if gamma is not None:
+        _req(gamma, torch.float32, "gamma", 1), _req(beta, torch.float32, "beta", 1)
+        if beta.numel() != D:
+            raise ValueError("layernorm_fwd: beta length")
     if out is None:
         out = torch.empty(M, D, device=x.device, dtype=out_dtype or half())
     if mean is None:
@@ -274,21 +311,24 @@ def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps:
             adds = row_stride if add_row_stride is None else add_row_stride  # e.g. a compact [M, D] branch added into strided rows
             if (M - 1) * adds + D > add.numel() or (M - 1) * row_stride + D > x_out.numel():
                 raise ValueError("layernorm_fwd: strided add / x_out exceed their buffers")
-    rc = lib().apla_layernorm_fwd(x.data_ptr(), _DT[x.dtype], xs, gamma.data_ptr(), beta.data_ptr(), out.data_ptr(),
+    rc = lib().apla_layernorm_fwd(x.data_ptr(), _DT[x.dtype], xs, _ptr(gamma), _ptr(beta), out.data_ptr(),
                                   _DT[out.dtype], out.stride(0), mean.data_ptr(), rstd.data_ptr(), M, D, float(eps),
                                   _ptr(add), adds, _ptr(x_out), xouts, _stream())
     check(rc, "apla_layernorm_fwd")
     return out, mean, rstd
 
 
-def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor, *,
+def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: Optional[torch.Tensor], mean: Optional[torch.Tensor],
+                  rstd: torch.Tensor, *,
                   dres: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
                   out_bf16: Optional[torch.Tensor] = None, inds: Optional[torch.Tensor] = None, r: int = 0,
                   gathered: Optional[torch.Tensor] = None, rows: Optional[int] = None,
-                  row_stride: Optional[int] = None):
+                  row_stride: Optional[int] = None, x_row_stride: Optional[int] = None, dres_period: int = 0):
     """dx = dres + LN_bwd_dx(dy).  Returns (dx, gathered | None).  ``out`` (the gradient stream, fp32|bf16) may alias
     ``dres``; ``out_bf16`` optionally receives a bf16 copy.  With rows/row_stride: x, out (and out_bf16) are flat
-    buffers whose row m starts at m*row_stride (only those rows are read/written)."""
+    buffers whose row m starts at m*row_stride (only those rows are read/written); ``x_row_stride`` gives x its own pitch.
+    mean = None: ``x`` is the normalised row saved by layernorm_fwd(gamma=None); gamma = None: no affine part;
+    dres_period p > 1: dres is read in rows m % p == 0 only and taken as zero elsewhere (apla_layernorm_bwd_ex)."""
     _req(dy, None, "dy", 2), _req(x, None, "x")
     M, D, lddy = _rows2d(dy, "dy")
     if rows is None:
@@ -306,7 +346,8 @@ def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mean: 
     else:
         if rows != M or out is None:
             raise ValueError("layernorm_bwd: strided mode needs rows == dy rows and an out buffer")
-        xs = dxs = cbs = row_stride
+        dxs = cbs = row_stride
+        xs = row_stride if x_row_stride is None else x_row_stride
         if (M - 1) * xs + D > x.numel() or (M - 1) * dxs + D > out.numel() or \
                 (out_bf16 is not None and (M - 1) * cbs + D > out_bf16.numel()):
             raise ValueError("layernorm_bwd: strided rows exceed the buffer")
@@ -326,9 +367,16 @@ def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mean: 
             raise ValueError("layernorm_bwd: gathered buffer")
     else:
         gathered = None
-    rc = lib().apla_layernorm_bwd(dy.data_ptr(), _DT[dy.dtype], lddy, x.data_ptr(), _DT[x.dtype], xs, gamma.data_ptr(),
-                                  mean.data_ptr(), rstd.data_ptr(), _ptr(dres), out.data_ptr(), _DT[out.dtype], dxs,
-                                  _ptr(out_bf16), cbs, _ptr(inds), r, _ptr(gathered), M, D, _stream())
+    if gamma is not None:
+        _req(gamma, torch.float32, "gamma", 1)
+    if mean is not None:
+        _req(mean, torch.float32, "mean", 1)
+    _req(rstd, torch.float32, "rstd", 1)
+    if rstd.numel() < M or (mean is not None and mean.numel() < M) or (gamma is not None and gamma.numel() != D) or dres_period < 0:
+        raise ValueError("layernorm_bwd: statistics / gamma sizes")
+    rc = lib().apla_layernorm_bwd_ex(dy.data_ptr(), _DT[dy.dtype], lddy, x.data_ptr(), _DT[x.dtype], xs, _ptr(gamma),
+                                     _ptr(mean), rstd.data_ptr(), _ptr(dres), int(dres_period), out.data_ptr(), _DT[out.dtype], dxs,
+                                     _ptr(out_bf16), cbs, _ptr(inds), r, _ptr(gathered), M, D, _stream())
     check(rc, "apla_layernorm_bwd")
     return out, gathered
 

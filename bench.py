@@ -171,12 +171,26 @@ def _free_port():
         return s.getsockname()[1]
 
 
+RCCL_CHANNELS = 8   # workgroups an RCCL all-reduce kernel may start = CUs the step's GEMM launches leave free (engine.reserve_cus)
+
+
+def rccl_channel_budget(env):
+    """The gradient exchange moves 10 MB per step in four chunks: bandwidth is not its limit, the CUs it takes from
+    the step's persistent kernels are.  RCCL is therefore held to RCCL_CHANNELS channels (one workgroup each) — the number of
+    CUs the GEMM launches of the world > 1 path leave free (AplaTrainEngine.reserve_cus, APLA_RESERVE_CUS).  setdefault: an
+    operator's own NCCL_* settings win.  tools/contention_probe.py measures what resident foreign workgroups cost the step."""
+    env.setdefault("NCCL_MAX_NCHANNELS", str(RCCL_CHANNELS))
+    env.setdefault("NCCL_MIN_NCHANNELS", "1")
+    env.setdefault("APLA_RESERVE_CUS", env["NCCL_MAX_NCHANNELS"])
+
+
 def launch_ranks(n, argv):
     """Parent of a self-launched multi-GPU run: N children of this file, one per GPU.  Never imports the engine, never
     initialises HIP.  Children inherit stdout (rank 0 prints the JSON line); the first failing child ends the run."""
     env = dict(os.environ)
     env.update(WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), LOCAL_WORLD_SIZE=str(n))
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL needs it on this host driver)
+    rccl_channel_budget(env)
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
     procs = []
     for r in range(n):
@@ -282,6 +296,7 @@ def main():
     if world > 1 or force_pg:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        rccl_channel_budget(os.environ)    # also under torch.distributed.run, before RCCL reads its environment
         if force_pg:
             os.environ.setdefault("MASTER_PORT", "29533")
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
@@ -300,6 +315,8 @@ def main():
     if args.res_dtype == "bf16" or args.grad_dtype == "bf16":  # "bf16" on these switches means "the 16-bit operand type"
         dt["bf16"] = hdt
     parity = parity_cfg1(hdt, loss_scale) if (rank == 0 and not args.no_parity) else None
+    # the fp16 build of the same kernels on the same config-1 check (the north-star's 1e-3 is an fp16-operand number)
+    parity_f16 = parity_cfg1(torch.float16, 1024.0) if (parity is not None and args.dtype == "bf16") else None
     model = build_model(args.backbone, args.partial_size, args.classes, img, patch, seed=0)  # same seed => same indices on all ranks
     eng = AplaTrainEngine(model, args.batch, img, res_dtype=dt[args.res_dtype], grad_dtype=dt[args.grad_dtype],
                           optim=OptimConfig(lr=1e-4, weight_decay=1e-5, grad_clipping=1.0), process_group=pg,
@@ -352,6 +369,9 @@ def main():
         with _ops.use_half(hdt):
             iso_ms, _ = time_dominant_kernel(M, bb.embed_dim, eng.blocks[0].F, hdt)    # back-to-back launches of the same GEMM
         Fdim = eng.blocks[0].F * (2 if eng.swiglu else 1)
+        with _ops.use_half(hdt):   # the kernel the dispatch actually picks for that launch (same decision code as the launch)
+            dom_kernel = _ops.gemm_kernel_name(M, Fdim, bb.embed_dim, _ops.EPI_SWIGLU if eng.swiglu else _ops.EPI_GELU,
+                                               out_image=bool(eng.h_img), aux_image=bool(eng.h_img and eng.act_io[0].ndim == 3))
         k_tf = 2.0 * M * bb.embed_dim * Fdim / (k_ms * 1e-3) / 1e12
         is_cfg2 = (args.backbone, img, patch, args.batch, args.partial_size) == ("vit_base", 224, 16, 128, 192)
         gf = STEP_GF_PER_IMG.get((args.backbone, img, patch))
@@ -380,7 +400,7 @@ def main():
                        "hip_graphs": not args.no_graphs},
             "images_per_sec_per_gpu": round(img_s / world, 1), "peak_mem_gib": round(peak_mem, 2),
             "final_loss": round(loss, 4),
-            "roofline": {"bound": "mfma", "kernel": f"gemm_persist_kernel<GELU> (apla_gemm_nt, fc1+GELU launch) M={M} N={eng.blocks[0].F} K={bb.embed_dim}",
+            "roofline": {"bound": "mfma", "kernel": f"{dom_kernel} (apla_gemm_nt, fc1+activation launch) M={M} N={Fdim} K={bb.embed_dim}",
                          "achieved": round(k_tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(k_tf / PEAK_BF16_TFLOPS, 4),
                          # register-only MFMA loop on random data on THIS GPU (tools/mfma_peak.hip): what the matrix pipes deliver
@@ -402,6 +422,8 @@ def main():
         }
         if parity is not None:
             out["parity"] = parity
+        if parity_f16 is not None:
+            out["parity_fp16"] = parity_f16
         if cpu_rec is not None:
             out["cpu_baseline"] = cpu_rec
         print(json.dumps(out), flush=True)

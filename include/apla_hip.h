@@ -84,7 +84,12 @@ int apla_gemm_nt(const void* A, int lda, const void* W, int ldw, const float* bi
  *              epilogues with row-major operands (they run on the 4-wave persistent kernel), so that fc1's h and dfc2's
  *              product reach the next GEMM (fc2, dfc1) as images without a conversion pass.
  *   bit 19     the epilogue's second operand (aux_out of GELU = gelu', aux_in of MUL) is an image [N/32][M][32] (`ld_aux_*` not
- *              read): private to those two epilogues, stored and loaded in whole lines.  Same kernels and conditions as bit 18. */
+ *              read): private to those two epilogues, stored and loaded in whole lines.  Same kernels and conditions as bit 18.
+ *   bits 20-27 CUs to leave FREE (0..191): the persistent kernels start one (ping-pong) or two (4-wave) workgroups per CU on
+ *              256 - n CUs instead of all 256.  The data-parallel step passes the CU budget of its collective here, so that the
+ *              RCCL kernels of the overlapped gradient all-reduce (wrappers.py:182-183) run beside the GEMMs instead of taking a
+ *              CU from a launch that wants them all.  At config 2 a reservation of up to 8 CUs costs the GEMMs nothing: their
+ *              tile counts (237 / 711 tiles of 320 x 256, 3 792 of 160 x 128) leave that many CUs idle in the last round anyway. */
 int apla_gemm_nt_panel_ok(int M, int N, int K, int epilogue, int out_dtype);
 int apla_gemm_nt_out_image_ok(int M, int N, int K, int epilogue, int out_dtype);   /* bit 18: is the image store available AND on the kernel the automatic schedule picks? */
 /* dst[(k / 32) * rows + r][k % 32] = src[r][k] for a 16-bit [rows, K] matrix with row pitch ld (K % 32 == 0): the K-panel image */
@@ -92,6 +97,11 @@ int apla_pack_k_panels(const void* src, long ld, void* dst, int rows, int K, hip
 int apla_gemm_nt_ex(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int M, int N,
                     int K, int epilogue, int out_dtype, const void* aux_in, int ld_aux_in, void* aux_out,
                     int ld_aux_out, int flags, hipStream_t stream);
+
+/* The kernel apla_gemm_nt_ex runs this problem on, as a rocprofv3 kernel trace shows it (tools/summarize_prof.py spelling), e.g.
+ * "gemm_persist_kernel<GELU,bf16,5>"; `flags` as for apla_gemm_nt_ex; buf needs >= 48 bytes.  Same decision code as the launch:
+ * bench.py names the kernel of its roofline record from this, not from a literal. */
+int apla_gemm_nt_kernel_name(int M, int N, int K, int epilogue, int out_dtype, int flags, char* buf, int buflen);
 
 /* apla_gemm_nt for FEW rows (the CLS-only tail of the last block: projection / MLP / Q of Block.forward on the B rows that
  * reach x[:, 0], vit.py:279-288,416-419): the K axis is split over K/64 (K <= 1536) or K/128 slices so that a few hundred
@@ -124,6 +134,21 @@ int apla_layernorm_bwd(const void* dy, int dy_dtype, int lddy, const void* x, in
                        const float* gamma, const float* mean, const float* rstd, const void* dres_in, void* dx_out,
                        int grad_dtype, long dx_row_stride, void* dx_bf16_copy, long copy_row_stride,
                        const int32_t* inds, int r, void* gather_out, int M, int D, hipStream_t stream);
+
+/* apla_layernorm_bwd with three more choices (what the fused step uses since round 3):
+ *   mean == NULL        `x` holds the NORMALISED row xhat = (x - mean) * rstd as apla_layernorm_fwd wrote it with gamma == beta ==
+ *                       NULL (16-bit, one buffer per LayerNorm of the model): the backward reads 2 bytes per element instead of
+ *                       the 4 of the fp32 residual row, and the residual stream itself need not be kept per block;
+ *   gamma == NULL       no affine part: gamma / beta of a frozen LayerNorm are folded into the weight / bias of the frozen Linear
+ *                       that follows it (qkv: appla_attn.py:53, fc1 / w12: vit.py:152-168,131-149), W' = W diag(gamma),
+ *                       b' = b + W beta, so dy already is the gradient of xhat;
+ *   dres_row_period p   p > 1: dres_in is non-zero only in rows m with m % p == 0 and is not read elsewhere (the residual gradient
+ *                       below the final norm lives in the CLS rows only, vit.py:416-419): no zero fill of the stream.
+ * apla_layernorm_fwd accepts gamma == beta == NULL accordingly (y = xhat). */
+int apla_layernorm_bwd_ex(const void* dy, int dy_dtype, int lddy, const void* x, int x_dtype, long x_row_stride,
+                          const float* gamma, const float* mean, const float* rstd, const void* dres_in, int dres_row_period,
+                          void* dx_out, int grad_dtype, long dx_row_stride, void* dx_bf16_copy, long copy_row_stride,
+                          const int32_t* inds, int r, void* gather_out, int M, int D, hipStream_t stream);
 
 /* Gather only (used when the projection output gradient is already materialised): out[m,j] = src[m,inds[j]] bf16. */
 int apla_gather_cols(const void* src, int res_dtype, long src_row_stride, const int32_t* inds, int r, void* out,
@@ -326,6 +351,11 @@ int apla_cross_entropy(const float* logits, int ldl, const int32_t* labels, floa
 int apla_cross_entropy_soft(const float* logits, int ldl, const float* targets, int ldt, float* dlogits, float* row_loss,
                             float* loss, int B, int C, hipStream_t stream);
 int apla_colsum(const float* X, long ld, float* out, int M, int N, hipStream_t stream);
+
+/* Diagnostic, not on the product path: `workgroups` workgroups of `threads` threads with `lds_bytes` of LDS each stay resident
+ * for `usec` microseconds.  tools/contention_probe.py launches it on the side stream where the data-parallel step launches its
+ * RCCL all-reduces (wrappers.py:182-183), to measure what foreign resident workgroups cost the step's persistent kernels. */
+int apla_probe_occupy(int workgroups, int threads, int lds_bytes, int usec, hipStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -180,6 +180,52 @@ def test_layernorm_cls_rows_strided(ops):
     assert rel_err(out.cpu(), ref) < 5 * F32_OUT
 
 
+@pytest.mark.parametrize("M,D,N", [(6 * 7, 128, 7), (515, 768, 5), (4 * 197, 384, 197)])
+def test_layernorm_normalised_row_mode(ops, M, D, N):
+    """What the fused step runs since round 3 (apla_layernorm_bwd_ex): the forward writes xhat itself (gamma / beta are folded into
+    the next frozen Linear: W' = W diag(gamma), b' = b + W beta), in place on ONE residual buffer; the backward reads that 16-bit
+    xhat + rstd instead of the fp32 row, takes dy as the gradient of xhat, and can treat the incoming residual gradient as
+    non-zero in every N-th row only.  Checked against the oracle's LayerNorm (vit.py:279-288) with the fold undone."""
+    x = rnd(M, D, seed=31) * 1.5 + 0.3
+    add, addd = bf(rnd(M, D, seed=32) * 0.5)
+    gamma, beta = 1 + 0.2 * rnd(D, seed=33), 0.1 * rnd(D, seed=34)
+    W = rnd(64, D, seed=35) * D ** -0.5
+    xd = x.double() + addd
+    yref, mref, rref = O.layernorm_fwd(xd, gamma.double(), beta.double(), 1e-6)
+    res = dev(x)
+    xh, _, rstd = ops.layernorm_fwd(res, None, None, 1e-6, add=dev(add), x_out=res)          # in place
+    assert rel_err(res.cpu(), xd) < 1e-6 and rel_err(rstd.cpu(), rref) < 1e-5
+    xhat_ref = (xd - mref[:, None]) * rref[:, None]
+    assert rel_err(xh.cpu(), xhat_ref) < BF16_OUT
+    # the fold: LN(x) W^T = xhat (W diag(gamma))^T + W beta
+    lhs = yref @ W.double().t()
+    rhs = xhat_ref @ (W.double() * gamma.double()[None, :]).t() + (W.double() @ beta.double())[None, :]
+    assert rel_err(rhs, lhs) < 1e-12
+    # backward: dy_hat = dy * gamma is what the dX GEMM on the folded weight delivers
+    dy, dyd = bf(rnd(M, D, seed=36))
+    ref_dx = O.layernorm_bwd_dx(dyd, xd, torch.ones(D, dtype=torch.float64), mref, rref)      # gradient of xhat given
+    dres = torch.zeros(M, D)
+    dres[::N] = rnd(M, D, seed=37)[::N]
+    G = dev(rnd(M, D, seed=38).to(torch.bfloat16))      # garbage everywhere ...
+    G[::N] = dev(dres[::N].to(torch.bfloat16))         # ... except the rows that carry gradient
+    dresd = G.cpu().double()
+    inds = torch.randperm(D, generator=torch.Generator().manual_seed(2)).int()
+    r = 64
+    out, gathered = ops.layernorm_bwd(dev(dy), xh, None, None, rstd, dres=G, out=G, dres_period=N, inds=dev(inds), r=r)
+    ref = ref_dx.clone()
+    ref[::N] += dresd[::N]
+    assert rel_err(out.cpu(), ref) < 1.5 * BF16_OUT          # xhat rounded to 16 bits enters the projection term
+    assert rel_err(gathered.cpu(), ref[:, inds[:r].long()]) < 1.5 * BF16_OUT
+    # strided rows with a compact xhat (the CLS-only last block): x_row_stride = D, gradient rows N*D apart
+    B = M // N
+    xh_c = xh.view(B, N * D)[:, :D].contiguous()
+    out2 = torch.zeros(M, D, device="cuda")
+    ops.layernorm_bwd(dev(dy[::N].contiguous()), xh_c, None, None, rstd[::N].contiguous(), out=out2, rows=B, row_stride=N * D, x_row_stride=D)
+    ref2 = torch.zeros(M, D, dtype=torch.float64)
+    ref2[::N] = ref_dx[::N]
+    assert rel_err(out2.cpu(), ref2) < 1.5 * BF16_OUT
+
+
 # ------------------------------------------------------------------------------------------- attention
 @pytest.fixture
 def attn_variant(request):
