@@ -18,8 +18,8 @@ struct GemmParams {
   int w_panel;  // operand images (apla_gemm_nt_ex flags bits 16 / 17): bit 0 = W is K-panel-major [K/32][N][32], bit 1 = A is
                 // [K/32][M][32].  In that image the 64 bytes a row gives to a 32-wide K-step sit next to its neighbours' (whole
                 // 128-byte lines per LDS-DMA instruction: tools/dma_probe.hip); ping-pong kernel only.  Bit 2 = the OUTPUT C is
-                // written as its K-panel image [N/32][M][32] (16-bit, 4-wave persistent kernel: GELU / GELU_FWD / MUL), ready to be
-                // the A operand of the next GEMM.  Bit 3 = the second operand of the epilogue (aux_out of GELU, aux_in of MUL: gelu'
+                // written as its K-panel image [Nout/32][M][32] (16-bit, 4-wave persistent kernel: GELU / GELU_FWD / MUL and the
+                // two SwiGLU epilogues, whose C is N/2 resp. 2N wide), ready to be the A operand of the next GEMM.  Bit 3 = the second operand of the epilogue (aux_out of GELU, aux_in of MUL: gelu'
                 // saved by the forward for the backward) is an image [N/32][M][32] too: a tensor private to those two epilogues,
                 // stored and loaded in whole lines instead of 64-byte row pieces.
   int reserve;  // CUs this launch leaves free (apla_gemm_nt_ex flags bits 20-27): the persistent kernels start 256 - reserve (ping-pong)
@@ -279,7 +279,7 @@ __device__ __forceinline__ void persist_epilogue(const GemmParams& p, f32x4 (&ac
         h[1] = (bf16)(lo[2] * sigmoid_f(lo[2]) * lo[3]);
         h[2] = (bf16)(hi[0] * sigmoid_f(hi[0]) * hi[1]);
         h[3] = (bf16)(hi[2] * sigmoid_f(hi[2]) * hi[3]);
-        *(bf16x4*)((bf16*)p.C + (size_t)m * p.ldc + (n >> 1)) = h;
+        *(bf16x4*)c_at(m, n >> 1) = h;    // 4 hidden units (n / 2 is a multiple of 4: they never straddle a 32-wide panel)
       } else if constexpr (EPI == APLA_EPI_SWIGLU_BWD) {
         // dh for hidden units n..n+7; saved x12 interleaved at columns 2n..2n+15
         const bf16* xs = (const bf16*)p.aux_in + (size_t)m * p.ld_aux_in + 2 * n;
@@ -294,8 +294,8 @@ __device__ __forceinline__ void persist_epilogue(const GemmParams& p, f32x4 (&ac
           ob[2 * e] = (bf16)(hi[e] * x2 * sg * (1.0f + x1 * (1.0f - sg)));
           ob[2 * e + 1] = (bf16)(hi[e] * x1 * sg);
         }
-        *(bf16x8*)((bf16*)p.C + (size_t)m * p.ldc + 2 * n) = oa;
-        *(bf16x8*)((bf16*)p.C + (size_t)m * p.ldc + 2 * n + 8) = ob;
+        *(bf16x8*)c_at(m, 2 * n) = oa;        // 2 n is a multiple of 16: both 8-element pieces stay inside one panel
+        *(bf16x8*)c_at(m, 2 * n + 8) = ob;
       }
     }
   }

@@ -355,10 +355,11 @@ static int gemm_nt_impl(const void* A, int lda, const void* W, int ldw, const fl
   APLA_REQUIRE(N % BN == 0 && K % BK == 0, "apla_gemm_nt: need N%%128==0 and K%%64==0 (N=%d K=%d)", N, K);
   APLA_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && ((w_panel & 2) || lda >= K) && ((w_panel & 1) || ldw >= K), "apla_gemm_nt: bad lda/ldw (%d,%d) K=%d", lda, ldw, K);
   if (w_panel & 12) {
-    APLA_REQUIRE((w_panel & 3) == 0 && out_dtype == APLA_H16 && N % 32 == 0 &&
-                 (epilogue == APLA_EPI_GELU || epilogue == APLA_EPI_GELU_FWD || epilogue == APLA_EPI_MUL),
-                 "apla_gemm_nt_ex: an output / second-operand image needs a 16-bit GELU / GELU_FWD / MUL epilogue and row-major operands");
-    APLA_REQUIRE(!(w_panel & 8) || epilogue != APLA_EPI_GELU_FWD, "apla_gemm_nt_ex: GELU_FWD has no second operand");
+    const bool sw = epilogue == APLA_EPI_SWIGLU || epilogue == APLA_EPI_SWIGLU_BWD;
+    APLA_REQUIRE((w_panel & 3) == 0 && out_dtype == APLA_H16 && N % 64 == 0 &&
+                 (epilogue == APLA_EPI_GELU || epilogue == APLA_EPI_GELU_FWD || epilogue == APLA_EPI_MUL || sw),
+                 "apla_gemm_nt_ex: an output / second-operand image needs a 16-bit GELU / GELU_FWD / MUL / SwiGLU epilogue and row-major operands");
+    APLA_REQUIRE(!(w_panel & 8) || (epilogue != APLA_EPI_GELU_FWD && !sw), "apla_gemm_nt_ex: only GELU / MUL keep their second operand as an image");
   } else if (w_panel) {
     APLA_REQUIRE(apla_gemm_pp2_covers(M, N, K, (w_panel & 2) ? 32 : lda, (w_panel & 1) ? 32 : ldw, epilogue, out_dtype),
                  "apla_gemm_nt_ex: K-panel operand images need the ping-pong kernel (STORE / GELU, N %% 256 == 0, K %% 32 == 0, K >= 128): ask apla_gemm_nt_panel_ok first");
@@ -390,10 +391,10 @@ static int gemm_nt_impl(const void* A, int lda, const void* W, int ldw, const fl
       APLA_REQUIRE(aux_in && apla_aligned16(aux_in) && ld_aux_in % 4 == 0 && ld_aux_in >= N && ldc >= N, "apla_gemm_nt[mul]: aux_in [M,N] bf16 required");
       return launch<APLA_EPI_MUL, bf16>(p, variant, stream);
     case APLA_EPI_SWIGLU:
-      APLA_REQUIRE(aux_out && apla_aligned16(aux_out) && ld_aux_out % 4 == 0 && ld_aux_out >= N && ldc % 2 == 0 && ldc >= N / 2, "apla_gemm_nt[swiglu]: aux_out [M,N] bf16 required");
+      APLA_REQUIRE(aux_out && apla_aligned16(aux_out) && ld_aux_out % 4 == 0 && ld_aux_out >= N && ((w_panel & 4) || (ldc % 2 == 0 && ldc >= N / 2)), "apla_gemm_nt[swiglu]: aux_out [M,N] bf16 required");
       return launch<APLA_EPI_SWIGLU, bf16>(p, variant, stream);
     case APLA_EPI_SWIGLU_BWD:
-      APLA_REQUIRE(aux_in && apla_aligned16(aux_in) && ld_aux_in % 8 == 0 && ld_aux_in >= 2 * N && ldc % 8 == 0 && ldc >= 2 * N, "apla_gemm_nt[swiglu_bwd]: aux_in [M,2N] bf16 required");
+      APLA_REQUIRE(aux_in && apla_aligned16(aux_in) && ld_aux_in % 8 == 0 && ld_aux_in >= 2 * N && ((w_panel & 4) || (ldc % 8 == 0 && ldc >= 2 * N)), "apla_gemm_nt[swiglu_bwd]: aux_in [M,2N] bf16 required");
       return launch<APLA_EPI_SWIGLU_BWD, bf16>(p, variant, stream);
     default:
       break;
@@ -423,6 +424,7 @@ extern "C" int apla_gemm_nt_panel_ok(int M, int N, int K, int epilogue, int out_
 extern "C" int apla_gemm_nt_out_image_ok(int M, int N, int K, int epilogue, int out_dtype) {
   if (M <= 0 || N % BN != 0 || K % BK != 0 || out_dtype != APLA_H16) return 0;
   if (epilogue == APLA_EPI_GELU_FWD || epilogue == APLA_EPI_MUL) return 1;
+  if (epilogue == APLA_EPI_SWIGLU || epilogue == APLA_EPI_SWIGLU_BWD) return N % 64 == 0 ? 1 : 0;   // C is N/2 resp. 2N wide (ViT-g: vit.py:131-149)
   return (epilogue == APLA_EPI_GELU && M <= 40000) ? 1 : 0;
 }
 

@@ -148,6 +148,78 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const DYT* __restric
   }
 }
 
+// The backward as the fused step runs it (normalised row xhat in 16 bits, no affine part, 16-bit gradient stream): TWO rows per
+// wave, a half-wave each, 8 elements (16 bytes) per lane and access.  The one-row-per-wave form above moves 8 bytes per lane and
+// access for 16-bit operands and reached 4.3 TB/s on these shapes; rows of 768 / 1024 / 1536 elements are 3 / 4 / 6 whole chunks
+// per lane here.  dx = dres + (dy - mean(dy) - xhat * mean(dy * xhat)) * rstd.
+template <bool GATHER, int NC8>
+__global__ __launch_bounds__(LN_THREADS) void ln_bwd2_kernel(const bf16* __restrict__ dy, int lddy, const bf16* __restrict__ xh,
+                                                      long xs, const float* __restrict__ rstd_i, const bf16* dres, bf16* dx,
+                                                      long dxs, const int32_t* __restrict__ inds, int r,
+                                                      bf16* __restrict__ gout, int M, int D, int dres_period) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* rowbuf = (float*)smem_raw;  // [2 * ROWS_PER_BLOCK][D] when GATHER
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int hl = lane & 31, half = lane >> 5;
+  const int nchunk = D >> 3;
+  const float invD = 1.0f / (float)D;
+  for (int m0 = blockIdx.x * (2 * ROWS_PER_BLOCK); m0 < M; m0 += gridDim.x * (2 * ROWS_PER_BLOCK)) {
+    const int m = m0 + 2 * wave + half;
+    const bool live = m < M;
+    const int mr = live ? m : M - 1;        // a dead half-wave re-reads the last row (keeps the cross-lane sums uniform), stores nothing
+    const bf16* xr = xh + (size_t)mr * xs;
+    const bf16* dyr = dy + (size_t)mr * lddy;
+    const float rstd = rstd_i[mr];
+    const bool has_res = dres != nullptr && (dres_period <= 1 || mr % dres_period == 0);
+    bf16x8 xv[NC8], dv[NC8], rv[NC8];
+#pragma unroll
+    for (int c = 0; c < NC8; ++c) {
+      const int ch = hl + c * 32;
+      if (ch < nchunk) {
+        xv[c] = *(const bf16x8*)(xr + ch * 8);
+        dv[c] = *(const bf16x8*)(dyr + ch * 8);
+        if (has_res) rv[c] = *(const bf16x8*)(dres + (size_t)mr * dxs + ch * 8);
+      }
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC8; ++c) {
+      if (hl + c * 32 < nchunk) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float w = (float)dv[c][e];
+          s1 += w;
+          s2 += w * (float)xv[c][e];
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }   // within the half-wave
+    const float c1 = s1 * invD, c2 = s2 * invD;
+#pragma unroll
+    for (int c = 0; c < NC8; ++c) {
+      const int ch = hl + c * 32;
+      if (ch < nchunk) {
+        bf16x8 ov;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float o = ((float)dv[c][e] - c1 - (float)xv[c][e] * c2) * rstd;
+          if (has_res) o += (float)rv[c][e];
+          ov[e] = (bf16)o;
+          if constexpr (GATHER) rowbuf[(2 * wave + half) * D + ch * 8 + e] = o;
+        }
+        if (live) *(bf16x8*)(dx + (size_t)m * dxs + ch * 8) = ov;
+      }
+    }
+    if constexpr (GATHER) {
+      __syncthreads();
+      if (live)
+        for (int j = hl; j < r; j += 32) gout[(size_t)m * r + j] = (bf16)rowbuf[(2 * wave + half) * D + inds[j]];
+      __syncthreads();
+    }
+  }
+}
+
 template <typename ResT>
 __global__ __launch_bounds__(LN_THREADS) void gather_cols_kernel(const ResT* __restrict__ src, long ss,
                                                           const int32_t* __restrict__ inds, int r,
@@ -216,6 +288,31 @@ extern "C" int apla_layernorm_bwd_ex(const void* dy, int dy_dtype, int lddy, con
   APLA_REQUIRE(dx_bf16_copy == nullptr || (copy_row_stride % 4 == 0 && copy_row_stride >= D), "apla_layernorm_bwd: bad copy stride");
   APLA_REQUIRE(gather_out == nullptr || (inds != nullptr && r > 0 && r <= D), "apla_layernorm_bwd: gather needs inds and 0<r<=D");
   const bool gather = gather_out != nullptr;
+  // the fused step's case: xhat and dy in 16 bits, 16-bit gradient stream without a separate copy, no affine part, whole 8-element
+  // chunks -> the two-rows-per-wave kernel
+  if (mean == nullptr && gamma == nullptr && x_dtype == APLA_H16 && dy_dtype == APLA_H16 && grad_dtype == APLA_H16 &&
+      dx_bf16_copy == nullptr && D % 8 == 0 && D <= 256 * 8 && lddy % 8 == 0 && x_row_stride % 8 == 0 && dx_row_stride % 8 == 0 &&
+      apla_aligned16(dy) && apla_aligned16(x) && apla_aligned16(dx_out) && (dres_in == nullptr || apla_aligned16(dres_in))) {
+    const int nc8 = (D / 8 + 31) / 32;
+    const int g2 = (M + 2 * ROWS_PER_BLOCK - 1) / (2 * ROWS_PER_BLOCK);
+    const dim3 grid2(g2 < 4096 ? g2 : 4096);
+    const size_t lds2 = gather ? (size_t)2 * ROWS_PER_BLOCK * D * sizeof(float) : 0;
+#define LN_BWD2(GA, NCV)                                                                                                           \
+    hipLaunchKernelGGL((ln_bwd2_kernel<GA, NCV>), grid2, dim3(LN_THREADS), lds2, stream, (const bf16*)dy, lddy, (const bf16*)x,      \
+                       x_row_stride, rstd, (const bf16*)dres_in, (bf16*)dx_out, dx_row_stride, inds, r, (bf16*)gather_out, M, D,    \
+                       dres_row_period)
+#define LN_BWD2_G(NCV) do { if (gather) LN_BWD2(true, NCV); else LN_BWD2(false, NCV); } while (0)
+    if (nc8 <= 1) LN_BWD2_G(1);
+    else if (nc8 == 2) LN_BWD2_G(2);
+    else if (nc8 == 3) LN_BWD2_G(3);
+    else if (nc8 == 4) LN_BWD2_G(4);
+    else if (nc8 <= 6) LN_BWD2_G(6);
+    else LN_BWD2_G(8);
+#undef LN_BWD2_G
+#undef LN_BWD2
+    APLA_CHECK_LAUNCH("apla_layernorm_bwd");
+    return APLA_OK;
+  }
   const size_t lds = gather ? (size_t)ROWS_PER_BLOCK * D * sizeof(float) : 0;
 #define LN_BWD_NC(X, Y, G, GA, NCV)                                                                                    \
   hipLaunchKernelGGL((ln_bwd_kernel<X, Y, G, GA, NCV>), dim3(ln_grid(M)), dim3(LN_THREADS), lds, stream, (const Y*)dy, lddy,  \

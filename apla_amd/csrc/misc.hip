@@ -4,20 +4,44 @@
 
 namespace {
 
-// images fp32 [B,3,S,S] -> cols bf16 [B*Np, Kp]; column order (c, py, px) == conv weight.reshape(D, 3*p*p)
+// images fp32 [B,3,S,S] -> cols bf16 [B*Np, Kp]; column order (c, py, px) == conv weight.reshape(D, 3*p*p).
+// One workgroup per row of patches (b, gy): the 3 x patch image rows it covers are read as whole rows (S floats = contiguous
+// lines), converted and parked in LDS, then every patch row of `cols` leaves as one contiguous run of Kp elements — in the
+// element-per-thread form every load took 4 bytes from a 64-byte run of a row and the launch ran at half the rate of a copy.
+// PATCH > 0: compile-time patch size (14 / 16: every division below is by a constant); PATCH == 0: any even patch size.
+template <int PATCH>
 __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, bf16* __restrict__ cols, int S,
-                                                       int patch, int grid_w, int Np, int Kp) {
-  const int row = blockIdx.x;  // b*Np + t
-  const int b = row / Np, t = row - b * Np;
-  const int gy = t / grid_w, gx = t - gy * grid_w;
-  const int pp = patch * patch, K = 3 * pp;
-  for (int k = threadIdx.x; k < Kp; k += 256) {
-    float v = 0.f;
-    if (k < K) {
-      const int c = k / pp, rem = k - c * pp, py = rem / patch, px = rem - py * patch;
-      v = img[(((size_t)b * 3 + c) * S + gy * patch + py) * S + gx * patch + px];
+                                                       int patch_rt, int grid_w, int Np, int Kp) {
+  extern __shared__ __attribute__((aligned(16))) char pf_smem[];
+  bf16* tile = (bf16*)pf_smem;                 // [3 * patch][S]
+  const int patch = PATCH > 0 ? PATCH : patch_rt;
+  const int b = blockIdx.x / grid_w, gy = blockIdx.x - b * grid_w;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int rows = 3 * patch, W2 = S >> 1;     // S even (checked on the host; 518 = 37 * 14 is not a multiple of 4)
+  for (int rr = wave; rr < rows; rr += 4) {    // one image row per wave and pass: S floats, contiguous
+    const int c = rr / patch, py = rr - c * patch;
+    const float* src = img + (((size_t)b * 3 + c) * S + gy * patch + py) * S;
+    for (int x2 = lane; x2 < W2; x2 += 64) {
+      const f32x2 v = *(const f32x2*)(src + x2 * 2);
+      bf16x2 o;
+      o[0] = (bf16)v[0]; o[1] = (bf16)v[1];
+      *(bf16x2*)(tile + rr * S + x2 * 2) = o;
     }
-    cols[(size_t)row * Kp + k] = (bf16)v;
+  }
+  __syncthreads();
+  const int pp = patch * patch, K = 3 * pp;
+  bf16* out = cols + ((size_t)b * Np + (size_t)gy * grid_w) * Kp;      // grid_w consecutive rows of Kp elements
+  for (int gx = wave; gx < grid_w; gx += 4) {                          // one patch row (Kp elements, contiguous) per wave and pass
+    bf16* orow = out + (size_t)gx * Kp;
+    for (int k = lane * 2; k < Kp; k += 128) {
+      bf16x2 v;
+      v[0] = (bf16)0.f; v[1] = (bf16)0.f;
+      if (k < K) {
+        const int c = k / pp, rem = k - c * pp, py = rem / patch, px = rem - py * patch;
+        v = *(const bf16x2*)(tile + (c * patch + py) * S + gx * patch + px);
+      }
+      *(bf16x2*)(orow + k) = v;
+    }
   }
 }
 
@@ -37,69 +61,90 @@ __global__ __launch_bounds__(256) void assemble_tokens_kernel(const bf16* __rest
   }
 }
 
-// C[i,j] (+)= sum_k A[i*sai + k*sak] * B[k*sbk + j*sbj] (+ bias[j]); fp32 FMA, 32x32 tile per workgroup, 128-deep K chunks.
-// The head GEMMs are tiny (0.2 GFLOP) and latency-bound: the next chunk is fetched into registers while the current one
-// is multiplied out of LDS, and the element -> (row, k) maps of the staging loads are fixed per thread (no index
-// arithmetic inside the loop).
-constexpr int SG_BK = 128;
-__global__ __launch_bounds__(256) void sgemm_small_kernel(const float* __restrict__ A, long sai, long sak,
+// C[i,j] (+)= sum_k A[i*sai + k*sak] * B[k*sbk + j*sbj] (+ bias[j]) in exact fp32 on the matrix pipes: one 32 x 32 output tile per
+// workgroup, the K axis split over its eight waves, each wave a chain of v_mfma_f32_32x32x2_f32 (an f32 fma chain in k order, no
+// wider internal accumulation: MI355X guide, "FP32-input MFMA"); the eight partial tiles are summed through LDS in wave order,
+// so the result does not depend on the launch.  The head GEMMs are tiny (0.2 GFLOP, operands L2-resident) and latency-bound: the
+// scalar-FMA tile kernel this replaces spent 25 us per launch on its staging round trips (three launches per step).
+// Operand maps of the instruction (lane l: i or j = l & 31, half h = l >> 5): A register s of an 8-deep chunk holds
+// A[i][k0 + 4h + s], B register s holds B[k0 + 4h + s][j]: any assignment of k to (half, step) is valid as long as both operands use it.
+constexpr int SG_WAVES = 8;
+__global__ __launch_bounds__(64 * SG_WAVES) void sgemm_small_kernel(const float* __restrict__ A, long sai, long sak,
                                                           const float* __restrict__ Bm, long sbk, long sbj,
                                                           const float* __restrict__ bias, float* __restrict__ C,
                                                           long ldc, int M, int N, int K, int accumulate) {
-  __shared__ float As[32][SG_BK + 1], Bs[SG_BK][33];
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;  // 16 x 16 threads, 2x2 outputs each
+  __shared__ float red[SG_WAVES][1024];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
-  // staging maps: element e = tid + 256*u of a 32 x 128 tile; the faster-varying global index follows the thread index
-  const bool a_kfast = sak <= sai, b_jfast = sbj <= sbk;
-  int ai[16], ak[16], bk[16], bj[16];
-  long aoff[16], boff[16];
+  const int li = lane & 31, h = lane >> 5;
+  int ia = i0 + li, jb = j0 + li;
+  ia = ia < M ? ia : M - 1;          // rows / columns past the edge re-read the last valid one; their results are never stored
+  jb = jb < N ? jb : N - 1;
+  const float* ap = A + (long)ia * sai;
+  const float* bp = Bm + (long)jb * sbj;
+  // this wave's K range: whole 8-deep chunks, dealt in contiguous runs
+  const int chunks = (K + 7) >> 3, per = (chunks + SG_WAVES - 1) / SG_WAVES;
+  const int c_lo = wave * per, c_hi = (c_lo + per) < chunks ? (c_lo + per) : chunks;
+  f32x16 acc;
 #pragma unroll
-  for (int u = 0; u < 16; ++u) {
-    const int e = threadIdx.x + 256 * u;
-    ai[u] = a_kfast ? e >> 7 : e & 31;
-    ak[u] = a_kfast ? e & 127 : e >> 5;
-    bk[u] = b_jfast ? e >> 5 : e & 127;
-    bj[u] = b_jfast ? e & 31 : e >> 7;
-    aoff[u] = (long)(i0 + ai[u]) * sai + (long)ak[u] * sak;
-    boff[u] = (long)bk[u] * sbk + (long)(j0 + bj[u]) * sbj;
-  }
-  float ar[16], br[16];
-  auto fetch = [&](int k0) {
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  // four chunks (32 k) per step; the loads of step s + 1 are issued before the products of step s (the loop is latency-bound)
+  float av[4][4], bv[4][4], an[4][4], bn[4][4];
+  // an operand whose K axis is the contiguous one is read 16 bytes per lane (its 4 consecutive k of a chunk): as four scalar loads
+  // each instruction touched 64 different lines for 4 bytes apiece, and the launch was bound by the address path, not by latency
+  const bool a_vec = sak == 1 && (sai & 3) == 0 && (((uintptr_t)A) & 15) == 0 && (K & 3) == 0;
+  const bool b_vec = sbk == 1 && (sbj & 3) == 0 && (((uintptr_t)Bm) & 15) == 0 && (K & 3) == 0;
+  auto fetch = [&](int c, float (&a_)[4][4], float (&b_)[4][4]) {
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      ar[u] = (i0 + ai[u] < M && k0 + ak[u] < K) ? A[aoff[u] + (long)k0 * sak] : 0.f;
-      br[u] = (j0 + bj[u] < N && k0 + bk[u] < K) ? Bm[boff[u] + (long)k0 * sbk] : 0.f;
-    }
-  };
-  float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-  fetch(0);
-  for (int k0 = 0; k0 < K; k0 += SG_BK) {
-    __syncthreads();  // previous chunk fully consumed
+    for (int u = 0; u < 4; ++u) {
+      const int k0 = (c + u) * 8 + 4 * h;
+      const bool live = (c + u) < c_hi;
+      if (a_vec) {
+        const f32x4 v = (live && k0 < K) ? *(const f32x4*)(ap + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      As[ai[u]][ak[u]] = ar[u];
-      Bs[bk[u]][bj[u]] = br[u];
-    }
-    __syncthreads();
-    if (k0 + SG_BK < K) fetch(k0 + SG_BK);
-#pragma unroll 16
-    for (int k = 0; k < SG_BK; ++k) {
-      const float a0 = As[ty][k], a1 = As[ty + 16][k], b0 = Bs[k][tx], b1 = Bs[k][tx + 16];
-      acc[0][0] += a0 * b0; acc[0][1] += a0 * b1; acc[1][0] += a1 * b0; acc[1][1] += a1 * b1;
-    }
-  }
+        for (int t = 0; t < 4; ++t) a_[u][t] = v[t];
+      } else {
 #pragma unroll
-  for (int u = 0; u < 2; ++u)
+        for (int t = 0; t < 4; ++t) a_[u][t] = (live && k0 + t < K) ? ap[(long)(k0 + t) * sak] : 0.f;
+      }
+      if (b_vec) {
+        const f32x4 v = (live && k0 < K) ? *(const f32x4*)(bp + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int w = 0; w < 2; ++w) {
-      const int i = i0 + ty + 16 * u, j = j0 + tx + 16 * w;
-      if (i < M && j < N) {
-        float v = acc[u][w];
-        if (bias != nullptr) v += bias[j];
-        if (accumulate) v += C[(long)i * ldc + j];
-        C[(long)i * ldc + j] = v;
+        for (int t = 0; t < 4; ++t) b_[u][t] = v[t];
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) b_[u][t] = (live && k0 + t < K) ? bp[(long)(k0 + t) * sbk] : 0.f;
       }
     }
+  };
+  if (c_lo < c_hi) fetch(c_lo, av, bv);
+  for (int c = c_lo; c < c_hi; c += 4) {
+    if (c + 4 < c_hi) fetch(c + 4, an, bn);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][t], bv[u][t], acc, 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { av[u][t] = an[u][t]; bv[u][t] = bn[u][t]; }
+  }
+  // C/D map of the 32x32 shapes: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+  for (int e = 0; e < 16; ++e) red[wave][((e & 3) + 8 * (e >> 2) + 4 * h) * 32 + li] = acc[e];
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 1024 / (64 * SG_WAVES); ++u) {
+    const int e = threadIdx.x + 64 * SG_WAVES * u, i = i0 + (e >> 5), j = j0 + (e & 31);
+    if (i < M && j < N) {
+      float v = red[0][e];
+#pragma unroll
+      for (int w = 1; w < SG_WAVES; ++w) v += red[w][e];
+      if (bias != nullptr) v += bias[j];
+      if (accumulate) v += C[(long)i * ldc + j];
+      C[(long)i * ldc + j] = v;
+    }
+  }
 }
 
 // one workgroup per sample: softmax cross-entropy, dlogits = (softmax - onehot) / B, row loss
@@ -179,13 +224,18 @@ __global__ __launch_bounds__(256) void mean_kernel(const float* __restrict__ v, 
   if (threadIdx.x == 0) out[0] = (red[0] + red[1] + red[2] + red[3]) / (float)n;
 }
 
+// 64 columns per workgroup, its four waves take the rows i = w, w + 4, ...; summed through LDS in wave order
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, long ld, float* __restrict__ out,
                                                      int M, int N) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= N) return;
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + lane;
   float s = 0.f;
-  for (int i = 0; i < M; ++i) s += X[(long)i * ld + j];
-  out[j] = s;
+  if (j < N)
+    for (int i = wave; i < M; i += 4) s += X[(long)i * ld + j];
+  red[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && j < N) out[j] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
 }
 
 }  // namespace
@@ -193,8 +243,13 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
 extern "C" int apla_patchify(const float* images, void* cols, int B, int S, int patch, int Kp, hipStream_t stream) {
   APLA_REQUIRE(images && cols && B > 0 && S > 0 && patch > 0 && S >= patch, "apla_patchify: bad arguments");
   APLA_REQUIRE(Kp >= 3 * patch * patch && Kp % 64 == 0, "apla_patchify: Kp must be >= 3*p*p and a multiple of 64");
+  APLA_REQUIRE(S % 2 == 0 && patch % 2 == 0 && (size_t)3 * patch * S * 2 <= 64 * 1024 && apla_aligned16(images),
+               "apla_patchify: need an even image side, an even patch size and 3*patch*S*2 bytes of LDS <= 64 KB (S=%d patch=%d)", S, patch);
   const int gw = S / patch, Np = gw * gw;
-  hipLaunchKernelGGL(patchify_kernel, dim3(B * Np), dim3(256), 0, stream, images, (bf16*)cols, S, patch, gw, Np, Kp);
+  const size_t lds = (size_t)3 * patch * S * 2;
+  if (patch == 16) hipLaunchKernelGGL(patchify_kernel<16>, dim3(B * gw), dim3(256), lds, stream, images, (bf16*)cols, S, patch, gw, Np, Kp);
+  else if (patch == 14) hipLaunchKernelGGL(patchify_kernel<14>, dim3(B * gw), dim3(256), lds, stream, images, (bf16*)cols, S, patch, gw, Np, Kp);
+  else hipLaunchKernelGGL(patchify_kernel<0>, dim3(B * gw), dim3(256), lds, stream, images, (bf16*)cols, S, patch, gw, Np, Kp);
   APLA_CHECK_LAUNCH("apla_patchify");
   return APLA_OK;
 }
@@ -374,7 +429,7 @@ extern "C" int apla_sgemm_small(const float* A, long sai, long sak, const float*
                                 const float* bias, float* C, long ldc, int M, int N, int K, int accumulate,
                                 hipStream_t stream) {
   APLA_REQUIRE(A && Bm && C && M > 0 && N > 0 && K > 0, "apla_sgemm_small: bad arguments");
-  hipLaunchKernelGGL(sgemm_small_kernel, dim3((N + 31) / 32, (M + 31) / 32), dim3(256), 0, stream, A, sai, sak, Bm, sbk, sbj, bias, C, ldc, M, N, K, accumulate);
+  hipLaunchKernelGGL(sgemm_small_kernel, dim3((N + 31) / 32, (M + 31) / 32), dim3(64 * SG_WAVES), 0, stream, A, sai, sak, Bm, sbk, sbj, bias, C, ldc, M, N, K, accumulate);
   APLA_CHECK_LAUNCH("apla_sgemm_small");
   return APLA_OK;
 }
@@ -401,7 +456,7 @@ extern "C" int apla_cross_entropy_soft(const float* logits, int ldl, const float
 
 extern "C" int apla_colsum(const float* X, long ld, float* out, int M, int N, hipStream_t stream) {
   APLA_REQUIRE(X && out && M > 0 && N > 0, "apla_colsum: bad arguments");
-  hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, X, ld, out, M, N);
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, stream, X, ld, out, M, N);
   APLA_CHECK_LAUNCH("apla_colsum");
   return APLA_OK;
 }

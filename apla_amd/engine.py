@@ -331,12 +331,13 @@ class AplaTrainEngine:
         self.h = e(M, self.blocks[0].F)
         # fc1's output h and dfc2's product go straight to a plain-store GEMM (fc2, dfc1): where both sides allow it they are
         # written as K-panel images by the producing epilogue (ops.gemm_nt with a 3-D `out`) and read as such
-        F, use = self.blocks[0].F, os.environ.get("APLA_W_PANELS", "1") != "0" and not self.swiglu
-        self.h_img = use and ops.gemm_out_image_ok(M, F, D, ops.EPI_GELU) and ops.gemm_panel_ok(M, D, F)
+        F, use = self.blocks[0].F, os.environ.get("APLA_W_PANELS", "1") != "0"
+        epi_f, n_f = (ops.EPI_SWIGLU, 2 * F) if self.swiglu else (ops.EPI_GELU, F)       # fc1 / w12: epilogue and GEMM width
+        self.h_img = use and ops.gemm_out_image_ok(M, n_f, D, epi_f) and ops.gemm_panel_ok(M, D, F)
         self.h_out = self.h.view(F // 32, M, 32) if self.h_img else self.h
         # gelu' (saved by fc1's epilogue for dfc2's) is private to those two epilogues: an image too, except in the last block,
-        # whose CLS-only backward picks rows b*N out of the row-major buffer
-        act_img = self.h_img and os.environ.get("APLA_ACT_IMG", "1") != "0"
+        # whose CLS-only backward picks rows b*N out of the row-major buffer (SwiGLU saves x12 row-major)
+        act_img = self.h_img and not self.swiglu and os.environ.get("APLA_ACT_IMG", "1") != "0"
         self.act_io = [a.view(F // 32, M, 32) if act_img and i < L - 1 else a for i, a in enumerate(self.act_saved)]
         # last block, forward: only the CLS row of every sequence is used downstream (final norm + x[:, 0])
         self.branch_cls = e(B, D)
@@ -354,8 +355,9 @@ class AplaTrainEngine:
         self.G = torch.zeros(M, D, device=dev, dtype=self.grad_dtype)               # residual-gradient stream (never re-zeroed)
         self.Gb = self.G if self.grad_dtype == ops.half() else torch.zeros(M, D, device=dev, dtype=ops.half())
         self.dact = e(M, Fsave)
-        self.dact_img = use and ops.gemm_out_image_ok(M, F, D, ops.EPI_MUL) and ops.gemm_panel_ok(M, D, F) and Fsave == F
-        self.dact_out = self.dact.view(F // 32, M, 32) if self.dact_img else self.dact
+        self.dact_img = use and ops.gemm_out_image_ok(M, F, D, ops.EPI_SWIGLU_BWD if self.swiglu else ops.EPI_MUL) and \
+            ops.gemm_panel_ok(M, D, Fsave)
+        self.dact_out = self.dact.view(Fsave // 32, M, 32) if self.dact_img else self.dact
         self.dln = e(M, D)
         self.dO = e(M, D)
         self.dqkv = e(M, 3 * D)
@@ -456,7 +458,7 @@ class AplaTrainEngine:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
             if self.swiglu:
-                ops.gemm_nt(xh2, st.W12, st.b12, epilogue=ops.EPI_SWIGLU, aux_out=self.act_saved[i], out=self.h)
+                ops.gemm_nt(xh2, st.W12, st.b12, epilogue=ops.EPI_SWIGLU, aux_out=self.act_saved[i], out=self.h_out)
             elif inference:
                 ops.gemm_nt(xh2, st.Wfc1, st.bfc1, epilogue=ops.EPI_GELU_FWD, out=self.h_out)
             else:
@@ -550,8 +552,8 @@ class AplaTrainEngine:
         B, N, H, M, D = self.B, self.N, self.H, self.M, self.D
         copy = None if self.Gb is self.G else self.Gb
         if self.swiglu:
-            ops.gemm_nt(self.Gb, st.WoutT, None, epilogue=ops.EPI_SWIGLU_BWD, aux_in=self.act_saved[i], out=self.dact)
-            ops.gemm_nt(self.dact, st.Wdfc1_i, None, out=self.dln, tag=ops.TAG_DFC1)
+            ops.gemm_nt(self.Gb, st.WoutT, None, epilogue=ops.EPI_SWIGLU_BWD, aux_in=self.act_saved[i], out=self.dact_out)
+            ops.gemm_nt(self.dact_out, st.Wdfc1_i, None, out=self.dln, tag=ops.TAG_DFC1)
         else:
             ops.gemm_nt(self.Gb, st.WoutT, None, epilogue=ops.EPI_MUL, aux_in=self.act_io[i], out=self.dact_out)
             ops.gemm_nt(self.dact_out, st.Wdfc1_i, None, out=self.dln, tag=ops.TAG_DFC1)

@@ -3,7 +3,7 @@ vectors produced by the actual reference (tests/golden/g5_cfg1_vits.npz: ViT-S/1
 
 Tolerances (stated, per SURVEY §7 "hard parts"): the reference CPU path is fp32; the HIP path multiplies in bf16 with
 fp32 accumulation and an fp32 residual stream.  Against the oracle on small synthetic models we require
-max|logits - ref| / max|ref| <= 1e-2, |loss - ref| <= 5e-3 and gradients within 3e-2 relative L2; against the REFERENCE's
+max|logits - ref| / max|ref| <= 1.5e-2 (see LOGIT_TOL), |loss - ref| <= 5e-3 and gradients within 3e-2 relative L2; against the REFERENCE's
 golden output on BASELINE config 1 the bounds are what is measured: logits <= 8e-3, gradients <= 2e-2 (the north-star
 1e-3 is met by the fp16 build, tests/test_fp16_gpu.py; bf16 operand rounding alone is 7.3e-3 on this model).  Index
 selection is bit-exact (CPU test)."""
@@ -18,7 +18,11 @@ from oracle import apla_oracle as O
 
 pytestmark = pytest.mark.gpu
 
-LOGIT_TOL = 1e-2
+# 1.5e-2 since round 3 (1e-2 before): on these width-128 models the 16-bit operand rounding alone moves the logits by 0.5e-2 ... 1.1e-2
+# of their range depending on the batch (tools/rounding_sim.py: fp64 oracle with rounded GEMM operands, 24 batches; mean 0.77e-2
+# for the SwiGLU model), the same whether the LayerNorm affine is applied before the rounding or folded into the next weight —
+# 1e-2 sat inside that distribution.  The bound that pins the real configuration (config 1 against the reference) stays 8e-3.
+LOGIT_TOL = 1.5e-2
 GRAD_TOL = 3e-2
 # BASELINE config 1 against the reference's own CPU output: what is measured (6.4e-3 logits, <1.3e-2 gradients; bench.py prints the
 # live figure as `parity`) with little slack — bf16 operand rounding alone gives 7.3e-3 on this model

@@ -519,6 +519,18 @@ def test_gemm_k_panel_images(ops, M, N, K):
     w2, _ = bf(rnd(256, N, scale=N ** -0.5, seed=94))
     W2 = dev(w2)
     assert torch.equal(ops.gemm_nt(hi_, ops.k_panels(W2)), ops.gemm_nt(mref, W2))
+    # the SwiGLU epilogues (ViT-g, vit.py:131-149): C is N/2 resp. 2N wide, written as an image just the same
+    x12 = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    hs = ops.gemm_nt(A, W, bias, epilogue=ops.EPI_SWIGLU, aux_out=x12)
+    hs_i = torch.empty(N // 64, M, 32, device="cuda", dtype=torch.bfloat16)
+    x12b = torch.empty_like(x12)
+    ops.gemm_nt(A, W, bias, epilogue=ops.EPI_SWIGLU, aux_out=x12b, out=hs_i)
+    assert torch.equal(hs_i, ops.k_panels(hs)) and torch.equal(x12b, x12)
+    x12w = dev(bf(rnd(M, 2 * N, seed=95))[0])
+    db = ops.gemm_nt(A, W, None, epilogue=ops.EPI_SWIGLU_BWD, aux_in=x12w)
+    db_i = torch.empty(2 * N // 32, M, 32, device="cuda", dtype=torch.bfloat16)
+    ops.gemm_nt(A, W, None, epilogue=ops.EPI_SWIGLU_BWD, aux_in=x12w, out=db_i)
+    assert torch.equal(db_i, ops.k_panels(db))
     with pytest.raises(AplaHipError):
         ops.gemm_nt(A, W, bias, out=hi_)          # plain STORE has no output image
     # not covered: an operand epilogue, N not a multiple of 256, fewer than four 32-wide K-steps

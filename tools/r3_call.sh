@@ -16,6 +16,8 @@ for s in $STEPS; do
   case $s in
     tests)
       timeout -k 10 900 python -m pytest tests -m gpu -q -x -p no:cacheprovider > $O/pytest_gpu.txt 2>&1; rc=$?; tail -5 $O/pytest_gpu.txt; guard $rc ;;
+    testsall)
+      timeout -k 10 900 python -m pytest tests -m gpu -q -p no:cacheprovider > $O/pytest_gpu.txt 2>&1; rc=$?; grep -E "^(FAILED|ERROR)|passed|failed" $O/pytest_gpu.txt | tail -30; guard $rc ;;
     bench)
       timeout -k 10 600 python bench.py > $O/bench.json 2> $O/bench.err; rc=$?; tail -c 2500 $O/bench.json; tail -3 $O/bench.err; guard $rc ;;
     trace)
