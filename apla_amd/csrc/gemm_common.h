@@ -24,6 +24,8 @@ struct GemmParams {
                 // stored and loaded in whole lines instead of 64-byte row pieces.
   int reserve;  // CUs this launch leaves free (apla_gemm_nt_ex flags bits 20-27): the persistent kernels start 256 - reserve (ping-pong)
                 // or 2 * (256 - reserve) (4-wave) workgroups, so that the kernels of a concurrent collective find CUs of their own
+  int exp;   // experiment selector (apla_gemm_nt_ex flags bits 28-30; tools/gemm_bench.py): schedule variants of the 4-wave kernel's
+             // K loop compiled beside the product one for A/B timing inside one process; 0 = product
   int tag;   // profiling tag (apla_gemm_nt_tagged): selects one of several identical kernel instantiations so that a rocprofv3
              // kernel trace tells the call sites of the step apart (qkv / proj / fc2 / dfc1 / dproj / dqkv …); 0 = untagged
 };

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams p) {
 // would make hipcc drain vmcnt(0) before every store (measured: 16 serialised load->wait->store round trips per tile).
 // Epilogue operands (residual / multiplier) are loaded up front, all at once.  BM = 32*MI (128/160) is picked on the
 // host to minimise tile-count quantisation over the 512 resident workgroups.
-template <int EPI, typename OutT, int MI>
+template <int EPI, typename OutT, int MI, int EXP = 0>
 __global__ __launch_bounds__(256, 2) void gemm_persist_kernel(GemmParams p, int tiles_m) {
   constexpr int BMv = 32 * MI;
   constexpr int STG = (BMv + BN) * BK * 2;
@@ -232,19 +232,25 @@ __global__ __launch_bounds__(256, 2) void gemm_persist_kernel(GemmParams p, int 
     for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr ((EXP & 4) != 0) __builtin_amdgcn_s_setprio(1);   // experiment 4: the whole K loop above the partner's epilogue
     for (int kt = 0; kt < nk; ++kt) {
       if (kt == 0 && counted) wait_vmcnt<EpiStores<EPI, OutT, MI>::N>(); else wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();
       const char* As = smem + cur * STG;
       const char* Ws = As + BMv * BK * 2;
-      if (kt + 1 < nk) {
-        stage(cur ^ 1, (kt + 1) * BK);
-      } else if (has_next) {
-        setup(xbeg + nidx);
-        stage(cur ^ 1, 0);
-        stage_bias(bb ^ 1);
+      auto issue_next = [&]() {
+        if (kt + 1 < nk) {
+          stage(cur ^ 1, (kt + 1) * BK);
+        } else if (has_next) {
+          setup(xbeg + nidx);
+          stage(cur ^ 1, 0);
+          stage_bias(bb ^ 1);
+        }
+      };
+      if constexpr ((EXP & 1) == 0) {
+        issue_next();
+        asm volatile("" ::: "memory");
       }
-      asm volatile("" ::: "memory");
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         bf16x8 af[MI], wf[4];
@@ -252,13 +258,25 @@ __global__ __launch_bounds__(256, 2) void gemm_persist_kernel(GemmParams p, int 
         for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(As + lds_off(wm * (MI * 16) + i * 16 + frow, ks * 4 + fq));
 #pragma unroll
         for (int j = 0; j < 4; ++j) wf[j] = *(const bf16x8*)(Ws + lds_off(wn * 64 + j * 16 + frow, ks * 4 + fq));
+        if constexpr ((EXP & 1) != 0) {
+          // experiment 1: the first K-half's fragment reads are issued BEFORE the next stage's LDS-DMA, whose ~9 issue slots then
+          // cover the reads' latency (as the ping-pong kernel's prepare phase does)
+          if (ks == 0) {
+            asm volatile("" ::: "memory");
+            issue_next();
+            asm volatile("" ::: "memory");
+          }
+        }
+        if constexpr ((EXP & 2) != 0) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j) acc[i][j] = MFMA_F32_16x16x32_H16(wf[j], af[i], acc[i][j]);
+        if constexpr ((EXP & 2) != 0) __builtin_amdgcn_s_setprio(0);
       }
       cur ^= 1;
     }
+    if constexpr ((EXP & 4) != 0) __builtin_amdgcn_s_setprio(0);
     persist_epilogue<EPI, OutT, MI>(p, acc, (const float*)(smem + 2 * STG + bb * 1024), m0, n0, wm, wn, lane);
     asm volatile("" ::: "memory");
     if (!has_next) break;
@@ -283,6 +301,20 @@ int launch_persist(const GemmParams& p_in, hipStream_t stream) {
   const int total = tiles_m * p.tiles_n;
   const int resident = RESIDENT_WGS - 2 * (p.reserve > 0 && p.reserve < 192 ? p.reserve : 0);
   int G = total < resident ? total : resident;
+  // K-loop schedule (the kernel's EXP bits): bit 0 = the first K-half's fragment reads are issued before the next stage's LDS-DMA,
+  // bit 1 = s_setprio 1 around each MFMA cluster.  The two-output GELU epilogue runs with both (measured, tools/gemm_bench.py
+  // GEMM_VARIANTS=0,...,7000: fc1 + GELU at M = 25216 180 -> 166 us back to back; with priority the co-resident workgroup's MFMA
+  // clusters win the issue arbitration against this workgroup's epilogue VALU work instead of being spaced out by it); the other
+  // epilogues do not move.  GemmParams::exp = 7 forces the plain loop (A/B), 1..3 force that schedule.
+  constexpr int DEF = (EPI == APLA_EPI_GELU && MI == 5 && std::is_same<OutT, bf16>::value) ? 2 : 0;
+  const int e = p.exp == 0 ? DEF : (p.exp == 7 ? 0 : p.exp);
+  if constexpr (MI == 5 && std::is_same<OutT, bf16>::value && (EPI == APLA_EPI_GELU || EPI == APLA_EPI_MUL)) {
+    if (e == 1) { hipLaunchKernelGGL((gemm_persist_kernel<EPI, OutT, MI, 1>), dim3(G), dim3(256), 0, stream, p, tiles_m); APLA_CHECK_LAUNCH("apla_gemm_nt"); return APLA_OK; }
+    if (e == 2) { hipLaunchKernelGGL((gemm_persist_kernel<EPI, OutT, MI, 2>), dim3(G), dim3(256), 0, stream, p, tiles_m); APLA_CHECK_LAUNCH("apla_gemm_nt"); return APLA_OK; }
+    if (e == 3) { hipLaunchKernelGGL((gemm_persist_kernel<EPI, OutT, MI, 3>), dim3(G), dim3(256), 0, stream, p, tiles_m); APLA_CHECK_LAUNCH("apla_gemm_nt"); return APLA_OK; }
+    if (e == 4) { hipLaunchKernelGGL((gemm_persist_kernel<EPI, OutT, MI, 4>), dim3(G), dim3(256), 0, stream, p, tiles_m); APLA_CHECK_LAUNCH("apla_gemm_nt"); return APLA_OK; }
+    if (e == 5) { hipLaunchKernelGGL((gemm_persist_kernel<EPI, OutT, MI, 5>), dim3(G), dim3(256), 0, stream, p, tiles_m); APLA_CHECK_LAUNCH("apla_gemm_nt"); return APLA_OK; }
+  }
   hipLaunchKernelGGL((gemm_persist_kernel<EPI, OutT, MI>), dim3(G), dim3(256), 0, stream, p, tiles_m);
   APLA_CHECK_LAUNCH("apla_gemm_nt");
   return APLA_OK;
@@ -350,7 +382,8 @@ int launch(const GemmParams& p, int g_variant, hipStream_t stream) {
 
 static int gemm_nt_impl(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int M,
                         int N, int K, int epilogue, int out_dtype, const void* aux_in, int ld_aux_in,
-                        void* aux_out, int ld_aux_out, int tag, int variant, hipStream_t stream, int w_panel = 0, int reserve = 0) {
+                        void* aux_out, int ld_aux_out, int tag, int variant, hipStream_t stream, int w_panel = 0, int reserve = 0,
+                        int exp = 0) {
   APLA_REQUIRE(M > 0 && N > 0 && K > 0, "apla_gemm_nt: empty problem M=%d N=%d K=%d", M, N, K);
   APLA_REQUIRE(N % BN == 0 && K % BK == 0, "apla_gemm_nt: need N%%128==0 and K%%64==0 (N=%d K=%d)", N, K);
   APLA_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && ((w_panel & 2) || lda >= K) && ((w_panel & 1) || ldw >= K), "apla_gemm_nt: bad lda/ldw (%d,%d) K=%d", lda, ldw, K);
@@ -368,7 +401,7 @@ static int gemm_nt_impl(const void* A, int lda, const void* W, int ldw, const fl
   APLA_REQUIRE(bias == nullptr || apla_aligned16(bias), "apla_gemm_nt: bias must be 16-byte aligned");
   APLA_REQUIRE((w_panel & 4) || ldc % 4 == 0, "apla_gemm_nt: ldc %% 4 != 0");
   if (w_panel & 8) { ld_aux_in = ld_aux_in ? N : 0; ld_aux_out = ld_aux_out ? N : 0; }   // not read for an image; keeps the row-major checks quiet
-  GemmParams p{(const bf16*)A, lda, (const bf16*)W, ldw, bias, C, ldc, aux_in, ld_aux_in, aux_out, ld_aux_out, M, N, K, N / BN, 0, w_panel, reserve,
+  GemmParams p{(const bf16*)A, lda, (const bf16*)W, ldw, bias, C, ldc, aux_in, ld_aux_in, aux_out, ld_aux_out, M, N, K, N / BN, 0, w_panel, reserve, exp,
                (tag >= 0 && tag < APLA_GEMM_TAGS) ? tag : 0};
   switch (epilogue) {
     case APLA_EPI_STORE:
@@ -436,7 +469,7 @@ extern "C" int apla_gemm_nt_ex(const void* A, int lda, const void* W, int ldw, c
   const int tag = flags & 0xff, v = (flags >> 8) & 0xff;
   APLA_REQUIRE(v == 0 || v == 1 || v == 4 || v == 9 || v == 14 || v == 15, "apla_gemm_nt_ex: unknown schedule %d", v);
   return gemm_nt_impl(A, lda, W, ldw, bias, C, ldc, M, N, K, epilogue, out_dtype, aux_in, ld_aux_in, aux_out, ld_aux_out, tag,
-                      v == 0 ? 4 : (v == 1 ? 0 : v), stream, (flags >> 16) & 15, (flags >> 20) & 0xff);
+                      v == 0 ? 4 : (v == 1 ? 0 : v), stream, (flags >> 16) & 15, (flags >> 20) & 0xff, (flags >> 28) & 7);
 }
 
 // Which kernel does apla_gemm_nt_ex run this problem on?  Writes e.g. "gemm_persist_kernel<GELU,bf16,5>" (the name a rocprofv3

@@ -77,6 +77,7 @@ def _rows2d(t: torch.Tensor, name: str):
 # stateless: the choice travels as a per-call argument of the *_ex entry points).  0 = auto.
 _GEMM_VARIANT = 0
 _ATTN_VARIANT = int(os.environ.get("APLA_ATTN_VARIANT", "0"))
+_GEMM_EXP = 0       # experiment selector of apla_gemm_nt_ex (flags bits 28-30): tools/gemm_bench.py only
 _RESERVED_CUS = 0   # CUs the persistent GEMM launches leave free (apla_gemm_nt_ex flags bits 20-27): see reserved_cus()
 # profiling tags of apla_gemm_nt_ex (kernel names in a rocprofv3 trace): call sites of the training step
 TAG_QKV, TAG_PROJ, TAG_FC2, TAG_DFC1, TAG_DPROJ, TAG_DQKV, TAG_PATCH = 2, 3, 4, 5, 6, 7, 8
@@ -213,7 +214,7 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = Non
         raise ValueError("gemm_nt: EPI_GELU_FWD saves nothing (use EPI_GELU to get gelu')")
     rc = lib().apla_gemm_nt_ex(a.data_ptr(), lda, w.data_ptr(), ldw, _ptr(bias), out.data_ptr(), ldc, M, N, K,
                                epilogue, _DT[out.dtype], _ptr(aux_in), ld_in, _ptr(aux_out), ld_out,
-                               (int(tag) & 0xff) | (_GEMM_VARIANT << 8) | (panel << 16) | (_RESERVED_CUS << 20), _stream())
+                               (int(tag) & 0xff) | (_GEMM_VARIANT << 8) | (panel << 16) | (_RESERVED_CUS << 20) | (_GEMM_EXP << 28), _stream())
     check(rc, "apla_gemm_nt")
     return out
 

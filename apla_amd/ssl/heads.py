@@ -69,8 +69,15 @@ class DINOHead(nn.Module):
 
     def forward(self, x):
         mods = [self.mlp] if isinstance(self.mlp, nn.Linear) else list(self.mlp)
-        for m in mods:
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, nn.Linear) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.GELU):
+                x = AF.linear_gelu(x, m.weight, m.bias)        # the activation rides in the GEMM epilogue
+                i += 2
+                continue
             x = AF.linear(x, m.weight, m.bias) if isinstance(m, nn.Linear) else F.gelu(x.float()).to(x.dtype)
+            i += 1
         x = F.normalize(x.float(), dim=-1, p=2, eps=1e-12)
         v, g = self.last_layer.weight_v, self.last_layer.weight_g
         W = v * (g / v.norm(dim=1, keepdim=True))           # torch.nn.utils.weight_norm, dim=0

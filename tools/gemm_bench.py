@@ -50,9 +50,10 @@ def main():
         w_rm, a_rm = w, a
         for v in VARIANTS:
             ops.set_gemm_variant(v % 100)
+            ops._GEMM_EXP = (v // 1000) % 8       # 1000 * e + ...: experiment e of the 4-wave kernel's K loop (GemmParams::exp)
             # v = 100 + schedule: W passed as its K-panel image; 300 + schedule: A too (ping-pong kernel only)
-            w = ops.k_panels(w_rm) if v >= 100 else w_rm
-            a = ops.k_panels(a_rm) if v >= 300 else a_rm
+            w = ops.k_panels(w_rm) if (v % 1000) >= 100 else w_rm
+            a = ops.k_panels(a_rm) if (v % 1000) >= 300 else a_rm
             o = ops.gemm_nt(a, w, bias, epilogue=epi, out=out, **{k: x for k, x in kw.items() if k != "out_dtype"}).clone()
             if ref is None:
                 ref = o
@@ -62,8 +63,9 @@ def main():
         for _ in range(ROUNDS):
             for v in VARIANTS:
                 ops.set_gemm_variant(v % 100)
-                w = ops.k_panels(w_rm) if v >= 100 else w_rm
-                a = ops.k_panels(a_rm) if v >= 300 else a_rm
+                ops._GEMM_EXP = (v // 1000) % 8
+                w = ops.k_panels(w_rm) if (v % 1000) >= 100 else w_rm
+                a = ops.k_panels(a_rm) if (v % 1000) >= 300 else a_rm
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for it in range(ITERS):

@@ -28,6 +28,16 @@ for s in $STEPS; do
     stats)
       timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-parity --no-peak-probe > $O/trace_bench.log 2>&1; rc=$?; guard $rc
       python3 tools/summarize_prof.py $(find $O/trace -name "*kernel_stats.csv" | head -1) 14 --cfg2 > $O/kernel_stats.md; cp $(find $O/trace -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv; rm -rf $O/trace; head -40 $O/kernel_stats.md ;;
+    ssl)
+      timeout -k 10 600 python3 tools/ssl_bench.py > $O/ssl_bench.json 2> $O/ssl_bench.err; rc=$?; cat $O/ssl_bench.json; tail -3 $O/ssl_bench.err; guard $rc
+      timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ssltrace -- python3 tools/ssl_bench.py --steps 4 --warmup 2 > $O/ssl_trace.log 2>&1; rc=$?; guard $rc
+      python3 tools/summarize_prof.py $(find $O/ssltrace -name "*kernel_stats.csv" | head -1) 6 > $O/ssl_kernel_stats.md; rm -rf $O/ssltrace; head -45 $O/ssl_kernel_stats.md ;;
+    ssltests)
+      timeout -k 10 900 python -m pytest tests/test_ssl_step_gpu.py tests/test_ssl_blocks_gpu.py tests/test_ssl_dist_gpu.py tests/test_ssl_losses_gpu.py tests/test_kernels_gpu.py -m gpu -q -x -p no:cacheprovider > $O/pytest_ssl.txt 2>&1; rc=$?; tail -5 $O/pytest_ssl.txt; guard $rc ;;
+    cfg5)
+      timeout -k 10 900 python bench.py --backbone vit_giant --img 518 --patch 14 --batch 32 --partial-size 512 --dtype fp16 --steps 5 --warmup 2 --no-cpu-baseline --no-parity --no-peak-probe > $O/bench_cfg5.json 2> $O/bench_cfg5.err; rc=$?; tail -c 1500 $O/bench_cfg5.json; tail -3 $O/bench_cfg5.err; guard $rc ;;
+    cfg3)
+      timeout -k 10 900 python bench.py --backbone vit_large --patch 14 --batch 256 --partial-size 256 --steps 8 --warmup 3 --no-cpu-baseline --no-parity --no-peak-probe > $O/bench_cfg3.json 2> $O/bench_cfg3.err; rc=$?; tail -c 1500 $O/bench_cfg3.json; tail -3 $O/bench_cfg3.err; guard $rc ;;
     gemm)
       timeout -k 10 600 python3 tools/gemm_bench.py > $O/gemm_bench.txt 2>&1; rc=$?; cat $O/gemm_bench.txt; guard $rc ;;
   esac

@@ -18,6 +18,45 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
+def build_cfg4(batch=64, backbone="vit_base", partial_size="128", prototypes=65536, seed=0):
+    """The trainer and ONE collated batch (on the GPU) at the shape of BASELINE config 4; deterministic in `seed`."""
+    from apla_amd.ssl import DINOv2, Dinov2Trainer, MaskingGenerator, collate_data_and_cast
+    from apla_amd.ssl.collate import synthetic_samples
+    from apla_amd.ssl.models import _GEOMETRY
+    torch.manual_seed(seed)
+    random.seed(seed)
+    D, depth = _GEOMETRY[backbone][:2]
+    if partial_size == "full":
+        adaptation, gpus = dict(mode="apla", params=dict(partial_size="full")), "0,1"
+    else:
+        r = int(partial_size)
+        g = torch.Generator().manual_seed(seed)
+        f = tempfile.NamedTemporaryFile("w", suffix=".json", delete=False)
+        json.dump({f"block_{i}": torch.randperm(D, generator=g)[:r].tolist() for i in range(depth)}, f)
+        f.close()
+        adaptation, gpus = dict(mode="apla", params=dict(partial_size=r, inds_path=f.name)), "0"
+    params = dict(
+        model_params=dict(backbone_type=backbone, pretrained=False, adaptation=adaptation,
+                          transformers_params=dict(student=dict(patch_size=14, pre_img_size=518, layerscale=1e-5, interpolate_offset=0.1,
+                                                                interpolate_antialias=False, drop_path_rate=0, num_register_tokens=0)),
+                          dinov2=dict(centering="centering",
+                                      dino=dict(loss_weight=1.0, head_n_prototypes=prototypes, head_bottleneck_dim=256, head_nlayers=3,
+                                                head_hidden_dim=2048, koleo_loss_weight=0.1),
+                                      ibot=dict(loss_weight=1.0, mask_sample_probability=0.5, mask_ratio_min_max=[0.1, 0.5], separate_head=False))),
+        crops_params=dict(n_global_crops=2, n_local_crops=8), system_params=dict(which_GPUs=gpus))
+    model = DINOv2(params).cuda().train()
+    tr = Dinov2Trainer(model, iters_per_epoch=1000, epochs=10, lr=1e-3, weight_decay=1e-5, grad_clipping=3.0, freeze_last_layer_epochs=1,
+                       warmup_teacher_temp_epochs=1)
+    mg = MaskingGenerator(input_size=(16, 16), max_num_patches=0.5 * 16 * 16)
+    gen = torch.Generator().manual_seed(seed + 1)
+    batch_ = collate_data_and_cast(synthetic_samples(batch, 224, 98, 8, gen), n_global_crops=2, n_local_crops=8,
+                                   mask_ratio_tuple=(0.1, 0.5), mask_probability=0.5, dtype=torch.float32, n_tokens=256, mask_generator=mg)
+    for k, v in batch_["images"].items():   # inputs resident in HBM before the timed region
+        if torch.is_tensor(v):
+            batch_["images"][k] = v.cuda()
+    return tr, batch_
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=64)
@@ -27,40 +66,8 @@ def main():
     ap.add_argument("--partial-size", default="128")
     ap.add_argument("--prototypes", type=int, default=65536)
     args = ap.parse_args()
-    from apla_amd.ssl import DINOv2, Dinov2Trainer, MaskingGenerator, collate_data_and_cast
-    from apla_amd.ssl.collate import synthetic_samples
-    from apla_amd.ssl.models import _GEOMETRY
-    torch.manual_seed(0)
-    random.seed(0)
-    D, depth = _GEOMETRY[args.backbone][:2]
-    if args.partial_size == "full":
-        adaptation, gpus = dict(mode="apla", params=dict(partial_size="full")), "0,1"
-    else:
-        r = int(args.partial_size)
-        g = torch.Generator().manual_seed(0)
-        f = tempfile.NamedTemporaryFile("w", suffix=".json", delete=False)
-        json.dump({f"block_{i}": torch.randperm(D, generator=g)[:r].tolist() for i in range(depth)}, f)
-        f.close()
-        adaptation, gpus = dict(mode="apla", params=dict(partial_size=r, inds_path=f.name)), "0"
-    params = dict(
-        model_params=dict(backbone_type=args.backbone, pretrained=False, adaptation=adaptation,
-                          transformers_params=dict(student=dict(patch_size=14, pre_img_size=518, layerscale=1e-5, interpolate_offset=0.1,
-                                                                interpolate_antialias=False, drop_path_rate=0, num_register_tokens=0)),
-                          dinov2=dict(centering="centering",
-                                      dino=dict(loss_weight=1.0, head_n_prototypes=args.prototypes, head_bottleneck_dim=256, head_nlayers=3,
-                                                head_hidden_dim=2048, koleo_loss_weight=0.1),
-                                      ibot=dict(loss_weight=1.0, mask_sample_probability=0.5, mask_ratio_min_max=[0.1, 0.5], separate_head=False))),
-        crops_params=dict(n_global_crops=2, n_local_crops=8), system_params=dict(which_GPUs=gpus))
-    model = DINOv2(params).cuda().train()
-    tr = Dinov2Trainer(model, iters_per_epoch=1000, epochs=10, lr=1e-3, weight_decay=1e-5, grad_clipping=3.0, freeze_last_layer_epochs=1,
-                       warmup_teacher_temp_epochs=1)
-    mg = MaskingGenerator(input_size=(16, 16), max_num_patches=0.5 * 16 * 16)
-    gen = torch.Generator().manual_seed(1)
-    batch = collate_data_and_cast(synthetic_samples(args.batch, 224, 98, 8, gen), n_global_crops=2, n_local_crops=8,
-                                  mask_ratio_tuple=(0.1, 0.5), mask_probability=0.5, dtype=torch.float32, n_tokens=256, mask_generator=mg)
-    for k, v in batch["images"].items():   # inputs resident in HBM before the timed region
-        if torch.is_tensor(v):
-            batch["images"][k] = v.cuda()
+    tr, batch = build_cfg4(args.batch, args.backbone, args.partial_size, args.prototypes)
+    model = tr.model
     for _ in range(args.warmup):
         tr.global_step(batch)
     torch.cuda.synchronize()
