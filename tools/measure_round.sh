@@ -16,17 +16,17 @@ python3 tools/summarize_prof.py $(find $O/trace -name "*kernel_stats.csv") 14 --
 cp $(find $O/trace -name "*kernel_stats.csv") $O/kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -- python3 tools/gemm_one.py 3072 768 1 4 6 > /dev/null 2>&1
-  python3 tools/pmc_summary.py $O/pmc_$c "ILi1E" > $O/pmc_$c.txt
+  python3 tools/pmc_summary.py $O/pmc_$c "gemm_persist_kernel" > $O/pmc_$c.txt
 done
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_sq -- python3 tools/gemm_one.py 3072 768 1 4 6 > /dev/null 2>&1
-python3 tools/pmc_summary.py $O/pmc_sq "ILi1E" > $O/pmc_sq.txt
+python3 tools/pmc_summary.py $O/pmc_sq "gemm_persist_kernel" > $O/pmc_sq.txt
 python3 - <<PY
 import re, json
 def val(path, name):
     for l in open(path):
         if name in l:
             return float(l.split("avg=")[1])
-d = {"kernel": "gemm_persist_kernel<GELU,bf16,5> M=25216 N=3072 K=768 (fc1+GELU launch)", "taken_at": "${APLA_ROUND_TAG:-round 2}",
+d = {"kernel": "gemm_persist_kernel<GELU,bf16,5> M=25216 N=3072 K=768 (fc1+GELU launch)", "taken_at": "${APLA_ROUND_TAG:-round 3}",
      "FETCH_SIZE_KiB": val("$O/pmc_FETCH_SIZE.txt", "FETCH_SIZE"), "WRITE_SIZE_KiB": val("$O/pmc_WRITE_SIZE.txt", "WRITE_SIZE"),
      "note": "rocprofv3 --pmc, one counter per pass, averaged over 6 launches; FETCH_SIZE must be doubled on gfx950 (MI355X_MICROARCH.md HBM section)"}
 json.dump(d, open("$O/pmc_dominant_kernel.json", "w"), indent=1)

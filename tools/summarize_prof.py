@@ -58,6 +58,9 @@ def short(name):
         name = demangle(name)
     name = re.sub(r"\(anonymous namespace\)::", "", name)
     name = name.replace("__bf16", "bf16")
+    # the profiler's own demangler garbles <EPI, __bf16, MI, EXP> (DF16b Li5E Li2E -> "bool _Accum, int, ELi2E"): only MI = 5 carries
+    # the fourth argument (the K-loop schedule of gemm_persist_kernel, GemmParams::exp)
+    name = re.sub(r"bool _Accum, int, ELi(\d+)E", r"bf16, 5, sched \1", name)
     m = re.match(r"(?:void )?(gemm_\w+_kernel|gemm_nt_kernel)<(\d), (\w+)(.*)>", name)
     if m:
         rest = m.group(4)
