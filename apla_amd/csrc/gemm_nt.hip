@@ -232,7 +232,6 @@ __global__ __launch_bounds__(256, 2) void gemm_persist_kernel(GemmParams p, int 
     for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if constexpr ((EXP & 4) != 0) __builtin_amdgcn_s_setprio(1);   // experiment 4: the whole K loop above the partner's epilogue
     for (int kt = 0; kt < nk; ++kt) {
       if (kt == 0 && counted) wait_vmcnt<EpiStores<EPI, OutT, MI>::N>(); else wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();
@@ -276,7 +275,6 @@ __global__ __launch_bounds__(256, 2) void gemm_persist_kernel(GemmParams p, int 
       }
       cur ^= 1;
     }
-    if constexpr ((EXP & 4) != 0) __builtin_amdgcn_s_setprio(0);
     persist_epilogue<EPI, OutT, MI>(p, acc, (const float*)(smem + 2 * STG + bb * 1024), m0, n0, wm, wn, lane);
     asm volatile("" ::: "memory");
     if (!has_next) break;
@@ -312,8 +310,6 @@ int launch_persist(const GemmParams& p_in, hipStream_t stream) {
     if (e == 1) { hipLaunchKernelGGL((gemm_persist_kernel<EPI, OutT, MI, 1>), dim3(G), dim3(256), 0, stream, p, tiles_m); APLA_CHECK_LAUNCH("apla_gemm_nt"); return APLA_OK; }
     if (e == 2) { hipLaunchKernelGGL((gemm_persist_kernel<EPI, OutT, MI, 2>), dim3(G), dim3(256), 0, stream, p, tiles_m); APLA_CHECK_LAUNCH("apla_gemm_nt"); return APLA_OK; }
     if (e == 3) { hipLaunchKernelGGL((gemm_persist_kernel<EPI, OutT, MI, 3>), dim3(G), dim3(256), 0, stream, p, tiles_m); APLA_CHECK_LAUNCH("apla_gemm_nt"); return APLA_OK; }
-    if (e == 4) { hipLaunchKernelGGL((gemm_persist_kernel<EPI, OutT, MI, 4>), dim3(G), dim3(256), 0, stream, p, tiles_m); APLA_CHECK_LAUNCH("apla_gemm_nt"); return APLA_OK; }
-    if (e == 5) { hipLaunchKernelGGL((gemm_persist_kernel<EPI, OutT, MI, 5>), dim3(G), dim3(256), 0, stream, p, tiles_m); APLA_CHECK_LAUNCH("apla_gemm_nt"); return APLA_OK; }
   }
   hipLaunchKernelGGL((gemm_persist_kernel<EPI, OutT, MI>), dim3(G), dim3(256), 0, stream, p, tiles_m);
   APLA_CHECK_LAUNCH("apla_gemm_nt");

@@ -5,9 +5,10 @@
  *     (APLA_EINVAL shape/alignment, APLA_ENOSYS unsupported configuration, APLA_EIO HIP launch error);
  *     a human-readable message for the calling thread is available from apla_last_error().
  *   - stateless and re-entrant: no allocation, no synchronisation, no global state (kernel-schedule choices used by the
- *     tests and the A/B benchmarks are per-call arguments of the *_ex entry points; the only process-wide datum is the
- *     cached CU count of the device); all buffers (including workspaces) are owned by the caller; kernels are enqueued on
- *     `stream` only (hipGraph-capturable).
+ *     tests and the A/B benchmarks are per-call arguments of the *_ex entry points; what the library remembers is per DEVICE
+ *     ordinal and idempotent: the CU count and "this kernel's dynamic-LDS limit was raised on this device"); no environment
+ *     variable is read outside the diagnostic -DAPLA_ABL_* builds; all buffers (including workspaces) are owned by the caller;
+ *     kernels are enqueued on `stream` only (hipGraph-capturable).
  *   - activations / frozen weights are bf16 (raw uint16 storage), trainable masters / statistics / gradients fp32,
  *     index vectors int32 on device.  "res" buffers (the residual stream and its gradient) are fp32 or bf16,
  *     selected by `res_dtype` (APLA_F32 / APLA_BF16).
