@@ -559,6 +559,21 @@ def test_attention_bwd_cls_only(ops, B, N, H):
     assert float(got[:, 1:, :D].abs().max()) == 0.0 if N > 1 else True
 
 
+@pytest.mark.parametrize("B,N,H", [(3, 197, 2), (2, 5, 1), (1, 1370, 3), (2, 257, 4)])
+def test_attention_fwd_cls_only(ops, B, N, H):
+    """The CLS-query forward of the last block (one query per head against all keys) equals row 0 of the full attention."""
+    D = 64 * H
+    scale = 64 ** -0.5
+    qkv, qkvd = bf(rnd(B, N, 3 * D, seed=96))
+    o_ref, lse_ref = O.attention_fwd(qkvd, H, scale)[:2]
+    o = torch.zeros(B * N, D, device="cuda", dtype=torch.bfloat16)
+    lse = torch.zeros(B, H, N, device="cuda")
+    ops.attn_fwd_cls(dev(qkv).reshape(B * N, 3 * D), B, N, H, scale, o=o, lse=lse)
+    assert rel_err(o.cpu().reshape(B, N, D)[:, 0], o_ref[:, 0]) < BF16_OUT
+    assert rel_err(lse.cpu()[:, :, 0], lse_ref[:, :, 0]) < 1e-5
+    assert float(o.cpu().reshape(B, N, D)[:, 1:].abs().max()) == 0.0 if N > 1 else True
+
+
 # ------------------------------------------------------------------------------------------- dynamic loss scaling
 def test_adamw_dynamic_loss_scaling_matches_gradscaler_semantics(ops):
     """apla_adamw_step_dynamic == scaler.unscale_ + clip_grad_norm_ + scaler.step(AdamW) + scaler.update() of
