@@ -1347,14 +1347,35 @@ __global__ __launch_bounds__(256) void attn_fwd_cls_kernel(const bf16* __restric
   const bf16* base = qkv + (long)b * N * ld + h * 64;
   const float q0 = (float)base[lane] * scale;
   float m = -INFINITY, l = 0.f, acc = 0.f;
-  for (int k = wave; k < N; k += 4) {
-    const float kv = (float)base[(long)k * ld + D + lane], vv = (float)base[(long)k * ld + 2 * D + lane];
-    const float s = wave_sum(q0 * kv);
+  auto fold = [&](float s, float vv) {      // online softmax update with one key
     const float mn = fmaxf(m, s);
     const float a = __expf(m - mn), pr = __expf(s - mn);
     l = l * a + pr;
     acc = acc * a + pr * vv;
     m = mn;
+  };
+  // four keys of this wave per iteration: their eight row loads are issued together and the four wave-wide sums are independent
+  // chains (one key at a time, every load waited for the previous key's sum and exp: the pass was latency-bound, not HBM-bound)
+  int k = wave;
+  for (; k + 12 < N; k += 16) {
+    float kv[4], vv[4], s[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      kv[u] = (float)base[(long)(k + 4 * u) * ld + D + lane];
+      vv[u] = (float)base[(long)(k + 4 * u) * ld + 2 * D + lane];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s[u] = q0 * kv[u];
+#pragma unroll
+    for (int o_ = 32; o_ > 0; o_ >>= 1)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s[u] += __shfl_xor(s[u], o_, 64);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) fold(s[u], vv[u]);
+  }
+  for (; k < N; k += 4) {
+    const float kv = (float)base[(long)k * ld + D + lane], vv = (float)base[(long)k * ld + 2 * D + lane];
+    fold(wave_sum(q0 * kv), vv);
   }
   if (lane == 0) { sm[wave] = m; sl[wave] = l; }
   sacc[wave][lane] = acc;
@@ -1394,9 +1415,7 @@ __global__ __launch_bounds__(256) void attn_bwd_cls_kernel(const bf16* __restric
   const float delta = wave_sum(do0 * o0);
   const float l0 = lse[((long)b * H + h) * N];
   float dq = 0.f;
-  for (int k = wave; k < N; k += 4) {
-    const float kv = (float)base[(long)k * ld + D + lane], vv = (float)base[(long)k * ld + 2 * D + lane];
-    const float s = wave_sum(q0 * kv), dp = wave_sum(do0 * vv);
+  auto one = [&](int k, float kv, float s, float dp) {
     const float pr = __expf(s * scale - l0);
     const float ds = pr * (dp - delta) * scale;
     dq += ds * kv;
@@ -1404,6 +1423,28 @@ __global__ __launch_bounds__(256) void attn_bwd_cls_kernel(const bf16* __restric
     orow[D + lane] = (bf16)(ds * q0);
     orow[2 * D + lane] = (bf16)(pr * do0);
     if (k > 0) orow[lane] = (bf16)0.f;
+  };
+  // four keys of this wave per iteration (eight loads in flight, eight independent wave-wide sums): see attn_fwd_cls_kernel
+  int k = wave;
+  for (; k + 12 < N; k += 16) {
+    float kv[4], s[4], dp[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      kv[u] = (float)base[(long)(k + 4 * u) * ld + D + lane];
+      const float vv = (float)base[(long)(k + 4 * u) * ld + 2 * D + lane];
+      s[u] = q0 * kv[u];
+      dp[u] = do0 * vv;
+    }
+#pragma unroll
+    for (int o_ = 32; o_ > 0; o_ >>= 1)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { s[u] += __shfl_xor(s[u], o_, 64); dp[u] += __shfl_xor(dp[u], o_, 64); }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) one(k + 4 * u, kv[u], s[u], dp[u]);
+  }
+  for (; k < N; k += 4) {
+    const float kv = (float)base[(long)k * ld + D + lane], vv = (float)base[(long)k * ld + 2 * D + lane];
+    one(k, kv, wave_sum(q0 * kv), wave_sum(do0 * vv));
   }
   red[wave][lane] = dq;
   __syncthreads();
