@@ -361,6 +361,77 @@ __global__ __launch_bounds__(256) void pack_proj_rows_batched_kernel(const float
   if (threadIdx.x == 0) bnat_all[(long)l * D + row] = g * b1[j];
 }
 
+// The same re-scatter organised by PANELS of 32 natural rows (round 3).  The row-per-workgroup kernel above writes a column of
+// the transposed copy (and of its K-panel image) per trainable row: 2-byte stores 1.5 KB apart, 3.5 million of them per step at
+// config 2 (40 us).  Here a workgroup owns the 32 natural rows of one panel of one block: it finds the trainable rows that fall
+// into its panel (a scan of the block's r indices), converts them once into LDS, writes their rows of the natural-order weight
+// and of its image, and PATCHES the panel's 64-byte segments of the transposed weight and the panel's contiguous D x 64 B block
+// of the transposed image: read 64 bytes, replace the trainable positions, write 64 bytes — whole sectors, coalesced over k.
+// Frozen entries are rewritten with their own values.  Needs D % 32 == 0; LDS 32 * (D / gridDim.z) * 2 bytes.
+__global__ __launch_bounds__(256) void pack_proj_panels_kernel(const float* __restrict__ flat, long block_stride,
+                                                               const int32_t* __restrict__ inds_all,
+                                                               const float* __restrict__ gamma_all, bf16* __restrict__ Wnat_all,
+                                                               bf16* __restrict__ WnatT_all, float* __restrict__ bnat_all,
+                                                               bf16* __restrict__ Wp_all, bf16* __restrict__ WTp_all, int r, int D) {
+  extern __shared__ __attribute__((aligned(16))) char pk_smem[];
+  bf16* tile = (bf16*)pk_smem;               // [32][Dz]: row (natural row & 31) of the panel, valid where owner[] >= 0; this
+                                             // workgroup's quarter of the k axis (blockIdx.z): 4x the workgroups of a panel-per-
+                                             // workgroup grid, which left the launch latency-bound (288 workgroups at config 2)
+  const int Dz = D / (int)gridDim.z, kz = blockIdx.z * Dz;
+  __shared__ int owner[32];                  // trainable index j of the panel's natural row, or -1
+  const int p = blockIdx.x, l = blockIdx.y, tid = threadIdx.x;
+  const float* W1 = flat + (long)l * block_stride;
+  const float* b1 = W1 + (long)r * D;
+  const int32_t* inds = inds_all + (long)l * D;
+  if (tid < 32) owner[tid] = -1;
+  __syncthreads();
+  for (int j = tid; j < r; j += 256) {       // every natural row has at most one j: no two threads write one slot
+    const int row = inds[j];
+    if ((row >> 5) == p) owner[row & 31] = j;
+  }
+  __syncthreads();
+  bf16* Wnat = Wnat_all + (long)l * D * D;
+  bf16* WnatT = WnatT_all + (long)l * D * D;
+  bf16* Wp = Wp_all ? Wp_all + (long)l * D * D : nullptr;
+  bf16* WTp = WTp_all ? WTp_all + (long)l * D * D : nullptr;
+  int any = 0;
+  for (int i = 0; i < 32; ++i) {             // uniform over the workgroup
+    const int j = owner[i];
+    if (j < 0) continue;
+    any = 1;
+    const int row = 32 * p + i;
+    const float g = gamma_all != nullptr ? gamma_all[(long)l * D + row] : 1.0f;
+    for (int q4 = tid; q4 < Dz / 4; q4 += 256) {
+      const int k4 = kz / 4 + q4;
+      const f32x4 w = *(const f32x4*)(W1 + (size_t)j * D + k4 * 4);
+      const bf16x4 v = pack4(g * w[0], g * w[1], g * w[2], g * w[3]);
+      *(bf16x4*)(tile + i * Dz + q4 * 4) = v;
+      *(bf16x4*)(Wnat + (size_t)row * D + k4 * 4) = v;
+      if (Wp) *(bf16x4*)(Wp + ((size_t)(k4 >> 3) * D + row) * 32 + (k4 & 7) * 4) = v;
+    }
+    if (tid == 0 && blockIdx.z == 0) bnat_all[(long)l * D + row] = g * b1[j];
+  }
+  if (!any) return;
+  __syncthreads();
+  for (int kq = tid; kq < Dz; kq += 256) {   // the panel's 32 entries of transposed row k: 64 bytes in either layout
+    const int k = kz + kq;
+    bf16x8 seg[4];
+    bf16* tp = WnatT + (size_t)k * D + 32 * p;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) seg[c] = *(const bf16x8*)(tp + 8 * c);
+#pragma unroll
+    for (int i = 0; i < 32; ++i)
+      if (owner[i] >= 0) seg[i >> 3][i & 7] = tile[i * Dz + kq];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) *(bf16x8*)(tp + 8 * c) = seg[c];
+    if (WTp) {
+      bf16* ip = WTp + ((size_t)p * D + k) * 32;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) *(bf16x8*)(ip + 8 * c) = seg[c];   // same 32 values: the image of the transposed weight
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" long apla_dw_workspace_bytes(int M, int r, int D) {
@@ -427,6 +498,14 @@ extern "C" int apla_pack_proj_rows_batched_ex(const float* flat, long block_stri
   APLA_REQUIRE(flat && inds_all && Wnat_all && WnatT_all && bnat_all && L > 0 && L <= 65535 && r > 0 && r <= D &&
                block_stride >= (long)r * D + r, "apla_pack_proj_rows_batched: bad arguments");
   APLA_REQUIRE((!Wnat_panels && !WnatT_panels) || D % 32 == 0, "apla_pack_proj_rows_batched_ex: K-panel images need D %% 32 == 0");
+  if (D % 32 == 0 && D <= 4096 && apla_aligned16(flat) && block_stride % 4 == 0 && apla_aligned16(Wnat_all) && apla_aligned16(WnatT_all) &&
+      apla_aligned16(Wnat_panels) && apla_aligned16(WnatT_panels)) {   // panel form (whole-sector writes): 32 * D * 2 <= 64 KB of LDS
+    const int zs = (D % 128 == 0) ? 4 : 1;
+    hipLaunchKernelGGL(pack_proj_panels_kernel, dim3(D / 32, L, zs), dim3(256), (size_t)32 * (D / zs) * 2, stream, flat, block_stride, inds_all, gamma_all,
+                       (bf16*)Wnat_all, (bf16*)WnatT_all, bnat_all, (bf16*)Wnat_panels, (bf16*)WnatT_panels, r, D);
+    APLA_CHECK_LAUNCH("apla_pack_proj_rows_batched");
+    return APLA_OK;
+  }
   hipLaunchKernelGGL(pack_proj_rows_batched_kernel, dim3(r, L), dim3(256), 0, stream, flat, block_stride, inds_all, gamma_all, (bf16*)Wnat_all, (bf16*)WnatT_all, bnat_all, (bf16*)Wnat_panels, (bf16*)WnatT_panels, r, D);
   APLA_CHECK_LAUNCH("apla_pack_proj_rows_batched");
   return APLA_OK;

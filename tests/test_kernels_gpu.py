@@ -559,6 +559,35 @@ def test_attention_bwd_cls_only(ops, B, N, H):
     assert float(got[:, 1:, :D].abs().max()) == 0.0 if N > 1 else True
 
 
+@pytest.mark.parametrize("L,D,r", [(3, 256, 64), (2, 768, 192), (2, 1536, 512), (1, 128, 8)])
+def test_pack_proj_rows_batched_all_layouts(ops, L, D, r):
+    """The per-step re-scatter of the trainable projection rows (appla_attn.py:62-79 folded into the weight layout): natural-order
+    weight, its transpose, both K-panel images and the bias, for every block in one launch — trainable rows replaced (LayerScale
+    folded), frozen entries untouched.  (D % 32 == 0: the panel-oriented kernel; D = 128 with one k slice.)"""
+    g = torch.Generator().manual_seed(5)
+    stride = r * D + r
+    flat = torch.randn(L * stride, generator=g)
+    inds = torch.stack([torch.randperm(D, generator=g) for _ in range(L)]).int()
+    gamma = 0.5 + torch.rand(L, D, generator=g)
+    W0 = torch.randn(L, D, D, generator=g).to(torch.bfloat16)          # frozen content before the call
+    b0 = torch.randn(L, D, generator=g)
+    Wnat, WnatT, bnat = dev(W0.clone()), dev(W0.transpose(1, 2).contiguous()), dev(b0.clone())
+    Wp = torch.stack([ops.k_panels(Wnat[l]) for l in range(L)]).contiguous()
+    WTp = torch.stack([ops.k_panels(WnatT[l]) for l in range(L)]).contiguous()
+    ops.pack_proj_rows_batched(dev(flat), stride, dev(inds), dev(gamma), Wnat, WnatT, bnat, r, Wp, WTp)
+    ref, bref = W0.clone().float(), b0.clone()
+    for l in range(L):
+        W1 = flat[l * stride:l * stride + r * D].view(r, D)
+        b1 = flat[l * stride + r * D:(l + 1) * stride]
+        rows = inds[l, :r].long()
+        ref[l, rows] = (gamma[l, rows, None] * W1).to(torch.bfloat16).float()
+        bref[l, rows] = gamma[l, rows] * b1
+    assert torch.equal(Wnat.cpu().float(), ref) and torch.equal(WnatT.cpu().float(), ref.transpose(1, 2))
+    assert torch.allclose(bnat.cpu(), bref, rtol=1e-6, atol=0)
+    for l in range(L):
+        assert torch.equal(Wp[l], ops.k_panels(Wnat[l])) and torch.equal(WTp[l], ops.k_panels(WnatT[l]))
+
+
 @pytest.mark.parametrize("B,N,H", [(3, 197, 2), (2, 5, 1), (1, 1370, 3), (2, 257, 4)])
 def test_attention_fwd_cls_only(ops, B, N, H):
     """The CLS-query forward of the last block (one query per head against all keys) equals row 0 of the full attention."""
