@@ -422,15 +422,20 @@ __device__ __forceinline__ void wide_epilogue(const GemmParams& p, f32x4 (&acc)[
       r0 = *(const bf16x8*)rd0;
       r1 = *(const bf16x8*)rd1;
     };
-    auto commit = [&](auto FULL, bf16* dst, int ld, int i, int h, bf16x8 r0, bf16x8 r1) {
+    // `img`: dst is the K-panel image [N/32][M][32] of the output (GemmParams::w_panel bits 2 / 3): a lane's 8 columns never
+    // straddle a panel, 8 consecutive rows are 512 contiguous bytes per panel: a store instruction writes two such runs
+    auto commit = [&](auto FULL, bf16* dst, int ld, bool img, int i, int h, bf16x8 r0, bf16x8 r1) {
       const int ma = mbase + i * 16, mb = ma + 8;
+      const size_t col = cbase + h * 64;
+      auto at = [&](int m) -> bf16* { return img ? dst + ((col >> 5) * (size_t)p.M + m) * 32 + (col & 31) : dst + (size_t)m * ld + col; };
 #if defined(APLA_ABL_NOSTORE)
       asm volatile("" :: "v"(r0), "v"(r1));
 #else
-      if (FULL.value || ma < p.M) *(bf16x8*)(dst + (size_t)ma * ld + cbase + h * 64) = r0;
-      if (FULL.value || mb < p.M) *(bf16x8*)(dst + (size_t)mb * ld + cbase + h * 64) = r1;
+      if (FULL.value || ma < p.M) *(bf16x8*)at(ma) = r0;
+      if (FULL.value || mb < p.M) *(bf16x8*)at(mb) = r1;
 #endif
     };
+    const bool c_img = (p.w_panel & 4) != 0, x_img = (p.w_panel & 8) != 0;
     auto run = [&](auto FULL) {
       if constexpr (EPI == APLA_EPI_GELU_FWD) {   // like GELU below, one output: no cross-step registers
 #pragma unroll
@@ -440,7 +445,7 @@ __device__ __forceinline__ void wide_epilogue(const GemmParams& p, f32x4 (&acc)[
           gelu8_fwd(acc[i][4 * h], acc[i][4 * h + 1], hc0);
           gelu8_fwd(acc[i][4 * h + 2], acc[i][4 * h + 3], hc1);
           stage(hc0, hc1, n0_, n1_);
-          commit(FULL, (bf16*)p.C, p.ldc, i, h, n0_, n1_);
+          commit(FULL, (bf16*)p.C, p.ldc, c_img, i, h, n0_, n1_);
           __builtin_amdgcn_sched_barrier(0);
         }
       } else if constexpr (EPI == APLA_EPI_STORE) {
@@ -451,7 +456,7 @@ __device__ __forceinline__ void wide_epilogue(const GemmParams& p, f32x4 (&acc)[
           bf16x8 n0_, n1_;
           if (k < 10)
             stage(Vec8IO<bf16>::pack(acc[i][4 * h], acc[i][4 * h + 1]), Vec8IO<bf16>::pack(acc[i][4 * h + 2], acc[i][4 * h + 3]), n0_, n1_);
-          if (k > 0) commit(FULL, (bf16*)p.C, p.ldc, (k - 1) >> 1, (k - 1) & 1, p0, p1);
+          if (k > 0) commit(FULL, (bf16*)p.C, p.ldc, false, (k - 1) >> 1, (k - 1) & 1, p0, p1);
           p0 = n0_; p1 = n1_;
         }
       } else {  // GELU: the two outputs of a step overlap each other; no cross-step registers (the kernel has none to spare)
@@ -463,8 +468,8 @@ __device__ __forceinline__ void wide_epilogue(const GemmParams& p, f32x4 (&acc)[
           gelu8(acc[i][4 * h + 2], acc[i][4 * h + 3], hc1, gc1);
           stage(hc0, hc1, n0_, n1_);
           stage(gc0, gc1, m0_, m1_);
-          commit(FULL, (bf16*)p.C, p.ldc, i, h, n0_, n1_);
-          commit(FULL, (bf16*)p.aux_out, p.ld_aux_out, i, h, m0_, m1_);
+          commit(FULL, (bf16*)p.C, p.ldc, c_img, i, h, n0_, n1_);
+          commit(FULL, (bf16*)p.aux_out, p.ld_aux_out, x_img, i, h, m0_, m1_);
           __builtin_amdgcn_sched_barrier(0);  // keep the steps apart: interleaving them costs registers, not time
         }
       }

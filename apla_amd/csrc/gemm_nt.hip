@@ -343,7 +343,15 @@ inline Sched pick_schedule(int epi, int out_dtype, int M, int N, int K, int lda,
   // (measured limit of that rule: the two-output GELU epilogue at M = 58 496, the packed student batch of the self-supervised
   // step — 719 MB of stores per launch — runs 480 us on the persistent kernel against 423 us on the ping-pong kernel, while the
   // one-output GELU_FWD and MUL do not care: above 40 000 rows GELU goes back to the ping-pong kernel)
-  if (w_panel & 12) return {1, 5};  // output / second-operand image: the 4-wave persistent kernel's GELU / GELU_FWD / MUL epilogues (checked by gemm_nt_impl)
+  if (w_panel & 12) {
+    // output / second-operand image: the 4-wave persistent kernel's GELU / GELU_FWD / MUL / SwiGLU epilogues (checked by
+    // gemm_nt_impl) — except the two-output GELU above 40 000 rows, which the automatic rule runs on the ping-pong kernel: its
+    // line-store epilogue writes the images as well (round 3: config 3's fc2 read a row-major h, 552 us against dfc1's 474 us)
+    if (epi == APLA_EPI_GELU && M > 40000 && (g_variant == 4 || g_variant == 9) &&
+        apla_gemm_pp2_covers(M, N, K, lda, ldw, epi, out_dtype))
+      return {2, 0};
+    return {1, 5};
+  }
   if (w_panel) return {2, 0};       // K-panel operand images exist on the ping-pong kernel only (gemm_nt_impl checked that it covers the problem)
   const bool pp2_auto = (epi == APLA_EPI_STORE) || (epi == APLA_EPI_GELU && M > 40000);
   if ((g_variant == 9 || (g_variant == 4 && pp2_auto && M >= 2048)) && apla_gemm_pp2_covers(M, N, K, lda, ldw, epi, out_dtype)) return {2, 0};
@@ -385,9 +393,10 @@ static int gemm_nt_impl(const void* A, int lda, const void* W, int ldw, const fl
   APLA_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && ((w_panel & 2) || lda >= K) && ((w_panel & 1) || ldw >= K), "apla_gemm_nt: bad lda/ldw (%d,%d) K=%d", lda, ldw, K);
   if (w_panel & 12) {
     const bool sw = epilogue == APLA_EPI_SWIGLU || epilogue == APLA_EPI_SWIGLU_BWD;
-    APLA_REQUIRE((w_panel & 3) == 0 && out_dtype == APLA_H16 && N % 64 == 0 &&
+    const bool on_pp2 = pick_schedule(epilogue, out_dtype, M, N, K, (w_panel & 2) ? 32 : lda, (w_panel & 1) ? 32 : ldw, w_panel, variant).kind == 2;
+    APLA_REQUIRE(((w_panel & 3) == 0 || on_pp2) && out_dtype == APLA_H16 && N % 64 == 0 &&
                  (epilogue == APLA_EPI_GELU || epilogue == APLA_EPI_GELU_FWD || epilogue == APLA_EPI_MUL || sw),
-                 "apla_gemm_nt_ex: an output / second-operand image needs a 16-bit GELU / GELU_FWD / MUL / SwiGLU epilogue and row-major operands");
+                 "apla_gemm_nt_ex: an output / second-operand image needs a 16-bit GELU / GELU_FWD / MUL / SwiGLU epilogue and (on the 4-wave kernel) row-major operands");
     APLA_REQUIRE(!(w_panel & 8) || (epilogue != APLA_EPI_GELU_FWD && !sw), "apla_gemm_nt_ex: only GELU / MUL keep their second operand as an image");
   } else if (w_panel) {
     APLA_REQUIRE(apla_gemm_pp2_covers(M, N, K, (w_panel & 2) ? 32 : lda, (w_panel & 1) ? 32 : ldw, epilogue, out_dtype),
@@ -447,14 +456,13 @@ extern "C" int apla_gemm_nt_panel_ok(int M, int N, int K, int epilogue, int out_
   return (epilogue == APLA_EPI_GELU && M > 40000) ? 1 : 0;
 }
 
-// May (and should) this problem write its output as a K-panel image?  Yes where the automatic schedule runs it on the 4-wave
-// persistent kernel anyway: GELU_FWD and MUL always, the two-output GELU up to 40 000 rows (above, the ping-pong kernel is the
-// faster one for it — see `launch` — and has no image store).
+// May (and should) this problem write its output as a K-panel image?  GELU, GELU_FWD, MUL and the SwiGLU epilogues: yes (the
+// two-output GELU above 40 000 rows runs on the ping-pong kernel, whose line-store epilogue writes images since round 3).
 extern "C" int apla_gemm_nt_out_image_ok(int M, int N, int K, int epilogue, int out_dtype) {
   if (M <= 0 || N % BN != 0 || K % BK != 0 || out_dtype != APLA_H16) return 0;
   if (epilogue == APLA_EPI_GELU_FWD || epilogue == APLA_EPI_MUL) return 1;
   if (epilogue == APLA_EPI_SWIGLU || epilogue == APLA_EPI_SWIGLU_BWD) return N % 64 == 0 ? 1 : 0;   // C is N/2 resp. 2N wide (ViT-g: vit.py:131-149)
-  return (epilogue == APLA_EPI_GELU && M <= 40000) ? 1 : 0;
+  return epilogue == APLA_EPI_GELU ? 1 : 0;   // up to 40 000 rows on the 4-wave kernel, above on the ping-pong kernel (both write images)
 }
 
 // flags: bits 0-7 = profiling tag (GemmParams::tag), bits 8-15 = kernel schedule (0 = auto; see `launch`), bit 16 / 17 = W / A

@@ -298,6 +298,8 @@ class AplaTrainEngine:
             st.Wqkv_i, st.WqkvT_i, st.Wout_i = img(st.Wqkv), img(st.WqkvT), img(st.Wout)
             st.Wkv_i = img(st.Wqkv[D:]) if i == L - 1 else None     # last block: K and V for every token, Q for the CLS rows only
             st.Wdfc1_i = img(st.W12T if self.swiglu else st.Wfc1T)
+            # fc1 itself takes a weight image where it runs on the ping-pong kernel (the two-output GELU above 40 000 rows)
+            st.Wfc1_i = None if self.swiglu else (ops.k_panels(st.Wfc1) if use and ops.gemm_panel_ok(M, st.Wfc1.shape[0], D, ops.EPI_GELU) else st.Wfc1)
             if nat:   # frozen rows now, trainable rows every step (refresh_weights)
                 self.Wnat_p_all[i].copy_(ops.k_panels(st.Wnat))
                 self.WnatT_p_all[i].copy_(ops.k_panels(st.WnatT))
@@ -462,7 +464,7 @@ class AplaTrainEngine:
             elif inference:
                 ops.gemm_nt(xh2, st.Wfc1, st.bfc1, epilogue=ops.EPI_GELU_FWD, out=self.h_out)
             else:
-                ops.gemm_nt(xh2, st.Wfc1, st.bfc1, epilogue=ops.EPI_GELU, aux_out=self.act_io[i], out=self.h_out)
+                ops.gemm_nt(xh2, st.Wfc1_i, st.bfc1, epilogue=ops.EPI_GELU, aux_out=self.act_io[i], out=self.h_out)
             if ev is not None:
                 e1.record()
                 ev.append((e0, e1))

@@ -536,10 +536,36 @@ def test_gemm_k_panel_images(ops, M, N, K):
     # not covered: an operand epilogue, N not a multiple of 256, fewer than four 32-wide K-steps
     assert not ops.gemm_panel_ok(M, 128, K) and not ops.gemm_panel_ok(M, N, K, ops.EPI_MUL) and not ops.gemm_panel_ok(1000, N, K)
     assert ops.gemm_panel_ok(50000, N, K, ops.EPI_GELU) and not ops.gemm_panel_ok(M, N, K, ops.EPI_GELU)
+    assert ops.gemm_out_image_ok(50000, N, K, ops.EPI_GELU) and ops.gemm_out_image_ok(M, N, K, ops.EPI_GELU)
     with pytest.raises(AplaHipError):
         ops.gemm_nt(A, Wi, None, epilogue=ops.EPI_MUL, aux_in=g0)
     with pytest.raises(AplaHipError):
         ops.gemm_nt(dev(a[:, :64].contiguous()), ops.k_panels(dev(w[:, :64].contiguous())), bias)   # K = 64 < 128
+
+
+def test_gemm_gelu_images_on_the_pingpong_kernel(ops):
+    """Above 40 000 rows the two-output GELU runs on the ping-pong kernel (the student fc1 of the self-supervised step, config 3's
+    fc1): its line-store epilogue writes h and gelu' as K-panel images too, with row-major or image operands — same bits."""
+    M, N, K = 40100, 512, 256
+    a, _ = bf(rnd(M, K, seed=97))
+    w, _ = bf(rnd(N, K, scale=K ** -0.5, seed=98))
+    bias = dev(rnd(N, seed=99))
+    A, W = dev(a), dev(w)
+    assert ops.gemm_kernel_name(M, N, K, ops.EPI_GELU).startswith("gemm_pp2_kernel<GELU")
+    assert ops.gemm_kernel_name(M, N, K, ops.EPI_GELU, out_image=True, aux_image=True).startswith("gemm_pp2_kernel<GELU")
+    g0 = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    h0 = ops.gemm_nt(A, W, bias, epilogue=ops.EPI_GELU, aux_out=g0)
+    for Ai, Wi in ((A, W), (A, ops.k_panels(W)), (ops.k_panels(A), ops.k_panels(W))):
+        hi_ = torch.zeros(N // 32, M, 32, device="cuda", dtype=torch.bfloat16)
+        gi = torch.zeros(N // 32, M, 32, device="cuda", dtype=torch.bfloat16)
+        ops.gemm_nt(Ai, Wi, bias, epilogue=ops.EPI_GELU, aux_out=gi, out=hi_)
+        assert torch.equal(hi_, ops.k_panels(h0)) and torch.equal(gi, ops.k_panels(g0))
+        g1 = torch.zeros_like(g0)                 # image output, row-major gelu'
+        ops.gemm_nt(Ai, Wi, bias, epilogue=ops.EPI_GELU, aux_out=g1, out=hi_.zero_())
+        assert torch.equal(hi_, ops.k_panels(h0)) and torch.equal(g1, g0)
+    # the MUL epilogue (4-wave kernel) reads that gelu' image
+    m0 = ops.gemm_nt(A, W, None, epilogue=ops.EPI_MUL, aux_in=g0)
+    assert torch.equal(ops.gemm_nt(A, W, None, epilogue=ops.EPI_MUL, aux_in=gi), m0)
 
 
 @pytest.mark.parametrize("B,N,H", [(3, 197, 2), (2, 5, 1), (1, 300, 3)])
