@@ -38,6 +38,9 @@ for s in $STEPS; do
       timeout -k 10 900 python bench.py --backbone vit_giant --img 518 --patch 14 --batch 32 --partial-size 512 --dtype fp16 --steps 5 --warmup 2 --no-cpu-baseline --no-parity --no-peak-probe > $O/bench_cfg5.json 2> $O/bench_cfg5.err; rc=$?; tail -c 1500 $O/bench_cfg5.json; tail -3 $O/bench_cfg5.err; guard $rc ;;
     cfg3)
       timeout -k 10 900 python bench.py --backbone vit_large --patch 14 --batch 256 --partial-size 256 --steps 8 --warmup 3 --no-cpu-baseline --no-parity --no-peak-probe > $O/bench_cfg3.json 2> $O/bench_cfg3.err; rc=$?; tail -c 1500 $O/bench_cfg3.json; tail -3 $O/bench_cfg3.err; guard $rc ;;
+    cfg5stats)
+      timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace5 -- python3 bench.py --backbone vit_giant --img 518 --patch 14 --batch 32 --partial-size 512 --dtype fp16 --steps 3 --warmup 2 --no-cpu-baseline --no-parity --no-peak-probe > $O/trace_cfg5.log 2>&1; rc=$?; guard $rc
+      python3 tools/summarize_prof.py $(find $O/trace5 -name "*kernel_stats.csv" | head -1) 9 > $O/kernel_stats_cfg5.md; rm -rf $O/trace5; head -30 $O/kernel_stats_cfg5.md ;;
     cfg3stats)
       timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace3 -- python3 bench.py --backbone vit_large --patch 14 --batch 256 --partial-size 256 --steps 4 --warmup 2 --no-cpu-baseline --no-parity --no-peak-probe > $O/trace_cfg3.log 2>&1; rc=$?; guard $rc
       python3 tools/summarize_prof.py $(find $O/trace3 -name "*kernel_stats.csv" | head -1) 10 > $O/kernel_stats_cfg3.md; rm -rf $O/trace3; head -30 $O/kernel_stats_cfg3.md ;;
