@@ -543,6 +543,30 @@ def test_gemm_k_panel_images(ops, M, N, K):
         ops.gemm_nt(dev(a[:, :64].contiguous()), ops.k_panels(dev(w[:, :64].contiguous())), bias)   # K = 64 < 128
 
 
+@pytest.mark.parametrize("reserve", [8, 40])
+def test_gemm_with_reserved_cus_is_bitwise_the_same(ops, reserve):
+    """The data-parallel step's GEMM launches leave CUs free for the RCCL kernels of the overlapped all-reduce (apla_gemm_nt_ex flags
+    bits 20-27, ops.reserved_cus): fewer persistent workgroups walk the same tiles — both kernels, multi-round tile counts."""
+    M, K = 25216, 768
+    a, _ = bf(rnd(M, K, seed=101))
+    A = dev(a)
+    for N, epi in ((2304, ops.EPI_STORE), (768, ops.EPI_STORE), (3072, ops.EPI_GELU), (3072, ops.EPI_MUL)):
+        w, _ = bf(rnd(N, K, scale=K ** -0.5, seed=102))
+        W, bias = dev(w), dev(rnd(N, seed=103))
+        kw = {}
+        if epi == ops.EPI_GELU:
+            kw = dict(aux_out=torch.empty(M, N, device="cuda", dtype=torch.bfloat16))
+        elif epi == ops.EPI_MUL:
+            kw = dict(aux_in=dev(bf(rnd(M, N, seed=104))[0]))
+        ref = ops.gemm_nt(A, W, bias, epilogue=epi, **kw).clone()
+        aux_ref = kw["aux_out"].clone() if epi == ops.EPI_GELU else None
+        with ops.reserved_cus(reserve):
+            got = ops.gemm_nt(A, W, bias, epilogue=epi, **kw)
+        assert torch.equal(got, ref), (N, epi)
+        if aux_ref is not None:
+            assert torch.equal(kw["aux_out"], aux_ref)
+
+
 def test_gemm_gelu_images_on_the_pingpong_kernel(ops):
     """Above 40 000 rows the two-output GELU runs on the ping-pong kernel (the student fc1 of the self-supervised step, config 3's
     fc1): its line-store epilogue writes h and gelu' as K-panel images too, with row-major or image operands — same bits."""
