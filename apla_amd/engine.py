@@ -13,7 +13,9 @@ APLA_Attention.forward, plus DDP's bucketed all-reduce, clip_grad_norm_ and Adam
   projection is kept in NATURAL feature order: its r trainable rows are re-scattered from the fp32 masters once per
   step (apla_pack_proj_rows), which removes the two activation-side scatter_ calls of appla_attn.py:70-79.
 * Activations bf16, accumulation fp32, residual stream fp32 (default) or bf16, LN statistics / softmax / LSE fp32.
-  Saved per block for backward: block input, mid residual, LN stats, qkv, attention output, LSE, gelu'(pre-activation).
+  The residual stream is ONE buffer updated in place; gamma / beta of the frozen LayerNorms are folded into qkv and fc1 / w12, so
+  the LayerNorm kernels write the normalised row itself.  Saved per block for backward: the two normalised rows (16-bit) and
+  their rstd, qkv, attention output, LSE, gelu'(pre-activation) (or SwiGLU's x12).
 * Trainable state is ONE flat fp32 buffer (params / grads / Adam moments) in ``named_parameters`` order; the module's
   Parameters are views into it, so ``state_dict()`` and checkpoints keep the reference layout.
 * Data parallel: one process per GPU; after backward the flat gradient buffer is all-reduced (RCCL, SUM) on a side
