@@ -498,7 +498,7 @@ extern "C" int apla_pack_proj_rows_batched_ex(const float* flat, long block_stri
   APLA_REQUIRE(flat && inds_all && Wnat_all && WnatT_all && bnat_all && L > 0 && L <= 65535 && r > 0 && r <= D &&
                block_stride >= (long)r * D + r, "apla_pack_proj_rows_batched: bad arguments");
   APLA_REQUIRE((!Wnat_panels && !WnatT_panels) || D % 32 == 0, "apla_pack_proj_rows_batched_ex: K-panel images need D %% 32 == 0");
-  if (D % 32 == 0 && D <= 4096 && apla_aligned16(flat) && block_stride % 4 == 0 && apla_aligned16(Wnat_all) && apla_aligned16(WnatT_all) &&
+  if (D % 32 == 0 && (D % 128 == 0 ? D <= 4096 : D <= 1024) && apla_aligned16(flat) && block_stride % 4 == 0 && apla_aligned16(Wnat_all) && apla_aligned16(WnatT_all) &&
       apla_aligned16(Wnat_panels) && apla_aligned16(WnatT_panels)) {   // panel form (whole-sector writes): 32 * D * 2 <= 64 KB of LDS
     const int zs = (D % 128 == 0) ? 4 : 1;
     hipLaunchKernelGGL(pack_proj_panels_kernel, dim3(D / 32, L, zs), dim3(256), (size_t)32 * (D / zs) * 2, stream, flat, block_stride, inds_all, gamma_all,
