@@ -34,6 +34,8 @@ constexpr int APLA_GEMM_TAGS = 9;   // tags 0 .. 8 (1 is not used: the profiler'
 // 8-wave ping-pong kernel (gemm_pp2.hip); returns APLA_ENOSYS when the shape / (epilogue, dtype) is not covered there
 int apla_gemm_pp2_launch(const GemmParams& p, int epilogue, int out_dtype, hipStream_t stream);
 bool apla_gemm_pp2_covers(int M, int N, int K, long lda, long ldw, int epilogue, int out_dtype);
+int apla_gemm_w4_launch(const GemmParams& p, int epilogue, int out_dtype, hipStream_t stream);   // gemm_w4.hip
+bool apla_gemm_w4_covers(int M, int N, int K, long lda, long ldw, int epilogue, int out_dtype);
 
 // Tile walk.  Linear tile ids are dealt to XCDs in contiguous runs (each XCD has its own 4 MB L2).  With n fastest, a run
 // touches ALL column tiles, i.e. the whole weight matrix: fine while W fits next to the streaming A panels (N = 768:

@@ -343,6 +343,14 @@ inline Sched pick_schedule(int epi, int out_dtype, int M, int N, int K, int lda,
   // (measured limit of that rule: the two-output GELU epilogue at M = 58 496, the packed student batch of the self-supervised
   // step — 719 MB of stores per launch — runs 480 us on the persistent kernel against 423 us on the ping-pong kernel, while the
   // one-output GELU_FWD and MUL do not care: above 40 000 rows GELU goes back to the ping-pong kernel)
+  // 16 forces the wide 4-wave kernel (gemm_w4.hip: 160 x 256 tiles, two workgroups per CU) wherever it is instantiated.  The
+  // automatic rule gives it the plain STORE problems with a short K (qkv, proj, dproj, the patch embedding: K <= 1024) and the
+  // forward-only GELU: measured back to back with W images, M = 25216 (tools/gemm_bench.py GEMM_VARIANTS=109,116): qkv 87.3 -> 85.4
+  // us, proj 32.3 -> 31.4, GELU_FWD 139.9 (4-wave 128-wide kernel) -> 137.4; at K = 2304 / 3072 the ping-pong kernel stays ahead
+  // (dqkv 75.5 vs 77.2, fc2 97.2 vs 100.0 us), the two-output GELU is a tie (153-155 us on either).
+  const bool w4_ok = apla_gemm_w4_covers(M, N, K, lda, ldw, epi, out_dtype);
+  if (g_variant == 16 && w4_ok) return {3, 0};
+  const bool w4_auto = g_variant == 4 && w4_ok && ((epi == APLA_EPI_STORE && K <= 1024 && M >= 2048) || (epi == APLA_EPI_GELU_FWD && M >= 8192));
   if (w_panel & 12) {
     // output / second-operand image: the 4-wave persistent kernel's GELU / GELU_FWD / MUL / SwiGLU epilogues (checked by
     // gemm_nt_impl) — except the two-output GELU above 40 000 rows, which the automatic rule runs on the ping-pong kernel: its
@@ -350,9 +358,11 @@ inline Sched pick_schedule(int epi, int out_dtype, int M, int N, int K, int lda,
     if (epi == APLA_EPI_GELU && M > 40000 && (g_variant == 4 || g_variant == 9) &&
         apla_gemm_pp2_covers(M, N, K, lda, ldw, epi, out_dtype))
       return {2, 0};
+    if (w4_auto) return {3, 0};
     return {1, 5};
   }
-  if (w_panel) return {2, 0};       // K-panel operand images exist on the ping-pong kernel only (gemm_nt_impl checked that it covers the problem)
+  if (w4_auto) return {3, 0};
+  if (w_panel) return {2, 0};       // K-panel operand images exist on the 32-wide-K-step kernels only (gemm_nt_impl checked that one covers the problem)
   const bool pp2_auto = (epi == APLA_EPI_STORE) || (epi == APLA_EPI_GELU && M > 40000);
   if ((g_variant == 9 || (g_variant == 4 && pp2_auto && M >= 2048)) && apla_gemm_pp2_covers(M, N, K, lda, ldw, epi, out_dtype)) return {2, 0};
   if (g_variant >= 4) {
@@ -371,6 +381,7 @@ int launch(const GemmParams& p, int g_variant, hipStream_t stream) {
   const int odt = std::is_same<OutT, float>::value ? APLA_F32 : APLA_H16;
   const Sched sc = pick_schedule(EPI, odt, p.M, p.N, p.K, (p.w_panel & 2) ? 32 : p.lda, (p.w_panel & 1) ? 32 : p.ldw, p.w_panel, g_variant);
   if (sc.kind == 2) return apla_gemm_pp2_launch(p, EPI, odt, stream);
+  if (sc.kind == 3) return apla_gemm_w4_launch(p, EPI, odt, stream);
   if (sc.kind == 1) {
     if (sc.mi == 5) return launch_persist<EPI, OutT, 5>(p, stream);
     return launch_persist<EPI, OutT, 4>(p, stream);
@@ -393,13 +404,15 @@ static int gemm_nt_impl(const void* A, int lda, const void* W, int ldw, const fl
   APLA_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && ((w_panel & 2) || lda >= K) && ((w_panel & 1) || ldw >= K), "apla_gemm_nt: bad lda/ldw (%d,%d) K=%d", lda, ldw, K);
   if (w_panel & 12) {
     const bool sw = epilogue == APLA_EPI_SWIGLU || epilogue == APLA_EPI_SWIGLU_BWD;
-    const bool on_pp2 = pick_schedule(epilogue, out_dtype, M, N, K, (w_panel & 2) ? 32 : lda, (w_panel & 1) ? 32 : ldw, w_panel, variant).kind == 2;
+    const bool on_pp2 = pick_schedule(epilogue, out_dtype, M, N, K, (w_panel & 2) ? 32 : lda, (w_panel & 1) ? 32 : ldw, w_panel, variant).kind >= 2;   // the two kernels with a 32-wide K-step
     APLA_REQUIRE(((w_panel & 3) == 0 || on_pp2) && out_dtype == APLA_H16 && N % 64 == 0 &&
                  (epilogue == APLA_EPI_GELU || epilogue == APLA_EPI_GELU_FWD || epilogue == APLA_EPI_MUL || sw),
                  "apla_gemm_nt_ex: an output / second-operand image needs a 16-bit GELU / GELU_FWD / MUL / SwiGLU epilogue and (on the 4-wave kernel) row-major operands");
     APLA_REQUIRE(!(w_panel & 8) || (epilogue != APLA_EPI_GELU_FWD && !sw), "apla_gemm_nt_ex: only GELU / MUL keep their second operand as an image");
   } else if (w_panel) {
-    APLA_REQUIRE(apla_gemm_pp2_covers(M, N, K, (w_panel & 2) ? 32 : lda, (w_panel & 1) ? 32 : ldw, epilogue, out_dtype),
+    APLA_REQUIRE(pick_schedule(epilogue, out_dtype, M, N, K, (w_panel & 2) ? 32 : lda, (w_panel & 1) ? 32 : ldw, w_panel, variant).kind >= 2 &&
+                 (apla_gemm_pp2_covers(M, N, K, (w_panel & 2) ? 32 : lda, (w_panel & 1) ? 32 : ldw, epilogue, out_dtype) ||
+                  apla_gemm_w4_covers(M, N, K, (w_panel & 2) ? 32 : lda, (w_panel & 1) ? 32 : ldw, epilogue, out_dtype)),
                  "apla_gemm_nt_ex: K-panel operand images need the ping-pong kernel (STORE / GELU, N %% 256 == 0, K %% 32 == 0, K >= 128): ask apla_gemm_nt_panel_ok first");
   }
   APLA_REQUIRE(apla_aligned16(A) && apla_aligned16(W) && apla_aligned16(C) && A && W && C, "apla_gemm_nt: pointers must be 16-byte aligned");
@@ -471,7 +484,7 @@ extern "C" int apla_gemm_nt_ex(const void* A, int lda, const void* W, int ldw, c
                                int N, int K, int epilogue, int out_dtype, const void* aux_in, int ld_aux_in,
                                void* aux_out, int ld_aux_out, int flags, hipStream_t stream) {
   const int tag = flags & 0xff, v = (flags >> 8) & 0xff;
-  APLA_REQUIRE(v == 0 || v == 1 || v == 4 || v == 9 || v == 14 || v == 15, "apla_gemm_nt_ex: unknown schedule %d", v);
+  APLA_REQUIRE(v == 0 || v == 1 || v == 4 || v == 9 || v == 14 || v == 15 || v == 16, "apla_gemm_nt_ex: unknown schedule %d", v);
   return gemm_nt_impl(A, lda, W, ldw, bias, C, ldc, M, N, K, epilogue, out_dtype, aux_in, ld_aux_in, aux_out, ld_aux_out, tag,
                       v == 0 ? 4 : (v == 1 ? 0 : v), stream, (flags >> 16) & 15, (flags >> 20) & 0xff, (flags >> 28) & 7);
 }
@@ -489,7 +502,8 @@ extern "C" int apla_gemm_nt_kernel_name(int M, int N, int K, int epilogue, int o
 #else
   const char* ot = out_dtype == APLA_F32 ? "float" : "bf16";
 #endif
-  if (sc.kind == 2) snprintf(buf, buflen, "gemm_pp2_kernel<%s,%s>", epi_names[epilogue], ot);
+  if (sc.kind == 3) snprintf(buf, buflen, "gemm_w4_kernel<%s,%s>", epi_names[epilogue], ot);
+  else if (sc.kind == 2) snprintf(buf, buflen, "gemm_pp2_kernel<%s,%s>", epi_names[epilogue], ot);
   else if (sc.kind == 1) snprintf(buf, buflen, "gemm_persist_kernel<%s,%s,%d>", epi_names[epilogue], ot, sc.mi);
   else snprintf(buf, buflen, "gemm_nt_kernel<%s,%s>", epi_names[epilogue], ot);
   return APLA_OK;

@@ -445,7 +445,7 @@ def test_head_and_cross_entropy(ops):
 
 
 # ------------------------------------------------------------------------------------------- GEMM schedule variants
-@pytest.mark.parametrize("variant", [4, 9, 14, 15, 1])
+@pytest.mark.parametrize("variant", [4, 9, 14, 15, 16, 1])
 @pytest.mark.parametrize("M,N,K", [(25216, 768, 768), (1000, 512, 256), (333, 256, 128), (161, 256, 192)])
 def test_gemm_variants_all_epilogues(ops, variant, M, N, K):
     """Every main-loop schedule (apla_gemm_nt_ex flags, pinned through ops.set_gemm_variant) must give the same results for every epilogue, including the
@@ -565,6 +565,51 @@ def test_gemm_with_reserved_cus_is_bitwise_the_same(ops, reserve):
         assert torch.equal(got, ref), (N, epi)
         if aux_ref is not None:
             assert torch.equal(kw["aux_out"], aux_ref)
+
+
+@pytest.mark.parametrize("M,N,K", [(25216, 768, 768), (9000, 512, 256), (4001, 256, 128), (161, 256, 192)])
+def test_gemm_wide_4wave_kernel(ops, M, N, K):
+    """gemm_w4.hip (schedule 16: 160 x 256 tiles, 80 x 128 wave tiles, two workgroups per CU): STORE, GELU and GELU_FWD, row-major or
+    K-panel-image operands, row-major or image outputs, with CUs reserved, on both ring depths — the bits of the other schedules
+    (same K order, same epilogue arithmetic); the automatic rule picks it for short-K STORE problems and the forward-only GELU."""
+    a, ad = bf(rnd(M, K, seed=111))
+    w, wd = bf(rnd(N, K, scale=K ** -0.5, seed=112))
+    bias = dev(rnd(N, seed=113))
+    A, W = dev(a), dev(w)
+    base = ad @ wd.t() + bias.cpu().double()
+    old = ops.set_gemm_variant(15)
+    try:
+        ref = ops.gemm_nt(A, W, bias).clone()
+        g_ref = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        h_ref = ops.gemm_nt(A, W, bias, epilogue=ops.EPI_GELU, aux_out=g_ref).clone()
+        ops.set_gemm_variant(16)
+        assert ops.gemm_kernel_name(M, N, K, ops.EPI_STORE).startswith("gemm_w4_kernel<STORE")
+        assert rel_err(ref.cpu(), base) < BF16_OUT
+        for Ai, Wi in ((A, W), (A, ops.k_panels(W)), (ops.k_panels(A), ops.k_panels(W))):
+            for exp in (0, 4, 7):      # default, three-stage ring, no priority
+                ops._GEMM_EXP = exp
+                assert torch.equal(ops.gemm_nt(Ai, Wi, bias), ref), exp
+                g = torch.zeros_like(g_ref)
+                assert torch.equal(ops.gemm_nt(Ai, Wi, bias, epilogue=ops.EPI_GELU, aux_out=g), h_ref) and torch.equal(g, g_ref), exp
+                assert torch.equal(ops.gemm_nt(Ai, Wi, bias, epilogue=ops.EPI_GELU_FWD), h_ref), exp
+            ops._GEMM_EXP = 0
+            hi_ = torch.zeros(N // 32, M, 32, device="cuda", dtype=torch.bfloat16)
+            gi = torch.zeros(N // 32, M, 32, device="cuda", dtype=torch.bfloat16)
+            ops.gemm_nt(Ai, Wi, bias, epilogue=ops.EPI_GELU, aux_out=gi, out=hi_)
+            assert torch.equal(hi_, ops.k_panels(h_ref)) and torch.equal(gi, ops.k_panels(g_ref))
+            ops.gemm_nt(Ai, Wi, bias, epilogue=ops.EPI_GELU_FWD, out=hi_.zero_())
+            assert torch.equal(hi_, ops.k_panels(h_ref))
+        with ops.reserved_cus(8):
+            assert torch.equal(ops.gemm_nt(A, W, bias), ref)
+        assert torch.equal(ops.gemm_nt(A, W, None), ops.gemm_nt(A, W, torch.zeros_like(bias)))   # no bias piece in the stream
+    finally:
+        ops._GEMM_EXP = 0
+        ops.set_gemm_variant(old)
+    if M >= 8192:
+        assert ops.gemm_kernel_name(M, N, K, ops.EPI_STORE).startswith("gemm_w4_kernel<STORE" if K <= 1024 else "gemm_pp2_kernel")
+        assert ops.gemm_kernel_name(M, N, K, ops.EPI_GELU_FWD).startswith("gemm_w4_kernel<GELU_FWD")
+        assert ops.gemm_kernel_name(M, N, 3072, ops.EPI_STORE).startswith("gemm_pp2_kernel<STORE")
+        assert ops.gemm_kernel_name(M, N, K, ops.EPI_GELU).startswith("gemm_persist_kernel<GELU")
 
 
 def test_gemm_gelu_images_on_the_pingpong_kernel(ops):

@@ -9,7 +9,9 @@
 #include <map>
 #include <vector>
 
-constexpr int LDS_KB = 74;
+#ifndef LDS_KB
+#define LDS_KB 74
+#endif
 
 __global__ __launch_bounds__(256, 2) void where_kernel(unsigned* out, long long spin_ticks) {
   __shared__ char smem[LDS_KB * 1024];
@@ -30,9 +32,17 @@ int main(int argc, char** argv) {
   unsigned* d;
   hipMalloc(&d, G * 8);
   std::vector<unsigned> h(2 * G);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
   for (int rep = 0; rep < 2; ++rep) {
+    hipEventRecord(e0, 0);
     hipLaunchKernelGGL(where_kernel, dim3(G), dim3(256), 0, 0, d, 5000LL);  // 100 MHz wall clock: 50 us
+    hipEventRecord(e1, 0);
     if (hipDeviceSynchronize() != hipSuccess) { printf("launch failed\n"); return 1; }
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    printf("%d workgroups x %d KB of LDS, 50 us each: launch took %.1f us (one round if all are co-resident)\n", G, LDS_KB, ms * 1e3f);
   }
   hipMemcpy(h.data(), d, G * 8, hipMemcpyDeviceToHost);
   int label_matches = 0, pair_adjacent = 0, pair_half = 0, pair_other = 0, singles = 0;

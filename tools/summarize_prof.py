@@ -61,6 +61,7 @@ def short(name):
     # the profiler's own demangler garbles <EPI, __bf16, MI, EXP> (DF16b Li5E Li2E -> "bool _Accum, int, ELi2E"): only MI = 5 carries
     # the fourth argument (the K-loop schedule of gemm_persist_kernel, GemmParams::exp)
     name = re.sub(r"bool _Accum, int, ELi(\d+)E", r"bf16, 5, sched \1", name)
+    name = re.sub(r"bool _Accum, bool, E, (\d+), (\d+)", r"bf16, true, \1, \2", name)      # gemm_w4_kernel<EPI, __bf16, true, VNS, TAG>
     m = re.match(r"(?:void )?(gemm_\w+_kernel|gemm_nt_kernel)<(\d), (\w+)(.*)>", name)
     if m:
         rest = m.group(4)
@@ -68,6 +69,10 @@ def short(name):
             t = re.match(r",\s*(\d+)$", rest)
             if t:
                 rest = f" [{TAGS[t.group(1)]}]" if t.group(1) in TAGS else ""
+        elif m.group(1) == "gemm_w4_kernel":   # <EPI, T, PRIO, VNS, TAG>
+            t = re.match(r",\s*(\w+),\s*(\d+),\s*(\d+)$", rest)
+            if t:
+                rest = (f" [{TAGS[t.group(3)]}]" if t.group(3) in TAGS else "") + ("" if (t.group(1), t.group(2)) in (("true", "2"), ("1", "2")) else f" prio={t.group(1)} ring={t.group(2)}")
         return f"{m.group(1)}<{EPI.get(m.group(2), m.group(2))},{m.group(3)}{rest}>"
     name = re.sub(r"^void ", "", name)
     name = re.sub(r"\(.*$", "", name)
