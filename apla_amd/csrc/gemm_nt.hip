@@ -20,6 +20,11 @@
 
 #include "gemm_common.h"
 
+#if defined(APLA_ABL_CLOCK)  // diagnostic build (tools/build_ablations.sh CLOCK): per-workgroup clock stamps of the persistent kernel
+__device__ unsigned long long apla_abl_clock_buf_nt[1024];
+extern "C" int apla_abl_clock_nt(unsigned long long* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(apla_abl_clock_buf_nt), sizeof(apla_abl_clock_buf_nt)); }
+#endif
+
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -215,6 +220,9 @@ __global__ __launch_bounds__(256, 2) void gemm_persist_kernel(GemmParams p, int 
 
   int idx = slot;
   if (idx >= xcnt) return;
+#if defined(APLA_ABL_CLOCK)  // diagnostic build: the core clock this workgroup ran at (tools/gemm_clock.py)
+  const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
   int tile = xbeg + idx;
   setup(tile);
   stage(0, 0);
@@ -285,6 +293,12 @@ __global__ __launch_bounds__(256, 2) void gemm_persist_kernel(GemmParams p, int 
     idx = nidx;
     tile = xbeg + idx;
   }
+#if defined(APLA_ABL_CLOCK)
+  if (tid == 0) {
+    apla_abl_clock_buf_nt[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - clk0;
+    apla_abl_clock_buf_nt[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - rt0;
+  }
+#endif
 }
 
 // kernel schedule, a per-call argument (apla_gemm_nt_ex): 4 = auto, 9 = ping-pong, 14/15 = 128-wide persistent MI 4/5,

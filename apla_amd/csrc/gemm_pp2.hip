@@ -16,6 +16,11 @@
 // persistent kernel, whose two co-resident workgroups overlap one workgroup's epilogue with the other's main loop.
 #include "gemm_common.h"
 
+#if defined(APLA_ABL_CLOCK)  // diagnostic build (tools/build_ablations.sh CLOCK): per-workgroup clock stamps
+__device__ unsigned long long apla_abl_clock_buf_pp2[512];
+extern "C" int apla_abl_clock_pp2(unsigned long long* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(apla_abl_clock_buf_pp2), sizeof(apla_abl_clock_buf_pp2)); }
+#endif
+
 namespace {
 
 constexpr int QBM = 320, QBN = 256, QBK = 32;
@@ -188,6 +193,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmParams p, int tile
     --relaxed;
   };
 
+#if defined(APLA_ABL_CLOCK)
+  const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
   // ------------------------------------------------------------------ prologue: K-steps 0..2 issued by everyone
   dma_issue();
   dma_issue();
@@ -242,6 +250,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmParams p, int tile
     epilogue(ord);
     __builtin_amdgcn_s_barrier();
   }
+#if defined(APLA_ABL_CLOCK)
+  if (tid == 0) {
+    apla_abl_clock_buf_pp2[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - clk0;
+    apla_abl_clock_buf_pp2[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - rt0;
+  }
+#endif
 }
 
 }  // namespace

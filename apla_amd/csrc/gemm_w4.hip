@@ -11,6 +11,11 @@
 // maps and the epilogues are gemm_pp2.hip's (wide_epilogue in gemm_common.h): one workgroup here is one of its two wave groups.
 #include "gemm_common.h"
 
+#if defined(APLA_ABL_CLOCK)  // diagnostic build (tools/build_ablations.sh CLOCK, tools/gemm_clock.py): per-workgroup clock stamps
+__device__ unsigned long long apla_abl_clock_buf[1024];
+extern "C" int apla_abl_clock_w4(unsigned long long* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(apla_abl_clock_buf), sizeof(apla_abl_clock_buf)); }
+#endif
+
 namespace {
 
 constexpr int VBM = 160, VBN = 256, VBK = 32;
@@ -113,6 +118,9 @@ __global__ __launch_bounds__(256, 2) void gemm_w4_kernel(GemmParams p, int tiles
       for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   };
 
+#if defined(APLA_ABL_CLOCK)  // diagnostic build (tools/build_ablations.sh CLOCK): the core clock this workgroup ran at
+  const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
 #pragma unroll
   for (int a = 0; a < VNS - 1; ++a) dma_issue();
   zero_acc();   // cleared here and after every epilogue: the MFMAs always update in place
@@ -163,6 +171,12 @@ __global__ __launch_bounds__(256, 2) void gemm_w4_kernel(GemmParams p, int tiles
     }
     cur = cur == VNS - 1 ? 0 : cur + 1;
   }
+#if defined(APLA_ABL_CLOCK)
+  if (tid == 0) {   // (core-clock ticks, 100 MHz ticks) of this workgroup
+    apla_abl_clock_buf[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - clk0;
+    apla_abl_clock_buf[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - rt0;
+  }
+#endif
 }
 
 }  // namespace

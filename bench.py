@@ -50,6 +50,24 @@ def dominant_kernel_traffic():
         return None, None
 
 
+def dominant_kernel_held_clock():
+    """The core clock the chip held inside the dominant kernel (a STORED figure from the diagnostic CLOCK build: the product kernel
+    executes no stamps) and what that makes of its roofline: the matrix pipes issue at most 4096 bf16 FLOP per CU and core cycle, so
+    peak_at_held_clock = 4096 x 256 CUs x that clock.  On all-zero operands the same instructions run at ~2.38 GHz and 20 % faster:
+    the launch is bound by the clock the chip grants random data, not by its cycle count alone (profiles/r03_gemm_clock.md)."""
+    try:
+        with open(PMC_FILE) as f:
+            h = json.load(f)["held_clock"]
+        ghz = float(h["core_clock_ghz_random_operands"])
+        peak = float(h["mfma_issue_peak_flop_per_cu_and_cycle"]) * 256 * ghz / 1e3
+        return {"stored": True, "source": h["source"], "core_clock_ghz": ghz, "core_clock_ghz_on_zero_operands": h["core_clock_ghz_zero_operands"],
+                "launch_us": h["launch_us_random_operands"], "launch_us_on_zero_operands": h["launch_us_zero_operands"],
+                "peak_at_held_clock": round(peak, 1), "unit": "TFLOP/s",
+                "frac_at_held_clock": round(float(h["flop_per_cu_and_core_cycle"]) / float(h["mfma_issue_peak_flop_per_cu_and_cycle"]), 4)}
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def build_model(backbone, r, n_classes, img, patch, seed=0):
     from apla_amd.models import Classifier
     torch.manual_seed(seed)
@@ -409,6 +427,7 @@ def main():
                          "frac_of_peak_measured": round(k_tf / peak_meas, 4) if peak_meas else None,
                          "peak_probe": peak_rec,
                          "traffic": traffic, "traffic_source": traffic_src,
+                         "held_clock": dominant_kernel_held_clock() if is_cfg2 else None,
                          "algorithmic_bytes": 2.0 * (M * bb.embed_dim + eng.blocks[0].F * bb.embed_dim + 2 * M * eng.blocks[0].F),
                          "kernel_ms": round(k_ms, 4), "kernel_ms_back_to_back": round(iso_ms, 4),
                          # whole step: algorithmic FLOPs and the FLOPs the kernels actually execute — the CLS-only

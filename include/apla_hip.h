@@ -68,25 +68,27 @@ int apla_gemm_nt(const void* A, int lda, const void* W, int ldw, const float* bi
  *   bits 0-7   profiling tag: picks one of several identical instantiations of the bf16 STORE kernel, so that a
  *              rocprofv3 kernel trace names the call sites of the step (2 qkv, 3 proj, 4 fc2, 5 dfc1, 6 dproj, 7 dqkv,
  *              8 patch embedding; 0 = untagged).  No effect on results or speed.
- *   bits 8-15  kernel schedule: 0 = auto (what apla_gemm_nt does): 8-wave ping-pong kernel (320x256x32 tile, gemm_pp2.hip)
- *              for M >= 2048, N % 256 == 0 and the STORE / GELU epilogues, else the 4-wave persistent kernel (128/160 x 128 x
- *              64 tile, gemm_nt.hip); 9 = ping-pong wherever instantiated; 14 / 15 = 4-wave persistent kernel with BM 128 /
- *              160; 1 = the simple non-persistent 2-stage kernel (the round-1 starting point; an in-tree A/B baseline).
- *              All schedules compute the same results (tests/test_kernels_gpu.py).
+ *   bits 8-15  kernel schedule: 0 = auto (what apla_gemm_nt does), for M >= 2048 and N % 256 == 0: the wide 4-wave kernel
+ *              (160x256x32 tile, two workgroups per CU, gemm_w4.hip) for STORE with K <= 1024 and for GELU_FWD, the 8-wave
+ *              ping-pong kernel (320x256x32 tile, one workgroup per CU, gemm_pp2.hip) for STORE with a longer K and for GELU
+ *              above 40 000 rows; else the 4-wave persistent kernel (128/160 x 128 x 64 tile, gemm_nt.hip).  9 = ping-pong
+ *              wherever instantiated; 16 = wide 4-wave wherever instantiated (16-bit STORE / GELU / GELU_FWD); 14 / 15 = 4-wave
+ *              persistent kernel with BM 128 / 160; 1 = the simple non-persistent 2-stage kernel (the round-1 starting point;
+ *              an in-tree A/B baseline).  All schedules compute the same results (tests/test_kernels_gpu.py).
  *   bit 16     W is given as its K-PANEL IMAGE [K/32][N][32] (apla_pack_k_panels; `ldw` is not read), bit 17 the same for A
  *              ([K/32][M][32], `lda` not read).  The fill path of a CU works in 128-byte lines: an LDS-DMA instruction that
  *              takes 64 bytes (a 32-wide K-step) from each of 16 rows of a row-major operand moves half of what one reading
  *              whole lines does (64 vs 115-129 GB/s per CU, tools/dma_probe.hip); in the panel image the 16 rows' 64 bytes are
  *              1 KB contiguous.  Same results bit for bit; the six STORE shapes of config 2 run 2-9 % faster with W as an
- *              image and 2-9 % more with A too.  Ping-pong kernel only: apla_gemm_nt_panel_ok(M, N, K, epilogue, out_dtype)
- *              tells whether a problem is covered AND runs on that kernel under the automatic schedule (an image passed anyway
+ *              image and 2-9 % more with A too.  The two kernels with a 32-wide K-step only (ping-pong, wide 4-wave): apla_gemm_nt_panel_ok(M, N, K, epilogue, out_dtype)
+ *              tells whether a problem is covered AND runs on one of them under the automatic schedule (an image passed anyway
  *              forces the kernel where it covers the problem and is an error where it does not).
  *   bit 18     the OUTPUT C [M, N] is written as its K-panel image [N/32][M][32] (`ldc` not read): 16-bit GELU / GELU_FWD / MUL
- *              epilogues with row-major operands (they run on the 4-wave persistent kernel), so that fc1's h and dfc2's
+ *              epilogues (on the 4-wave persistent kernel: row-major operands only), so that fc1's h and dfc2's
  *              product reach the next GEMM (fc2, dfc1) as images without a conversion pass.
  *   bit 19     the epilogue's second operand (aux_out of GELU = gelu', aux_in of MUL) is an image [N/32][M][32] (`ld_aux_*` not
  *              read): private to those two epilogues, stored and loaded in whole lines.  Same kernels and conditions as bit 18.
- *   bits 20-27 CUs to leave FREE (0..191): the persistent kernels start one (ping-pong) or two (4-wave) workgroups per CU on
+ *   bits 20-27 CUs to leave FREE (0..191): the persistent kernels start one (ping-pong) or two (both 4-wave kernels) workgroups per CU on
  *              256 - n CUs instead of all 256.  The data-parallel step passes the CU budget of its collective here, so that the
  *              RCCL kernels of the overlapped gradient all-reduce (wrappers.py:182-183) run beside the GEMMs instead of taking a
  *              CU from a launch that wants them all.  At config 2 a reservation of up to 8 CUs costs the GEMMs nothing: their

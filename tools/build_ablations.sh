@@ -8,7 +8,7 @@ cd "$(dirname "$0")/../apla_amd/build"
 mkdir -p exp
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result"
-OBJS="errors gemm_nt gemm_pp2 gemm_small layernorm attention apla_dw optim misc"
+OBJS="errors gemm_nt gemm_pp2 gemm_w4 gemm_small layernorm attention apla_dw optim misc"
 build() {  # name source "defines"
   $HIPCC $FLAGS $3 -c ../csrc/$2.hip -o exp/$2_$1.o
   local objs=""
@@ -29,3 +29,14 @@ build ATT_NOS attention "-DAPLA_ABL_ATT_NOS"         # split kernels without the
 build ATT_NOTR attention "-DAPLA_ABL_ATT_NOTR"       # split kernels without the transposed reads and second-stage products
 build LNGRID layernorm "-DAPLA_ABL_LNGRID"           # LayerNorm grid cap from APLA_LN_GRID
 build NGRP gemm_pp2 "-DAPLA_ABL_NGRP"                # n-tiles per column group of the tile walk from APLA_NGRP (ping-pong kernel)
+# tile-walk sweep over all three tiled GEMM kernels (tools/l2_traffic.sh): column-group width from APLA_NGRP
+$HIPCC $FLAGS -DAPLA_ABL_NGRP -c ../csrc/gemm_nt.hip -o exp/gemm_nt_NGRPALL.o
+$HIPCC $FLAGS -DAPLA_ABL_NGRP -c ../csrc/gemm_w4.hip -o exp/gemm_w4_NGRPALL.o
+objs=""; for o in $OBJS; do case $o in gemm_nt) objs="$objs exp/gemm_nt_NGRPALL.o";; gemm_w4) objs="$objs exp/gemm_w4_NGRPALL.o";; gemm_pp2) objs="$objs exp/gemm_pp2_NGRP.o";; *) objs="$objs $o.o";; esac; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o exp/libapla_NGRPALL.so $objs
+echo "built exp/libapla_NGRPALL.so"
+# all three tiled GEMM kernels stamp their core clock per workgroup (tools/gemm_clock.py)
+for f in gemm_nt gemm_w4 gemm_pp2; do $HIPCC $FLAGS -DAPLA_ABL_CLOCK -c ../csrc/$f.hip -o exp/${f}_CLOCK.o; done
+objs=""; for o in $OBJS; do case $o in gemm_nt|gemm_w4|gemm_pp2) objs="$objs exp/${o}_CLOCK.o";; *) objs="$objs $o.o";; esac; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o exp/libapla_CLOCK.so $objs
+echo "built exp/libapla_CLOCK.so"

@@ -3,6 +3,9 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from apla_amd import _lib
+if os.environ.get("APLA_LIB"):  # another build of the library (tools/build_ablations.sh)
+    _lib.LIB_PATH = os.environ["APLA_LIB"]
 from apla_amd import ops
 from apla_amd._lib import lib
 N, K, epi = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
@@ -22,7 +25,9 @@ elif epi == ops.EPI_GELU:
 elif epi == ops.EPI_MUL:
     kw = dict(aux_in=torch.randn(M, N, device=dev).to(torch.bfloat16))
 out = torch.empty(M, N, device=dev, dtype=out_dtype)
-ops.set_gemm_variant(variant)
+ops.set_gemm_variant(variant % 100)
+if variant >= 100:   # 100 + schedule: W as its K-panel image
+    w = ops.k_panels(w)
 for _ in range(iters):
     ops.gemm_nt(a, w, bias, epilogue=epi, out=out, **kw)
 torch.cuda.synchronize()

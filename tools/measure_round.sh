@@ -29,6 +29,10 @@ def val(path, name):
 d = {"kernel": "gemm_persist_kernel<GELU,bf16,5> M=25216 N=3072 K=768 (fc1+GELU launch)", "taken_at": "${APLA_ROUND_TAG:-round 3}",
      "FETCH_SIZE_KiB": val("$O/pmc_FETCH_SIZE.txt", "FETCH_SIZE"), "WRITE_SIZE_KiB": val("$O/pmc_WRITE_SIZE.txt", "WRITE_SIZE"),
      "note": "rocprofv3 --pmc, one counter per pass, averaged over 6 launches; FETCH_SIZE must be doubled on gfx950 (MI355X_MICROARCH.md HBM section)"}
+try:   # the in-kernel clock record comes from its own tool (tools/gemm_clock.py, CLOCK build): carried over
+    d["held_clock"] = json.load(open("profiles/pmc_dominant_kernel.json"))["held_clock"]
+except (OSError, KeyError, ValueError):
+    pass
 json.dump(d, open("$O/pmc_dominant_kernel.json", "w"), indent=1)
 print(d)
 PY
