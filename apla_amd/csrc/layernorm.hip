@@ -78,65 +78,6 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const ResT* x, long 
   }
 }
 
-// The fused step's forward case (fp32 residual stream in, 16-bit xhat out, no affine part, no fused add): two rows per wave, a
-// half-wave per row, 8 consecutive features per lane and chunk — two 16-byte loads and ONE 16-byte store per chunk (the one-row
-// kernel above stores 8 bytes per lane: 512-byte store instructions).
-template <int NC8>
-__global__ __launch_bounds__(LN_THREADS) void ln_fwd2_kernel(const float* __restrict__ x, long xs, bf16* __restrict__ y, int ldy,
-                                                      float* __restrict__ mean_o, float* __restrict__ rstd_o, int M, int D,
-                                                      float eps) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int hl = lane & 31, half = lane >> 5;
-  const int nchunk = D >> 3;
-  const float invD = 1.0f / (float)D;
-  for (int m0 = blockIdx.x * (2 * ROWS_PER_BLOCK); m0 < M; m0 += gridDim.x * (2 * ROWS_PER_BLOCK)) {
-    const int m = m0 + 2 * wave + half;
-    const bool live = m < M;
-    const float* xr = x + (size_t)(live ? m : M - 1) * xs;   // a dead half-wave re-reads the last row, stores nothing
-    f32x4 v[NC8][2];
-    float s = 0.f;
-#pragma unroll
-    for (int c = 0; c < NC8; ++c) {
-      const int ch = hl + c * 32;
-      if (ch < nchunk) {
-        v[c][0] = *(const f32x4*)(xr + ch * 8);
-        v[c][1] = *(const f32x4*)(xr + ch * 8 + 4);
-      }
-    }
-#pragma unroll
-    for (int c = 0; c < NC8; ++c)
-      if (hl + c * 32 < nchunk) s += (v[c][0][0] + v[c][0][1] + v[c][0][2] + v[c][0][3]) + (v[c][1][0] + v[c][1][1] + v[c][1][2] + v[c][1][3]);
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    const float mean = s * invD;
-    float q = 0.f;
-#pragma unroll
-    for (int c = 0; c < NC8; ++c)
-      if (hl + c * 32 < nchunk) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { const float d = v[c][h][e] - mean; q += d * d; }
-      }
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
-    const float rstd = rsqrtf(q * invD + eps);
-    if (live && hl == 0) { mean_o[m] = mean; rstd_o[m] = rstd; }
-#pragma unroll
-    for (int c = 0; c < NC8; ++c) {
-      const int ch = hl + c * 32;
-      if (ch < nchunk && live) {
-        bf16x8 o;
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[4 * h + e] = (bf16)((v[c][h][e] - mean) * rstd);
-        *(bf16x8*)(y + (size_t)m * ldy + ch * 8) = o;
-      }
-    }
-  }
-}
-
 // dx_out = dres_in + ((dy*g) - mean(dy*g) - xhat*mean(dy*g*xhat)) * rstd ; optional bf16 copy of dx_out (GEMM operand
 // when the gradient stream is fp32) and optional gather of the APLA-trainable columns.
 template <typename XT, typename DYT, typename GT, bool GATHER, int NC>
@@ -311,22 +252,6 @@ extern "C" int apla_layernorm_fwd(const void* x, int res_dtype, long x_row_strid
   APLA_REQUIRE(apla_aligned16(x) && (gamma == nullptr || (apla_aligned16(gamma) && apla_aligned16(beta))) && (((uintptr_t)y) & 7) == 0, "apla_layernorm_fwd: alignment");
   APLA_REQUIRE(add_in == nullptr || (x_out != nullptr && add_row_stride % 4 == 0 && add_row_stride >= D && x_out_row_stride % 4 == 0 && x_out_row_stride >= D),
                "apla_layernorm_fwd: fused residual add needs x_out and valid strides");
-  if (gamma == nullptr && add_in == nullptr && res_dtype == APLA_F32 && y_dtype == APLA_H16 && D % 8 == 0 && x_row_stride % 4 == 0 &&
-      ldy % 8 == 0 && apla_aligned16(y)) {
-    const int nc8 = (D / 8 + 31) / 32;
-    const int g2 = (M + 2 * ROWS_PER_BLOCK - 1) / (2 * ROWS_PER_BLOCK);
-    const dim3 grid2(g2 < 4096 ? g2 : 4096);
-#define LN_FWD2(NCV) hipLaunchKernelGGL((ln_fwd2_kernel<NCV>), grid2, dim3(LN_THREADS), 0, stream, (const float*)x, x_row_stride, (bf16*)y, ldy, mean, rstd, M, D, eps)
-    if (nc8 <= 1) LN_FWD2(1);
-    else if (nc8 == 2) LN_FWD2(2);
-    else if (nc8 == 3) LN_FWD2(3);
-    else if (nc8 == 4) LN_FWD2(4);
-    else if (nc8 <= 6) LN_FWD2(6);
-    else LN_FWD2(8);
-#undef LN_FWD2
-    APLA_CHECK_LAUNCH("apla_layernorm_fwd");
-    return APLA_OK;
-  }
 #define LN_FWD_NC(T, Y, NCV) hipLaunchKernelGGL((ln_fwd_kernel<T, Y, NCV>), dim3(ln_grid(M)), dim3(LN_THREADS), 0, stream, (const T*)x, x_row_stride, gamma, beta, (Y*)y, ldy, mean, rstd, M, D, eps, (const bf16*)add_in, add_row_stride, (T*)x_out, x_out_row_stride)
 #define LN_FWD(T, Y)                                    \
   do {                                                  \
