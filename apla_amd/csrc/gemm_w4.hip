@@ -69,6 +69,9 @@ __global__ __launch_bounds__(256, 2) void gemm_w4_kernel(GemmParams p, int tiles
   const char* w_base = nullptr;
   auto dma_issue = [&]() {
     if (d_step >= s_total) return;
+#if defined(APLA_ABL_NODMA)  // diagnostic build: only the first stages are streamed (wrong results; timed by tools/gemm_clock.py)
+    if (d_step > 4) { ++d_step; d_slot = d_slot == VNS - 1 ? 0 : d_slot + 1; if (++d_k == nk) { d_k = 0; ++d_tile; } return; }
+#endif
     if (d_k == 0) {
       int tn;
       tile_coords(xbeg + slot + d_tile * slots, tiles_m, tiles_n, p.ngrp, d_tm, tn);
@@ -79,7 +82,11 @@ __global__ __launch_bounds__(256, 2) void gemm_w4_kernel(GemmParams p, int tiles
         __builtin_amdgcn_global_load_lds(GLBP(p.bias + tn * VBN + lane * 4), LDSP(smem + VBIAS + (d_tile & 1) * 1024), 16, 0, 0);
     }
     char* base = smem + d_slot * VSTG;
+#if defined(APLA_ABL_SAMEK)  // diagnostic build: every K-step streams the k = 0 slice again (an L2-resident source, same LDS-DMA count)
+    const size_t ka = 0, kw = 0;
+#else
     const size_t ka = (size_t)d_k * akstep, kw = (size_t)d_k * wkstep;
+#endif
     // W piece pw fills LDS rows 16*pw + srow = (pw>>3)*128 + (j = pw&7)*16 + srow, which hold W row
     //   (pw>>3)*128 + 32*(j>>1) + 8*(srow>>2) + 4*(j&1) + (srow&3)        (MFMA order, see gemm_common.h)
 #pragma unroll
@@ -139,10 +146,21 @@ __global__ __launch_bounds__(256, 2) void gemm_w4_kernel(GemmParams p, int tiles
     const char* st = smem + cur * VSTG;
     dma_issue();   // K-step s + VNS - 1, into the stage that was read during K-step s-1
     asm volatile("" ::: "memory");
+#if defined(APLA_ABL_NOREAD)  // diagnostic build: fragments are read for the first K-steps only
+    if (s < 4)
+#endif
+    {
 #pragma unroll
-    for (int i = 0; i < 5; ++i) af[i] = *(const bf16x8*)(st + a_off + i * 1024);
+      for (int i = 0; i < 5; ++i) af[i] = *(const bf16x8*)(st + a_off + i * 1024);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) wf[j] = *(const bf16x8*)(st + w_off + j * 1024);
+      for (int j = 0; j < 8; ++j) wf[j] = *(const bf16x8*)(st + w_off + j * 1024);
+    }
+#if defined(APLA_ABL_NOREAD)
+#pragma unroll
+    for (int i = 0; i < 5; ++i) asm volatile("" : "+v"(af[i]));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(wf[j]));
+#endif
     if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int i = 0; i < 5; ++i)

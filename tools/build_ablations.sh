@@ -36,7 +36,15 @@ objs=""; for o in $OBJS; do case $o in gemm_nt) objs="$objs exp/gemm_nt_NGRPALL.
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o exp/libapla_NGRPALL.so $objs
 echo "built exp/libapla_NGRPALL.so"
 # all three tiled GEMM kernels stamp their core clock per workgroup (tools/gemm_clock.py)
-for f in gemm_nt gemm_w4 gemm_pp2; do $HIPCC $FLAGS -DAPLA_ABL_CLOCK -c ../csrc/$f.hip -o exp/${f}_CLOCK.o; done
+for f in gemm_nt gemm_w4 gemm_pp2; do $HIPCC $FLAGS -DAPLA_ABL_CLOCK -DAPLA_ABL_NGRP -c ../csrc/$f.hip -o exp/${f}_CLOCK.o; done
 objs=""; for o in $OBJS; do case $o in gemm_nt|gemm_w4|gemm_pp2) objs="$objs exp/${o}_CLOCK.o";; *) objs="$objs $o.o";; esac; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o exp/libapla_CLOCK.so $objs
 echo "built exp/libapla_CLOCK.so"
+# the wide 4-wave kernel without LDS-DMA / without fragment reads / without both, with clock stamps (APLA_LIB=... python3 tools/gemm_clock.py)
+for v in NODMA NOREAD "NODMA -DAPLA_ABL_NOREAD" SAMEK; do
+  n=W4_$(echo $v | sed 's/ -DAPLA_ABL_//')
+  $HIPCC $FLAGS -DAPLA_ABL_CLOCK -DAPLA_ABL_$v -c ../csrc/gemm_w4.hip -o exp/gemm_w4_$n.o
+  objs=""; for o in $OBJS; do case $o in gemm_w4) objs="$objs exp/gemm_w4_$n.o";; gemm_nt|gemm_pp2) objs="$objs exp/${o}_CLOCK.o";; *) objs="$objs $o.o";; esac; done
+  $HIPCC --offload-arch=gfx950 -shared -fPIC -o exp/libapla_$n.so $objs
+  echo "built exp/libapla_$n.so"
+done

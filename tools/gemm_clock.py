@@ -16,7 +16,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from apla_amd import _lib
-_lib.LIB_PATH = os.path.join(os.path.dirname(_lib.__file__), "build", "exp", "libapla_CLOCK.so")
+_lib.LIB_PATH = os.environ.get("APLA_LIB") or os.path.join(os.path.dirname(_lib.__file__), "build", "exp", "libapla_CLOCK.so")
 from apla_amd import ops
 from apla_amd._lib import lib
 
@@ -46,6 +46,8 @@ def main():
     print(f"# Core clock inside the GEMM launches of the step (config 2, M = {M}; {seconds:g} s of back-to-back launches before each reading)\n")
     print("| launch | kernel | operands | launch us | TFLOP/s | core clock GHz (median workgroup; min / max) | FLOP per CU and core cycle | of 4096 |")
     print("|---|---|---|---:|---:|---:|---:|---:|")
+    if os.environ.get("CLOCK_ONLY"):   # e.g. CLOCK_ONLY=qkv,fc1 with an ablation build of one kernel
+        cases = [c for c in cases if any(c[0].startswith(k) for k in os.environ["CLOCK_ONLY"].split(",")) and (os.environ.get("CLOCK_KERNEL", "") in c[5])]
     for name, N, K, epi, variant, kname, reader, n_wg in cases:
         for data in ("random", "zeros"):
             if data == "random":
