@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256, 2) void gemm_w4_kernel(GemmParams p, int tiles
 
   // ---- LDS-DMA stream (its own position d_*: two K-steps ahead of the products, across tile boundaries).  A piece is 16 LDS rows
   // x 64 B: lane i fills row 16*piece + (i>>2), physical chunk i&3, from logical chunk (i&3) ^ ((-(i>>4)) & 3) (gemm_pp2.hip's
-  // image).  Wave w streams the W pieces 4w .. 4w+3 and the A pieces {0,1,2} {3,4,5} {6,7,7} {8,9,9}.
+  // image).  Wave w streams the W pieces 4w .. 4w+3 and the A pieces {0,1,2} {3,4,5} {6,7} {8,9}.
   const int srow = lane >> 2;
   const int koff = ((lane & 3) ^ ((-(srow >> 2)) & 3)) * 8;
   const unsigned wrow = (p.w_panel & 1) ? 32u : (unsigned)p.ldw;   // elements between consecutive W rows
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256, 2) void gemm_w4_kernel(GemmParams p, int tiles
       d_edge = d_tm * VBM + VBM > p.M;
       a_base = (const char*)(p.A + (size_t)(d_tm * VBM) * arow);
       w_base = (const char*)(p.W + (size_t)(tn * VBN) * wrow);
-      if (has_bias)   // every wave issues the piece (same bytes, same place): the waits below count the same on all waves
+      if (has_bias && (VNS >= 3 || wave == 0))   // deeper ring: every wave issues the piece (same bytes, same place), so that its waits count the same on all waves
         __builtin_amdgcn_global_load_lds(GLBP(p.bias + tn * VBN + lane * 4), LDSP(smem + VBIAS + (d_tile & 1) * 1024), 16, 0, 0);
     }
     char* base = smem + d_slot * VSTG;
@@ -98,7 +98,10 @@ __global__ __launch_bounds__(256, 2) void gemm_w4_kernel(GemmParams p, int tiles
 #pragma unroll
     for (int it = 0; it < 3; ++it) {
       int c = a_first + it;
-      c = (wave >= 2 && it == 2) ? c - 1 : c;   // waves 2 and 3 own two pieces: the third issue repeats the second
+      if (wave >= 2 && it == 2) {   // waves 2 and 3 own two pieces.  The deeper ring counts its waits per wave, so there the third issue
+        if (VNS < 3) continue;      // repeats the second (same bytes, same place); the two-stage ring waits for everything: no repeat
+        c -= 1;
+      }
       if (!d_edge) {
         __builtin_amdgcn_global_load_lds(GLBP(a_base + ka + (unsigned)(c * 16) * arow * 2u + a_lane), LDSP(base + c * 1024), 16, 0, 0);
       } else {  // A rows hang over the M edge: clamp them (reads stay inside A; those rows are never stored)
