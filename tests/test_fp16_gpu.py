@@ -50,6 +50,9 @@ def test_fp16_gemm_epilogues(M, N, K):
         mul, muld = hf(rnd(M, N, seed=4))
         out = ops.gemm_nt(a.cuda(), w.cuda(), None, epilogue=ops.EPI_MUL, aux_in=mul.cuda())
         assert rel_err(out.cpu(), (ad @ wd.t()) * muld) < F16_OUT
+        if M >= 8192:   # the wide 4-wave kernel in the fp16 build (automatic schedule: short-K STORE, forward-only GELU)
+            assert ops.gemm_kernel_name(M, N, K).startswith("gemm_w4_kernel<STORE,f16") and ops.gemm_kernel_name(M, N, K, ops.EPI_GELU_FWD).startswith("gemm_w4_kernel<GELU_FWD")
+            assert torch.equal(ops.gemm_nt(a.cuda(), w.cuda(), bias.cuda(), epilogue=ops.EPI_GELU_FWD), h)
 
 
 def test_fp16_attention_and_layernorm():
