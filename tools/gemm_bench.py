@@ -42,6 +42,12 @@ def main():
         elif epi == ops.EPI_MUL:
             kw = dict(aux_in=torch.randn(M, N, device=dev).to(torch.bfloat16))
         out = torch.empty(M, N, device=dev, dtype=kw.get("out_dtype", torch.bfloat16))
+        if os.environ.get("GEMM_IMAGES") and epi in (ops.EPI_GELU, ops.EPI_GELU_FWD, ops.EPI_MUL):   # outputs / gelu' as K-panel images, as the step keeps them
+            out = out.view(N // 32, M, 32)
+            if "aux_out" in kw:
+                kw["aux_out"] = kw["aux_out"].view(N // 32, M, 32)
+            if "aux_in" in kw:
+                kw["aux_in"] = ops.k_panels(kw["aux_in"])
         rot = [(out, kw)]
         for _ in range(ROTATE - 1):
             rot.append((torch.empty_like(out), {k: (torch.empty_like(x) if k == "aux_out" else x.clone() if torch.is_tensor(x) else x)
