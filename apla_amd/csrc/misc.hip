@@ -348,9 +348,146 @@ __global__ __launch_bounds__(256) void distill_ce_kernel(const ST* __restrict__ 
   }
 }
 
+// Wide versions of the two kernels above (K % 8 == 0, 16-byte aligned rows): 8 prototypes per thread and access, the row's
+// statistics in ONE pass (running maximum + rescaled sum per thread, combined across the workgroup in a fixed order), and the row's
+// output split over `S` workgroups — each of them walks the whole row for the statistics (it sits in L2 / the Infinity Cache after
+// the first) and writes only its own slice.  With 64 student rows per call (DINO: one call per crop) one workgroup per row keeps
+// 64 of 256 CUs busy with 2-byte loads: 312 us per call; S = 16 there.
+template <typename T> __device__ __forceinline__ void ld8f(const T* p, float (&v)[8]);
+template <> __device__ __forceinline__ void ld8f<float>(const float* p, float (&v)[8]) {
+  const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
+}
+template <> __device__ __forceinline__ void ld8f<bf16>(const bf16* p, float (&v)[8]) {
+  const bf16x8 a = *(const bf16x8*)p;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = (float)a[e];
+}
+// (m, s) of the workgroup from every thread's running maximum m and sum s of exp(z - m); all threads return the same pair
+__device__ __forceinline__ void block_max_sumexp(float& m, float& sm, float* red /* [8] */) {
+  const float wm = wave_max(m);
+  sm = wave_sum(m == -INFINITY ? 0.f : sm * __expf(m - wm));   // a thread (or a whole wave, K < 2048) that saw no element: m = -inf, sm = 0
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = wm; red[4 + (threadIdx.x >> 6)] = sm; }
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  sm = red[4] * __expf(red[0] - m) + red[5] * __expf(red[1] - m) + red[6] * __expf(red[2] - m) + red[7] * __expf(red[3] - m);
+}
+__device__ __forceinline__ float block_sum(float v, float* red /* [4] */) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+template <typename XT>
+__global__ __launch_bounds__(256) void softmax_center_wide_kernel(const XT* __restrict__ x, long ldx, const float* __restrict__ center,
+                                                                  float inv_temp, float* __restrict__ out, long ldo, int K, int slice) {
+  __shared__ float red[8];
+  const XT* xr = x + (long)blockIdx.y * ldx;
+  float* orow = out + (long)blockIdx.y * ldo;
+  float m = -INFINITY, sm = 0.f;
+  for (int k = threadIdx.x * 8; k < K; k += 2048) {
+    float v[8], c[8];
+    ld8f<XT>(xr + k, v);
+    ld8f<float>(center + k, c);
+    float vm = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { v[e] = (v[e] - c[e]) * inv_temp; vm = fmaxf(vm, v[e]); }
+    if (vm > m) { sm *= __expf(m - vm); m = vm; }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sm += __expf(v[e] - m);
+  }
+  block_max_sumexp(m, sm, red);
+  const float inv = 1.0f / sm;
+  const int k0 = blockIdx.x * slice, k1 = k0 + slice < K ? k0 + slice : K;
+  for (int k = k0 + threadIdx.x * 8; k < k1; k += 2048) {
+    float v[8], c[8];
+    ld8f<XT>(xr + k, v);
+    ld8f<float>(center + k, c);
+    f32x4 o0, o1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      o0[e] = __expf((v[e] - c[e]) * inv_temp - m) * inv;
+      o1[e] = __expf((v[4 + e] - c[4 + e]) * inv_temp - m) * inv;
+    }
+    *(f32x4*)(orow + k) = o0;
+    *(f32x4*)(orow + k + 4) = o1;
+  }
+}
+
+template <typename ST>
+__global__ __launch_bounds__(256) void distill_ce_wide_kernel(const ST* __restrict__ s, long lds, const float* __restrict__ t, long ldt,
+                                                              float inv_temp, const float* __restrict__ row_weight, float weight,
+                                                              float* __restrict__ ds, long ldds, int accumulate,
+                                                              float* __restrict__ row_loss, int K, int slice) {
+  __shared__ float red[8];
+  const int r = blockIdx.y;
+  const ST* sr = s + (long)r * lds;
+  const float* tr = t + (long)r * ldt;
+  const float w = row_weight != nullptr ? row_weight[r] * weight : weight;
+  float m = -INFINITY, sm = 0.f, dot = 0.f, tsum = 0.f;
+  for (int k = threadIdx.x * 8; k < K; k += 2048) {
+    float z[8], tv[8];
+    ld8f<ST>(sr + k, z);
+    ld8f<float>(tr + k, tv);
+    float vm = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { z[e] *= inv_temp; vm = fmaxf(vm, z[e]); }
+    if (vm > m) { sm *= __expf(m - vm); m = vm; }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sm += __expf(z[e] - m); dot += tv[e] * z[e]; tsum += tv[e]; }
+  }
+  block_max_sumexp(m, sm, red);
+  dot = block_sum(dot, red);
+  tsum = block_sum(tsum, red);
+  const float lse = m + __logf(sm);
+  if (blockIdx.x == 0 && threadIdx.x == 0) row_loss[r] = w * (tsum * lse - dot);
+  if (ds != nullptr) {
+    float* dr = ds + (long)r * ldds;
+    const float c = w * inv_temp;
+    const int k0 = blockIdx.x * slice, k1 = k0 + slice < K ? k0 + slice : K;
+    for (int k = k0 + threadIdx.x * 8; k < k1; k += 2048) {
+      float z[8], tv[8];
+      ld8f<ST>(sr + k, z);
+      ld8f<float>(tr + k, tv);
+      f32x4 g0, g1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        g0[e] = c * (__expf(z[e] * inv_temp - lse) * tsum - tv[e]);
+        g1[e] = c * (__expf(z[4 + e] * inv_temp - lse) * tsum - tv[4 + e]);
+      }
+      if (accumulate) { g0 += *(const f32x4*)(dr + k); g1 += *(const f32x4*)(dr + k + 4); }
+      *(f32x4*)(dr + k) = g0;
+      *(f32x4*)(dr + k + 4) = g1;
+    }
+  }
+}
+
+// workgroups per row: enough of them to fill the chip when the call has few rows; a slice is a multiple of one workgroup pass
+static inline int wide_row_split(int R, int K, int* slice) {
+  int S = R >= 512 ? 1 : (1024 + R - 1) / R;
+  S = S > 16 ? 16 : S;
+  int len = ((K + S - 1) / S + 2047) / 2048 * 2048;
+  *slice = len;
+  return (K + len - 1) / len;
+}
+
 extern "C" int apla_softmax_center(const void* x, int x_dtype, long ldx, const float* center, float inv_temp, float* out,
                                    long ldo, int R, int K, hipStream_t stream) {
   APLA_REQUIRE(x && center && out && R > 0 && K > 0 && ldx >= K && ldo >= K && inv_temp > 0.f, "apla_softmax_center: bad arguments");
+  const bool wide = K % 8 == 0 && R <= 65535 && apla_aligned16(x) && apla_aligned16(center) && apla_aligned16(out) && ldo % 4 == 0 &&
+                    ldx % (x_dtype == APLA_F32 ? 4 : 8) == 0 && (x_dtype == APLA_F32 || x_dtype == APLA_H16);
+  if (wide) {
+    int slice = 0;
+    const int S = wide_row_split(R, K, &slice);
+    if (x_dtype == APLA_F32) hipLaunchKernelGGL(softmax_center_wide_kernel<float>, dim3(S, R), dim3(256), 0, stream, (const float*)x, ldx, center, inv_temp, out, ldo, K, slice);
+    else hipLaunchKernelGGL(softmax_center_wide_kernel<bf16>, dim3(S, R), dim3(256), 0, stream, (const bf16*)x, ldx, center, inv_temp, out, ldo, K, slice);
+    APLA_CHECK_LAUNCH("apla_softmax_center");
+    return APLA_OK;
+  }
   if (x_dtype == APLA_F32) hipLaunchKernelGGL(softmax_center_kernel<float>, dim3(R), dim3(256), 0, stream, (const float*)x, ldx, center, inv_temp, out, ldo, K);
   else if (x_dtype == APLA_H16) hipLaunchKernelGGL(softmax_center_kernel<bf16>, dim3(R), dim3(256), 0, stream, (const bf16*)x, ldx, center, inv_temp, out, ldo, K);
   else { apla_set_error("apla_softmax_center: unsupported dtype %d", x_dtype); return APLA_ENOSYS; }
@@ -363,6 +500,17 @@ extern "C" int apla_distill_ce(const void* student, int s_dtype, long lds, const
                                float* row_loss, int R, int K, hipStream_t stream) {
   APLA_REQUIRE(student && teacher_probs && row_loss && R > 0 && K > 0 && lds >= K && ldt >= K && inv_temp > 0.f &&
                (dstudent == nullptr || ldds >= K), "apla_distill_ce: bad arguments");
+  const bool wide = K % 8 == 0 && R <= 65535 && apla_aligned16(student) && apla_aligned16(teacher_probs) && ldt % 4 == 0 &&
+                    (dstudent == nullptr || (apla_aligned16(dstudent) && ldds % 4 == 0)) &&
+                    lds % (s_dtype == APLA_F32 ? 4 : 8) == 0 && (s_dtype == APLA_F32 || s_dtype == APLA_H16);
+  if (wide) {
+    int slice = K;
+    const int S = dstudent != nullptr ? wide_row_split(R, K, &slice) : 1;
+    if (s_dtype == APLA_F32) hipLaunchKernelGGL(distill_ce_wide_kernel<float>, dim3(S, R), dim3(256), 0, stream, (const float*)student, lds, teacher_probs, ldt, inv_temp, row_weight, weight, dstudent, ldds, accumulate, row_loss, K, slice);
+    else hipLaunchKernelGGL(distill_ce_wide_kernel<bf16>, dim3(S, R), dim3(256), 0, stream, (const bf16*)student, lds, teacher_probs, ldt, inv_temp, row_weight, weight, dstudent, ldds, accumulate, row_loss, K, slice);
+    APLA_CHECK_LAUNCH("apla_distill_ce");
+    return APLA_OK;
+  }
   if (s_dtype == APLA_F32) hipLaunchKernelGGL(distill_ce_kernel<float>, dim3(R), dim3(256), 0, stream, (const float*)student, lds, teacher_probs, ldt, inv_temp, row_weight, weight, dstudent, ldds, accumulate, row_loss, K);
   else if (s_dtype == APLA_H16) hipLaunchKernelGGL(distill_ce_kernel<bf16>, dim3(R), dim3(256), 0, stream, (const bf16*)student, lds, teacher_probs, ldt, inv_temp, row_weight, weight, dstudent, ldds, accumulate, row_loss, K);
   else { apla_set_error("apla_distill_ce: unsupported dtype %d", s_dtype); return APLA_ENOSYS; }
