@@ -418,10 +418,28 @@ __global__ __launch_bounds__(256) void softmax_center_wide_kernel(const XT* __re
   }
 }
 
-template <typename ST>
+template <typename T> __device__ __forceinline__ void st8f(T* p, f32x4 a, f32x4 b, bool accumulate);
+template <> __device__ __forceinline__ void st8f<float>(float* p, f32x4 a, f32x4 b, bool accumulate) {
+  if (accumulate) { a += *(const f32x4*)p; b += *(const f32x4*)(p + 4); }
+  *(f32x4*)p = a;
+  *(f32x4*)(p + 4) = b;
+}
+template <> __device__ __forceinline__ void st8f<bf16>(bf16* p, f32x4 a, f32x4 b, bool accumulate) {
+  if (accumulate) {
+    const bf16x8 o = *(const bf16x8*)p;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { a[e] += (float)o[e]; b[e] += (float)o[4 + e]; }
+  }
+  bf16x8 v;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { v[e] = (bf16)a[e]; v[4 + e] = (bf16)b[e]; }
+  *(bf16x8*)p = v;
+}
+
+template <typename ST, typename GT>
 __global__ __launch_bounds__(256) void distill_ce_wide_kernel(const ST* __restrict__ s, long lds, const float* __restrict__ t, long ldt,
                                                               float inv_temp, const float* __restrict__ row_weight, float weight,
-                                                              float* __restrict__ ds, long ldds, int accumulate,
+                                                              GT* __restrict__ ds, long ldds, int accumulate,
                                                               float* __restrict__ row_loss, int K, int slice) {
   __shared__ float red[8];
   const int r = blockIdx.y;
@@ -446,7 +464,7 @@ __global__ __launch_bounds__(256) void distill_ce_wide_kernel(const ST* __restri
   const float lse = m + __logf(sm);
   if (blockIdx.x == 0 && threadIdx.x == 0) row_loss[r] = w * (tsum * lse - dot);
   if (ds != nullptr) {
-    float* dr = ds + (long)r * ldds;
+    GT* dr = ds + (long)r * ldds;
     const float c = w * inv_temp;
     const int k0 = blockIdx.x * slice, k1 = k0 + slice < K ? k0 + slice : K;
     for (int k = k0 + threadIdx.x * 8; k < k1; k += 2048) {
@@ -459,9 +477,7 @@ __global__ __launch_bounds__(256) void distill_ce_wide_kernel(const ST* __restri
         g0[e] = c * (__expf(z[e] * inv_temp - lse) * tsum - tv[e]);
         g1[e] = c * (__expf(z[4 + e] * inv_temp - lse) * tsum - tv[4 + e]);
       }
-      if (accumulate) { g0 += *(const f32x4*)(dr + k); g1 += *(const f32x4*)(dr + k + 4); }
-      *(f32x4*)(dr + k) = g0;
-      *(f32x4*)(dr + k + 4) = g1;
+      st8f<GT>(dr + k, g0, g1, accumulate != 0);
     }
   }
 }
@@ -495,27 +511,39 @@ extern "C" int apla_softmax_center(const void* x, int x_dtype, long ldx, const f
   return APLA_OK;
 }
 
-extern "C" int apla_distill_ce(const void* student, int s_dtype, long lds, const float* teacher_probs, long ldt, float inv_temp,
-                               const float* row_weight, float weight, float* dstudent, long ldds, int accumulate,
-                               float* row_loss, int R, int K, hipStream_t stream) {
+extern "C" int apla_distill_ce_ex(const void* student, int s_dtype, long lds, const float* teacher_probs, long ldt, float inv_temp,
+                                  const float* row_weight, float weight, void* dstudent, int ds_dtype, long ldds, int accumulate,
+                                  float* row_loss, int R, int K, hipStream_t stream) {
   APLA_REQUIRE(student && teacher_probs && row_loss && R > 0 && K > 0 && lds >= K && ldt >= K && inv_temp > 0.f &&
                (dstudent == nullptr || ldds >= K), "apla_distill_ce: bad arguments");
+  APLA_REQUIRE((s_dtype == APLA_F32 || s_dtype == APLA_H16) && (dstudent == nullptr || ds_dtype == APLA_F32 || ds_dtype == APLA_H16),
+               "apla_distill_ce: unsupported dtype (student %d, gradient %d)", s_dtype, ds_dtype);
+  const bool g16 = dstudent != nullptr && ds_dtype == APLA_H16;
   const bool wide = K % 8 == 0 && R <= 65535 && apla_aligned16(student) && apla_aligned16(teacher_probs) && ldt % 4 == 0 &&
-                    (dstudent == nullptr || (apla_aligned16(dstudent) && ldds % 4 == 0)) &&
-                    lds % (s_dtype == APLA_F32 ? 4 : 8) == 0 && (s_dtype == APLA_F32 || s_dtype == APLA_H16);
+                    (dstudent == nullptr || (apla_aligned16(dstudent) && ldds % (g16 ? 8 : 4) == 0)) &&
+                    lds % (s_dtype == APLA_F32 ? 4 : 8) == 0;
+  APLA_REQUIRE(wide || !g16, "apla_distill_ce_ex: a 16-bit gradient needs K %% 8 == 0 and 16-byte aligned rows");
   if (wide) {
     int slice = K;
     const int S = dstudent != nullptr ? wide_row_split(R, K, &slice) : 1;
-    if (s_dtype == APLA_F32) hipLaunchKernelGGL(distill_ce_wide_kernel<float>, dim3(S, R), dim3(256), 0, stream, (const float*)student, lds, teacher_probs, ldt, inv_temp, row_weight, weight, dstudent, ldds, accumulate, row_loss, K, slice);
-    else hipLaunchKernelGGL(distill_ce_wide_kernel<bf16>, dim3(S, R), dim3(256), 0, stream, (const bf16*)student, lds, teacher_probs, ldt, inv_temp, row_weight, weight, dstudent, ldds, accumulate, row_loss, K, slice);
+#define DCE_WIDE(ST, GT) hipLaunchKernelGGL((distill_ce_wide_kernel<ST, GT>), dim3(S, R), dim3(256), 0, stream, (const ST*)student, lds, teacher_probs, ldt, inv_temp, row_weight, weight, (GT*)dstudent, ldds, accumulate, row_loss, K, slice)
+    if (s_dtype == APLA_F32) { if (g16) DCE_WIDE(float, bf16); else DCE_WIDE(float, float); }
+    else { if (g16) DCE_WIDE(bf16, bf16); else DCE_WIDE(bf16, float); }
+#undef DCE_WIDE
     APLA_CHECK_LAUNCH("apla_distill_ce");
     return APLA_OK;
   }
-  if (s_dtype == APLA_F32) hipLaunchKernelGGL(distill_ce_kernel<float>, dim3(R), dim3(256), 0, stream, (const float*)student, lds, teacher_probs, ldt, inv_temp, row_weight, weight, dstudent, ldds, accumulate, row_loss, K);
-  else if (s_dtype == APLA_H16) hipLaunchKernelGGL(distill_ce_kernel<bf16>, dim3(R), dim3(256), 0, stream, (const bf16*)student, lds, teacher_probs, ldt, inv_temp, row_weight, weight, dstudent, ldds, accumulate, row_loss, K);
-  else { apla_set_error("apla_distill_ce: unsupported dtype %d", s_dtype); return APLA_ENOSYS; }
+  if (s_dtype == APLA_F32) hipLaunchKernelGGL(distill_ce_kernel<float>, dim3(R), dim3(256), 0, stream, (const float*)student, lds, teacher_probs, ldt, inv_temp, row_weight, weight, (float*)dstudent, ldds, accumulate, row_loss, K);
+  else hipLaunchKernelGGL(distill_ce_kernel<bf16>, dim3(R), dim3(256), 0, stream, (const bf16*)student, lds, teacher_probs, ldt, inv_temp, row_weight, weight, (float*)dstudent, ldds, accumulate, row_loss, K);
   APLA_CHECK_LAUNCH("apla_distill_ce");
   return APLA_OK;
+}
+
+extern "C" int apla_distill_ce(const void* student, int s_dtype, long lds, const float* teacher_probs, long ldt, float inv_temp,
+                               const float* row_weight, float weight, float* dstudent, long ldds, int accumulate,
+                               float* row_loss, int R, int K, hipStream_t stream) {
+  return apla_distill_ce_ex(student, s_dtype, lds, teacher_probs, ldt, inv_temp, row_weight, weight, dstudent, APLA_F32, ldds, accumulate,
+                            row_loss, R, K, stream);
 }
 
 // ---- input side: uint8 images -> normalised fp32 batch, per-sample horizontal flip, Mixup / CutMix against a partner ----

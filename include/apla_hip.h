@@ -327,6 +327,11 @@ int apla_softmax_center(const void* x, int x_dtype, long ldx, const float* cente
 int apla_distill_ce(const void* student, int s_dtype, long lds, const float* teacher_probs, long ldt, float inv_temp,
                     const float* row_weight, float weight, float* dstudent, long ldds, int accumulate, float* row_loss,
                     int R, int K, hipStream_t stream);
+/* the same with the gradient written in `ds_dtype` (APLA_F32 or the build's 16-bit type: the student's own dtype saves the fp32
+ * round trip of a [rows, 65 536] gradient; 16-bit needs K % 8 == 0 and 16-byte aligned rows) */
+int apla_distill_ce_ex(const void* student, int s_dtype, long lds, const float* teacher_probs, long ldt, float inv_temp,
+                       const float* row_weight, float weight, void* dstudent, int ds_dtype, long ldds, int accumulate,
+                       float* row_loss, int R, int K, hipStream_t stream);
 
 /* Input side of the step (bases.py:69-231 ToTensor + Normalize + horizontal flip, utils/_utils.py:424-441
  * timm Mixup / CutMix applied by the collate function): decoded uint8 images already in device memory ->
