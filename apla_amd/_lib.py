@@ -95,6 +95,7 @@ SIGNATURES = {
     "apla_cross_entropy": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "apla_cross_entropy_soft": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "apla_colsum": (c_int, [c_void_p, c_long, c_void_p, c_int, c_int, c_void_p]),
+    "apla_colsum_h16": (c_int, [c_void_p, c_long, c_void_p, c_int, c_int, c_void_p]),
 }
 
 _libs = {}      # operand code (APLA_BF16 / APLA_F16) -> ctypes handle

@@ -238,6 +238,35 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
   if (wave == 0 && j < N) out[j] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
 }
 
+// 16-bit input, many rows (the iBOT centre: the column mean of a [~5000, 65536] teacher output): 256 columns per workgroup,
+// four per lane and access, its four waves take the rows i = w, w + 4, ... four at a time; fp32 sums, combined in wave order
+__global__ __launch_bounds__(256) void colsum16_kernel(const bf16* __restrict__ X, long ld, float* __restrict__ out, int M, int N) {
+  __shared__ f32x4 red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = blockIdx.x * 256 + lane * 4;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (j < N) {
+    int i = wave;
+    for (; i + 12 < M; i += 16) {
+      bf16x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *(const bf16x4*)(X + (long)(i + 4 * u) * ld + j);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[e] += (float)v[u][e];
+    }
+    for (; i < M; i += 4) {
+      const bf16x4 v = *(const bf16x4*)(X + (long)i * ld + j);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[e] += (float)v[e];
+    }
+  }
+  red[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && j < N) *(f32x4*)(out + j) = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+}
+
 }  // namespace
 
 extern "C" int apla_patchify(const float* images, void* cols, int B, int S, int patch, int Kp, hipStream_t stream) {
@@ -634,6 +663,15 @@ extern "C" int apla_colsum(const float* X, long ld, float* out, int M, int N, hi
   APLA_REQUIRE(X && out && M > 0 && N > 0, "apla_colsum: bad arguments");
   hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, stream, X, ld, out, M, N);
   APLA_CHECK_LAUNCH("apla_colsum");
+  return APLA_OK;
+}
+
+// out[j] = sum_i X[i][j] for a 16-bit X (N % 4 == 0, rows 8-byte aligned) — fp32 accumulation
+extern "C" int apla_colsum_h16(const void* X, long ld, float* out, int M, int N, hipStream_t stream) {
+  APLA_REQUIRE(X && out && M > 0 && N > 0 && N % 4 == 0 && ld % 4 == 0 && ld >= N && (((uintptr_t)X) & 7) == 0 && apla_aligned16(out),
+               "apla_colsum_h16: [M, N] 16-bit matrix with N %% 4 == 0 and 8-byte aligned rows");
+  hipLaunchKernelGGL(colsum16_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, (const bf16*)X, ld, out, M, N);
+  APLA_CHECK_LAUNCH("apla_colsum_h16");
   return APLA_OK;
 }
 

@@ -751,9 +751,15 @@ def cross_entropy(logits: torch.Tensor, labels: torch.Tensor, *, dlogits=None, r
 
 
 def colsum(X: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    _req(X, torch.float32, "X", 2)
+    """out[j] = sum_i X[i, j] in fp32; X fp32, or the build's 16-bit type with N % 4 == 0 (apla_colsum_h16)."""
+    _req(X, None, "X", 2)
     M, N = X.shape
     if out is None:
         out = torch.empty(N, device=X.device, dtype=torch.float32)
-    check(lib().apla_colsum(X.data_ptr(), X.stride(0), out.data_ptr(), M, N, _stream()), "apla_colsum")
+    if X.dtype == torch.float32:
+        check(lib().apla_colsum(X.data_ptr(), X.stride(0), out.data_ptr(), M, N, _stream()), "apla_colsum")
+    elif X.dtype == half():
+        check(lib().apla_colsum_h16(X.data_ptr(), X.stride(0), out.data_ptr(), M, N, _stream()), "apla_colsum_h16")
+    else:
+        raise TypeError(f"colsum: fp32 or {half()} expected, got {X.dtype}")
     return out

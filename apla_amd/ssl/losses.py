@@ -201,7 +201,12 @@ class iBOTPatchLoss(_CenteredLoss):
     def reduce_center_update(self, teacher_patch_tokens):
         self.updated = False
         self.len_teacher_patch_tokens = len(teacher_patch_tokens)
-        self.async_batch_center = torch.sum(teacher_patch_tokens.float().mean(1), dim=0, keepdim=True)
+        x = teacher_patch_tokens
+        if x.dim() == 3 and x.shape[0] == 1 and x.dtype == ops.half() and x.is_cuda and x.shape[-1] % 4 == 0 and x.stride(-1) == 1 and x.stride(1) % 4 == 0:
+            # one fp32-accumulating pass over the 16-bit rows (torch: a float copy of the [~5000, 65536] tensor, then a mean kernel)
+            self.async_batch_center = (ops.colsum(x[0]) / x.shape[1]).unsqueeze(0)
+        else:
+            self.async_batch_center = torch.sum(x.float().mean(1), dim=0, keepdim=True)
         if dist.is_initialized():
             self.reduce_handle = dist.all_reduce(self.async_batch_center, async_op=True)
 

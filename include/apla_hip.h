@@ -359,6 +359,8 @@ int apla_cross_entropy(const float* logits, int ldl, const int32_t* labels, floa
 int apla_cross_entropy_soft(const float* logits, int ldl, const float* targets, int ldt, float* dlogits, float* row_loss,
                             float* loss, int B, int C, hipStream_t stream);
 int apla_colsum(const float* X, long ld, float* out, int M, int N, hipStream_t stream);
+/* the same for a 16-bit X (fp32 sums; N % 4 == 0): the iBOT centre's column mean over a few thousand teacher rows (ibot_patch_loss.py:123-135) */
+int apla_colsum_h16(const void* X, long ld, float* out, int M, int N, hipStream_t stream);
 
 /* Diagnostic, not on the product path: `workgroups` workgroups of `threads` threads with `lds_bytes` of LDS each stay resident
  * for `usec` microseconds.  tools/contention_probe.py launches it on the side stream where the data-parallel step launches its

@@ -444,6 +444,15 @@ def test_head_and_cross_entropy(ops):
     assert rel_err(db.cpu(), rdl.sum(0)) < 1e-5
 
 
+@pytest.mark.parametrize("M,N", [(4879, 1024), (7, 260), (1, 4)])
+def test_colsum_16bit_rows(ops, M, N):
+    """apla_colsum_h16: fp32 column sums of a 16-bit matrix (the iBOT centre update, ibot_patch_loss.py:123-135), strided rows too."""
+    x, xd = bf(rnd(M, N + 12, seed=131))
+    X = dev(x)[:, :N]
+    got = ops.colsum(X).cpu().double()
+    assert rel_err(got, xd[:, :N].sum(0)) < 1e-5
+
+
 # ------------------------------------------------------------------------------------------- GEMM schedule variants
 @pytest.mark.parametrize("variant", [4, 9, 14, 15, 16, 1])
 @pytest.mark.parametrize("M,N,K", [(25216, 768, 768), (1000, 512, 256), (333, 256, 128), (161, 256, 192)])
