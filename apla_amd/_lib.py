@@ -27,6 +27,9 @@ SIGNATURES = {
     "apla_gemm_small_workspace_bytes": (c_long, [c_int, c_int, c_int]),
     "apla_gemm_nt_small": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                    c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_long, c_void_p]),
+    "apla_gemm_nt_splitk_workspace_bytes": (c_long, [c_int, c_int, c_int]),
+    "apla_gemm_nt_splitk": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_long,
+                                    c_void_p]),
     "apla_attn_fwd_ex": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "apla_attn_bwd_ex": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
                                  c_int, c_void_p]),

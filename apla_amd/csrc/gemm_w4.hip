@@ -29,8 +29,11 @@ constexpr int VGRP = 7;                  // LDS-DMA issues per wave and K-step (
 // their own (the default: measured back to back, STORE shapes ran 2-4 % slower on the deeper ring — qkv 85.4 vs 88.8 us — and the
 // GELU epilogues the same on both).  PRIO: s_setprio 1 around the MFMA cluster (qkv 85.6 vs 93.8 us without).  TAG: profiling tag
 // only (GemmParams::tag), as in gemm_pp2.hip.
-template <int EPI, typename OutT, bool PRIO, int VNS, int TAG = 0>
-__global__ __launch_bounds__(256, 2) void gemm_w4_kernel(GemmParams p, int tiles_m) {
+// KSPLIT: the K axis is cut into `ksplit` equal parts and the work items are (tile, part) pairs, part fastest; part s writes its fp32
+// partial tile into slice s of a workspace [ksplit][M][ldc] (p.C), summed afterwards in a fixed order (apla_gemm_nt_splitk: few
+// tiles and a long K — the prototype layer's input gradient of the self-supervised step is 35 tiles x 2 048 K-steps).
+template <int EPI, typename OutT, bool PRIO, int VNS, int TAG = 0, bool KSPLIT = false>
+__global__ __launch_bounds__(256, 2) void gemm_w4_kernel(GemmParams p, int tiles_m, int ksplit) {
   using E = WideEpi<EPI, OutT>;
   constexpr int VBIAS = VNS * VSTG;
   constexpr bool OWN_TBUF = VNS < 3;
@@ -39,9 +42,9 @@ __global__ __launch_bounds__(256, 2) void gemm_w4_kernel(GemmParams p, int tiles
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int frow = lane & 15, fq = lane >> 4;
-  const int nk = p.K / VBK;
+  const int nk = KSPLIT ? p.K / VBK / ksplit : p.K / VBK;
   const int tiles_n = p.N / VBN;
-  const int total = tiles_m * tiles_n;
+  const int total = KSPLIT ? tiles_m * tiles_n * ksplit : tiles_m * tiles_n;
   const int G = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int q = total >> 3, rr = total & 7;
   const int xbeg = xcd * q + (xcd < rr ? xcd : rr), xcnt = q + (xcd < rr ? 1 : 0);
@@ -63,7 +66,7 @@ __global__ __launch_bounds__(256, 2) void gemm_w4_kernel(GemmParams p, int tiles
   const unsigned a_lane = ((unsigned)srow * arow + koff) * 2u;
   const unsigned w_lane = ((unsigned)(8 * (srow >> 2) + (srow & 3)) * wrow + koff) * 2u;
   const int a_first = wave < 2 ? 3 * wave : 6 + 2 * (wave - 2);
-  int d_step = 0, d_k = 0, d_tile = 0, d_slot = 0, d_tm = 0;
+  int d_step = 0, d_k = 0, d_tile = 0, d_slot = 0, d_tm = 0, d_k0 = 0;
   bool d_edge = false;
   const char* a_base = nullptr;
   const char* w_base = nullptr;
@@ -73,8 +76,9 @@ __global__ __launch_bounds__(256, 2) void gemm_w4_kernel(GemmParams p, int tiles
     if (d_step > 4) { ++d_step; d_slot = d_slot == VNS - 1 ? 0 : d_slot + 1; if (++d_k == nk) { d_k = 0; ++d_tile; } return; }
 #endif
     if (d_k == 0) {
-      int tn;
-      tile_coords(xbeg + slot + d_tile * slots, tiles_m, tiles_n, p.ngrp, d_tm, tn);
+      int tn, item = xbeg + slot + d_tile * slots;
+      if constexpr (KSPLIT) { const int t = item / ksplit; d_k0 = (item - t * ksplit) * nk; item = t; }
+      tile_coords(item, tiles_m, tiles_n, p.ngrp, d_tm, tn);
       d_edge = d_tm * VBM + VBM > p.M;
       a_base = (const char*)(p.A + (size_t)(d_tm * VBM) * arow);
       w_base = (const char*)(p.W + (size_t)(tn * VBN) * wrow);
@@ -85,7 +89,7 @@ __global__ __launch_bounds__(256, 2) void gemm_w4_kernel(GemmParams p, int tiles
 #if defined(APLA_ABL_SAMEK)  // diagnostic build: every K-step streams the k = 0 slice again (an L2-resident source, same LDS-DMA count)
     const size_t ka = 0, kw = 0;
 #else
-    const size_t ka = (size_t)d_k * akstep, kw = (size_t)d_k * wkstep;
+    const size_t ka = (size_t)(d_k0 + d_k) * akstep, kw = (size_t)(d_k0 + d_k) * wkstep;
 #endif
     // W piece pw fills LDS rows 16*pw + srow = (pw>>3)*128 + (j = pw&7)*16 + srow, which hold W row
     //   (pw>>3)*128 + 32*(j>>1) + 8*(srow>>2) + 4*(j&1) + (srow&3)        (MFMA order, see gemm_common.h)
@@ -172,8 +176,9 @@ __global__ __launch_bounds__(256, 2) void gemm_w4_kernel(GemmParams p, int tiles
     if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
     if (++kk == nk) {
       kk = 0;
-      int tm, tn;
-      tile_coords(xbeg + slot + ord * slots, tiles_m, tiles_n, p.ngrp, tm, tn);
+      int tm, tn, item = xbeg + slot + ord * slots, part = 0;
+      if constexpr (KSPLIT) { const int t = item / ksplit; part = item - t * ksplit; item = t; }
+      tile_coords(item, tiles_m, tiles_n, p.ngrp, tm, tn);
       const int m0 = tm * VBM, n0 = tn * VBN;
       const bool full = m0 + VBM <= p.M;
       char* tbuf = smem + VBIAS + 2048 + wave * 2048;
@@ -184,7 +189,13 @@ __global__ __launch_bounds__(256, 2) void gemm_w4_kernel(GemmParams p, int tiles
         __builtin_amdgcn_s_barrier();
         tbuf = smem + cur * VSTG + wave * 2048;
       }
-      wide_epilogue<EPI, OutT>(p, acc, (const float*)(smem + VBIAS + (ord & 1) * 1024), tbuf, m0, n0, wm, wn, lane, full);
+      if constexpr (KSPLIT) {
+        GemmParams q = p;
+        q.C = (char*)p.C + (size_t)part * p.M * p.ldc * sizeof(OutT);
+        wide_epilogue<EPI, OutT>(q, acc, (const float*)(smem + VBIAS + (ord & 1) * 1024), tbuf, m0, n0, wm, wn, lane, full);
+      } else {
+        wide_epilogue<EPI, OutT>(p, acc, (const float*)(smem + VBIAS + (ord & 1) * 1024), tbuf, m0, n0, wm, wn, lane, full);
+      }
       asm volatile("" ::: "memory");
       zero_acc();
       relaxed = full ? VNS - 1 : 0;
@@ -218,7 +229,7 @@ int apla_gemm_w4_launch(const GemmParams& p_in, int epilogue, int out_dtype, hip
   const int resident = 512 - 2 * (p.reserve > 0 && p.reserve < 192 ? p.reserve : 0);
   const int G = total < resident ? total : resident;
   // GemmParams::exp (A/B runs, tools/gemm_bench.py): 0 = the default; 7 = no priority; 4 = the three-stage ring
-#define W4_LAUNCH(...) hipLaunchKernelGGL((gemm_w4_kernel<__VA_ARGS__>), dim3(G), dim3(256), 0, stream, p, tiles_m)
+#define W4_LAUNCH(...) hipLaunchKernelGGL((gemm_w4_kernel<__VA_ARGS__>), dim3(G), dim3(256), 0, stream, p, tiles_m, 1)
 #define W4_AB(E)                                        \
   do {                                                  \
     if (p.exp == 7) W4_LAUNCH(E, bf16, false, 2);       \
@@ -245,5 +256,63 @@ int apla_gemm_w4_launch(const GemmParams& p_in, int epilogue, int out_dtype, hip
 #undef W4_LAUNCH
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { apla_set_error("apla_gemm_nt[w4]: launch failed: %s", hipGetErrorString(e)); return APLA_EIO; }
+  return APLA_OK;
+}
+
+// ---- split-K: few tiles, long K -------------------------------------------------------------------------------------------------
+namespace {
+template <typename OutT>
+__global__ __launch_bounds__(256) void w4_splitk_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bias,
+                                                               OutT* __restrict__ C, int ldc, int M, int N, int S) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const int n4 = N / 4;
+  if (t >= (long)M * n4) return;
+  const int m = (int)(t / n4), n = (int)(t - (long)m * n4) * 4;
+  const size_t stride = (size_t)M * N;
+  const float* src = partial + (size_t)m * N + n;
+  f32x4 v = *(const f32x4*)src;
+  for (int s = 1; s < S; ++s) v += *(const f32x4*)(src + s * stride);   // fixed order: bitwise reproducible
+  if (bias != nullptr) v += *(const f32x4*)(bias + n);
+  Vec4IO<OutT>::store(C + (size_t)m * ldc + n, v);
+}
+// parts of the K axis: enough work items for two workgroups per CU, each part a whole number of 32-wide K-steps and at least 8 of them
+inline int w4_pick_split(int M, int N, int K) {
+  const long tiles = (long)((M + VBM - 1) / VBM) * (N / VBN);
+  int S = (int)((512 + tiles - 1) / tiles);
+  S = S > 64 ? 64 : S;
+  while (S > 1 && ((K / VBK) % S != 0 || K / VBK / S < 8)) --S;
+  return S;
+}
+}  // namespace
+
+extern "C" long apla_gemm_nt_splitk_workspace_bytes(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0 || N % VBN != 0 || K % VBK != 0) return -1;
+  return (long)w4_pick_split(M, N, K) * M * N * (long)sizeof(float);
+}
+
+extern "C" int apla_gemm_nt_splitk(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int M, int N,
+                                   int K, int out_dtype, void* workspace, long workspace_bytes, hipStream_t stream) {
+  APLA_REQUIRE(A && W && C && workspace && M > 0 && N > 0 && K > 0, "apla_gemm_nt_splitk: bad arguments");
+  APLA_REQUIRE(N % VBN == 0 && K % VBK == 0 && K >= 8 * VBK, "apla_gemm_nt_splitk: need N %% 256 == 0, K %% 32 == 0, K >= 256 (N=%d K=%d)", N, K);
+  APLA_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && lda >= K && ldw >= K && ldc % 4 == 0 && ldc >= N, "apla_gemm_nt_splitk: bad leading dimensions");
+  APLA_REQUIRE((size_t)M * lda < (1ull << 30) && (size_t)N * ldw < (1ull << 30), "apla_gemm_nt_splitk: operand too large for 32-bit offsets");
+  APLA_REQUIRE(apla_aligned16(A) && apla_aligned16(W) && apla_aligned16(C) && apla_aligned16(workspace) && (bias == nullptr || apla_aligned16(bias)),
+               "apla_gemm_nt_splitk: pointers must be 16-byte aligned");
+  APLA_REQUIRE(out_dtype == APLA_F32 || out_dtype == APLA_H16, "apla_gemm_nt_splitk: unsupported out_dtype %d", out_dtype);
+  const int S = w4_pick_split(M, N, K);
+  APLA_REQUIRE(workspace_bytes >= (long)S * M * N * (long)sizeof(float), "apla_gemm_nt_splitk: workspace too small (ask apla_gemm_nt_splitk_workspace_bytes)");
+  GemmParams p{(const bf16*)A, lda, (const bf16*)W, ldw, nullptr, workspace, N, nullptr, 0, nullptr, 0, M, N, K, N / 128, 0, 0, 0, 0, 0};
+  p.ngrp = pick_ngrp(p.N / VBN, VBN, p.K);
+  const int tiles_m = (M + VBM - 1) / VBM;
+  const long items = (long)tiles_m * (N / VBN) * S;
+  const int G = items < 512 ? (int)items : 512;
+  hipLaunchKernelGGL((gemm_w4_kernel<APLA_EPI_STORE, float, true, 2, 0, true>), dim3(G), dim3(256), 0, stream, p, tiles_m, S);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { apla_set_error("apla_gemm_nt_splitk: launch failed: %s", hipGetErrorString(e)); return APLA_EIO; }
+  const unsigned blocks = (unsigned)(((long)M * (N / 4) + 255) / 256);
+  if (out_dtype == APLA_F32) hipLaunchKernelGGL(w4_splitk_reduce_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)workspace, bias, (float*)C, ldc, M, N, S);
+  else hipLaunchKernelGGL(w4_splitk_reduce_kernel<bf16>, dim3(blocks), dim3(256), 0, stream, (const float*)workspace, bias, (bf16*)C, ldc, M, N, S);
+  e = hipGetLastError();
+  if (e != hipSuccess) { apla_set_error("apla_gemm_nt_splitk[reduce]: launch failed: %s", hipGetErrorString(e)); return APLA_EIO; }
   return APLA_OK;
 }

@@ -219,6 +219,39 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = Non
     return out
 
 
+_SPLITK_WS = {}
+
+
+def gemm_nt_splitk(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, out: Optional[torch.Tensor] = None,
+                   out_dtype=None) -> torch.Tensor:
+    """out[M,N] = a[M,K] @ w[N,K]^T (+ bias) for few output tiles and a long K (include/apla_hip.h:apla_gemm_nt_splitk): the K axis is
+    cut into parts that run side by side, fp32 partials summed in a fixed order.  The workspace is cached per (device, size)."""
+    _req(a, half(), "a", 2), _req(w, half(), "w", 2)
+    (M, K, lda), (N, Kw, ldw) = _rows2d(a, "a"), _rows2d(w, "w")
+    if K != Kw:
+        raise ValueError(f"gemm_nt_splitk: K mismatch {K} vs {Kw}")
+    if bias is not None:
+        _req(bias, torch.float32, "bias", 1)
+    if out is None:
+        out = torch.empty(M, N, device=a.device, dtype=out_dtype or half())
+    nbytes = lib().apla_gemm_nt_splitk_workspace_bytes(M, N, K)
+    if nbytes < 0:
+        raise ValueError(f"gemm_nt_splitk: shape not covered (N % 256 == 0, K % 32 == 0): {(M, N, K)}")
+    key = (a.device, nbytes)
+    ws = _SPLITK_WS.get(key)
+    if ws is None:
+        _SPLITK_WS.clear()     # one live workspace: the shapes of a training loop repeat
+        ws = _SPLITK_WS[key] = torch.empty(nbytes // 4, device=a.device, dtype=torch.float32)
+    check(lib().apla_gemm_nt_splitk(a.data_ptr(), lda, w.data_ptr(), ldw, _ptr(bias), out.data_ptr(), out.stride(0), M, N, K,
+                                    _DT[out.dtype], ws.data_ptr(), nbytes, _stream()), "apla_gemm_nt_splitk")
+    return out
+
+
+def gemm_splitk_wanted(M: int, N: int, K: int) -> bool:
+    """Few tiles of the tiled kernels (fewer than half the CUs) and a K long enough to cut."""
+    return N % 256 == 0 and K % 32 == 0 and K >= 4096 and ((M + 159) // 160) * (N // 256) < 128
+
+
 def gemm_small_workspace(M: int, N: int, K: int, device) -> Optional[torch.Tensor]:
     """Workspace of gemm_nt_small for this shape, or None when the few-row kernel does not take it."""
     nbytes = lib().apla_gemm_small_workspace_bytes(M, N, K)

@@ -33,7 +33,11 @@ class _ProtoLinear(torch.autograd.Function):
     def backward(ctx, dy):
         x2, Wh = ctx.saved_tensors
         dy2 = AF._as2d_bf16(dy)
-        dx = ops.gemm_nt(dy2, Wh.t().contiguous()).reshape(ctx.shape) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:   # [rows, 256] = dy [rows, K] W [K, 256]: 35 tiles with a 65 536-long reduction -> split along K
+            WhT = Wh.t().contiguous()
+            gemm = ops.gemm_nt_splitk if ops.gemm_splitk_wanted(dy2.shape[0], WhT.shape[0], WhT.shape[1]) else ops.gemm_nt
+            dx = gemm(dy2, WhT).reshape(ctx.shape)
         dW = None
         if ctx.needs_input_grad[1]:
             K, Din = Wh.shape

@@ -101,6 +101,15 @@ int apla_gemm_nt_ex(const void* A, int lda, const void* W, int ldw, const float*
                     int K, int epilogue, int out_dtype, const void* aux_in, int ld_aux_in, void* aux_out,
                     int ld_aux_out, int flags, hipStream_t stream);
 
+/* C[M,N] = A[M,K] @ W[N,K]^T (+ bias) for problems with FEW output tiles and a LONG K (the input gradient of the DINO head's prototype
+ * layer, dino_head.py:12-40: M = a few thousand rows, N = 256, K = 65 536 prototypes — 35 tiles of the tiled kernels, 2 048 K-steps
+ * each): the K axis is cut into S parts (apla_gemm_nt_splitk_workspace_bytes / (M*N*4)), every (tile, part) pair is a work item of
+ * the wide 4-wave kernel writing an fp32 partial tile into `workspace`, and a second launch sums the parts in a fixed order (bitwise
+ * reproducible).  16-bit operands, N % 256 == 0, K % 32 == 0, K >= 256; out_dtype APLA_F32 or the build's 16-bit type. */
+long apla_gemm_nt_splitk_workspace_bytes(int M, int N, int K);
+int apla_gemm_nt_splitk(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int M, int N, int K,
+                        int out_dtype, void* workspace, long workspace_bytes, hipStream_t stream);
+
 /* The kernel apla_gemm_nt_ex runs this problem on, as a rocprofv3 kernel trace shows it (tools/summarize_prof.py spelling), e.g.
  * "gemm_persist_kernel<GELU,bf16,5>"; `flags` as for apla_gemm_nt_ex; buf needs >= 48 bytes.  Same decision code as the launch:
  * bench.py names the kernel of its roofline record from this, not from a literal. */

@@ -621,6 +621,25 @@ def test_gemm_wide_4wave_kernel(ops, M, N, K):
         assert ops.gemm_kernel_name(M, N, K, ops.EPI_GELU).startswith("gemm_persist_kernel<GELU")
 
 
+@pytest.mark.parametrize("M,N,K", [(5581, 256, 8192), (300, 512, 4096), (161, 256, 256)])
+def test_gemm_split_k(ops, M, N, K):
+    """apla_gemm_nt_splitk (few tiles, long K: the prototype layer's input gradient of the self-supervised step): the K axis cut into
+    parts on the wide 4-wave kernel, fp32 partials summed in a fixed order — equal to the one-pass kernels up to fp32 summation order,
+    and the same bits on every call."""
+    a, ad = bf(rnd(M, K, seed=121))
+    w, wd = bf(rnd(N, K, scale=K ** -0.5, seed=122))
+    bias = rnd(N, seed=123)
+    A, W, Bv = dev(a), dev(w), dev(bias)
+    base = ad @ wd.t()
+    o32 = ops.gemm_nt_splitk(A, W, out_dtype=torch.float32)
+    assert rel_err(o32.cpu(), base) < F32_OUT
+    o16 = ops.gemm_nt_splitk(A, W, Bv)
+    assert o16.dtype == torch.bfloat16 and rel_err(o16.cpu(), base + bias.double()) < BF16_OUT
+    assert torch.equal(ops.gemm_nt_splitk(A, W, out_dtype=torch.float32), o32)
+    assert rel_err(o32.cpu(), ops.gemm_nt(A, W, out_dtype=torch.float32).cpu().double()) < 1e-5
+    assert ops.gemm_splitk_wanted(5581, 256, 65536) and not ops.gemm_splitk_wanted(25216, 768, 3072)
+
+
 def test_gemm_gelu_images_on_the_pingpong_kernel(ops):
     """Above 40 000 rows the two-output GELU runs on the ping-pong kernel (the student fc1 of the self-supervised step, config 3's
     fc1): its line-store epilogue writes h and gelu' as K-panel images too, with row-major or image operands — same bits."""
