@@ -89,6 +89,8 @@ SIGNATURES = {
                                 c_void_p, c_int, c_int, c_void_p]),
     "apla_distill_ce_ex": (c_int, [c_void_p, c_int, c_long, c_void_p, c_long, c_float, c_void_p, c_float, c_void_p, c_int, c_long, c_int,
                                    c_void_p, c_int, c_int, c_void_p]),
+    "apla_distill_ce_centered": (c_int, [c_void_p, c_int, c_long, c_void_p, c_int, c_long, c_void_p, c_float, c_float, c_void_p, c_float,
+                                         c_void_p, c_int, c_long, c_void_p, c_int, c_int, c_void_p]),
     "apla_augment_images": (c_int, [c_void_p, c_void_p, ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "apla_assemble_tokens": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,

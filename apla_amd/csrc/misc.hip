@@ -511,6 +511,80 @@ __global__ __launch_bounds__(256) void distill_ce_wide_kernel(const ST* __restri
   }
 }
 
+// (m, s, d) of the workgroup from every thread's running maximum m, sum s of exp(z - m) and weighted sum d of exp(z - m) * y
+__device__ __forceinline__ void block_max_sumexp2(float& m, float& sm, float& d, float* red /* [12] */) {
+  const float wm = wave_max(m);
+  const float sc = m == -INFINITY ? 0.f : __expf(m - wm);
+  sm = wave_sum(sm * sc);
+  d = wave_sum(d * sc);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = wm; red[4 + (threadIdx.x >> 6)] = sm; red[8 + (threadIdx.x >> 6)] = d; }
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float ws[4];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) ws[w] = red[w] == -INFINITY ? 0.f : __expf(red[w] - m);
+  sm = red[4] * ws[0] + red[5] * ws[1] + red[6] * ws[2] + red[7] * ws[3];
+  d = red[8] * ws[0] + red[9] * ws[1] + red[10] * ws[2] + red[11] * ws[3];
+}
+
+// distill_ce with the teacher's centring + sharpening inside: t[r,:] = softmax((x[r,:] - center) * inv_temp_t) is never written.
+// Pass 1 (whole row, every workgroup of the row): the student's (max, sum exp) and the teacher's (max, sum exp, sum exp * z_student),
+// all running and rescaled; pass 2 (this workgroup's slice): ds = w * inv_temp_s * (softmax_s - t).  sum_k t = 1 by construction.
+// iBOT at the shipped width moves 10 bytes per logit instead of 22 (softmax_center 2+2+4, distill_ce 2+4 and 2+4+2).
+template <typename ST, typename XT, typename GT>
+__global__ __launch_bounds__(256) void distill_ce_centered_kernel(const ST* __restrict__ s, long lds, const XT* __restrict__ x, long ldx,
+                                                                  const float* __restrict__ center, float inv_temp_s, float inv_temp_t,
+                                                                  const float* __restrict__ row_weight, float weight,
+                                                                  GT* __restrict__ ds, long ldds, float* __restrict__ row_loss, int K, int slice) {
+  __shared__ float red[12];
+  const int r = blockIdx.y;
+  const ST* sr = s + (long)r * lds;
+  const XT* xr = x + (long)r * ldx;
+  const float w = row_weight != nullptr ? row_weight[r] * weight : weight;
+  float ms = -INFINITY, ss = 0.f, mt = -INFINITY, st = 0.f, dt = 0.f;
+  for (int k = threadIdx.x * 8; k < K; k += 2048) {
+    float z[8], y[8], c[8];
+    ld8f<ST>(sr + k, z);
+    ld8f<XT>(xr + k, y);
+    ld8f<float>(center + k, c);
+    float vs = -INFINITY, vt = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { z[e] *= inv_temp_s; y[e] = (y[e] - c[e]) * inv_temp_t; vs = fmaxf(vs, z[e]); vt = fmaxf(vt, y[e]); }
+    if (vs > ms) { ss *= __expf(ms - vs); ms = vs; }
+    if (vt > mt) { const float f = __expf(mt - vt); st *= f; dt *= f; mt = vt; }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      ss += __expf(z[e] - ms);
+      const float pe = __expf(y[e] - mt);
+      st += pe;
+      dt += pe * z[e];
+    }
+  }
+  block_max_sumexp(ms, ss, red);
+  block_max_sumexp2(mt, st, dt, red);
+  const float lse = ms + __logf(ss), inv_t = 1.0f / st;
+  if (blockIdx.x == 0 && threadIdx.x == 0) row_loss[r] = w * (lse - dt * inv_t);
+  if (ds != nullptr) {
+    GT* dr = ds + (long)r * ldds;
+    const float cw = w * inv_temp_s;
+    const int k0 = blockIdx.x * slice, k1 = k0 + slice < K ? k0 + slice : K;
+    for (int k = k0 + threadIdx.x * 8; k < k1; k += 2048) {
+      float z[8], y[8], c[8];
+      ld8f<ST>(sr + k, z);
+      ld8f<XT>(xr + k, y);
+      ld8f<float>(center + k, c);
+      f32x4 g0, g1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        g0[e] = cw * (__expf(z[e] * inv_temp_s - lse) - __expf((y[e] - c[e]) * inv_temp_t - mt) * inv_t);
+        g1[e] = cw * (__expf(z[4 + e] * inv_temp_s - lse) - __expf((y[4 + e] - c[4 + e]) * inv_temp_t - mt) * inv_t);
+      }
+      st8f<GT>(dr + k, g0, g1, false);
+    }
+  }
+}
+
 // workgroups per row: enough of them to fill the chip when the call has few rows; a slice is a multiple of one workgroup pass
 static inline int wide_row_split(int R, int K, int* slice) {
   int S = R >= 512 ? 1 : (1024 + R - 1) / R;
@@ -573,6 +647,29 @@ extern "C" int apla_distill_ce(const void* student, int s_dtype, long lds, const
                                float* row_loss, int R, int K, hipStream_t stream) {
   return apla_distill_ce_ex(student, s_dtype, lds, teacher_probs, ldt, inv_temp, row_weight, weight, dstudent, APLA_F32, ldds, accumulate,
                             row_loss, R, K, stream);
+}
+
+extern "C" int apla_distill_ce_centered(const void* student, int s_dtype, long lds, const void* teacher_logits, int x_dtype, long ldx,
+                                        const float* center, float inv_temp_s, float inv_temp_t, const float* row_weight, float weight,
+                                        void* dstudent, int ds_dtype, long ldds, float* row_loss, int R, int K, hipStream_t stream) {
+  APLA_REQUIRE(student && teacher_logits && center && row_loss && R > 0 && R <= 65535 && K > 0 && K % 8 == 0 && lds >= K && ldx >= K &&
+               inv_temp_s > 0.f && inv_temp_t > 0.f && (dstudent == nullptr || ldds >= K), "apla_distill_ce_centered: bad arguments");
+  APLA_REQUIRE((s_dtype == APLA_F32 || s_dtype == APLA_H16) && (x_dtype == APLA_F32 || x_dtype == APLA_H16) &&
+               (dstudent == nullptr || ds_dtype == APLA_F32 || ds_dtype == APLA_H16), "apla_distill_ce_centered: unsupported dtype");
+  const bool g16 = dstudent != nullptr && ds_dtype == APLA_H16;
+  APLA_REQUIRE(apla_aligned16(student) && apla_aligned16(teacher_logits) && apla_aligned16(center) && lds % (s_dtype == APLA_F32 ? 4 : 8) == 0 &&
+               ldx % (x_dtype == APLA_F32 ? 4 : 8) == 0 && (dstudent == nullptr || (apla_aligned16(dstudent) && ldds % (g16 ? 8 : 4) == 0)),
+               "apla_distill_ce_centered: rows must be 16-byte aligned");
+  int slice = K;
+  const int S = dstudent != nullptr ? wide_row_split(R, K, &slice) : 1;
+#define DCC(ST, XT, GT) hipLaunchKernelGGL((distill_ce_centered_kernel<ST, XT, GT>), dim3(S, R), dim3(256), 0, stream, (const ST*)student, lds, (const XT*)teacher_logits, ldx, center, inv_temp_s, inv_temp_t, row_weight, weight, (GT*)dstudent, ldds, row_loss, K, slice)
+#define DCC_G(ST, XT) do { if (g16) DCC(ST, XT, bf16); else DCC(ST, XT, float); } while (0)
+  if (s_dtype == APLA_F32) { if (x_dtype == APLA_F32) DCC_G(float, float); else DCC_G(float, bf16); }
+  else { if (x_dtype == APLA_F32) DCC_G(bf16, float); else DCC_G(bf16, bf16); }
+#undef DCC_G
+#undef DCC
+  APLA_CHECK_LAUNCH("apla_distill_ce_centered");
+  return APLA_OK;
 }
 
 // ---- input side: uint8 images -> normalised fp32 batch, per-sample horizontal flip, Mixup / CutMix against a partner ----

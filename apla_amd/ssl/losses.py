@@ -75,7 +75,71 @@ class _DistillCE(torch.autograd.Function):
 
 
 def distill_ce(student, teacher_probs, temp, row_weight=None, weight=1.0):
+    if isinstance(teacher_probs, CenteredTeacher):
+        return _DistillCECentered.apply(student, teacher_probs, temp, row_weight, weight)
     return _DistillCE.apply(student, teacher_probs, temp, row_weight, weight)
+
+
+class CenteredTeacher:
+    """softmax((logits - center) / temp) of the teacher, NOT materialised: the cross-entropy kernel computes the targets on the fly
+    (apla_distill_ce_centered).  What `softmax_center_teacher(..., lazy=True)` returns; `.probs()` gives the tensor the eager call
+    would have returned.  `center` is the tensor the loss held at call time (the EMA update replaces it, never writes into it)."""
+
+    def __init__(self, logits, center, temp):
+        self.logits, self.center, self.temp = logits, center, float(temp)
+        self.shape = logits.shape
+
+    def probs(self):
+        return softmax_center(self.logits, self.center, self.temp)
+
+    def __getitem__(self, idx):   # row slices only (forward_masked: t[:n_masked_patches])
+        return CenteredTeacher(self.logits[idx], self.center, self.temp)
+
+    def squeeze(self, dim):
+        return CenteredTeacher(self.logits.squeeze(dim), self.center, self.temp)
+
+    @staticmethod
+    def usable(logits):
+        K = logits.shape[-1]
+        return logits.is_cuda and logits.dtype in (ops.half(), torch.float32) and K % 8 == 0 and logits.stride(-1) == 1
+
+
+class _DistillCECentered(torch.autograd.Function):
+    """_DistillCE with the teacher given as (logits, centre, temperature): one kernel, no [rows, K] probability tensor."""
+
+    @staticmethod
+    def forward(ctx, s, teacher, temp, row_weight, weight):
+        K = s.shape[-1]
+        s2, x2 = s.reshape(-1, K), teacher.logits.reshape(-1, K)
+        s2 = s2 if s2.stride(-1) == 1 else s2.contiguous()
+        ops._req(s2, None, "student", 2), ops._req(x2, None, "teacher logits", 2)
+        R = s2.shape[0]
+        if x2.shape != s2.shape:
+            raise ValueError(f"distill_ce: student {tuple(s2.shape)} vs teacher {tuple(x2.shape)}")
+        c = teacher.center.reshape(-1).float().contiguous()
+        rw = None
+        if row_weight is not None:
+            rw = row_weight.reshape(-1).float().contiguous()
+            if rw.numel() != R:
+                raise ValueError("distill_ce: one weight per row expected")
+        g16 = s2.dtype == ops.half()
+        ds = torch.empty(R, K, device=s.device, dtype=s2.dtype if g16 else torch.float32) if s.requires_grad else None
+        row_loss = torch.empty(R, device=s.device, dtype=torch.float32)
+        check(lib().apla_distill_ce_centered(s2.data_ptr(), ops._DT[s2.dtype], s2.stride(0), x2.data_ptr(), ops._DT[x2.dtype], x2.stride(0),
+                                             c.data_ptr(), 1.0 / float(temp), 1.0 / teacher.temp, ops._ptr(rw), float(weight), ops._ptr(ds),
+                                             ops._DT[ds.dtype] if ds is not None else ops._DT[torch.float32], K, row_loss.data_ptr(), R, K,
+                                             ops._stream()), "apla_distill_ce_centered")
+        ctx.save_for_backward(ds)
+        ctx.meta = (s.shape, s.dtype)
+        return row_loss.sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        (ds,) = ctx.saved_tensors
+        shape, dtype = ctx.meta
+        if ds.dtype == dtype:
+            return (ds * g.to(dtype)).reshape(shape), None, None, None, None
+        return (ds * g).reshape(shape).to(dtype), None, None, None, None
 
 
 class _CenteredLoss(nn.Module):
@@ -173,8 +237,12 @@ class iBOTPatchLoss(_CenteredLoss):
         self._init_center_state(center_momentum)
 
     @torch.no_grad()
-    def softmax_center_teacher(self, teacher_patch_tokens, teacher_temp):
+    def softmax_center_teacher(self, teacher_patch_tokens, teacher_temp, lazy=False):
+        """ibot_patch_loss.py:46-55.  lazy=True: the targets stay (logits, centre, temperature) and forward / forward_masked compute
+        them inside the cross-entropy kernel (same values; the [rows, 65 536] fp32 tensor is never written or re-read)."""
         self.apply_center_update()
+        if lazy and CenteredTeacher.usable(teacher_patch_tokens):
+            return CenteredTeacher(teacher_patch_tokens, self.center, teacher_temp)
         return softmax_center(teacher_patch_tokens, self.center, teacher_temp)
 
     def forward(self, student_patch_tokens, teacher_patch_tokens, student_masks_flat):

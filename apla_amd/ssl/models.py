@@ -163,7 +163,7 @@ class DINOv2(nn.Module):
                     t_dino = self.dino_loss.softmax_center_teacher(tcls_h, teacher_temp=teacher_temp).view(n_global, -1, tcls_h.shape[-1])
                     self.dino_loss.update_center(tcls_h)
                 if do_ibot:
-                    t_ibot = self.ibot_patch_loss.softmax_center_teacher(tpatch_h.unsqueeze(0), teacher_temp=teacher_temp).squeeze(0)
+                    t_ibot = self.ibot_patch_loss.softmax_center_teacher(tpatch_h.unsqueeze(0), teacher_temp=teacher_temp, lazy=True).squeeze(0)
                     self.ibot_patch_loss.update_center(tpatch_h.unsqueeze(0))
             elif centering == "sinkhorn_knopp":
                 if do_dino:

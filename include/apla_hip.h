@@ -341,6 +341,12 @@ int apla_distill_ce(const void* student, int s_dtype, long lds, const float* tea
 int apla_distill_ce_ex(const void* student, int s_dtype, long lds, const float* teacher_probs, long ldt, float inv_temp,
                        const float* row_weight, float weight, void* dstudent, int ds_dtype, long ldds, int accumulate,
                        float* row_loss, int R, int K, hipStream_t stream);
+/* apla_softmax_center + apla_distill_ce_ex in one: the targets are softmax((teacher_logits - center) * inv_temp_t), computed on the
+ * fly and never written (iBOTPatchLoss.softmax_center_teacher + forward_masked, ibot_patch_loss.py:46-55, 103-121: 4 879 rows of
+ * 65 536 prototypes per iteration at config 4 — 10 bytes per logit instead of 22).  K % 8 == 0, 16-byte aligned rows. */
+int apla_distill_ce_centered(const void* student, int s_dtype, long lds, const void* teacher_logits, int x_dtype, long ldx,
+                             const float* center, float inv_temp_s, float inv_temp_t, const float* row_weight, float weight,
+                             void* dstudent, int ds_dtype, long ldds, float* row_loss, int R, int K, hipStream_t stream);
 
 /* Input side of the step (bases.py:69-231 ToTensor + Normalize + horizontal flip, utils/_utils.py:424-441
  * timm Mixup / CutMix applied by the collate function): decoded uint8 images already in device memory ->

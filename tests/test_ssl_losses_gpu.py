@@ -81,3 +81,39 @@ def test_distill_ce_at_shipped_width_and_16bit_student():
     ref.backward()
     assert abs(float(loss) - float(ref)) < 1e-4 * abs(float(ref))
     assert rel_err(sd.grad.float().cpu(), s64.grad) < 4e-3    # gradient returned in the student's dtype (bf16)
+
+
+@pytest.mark.parametrize("R,K,sdt,xdt", [(24, 65536, torch.bfloat16, torch.bfloat16), (700, 1024, torch.float32, torch.float32),
+                                         (5, 512, torch.bfloat16, torch.float32)])
+def test_centered_teacher_inside_the_cross_entropy(R, K, sdt, xdt):
+    """iBOT's targets left as (teacher logits, centre, temperature) and computed inside the cross-entropy kernel
+    (apla_distill_ce_centered; iBOTPatchLoss.softmax_center_teacher(lazy=True) + forward_masked): loss, gradient and the row
+    weights as the two-kernel path (apla_softmax_center + apla_distill_ce) and as the fp64 formula."""
+    from apla_amd.ssl import iBOTPatchLoss
+    from apla_amd.ssl.losses import CenteredTeacher
+    g = torch.Generator().manual_seed(3)
+    s = (torch.randn(R, K, generator=g) * 3).to(sdt)
+    x = (torch.randn(R, K, generator=g) * 2).to(xdt)
+    center = torch.randn(1, 1, K, generator=g) * 0.1
+    w = torch.rand(R, generator=g)
+    w[-1] = 0.0                                       # a row that must get exactly zero gradient
+    ibot = iBOTPatchLoss(K, student_temp=0.1).cuda()
+    ibot.center = center.cuda()
+    masks = torch.ones(4, 8, dtype=torch.bool).cuda()
+    lazy = ibot.softmax_center_teacher(x.cuda().unsqueeze(0), 0.05, lazy=True).squeeze(0)
+    eager = ibot.softmax_center_teacher(x.cuda().unsqueeze(0), 0.05).squeeze(0)
+    assert isinstance(lazy, CenteredTeacher) and torch.is_tensor(eager)
+    assert rel_err(lazy.probs().cpu(), eager.cpu()) == 0.0
+    s1, s2 = s.cuda().requires_grad_(True), s.cuda().requires_grad_(True)
+    l1 = ibot.forward_masked(s1, lazy, student_masks_flat=masks, n_masked_patches=R, masks_weight=w.cuda())
+    l2 = ibot.forward_masked(s2, eager, student_masks_flat=masks, n_masked_patches=R, masks_weight=w.cuda())
+    (3.0 * l1).backward()
+    (3.0 * l2).backward()
+    tp = torch.softmax((x.double() - center.double().view(1, K)) / 0.05, -1)
+    s64 = s.double().requires_grad_(True)
+    ref = -((tp * torch.log_softmax(s64 / 0.1, -1)).sum(-1) * w.double()).sum() / 4
+    (3.0 * ref).backward()
+    tol_g = 8e-3 if sdt == torch.bfloat16 else 2e-5   # bf16: rounded by the kernel and again after the scaling by the upstream gradient (2 x 2^-8)
+    assert abs(float(l1) - float(ref)) < 1e-4 * abs(float(ref)) and abs(float(l1) - float(l2)) < 1e-5 * abs(float(l2))
+    assert rel_err(s1.grad.float().cpu(), s64.grad) < tol_g and rel_err(s1.grad.float().cpu(), s2.grad.float().cpu().double()) < tol_g
+    assert float(s1.grad[-1].abs().max()) == 0.0
