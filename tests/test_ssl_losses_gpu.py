@@ -117,3 +117,27 @@ def test_centered_teacher_inside_the_cross_entropy(R, K, sdt, xdt):
     assert abs(float(l1) - float(ref)) < 1e-4 * abs(float(ref)) and abs(float(l1) - float(l2)) < 1e-5 * abs(float(l2))
     assert rel_err(s1.grad.float().cpu(), s64.grad) < tol_g and rel_err(s1.grad.float().cpu(), s2.grad.float().cpu().double()) < tol_g
     assert float(s1.grad[-1].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("R,K,pad", [(3, 1000, 24), (600, 2056, 0), (17, 8, 8)])
+def test_wide_loss_kernels_ragged_widths_and_strided_rows(R, K, pad):
+    """apla_softmax_center / apla_distill_ce (8 prototypes per access, rows split over several workgroups): widths that are not a
+    multiple of a workgroup pass (2 048), more rows than the split threshold (512), rows with a pitch larger than K."""
+    from apla_amd.ssl.losses import distill_ce, softmax_center
+    g = torch.Generator().manual_seed(5)
+    s = (torch.randn(R, K + pad, generator=g) * 3).to(torch.bfloat16)
+    x = torch.randn(R, K + pad, generator=g) * 2
+    center = torch.randn(K, generator=g) * 0.1
+    tp = softmax_center(x.cuda()[:, :K], center.cuda(), 0.07)
+    ref_tp = torch.softmax((x[:, :K].double() - center.double()) / 0.07, -1)
+    assert rel_err(tp.cpu(), ref_tp) < 1e-4
+    sd = s.cuda().requires_grad_(True)
+    w = torch.rand(R, generator=g)
+    loss = distill_ce(sd[:, :K], tp, 0.1, w.cuda(), 0.5)
+    loss.backward()
+    s64 = s.double().requires_grad_(True)
+    ref = -0.5 * ((ref_tp * torch.log_softmax(s64[:, :K] / 0.1, -1)).sum(-1) * w.double()).sum()
+    ref.backward()
+    assert abs(float(loss) - float(ref)) < 1e-4 * abs(float(ref))
+    assert rel_err(sd.grad.float().cpu()[:, :K], s64.grad[:, :K]) < 4e-3
+    assert float(sd.grad[:, K:].abs().max()) == 0.0 if pad else True
