@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libapla_hip.so")          # bf16 operands (default, benchmarked)
 OUT_F16 = os.path.join(HERE, "libapla_hip_f16.so")  # same sources with -DAPLA_FP16: IEEE fp16 operands
-SOURCES = ["errors.cpp", "gemm_nt.hip", "gemm_pp2.hip", "gemm_w4.hip", "gemm_small.hip", "layernorm.hip", "attention.hip", "apla_dw.hip", "optim.hip", "misc.hip"]
+SOURCES = ["errors.cpp", "gemm_nt.hip", "gemm_pp2.hip", "gemm_w4.hip", "gemm_tp.hip", "gemm_small.hip", "layernorm.hip", "attention.hip", "apla_dw.hip", "optim.hip", "misc.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"]
 

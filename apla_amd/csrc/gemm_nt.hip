@@ -363,6 +363,9 @@ inline Sched pick_schedule(int epi, int out_dtype, int M, int N, int K, int lda,
   // us, proj 32.3 -> 31.4, GELU_FWD 139.9 (4-wave 128-wide kernel) -> 137.4; at K = 2304 / 3072 the ping-pong kernel stays ahead
   // (dqkv 75.5 vs 77.2, fc2 97.2 vs 100.0 us), the two-output GELU is a tie (153-155 us on either).
   const bool w4_ok = apla_gemm_w4_covers(M, N, K, lda, ldw, epi, out_dtype);
+  // 17 forces the tile-alternating kernel (gemm_tp.hip: 160 x 256 tiles, one 8-wave workgroup per CU whose two wave groups swap the
+  // compute and the service role per tile) wherever it is instantiated
+  if (g_variant == 17 && apla_gemm_tp_covers(M, N, K, lda, ldw, epi, out_dtype)) return {4, 0};
   if (g_variant == 16 && w4_ok) return {3, 0};
   const bool w4_auto = g_variant == 4 && w4_ok && ((epi == APLA_EPI_STORE && K <= 1024 && M >= 2048) || (epi == APLA_EPI_GELU_FWD && M >= 8192));
   if (w_panel & 12) {
@@ -396,6 +399,7 @@ int launch(const GemmParams& p, int g_variant, hipStream_t stream) {
   const Sched sc = pick_schedule(EPI, odt, p.M, p.N, p.K, (p.w_panel & 2) ? 32 : p.lda, (p.w_panel & 1) ? 32 : p.ldw, p.w_panel, g_variant);
   if (sc.kind == 2) return apla_gemm_pp2_launch(p, EPI, odt, stream);
   if (sc.kind == 3) return apla_gemm_w4_launch(p, EPI, odt, stream);
+  if (sc.kind == 4) return apla_gemm_tp_launch(p, EPI, odt, stream);
   if (sc.kind == 1) {
     if (sc.mi == 5) return launch_persist<EPI, OutT, 5>(p, stream);
     return launch_persist<EPI, OutT, 4>(p, stream);
@@ -426,7 +430,8 @@ static int gemm_nt_impl(const void* A, int lda, const void* W, int ldw, const fl
   } else if (w_panel) {
     APLA_REQUIRE(pick_schedule(epilogue, out_dtype, M, N, K, (w_panel & 2) ? 32 : lda, (w_panel & 1) ? 32 : ldw, w_panel, variant).kind >= 2 &&
                  (apla_gemm_pp2_covers(M, N, K, (w_panel & 2) ? 32 : lda, (w_panel & 1) ? 32 : ldw, epilogue, out_dtype) ||
-                  apla_gemm_w4_covers(M, N, K, (w_panel & 2) ? 32 : lda, (w_panel & 1) ? 32 : ldw, epilogue, out_dtype)),
+                  apla_gemm_w4_covers(M, N, K, (w_panel & 2) ? 32 : lda, (w_panel & 1) ? 32 : ldw, epilogue, out_dtype) ||
+                  apla_gemm_tp_covers(M, N, K, (w_panel & 2) ? 32 : lda, (w_panel & 1) ? 32 : ldw, epilogue, out_dtype)),
                  "apla_gemm_nt_ex: K-panel operand images need the ping-pong kernel (STORE / GELU, N %% 256 == 0, K %% 32 == 0, K >= 128): ask apla_gemm_nt_panel_ok first");
   }
   APLA_REQUIRE(apla_aligned16(A) && apla_aligned16(W) && apla_aligned16(C) && A && W && C, "apla_gemm_nt: pointers must be 16-byte aligned");
@@ -498,7 +503,7 @@ extern "C" int apla_gemm_nt_ex(const void* A, int lda, const void* W, int ldw, c
                                int N, int K, int epilogue, int out_dtype, const void* aux_in, int ld_aux_in,
                                void* aux_out, int ld_aux_out, int flags, hipStream_t stream) {
   const int tag = flags & 0xff, v = (flags >> 8) & 0xff;
-  APLA_REQUIRE(v == 0 || v == 1 || v == 4 || v == 9 || v == 14 || v == 15 || v == 16, "apla_gemm_nt_ex: unknown schedule %d", v);
+  APLA_REQUIRE(v == 0 || v == 1 || v == 4 || v == 9 || v == 14 || v == 15 || v == 16 || v == 17, "apla_gemm_nt_ex: unknown schedule %d", v);
   return gemm_nt_impl(A, lda, W, ldw, bias, C, ldc, M, N, K, epilogue, out_dtype, aux_in, ld_aux_in, aux_out, ld_aux_out, tag,
                       v == 0 ? 4 : (v == 1 ? 0 : v), stream, (flags >> 16) & 15, (flags >> 20) & 0xff, (flags >> 28) & 7);
 }
@@ -516,7 +521,8 @@ extern "C" int apla_gemm_nt_kernel_name(int M, int N, int K, int epilogue, int o
 #else
   const char* ot = out_dtype == APLA_F32 ? "float" : "bf16";
 #endif
-  if (sc.kind == 3) snprintf(buf, buflen, "gemm_w4_kernel<%s,%s>", epi_names[epilogue], ot);
+  if (sc.kind == 4) snprintf(buf, buflen, "gemm_tp_kernel<%s,%s>", epi_names[epilogue], ot);
+  else if (sc.kind == 3) snprintf(buf, buflen, "gemm_w4_kernel<%s,%s>", epi_names[epilogue], ot);
   else if (sc.kind == 2) snprintf(buf, buflen, "gemm_pp2_kernel<%s,%s>", epi_names[epilogue], ot);
   else if (sc.kind == 1) snprintf(buf, buflen, "gemm_persist_kernel<%s,%s,%d>", epi_names[epilogue], ot, sc.mi);
   else snprintf(buf, buflen, "gemm_nt_kernel<%s,%s>", epi_names[epilogue], ot);
