@@ -37,7 +37,7 @@ bool apla_gemm_pp2_covers(int M, int N, int K, long lda, long ldw, int epilogue,
 int apla_gemm_w4_launch(const GemmParams& p, int epilogue, int out_dtype, hipStream_t stream);   // gemm_w4.hip
 bool apla_gemm_w4_covers(int M, int N, int K, long lda, long ldw, int epilogue, int out_dtype);
 int apla_gemm_tp_launch(const GemmParams& p, int epilogue, int out_dtype, hipStream_t stream);   // gemm_tp.hip
-bool apla_gemm_tp_covers(int M, int N, int K, long lda, long ldw, int epilogue, int out_dtype);
+bool apla_gemm_tp_covers(int M, int N, int K, long lda, long ldw, int epilogue, int out_dtype, int w_panel);
 
 // Tile walk.  Linear tile ids are dealt to XCDs in contiguous runs (each XCD has its own 4 MB L2).  With n fastest, a run
 // touches ALL column tiles, i.e. the whole weight matrix: fine while W fits next to the streaming A panels (N = 768:

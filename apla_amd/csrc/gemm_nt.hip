@@ -365,7 +365,7 @@ inline Sched pick_schedule(int epi, int out_dtype, int M, int N, int K, int lda,
   const bool w4_ok = apla_gemm_w4_covers(M, N, K, lda, ldw, epi, out_dtype);
   // 17 forces the tile-alternating kernel (gemm_tp.hip: 160 x 256 tiles, one 8-wave workgroup per CU whose two wave groups swap the
   // compute and the service role per tile) wherever it is instantiated
-  if (g_variant == 17 && apla_gemm_tp_covers(M, N, K, lda, ldw, epi, out_dtype)) return {4, 0};
+  if (g_variant == 17 && apla_gemm_tp_covers(M, N, K, lda, ldw, epi, out_dtype, w_panel)) return {4, 0};
   if (g_variant == 16 && w4_ok) return {3, 0};
   const bool w4_auto = g_variant == 4 && w4_ok && ((epi == APLA_EPI_STORE && K <= 1024 && M >= 2048) || (epi == APLA_EPI_GELU_FWD && M >= 8192));
   if (w_panel & 12) {
@@ -431,7 +431,7 @@ static int gemm_nt_impl(const void* A, int lda, const void* W, int ldw, const fl
     APLA_REQUIRE(pick_schedule(epilogue, out_dtype, M, N, K, (w_panel & 2) ? 32 : lda, (w_panel & 1) ? 32 : ldw, w_panel, variant).kind >= 2 &&
                  (apla_gemm_pp2_covers(M, N, K, (w_panel & 2) ? 32 : lda, (w_panel & 1) ? 32 : ldw, epilogue, out_dtype) ||
                   apla_gemm_w4_covers(M, N, K, (w_panel & 2) ? 32 : lda, (w_panel & 1) ? 32 : ldw, epilogue, out_dtype) ||
-                  apla_gemm_tp_covers(M, N, K, (w_panel & 2) ? 32 : lda, (w_panel & 1) ? 32 : ldw, epilogue, out_dtype)),
+                  apla_gemm_tp_covers(M, N, K, (w_panel & 2) ? 32 : lda, (w_panel & 1) ? 32 : ldw, epilogue, out_dtype, w_panel)),
                  "apla_gemm_nt_ex: K-panel operand images need the ping-pong kernel (STORE / GELU, N %% 256 == 0, K %% 32 == 0, K >= 128): ask apla_gemm_nt_panel_ok first");
   }
   APLA_REQUIRE(apla_aligned16(A) && apla_aligned16(W) && apla_aligned16(C) && A && W && C, "apla_gemm_nt: pointers must be 16-byte aligned");

@@ -8,7 +8,7 @@ cd "$(dirname "$0")/../apla_amd/build"
 mkdir -p exp
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result"
-OBJS="errors gemm_nt gemm_pp2 gemm_w4 gemm_small layernorm attention apla_dw optim misc"
+OBJS="errors gemm_nt gemm_pp2 gemm_w4 gemm_tp gemm_small layernorm attention apla_dw optim misc"
 build() {  # name source "defines"
   $HIPCC $FLAGS $3 -c ../csrc/$2.hip -o exp/$2_$1.o
   local objs=""
@@ -16,6 +16,8 @@ build() {  # name source "defines"
   $HIPCC --offload-arch=gfx950 -shared -fPIC -o exp/libapla_$1.so $objs
   echo "built exp/libapla_$1.so"
 }
+if [ "$1" = "tp" ]; then build TPSTAMPS gemm_tp "-DAPLA_ABL_TPSTAMPS"; exit 0; fi   # tile-alternating kernel with role stamps only (tools/tp_stamps.py)
+build TPSTAMPS gemm_tp "-DAPLA_ABL_TPSTAMPS"         # tile-alternating kernel: cycles per role and activity (tools/tp_stamps.py)
 build NOSTORE gemm_pp2 "-DAPLA_ABL_NOSTORE"          # ping-pong GEMM epilogue computes but does not store
 build NOGELU gemm_pp2 "-DAPLA_ABL_NOGELU"            # GELU epilogue without the GELU arithmetic (two stores of the accumulators)
 build NOREAD gemm_pp2 "-DAPLA_ABL_NOREAD"            # K loop without LDS fragment reads
