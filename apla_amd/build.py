@@ -17,8 +17,44 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-res
 def _stale(obj, src):
     if not os.path.exists(obj):
         return True
-    deps = [src, os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_common.h"), os.path.join(HERE, "..", "include", "apla_hip.h")]
+    deps = [src, os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_common.h"), os.path.join(CSRC, "gemm_tp_asm.inc"), os.path.join(HERE, "..", "include", "apla_hip.h")]
     return any(os.path.getmtime(d) > os.path.getmtime(obj) for d in deps)
+
+
+def audit_gemm_tp(defines=(), verbose: bool = True) -> dict:
+    """gemm_tp.hip keeps its 160 accumulators in AGPRs under literal names hipcc's allocator cannot see (the file says why).  That is
+    sound only while hipcc itself uses no AGPR and spills nothing in those kernels: compile the device code to assembly and check —
+    no scratch, no spill, no accumulator-register access outside the file's own asm statements.  Raises on a violation."""
+    import re
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "gemm_tp.s")
+        cmd = [HIPCC] + FLAGS + list(defines) + ["--cuda-device-only", "-S", os.path.join(CSRC, "gemm_tp.hip"), "-o", out]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed:\n{r.stdout}\n{r.stderr}")
+        text = open(out).read()
+    kernels = 0
+    in_asm = False
+    bad = []
+    for n, line in enumerate(text.splitlines(), 1):
+        if "#ASMSTART" in line:
+            in_asm = True
+        elif "#ASMEND" in line:
+            in_asm = False
+        elif not in_asm and not line.lstrip().startswith((";", ".")) and re.search(r"v_accvgpr|[\s,]a\[?\d+", line):
+            bad.append((n, line.strip()))
+    meta = {k: [int(v) for v in re.findall(rf"\.{k}:\s+(\d+)", text)] for k in ("vgpr_spill_count", "sgpr_spill_count", "private_segment_fixed_size", "agpr_count", "vgpr_count")}
+    kernels = len(meta["agpr_count"])
+    if bad:
+        raise RuntimeError(f"gemm_tp.hip: hipcc touches accumulator registers outside the kernel's asm statements ({len(bad)} lines, first: {bad[0]})")
+    if any(meta["vgpr_spill_count"]) or any(meta["private_segment_fixed_size"]):
+        raise RuntimeError(f"gemm_tp.hip: register spills / scratch in a kernel that must have none: {meta}")
+    if kernels == 0 or any(a != 160 for a in meta["agpr_count"]) or any(v > 256 for v in meta["vgpr_count"]):
+        raise RuntimeError(f"gemm_tp.hip: unexpected register counts {meta}")
+    if verbose:
+        print(f"gemm_tp audit: {kernels} kernels, registers {meta['vgpr_count']} (160 of them AGPRs), no spill, no scratch, no foreign accumulator access")
+    return meta
 
 
 def build(force: bool = False, verbose: bool = True, fp16: bool = True) -> str:
@@ -47,6 +83,8 @@ def _build_one(out, objsub, defines, force, verbose):
             raise RuntimeError(f"hipcc failed:\n{r.stdout}\n{r.stderr}")
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
+    if any("gemm_tp.hip" in " ".join(j) for j in jobs):
+        audit_gemm_tp(defines, verbose)     # a fresh gemm_tp object is only accepted with its register audit
     objs = [os.path.join(objdir, s.rsplit(".", 1)[0] + ".o") for s in SOURCES]
     if jobs or not os.path.exists(out):
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)

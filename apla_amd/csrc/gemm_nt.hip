@@ -366,6 +366,9 @@ inline Sched pick_schedule(int epi, int out_dtype, int M, int N, int K, int lda,
   // 17 forces the tile-alternating kernel (gemm_tp.hip: 160 x 256 tiles, one 8-wave workgroup per CU whose two wave groups swap the
   // compute and the service role per tile) wherever it is instantiated
   if (g_variant == 17 && apla_gemm_tp_covers(M, N, K, lda, ldw, epi, out_dtype, w_panel)) return {4, 0};
+  // automatic: the forward-only GELU from 8192 rows (measured back to back, M = 25216, image outputs, one process: 141.4 us against
+  // 149.2 us on the wide 4-wave kernel; the two-output GELU and the plain stores tie or lose there: profiles/r04_tp_*)
+  if (g_variant == 4 && epi == APLA_EPI_GELU_FWD && M >= 8192 && apla_gemm_tp_covers(M, N, K, lda, ldw, epi, out_dtype, w_panel)) return {4, 0};
   if (g_variant == 16 && w4_ok) return {3, 0};
   const bool w4_auto = g_variant == 4 && w4_ok && ((epi == APLA_EPI_STORE && K <= 1024 && M >= 2048) || (epi == APLA_EPI_GELU_FWD && M >= 8192));
   if (w_panel & 12) {

@@ -69,10 +69,13 @@ int apla_gemm_nt(const void* A, int lda, const void* W, int ldw, const float* bi
  *              rocprofv3 kernel trace names the call sites of the step (2 qkv, 3 proj, 4 fc2, 5 dfc1, 6 dproj, 7 dqkv,
  *              8 patch embedding; 0 = untagged).  No effect on results or speed.
  *   bits 8-15  kernel schedule: 0 = auto (what apla_gemm_nt does), for M >= 2048 and N % 256 == 0: the wide 4-wave kernel
- *              (160x256x32 tile, two workgroups per CU, gemm_w4.hip) for STORE with K <= 1024 and for GELU_FWD, the 8-wave
- *              ping-pong kernel (320x256x32 tile, one workgroup per CU, gemm_pp2.hip) for STORE with a longer K and for GELU
- *              above 40 000 rows; else the 4-wave persistent kernel (128/160 x 128 x 64 tile, gemm_nt.hip).  9 = ping-pong
- *              wherever instantiated; 16 = wide 4-wave wherever instantiated (16-bit STORE / GELU / GELU_FWD); 14 / 15 = 4-wave
+ *              (160x256x32 tile, two workgroups per CU, gemm_w4.hip) for STORE with K <= 1024, the 8-wave ping-pong kernel
+ *              (320x256x32 tile, one workgroup per CU, gemm_pp2.hip) for STORE with a longer K and for GELU above 40 000 rows, the
+ *              tile-alternating kernel (160x256x32 tile, one 8-wave workgroup per CU whose two wave groups swap a compute and a
+ *              service role per tile, gemm_tp.hip) for GELU_FWD from 8192 rows (K >= 704, K % 64 == 0); else the 4-wave
+ *              persistent kernel (128/160 x 128 x 64 tile, gemm_nt.hip).  9 = ping-pong wherever instantiated; 16 = wide 4-wave
+ *              wherever instantiated (16-bit STORE / GELU / GELU_FWD); 17 = tile-alternating wherever instantiated (16-bit
+ *              STORE and GELU_FWD, and GELU with both outputs as images: bits 18 + 19); 14 / 15 = 4-wave
  *              persistent kernel with BM 128 / 160; 1 = the simple non-persistent 2-stage kernel (the round-1 starting point;
  *              an in-tree A/B baseline).  All schedules compute the same results (tests/test_kernels_gpu.py).
  *   bit 16     W is given as its K-PANEL IMAGE [K/32][N][32] (apla_pack_k_panels; `ldw` is not read), bit 17 the same for A

@@ -75,3 +75,16 @@ def test_product_never_imports_oracle():
             if f.endswith(".py"):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f"{f} imports the oracle"
+
+
+def test_gemm_tp_register_audit():
+    """gemm_tp.hip names its 160 accumulator registers literally (AGPRs hipcc's allocator does not know about): the build accepts
+    the object only if hipcc itself uses no accumulator register and spills nothing in those kernels.  Re-run here on the sources
+    as they are (device-only compile to assembly, ~30 s), and check that the committed asm include is what the generator emits."""
+    import subprocess, sys, os
+    from apla_amd import build
+    meta = build.audit_gemm_tp(verbose=False)
+    assert len(meta["agpr_count"]) >= 4 and all(a == 160 for a in meta["agpr_count"])
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gen = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_tp_asm.py")], capture_output=True, text=True, check=True).stdout
+    assert gen == open(os.path.join(root, "apla_amd", "csrc", "gemm_tp_asm.inc")).read()

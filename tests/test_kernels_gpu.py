@@ -616,7 +616,7 @@ def test_gemm_wide_4wave_kernel(ops, M, N, K):
         ops.set_gemm_variant(old)
     if M >= 8192:
         assert ops.gemm_kernel_name(M, N, K, ops.EPI_STORE).startswith("gemm_w4_kernel<STORE" if K <= 1024 else "gemm_pp2_kernel")
-        assert ops.gemm_kernel_name(M, N, K, ops.EPI_GELU_FWD).startswith("gemm_w4_kernel<GELU_FWD")
+        assert ops.gemm_kernel_name(M, N, K, ops.EPI_GELU_FWD).startswith("gemm_tp_kernel<GELU_FWD" if K >= 704 else "gemm_w4_kernel<GELU_FWD")
         assert ops.gemm_kernel_name(M, N, 3072, ops.EPI_STORE).startswith("gemm_pp2_kernel<STORE")
         assert ops.gemm_kernel_name(M, N, K, ops.EPI_GELU).startswith("gemm_persist_kernel<GELU")
 

@@ -13,7 +13,7 @@ from apla_amd import ops
 from apla_amd._lib import lib
 
 M = 25216
-NAMES = ["barrier (compute role)", "compute periods, rest", "barrier (service role)", "LDS-DMA issue", "slices", "vmcnt waits", "whole run", "K-steps computed"]
+NAMES = ["(unused)", "compute periods (asm block: barriers, LDS-DMA, products)", "barrier (service role)", "whole run, 100 MHz ticks", "slices", "vmcnt waits (service role)", "whole run, core cycles", "K-steps computed"]
 
 
 def main():
@@ -54,7 +54,11 @@ def main():
                     v = sorted(buf[(b * 2 + g) * 8 + i] for b in range(256))
                     cols.append(v[128])
                 print(f"| {nm} | {cols[0]} | {cols[1]} |")
-            print()
+            clk = sorted(buf[(b * 2) * 8 + 6] / max(1, buf[(b * 2) * 8 + 3]) * 0.1 for b in range(256))
+            fl = 2.0 * M * N * K / 256
+            cyc = sorted(buf[(b * 2) * 8 + 6] for b in range(256))[128]
+            print(f"\ncore clock inside the launch (median workgroup): {clk[128]:.2f} GHz (min {clk[0]:.2f}, max {clk[-1]:.2f}); "
+                  f"{fl / cyc:.0f} FLOP per CU and core cycle = {fl / cyc / 4096:.2f} of the matrix pipes' 4096\n")
 
 
 if __name__ == "__main__":
