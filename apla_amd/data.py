@@ -111,19 +111,72 @@ class DeviceAugment:
         return x, (self.targets(labels, lam) if self.soft_targets else labels)
 
 
-class ClassificationMeter:
-    """Confusion matrix kept on the device (row: truth, column: prediction); nothing is copied to the host per step."""
+def _auc(pos: torch.Tensor, score: torch.Tensor) -> torch.Tensor:
+    """Area under the ROC curve of `score` for the boolean truths `pos` (ties count one half), on the tensors' device."""
+    s = score.double()
+    srt = torch.sort(s).values
+    rank = 0.5 * (torch.searchsorted(srt, s, right=False) + torch.searchsorted(srt, s, right=True) + 1).double()   # average rank
+    n1 = pos.sum().double()
+    n0 = pos.numel() - n1
+    return (rank[pos].sum() - n1 * (n1 + 1) / 2) / (n1 * n0)
 
-    def __init__(self, n_classes: int, device="cuda"):
+
+def _average_precision(truth: torch.Tensor, score: torch.Tensor) -> torch.Tensor:
+    """sum over thresholds of (R_n - R_{n-1}) P_n, one threshold per distinct score from the highest down (sklearn's definition)."""
+    order = torch.argsort(score.double(), descending=True, stable=True)
+    ys, ss = truth.double()[order], score.double()[order]
+    last = torch.ones_like(ss, dtype=torch.bool)
+    last[:-1] = ss[1:] != ss[:-1]                                   # last element of every run of equal scores
+    tp = torch.cumsum(ys, 0)[last]
+    n = (torch.nonzero(last).squeeze(1) + 1).double()
+    rec = tp / ys.sum()
+    return ((rec - torch.cat([rec.new_zeros(1), rec[:-1]])) * (tp / n)).sum()
+
+
+class ClassificationMeter:
+    """The numbers of the reference's ``ClassificationMetrics`` (utils/metrics.py:38-112) from state kept on the device: a
+    confusion matrix (row: truth, column: prediction) and, with ``keep_probs``, the softmax rows for the ROC-AUC — the reference
+    copies every batch's logits to the host (:52-65); here nothing leaves the device before ``get_values``.
+    accuracy, mean_per_class_accuracy (:67-72), quadratic_kappa (Cohen's kappa, quadratic weights, 0 for two classes: :87-90),
+    recall (macro over the labels that occur, :92) and roc_auc (one-vs-one macro, 0.5 when a class has no sample: :93-98; computed
+    for up to 64 classes, else not reported).  Values are not rounded (the reference rounds to three decimals)."""
+
+    def __init__(self, n_classes: int, device="cuda", keep_probs: bool = False):
         self.C = n_classes
         self.cm = torch.zeros(n_classes, n_classes, device=device, dtype=torch.int64)
+        self.keep_probs = keep_probs and n_classes <= 64
+        self._probs, self._truths = [], []
 
     def reset(self):
         self.cm.zero_()
+        self._probs, self._truths = [], []
 
     def add_preds(self, logits: torch.Tensor, truths: torch.Tensor):
         preds = logits.argmax(1)
         self.cm.view(-1).index_add_(0, truths.long() * self.C + preds, torch.ones_like(preds, dtype=torch.int64))
+        if self.keep_probs:
+            self._probs.append(torch.softmax(logits.float(), dim=1))
+            self._truths.append(truths.long().clone())
+
+    def _roc_auc(self, process_group=None) -> float:
+        prob, truth = torch.cat(self._probs), torch.cat(self._truths)
+        if process_group is not None and torch.distributed.get_world_size(process_group) > 1:
+            world = torch.distributed.get_world_size(process_group)
+            pl, tl = [torch.empty_like(prob) for _ in range(world)], [torch.empty_like(truth) for _ in range(world)]
+            torch.distributed.all_gather(pl, prob, group=process_group)
+            torch.distributed.all_gather(tl, truth, group=process_group)
+            prob, truth = torch.cat(pl), torch.cat(tl)
+        if int(torch.unique(truth).numel()) < self.C:
+            return 0.5
+        if self.C == 2:
+            return float(_auc(truth == 1, prob[:, 1]))
+        tot, pairs = prob.new_zeros((), dtype=torch.float64), 0
+        for a in range(self.C):
+            for b in range(a + 1, self.C):
+                m = (truth == a) | (truth == b)
+                tot += 0.5 * (_auc(truth[m] == a, prob[m, a]) + _auc(truth[m] == b, prob[m, b]))
+                pairs += 1
+        return float(tot / pairs)
 
     def get_values(self, process_group=None, do_reset: bool = True) -> dict:
         cm = self.cm.clone()
@@ -134,6 +187,61 @@ class ClassificationMeter:
         per_class = cmf.diagonal() / cmf.sum(1)                     # nan for absent classes
         per_class = torch.nan_to_num(per_class, nan=0.0, posinf=0.0)  # utils/metrics.py:67-72 fills invalid entries with 0
         out = {"accuracy": float(cmf.diagonal().sum() / total), "mean_per_class_accuracy": float(per_class.mean())}
+        present = (cmf.sum(0) + cmf.sum(1)) > 0                     # sklearn works on the labels that occur in truths or predictions
+        sub = cmf[present][:, present]
+        n = int(present.sum())
+        if self.C > 2 and n > 1:
+            idx = torch.arange(n, device=cm.device, dtype=torch.float64)
+            w = (idx[:, None] - idx[None, :]) ** 2
+            expected = torch.outer(sub.sum(1), sub.sum(0)) / sub.sum().clamp_min(1)
+            out["quadratic_kappa"] = float(1.0 - (w * sub).sum() / (w * expected).sum())
+        else:
+            out["quadratic_kappa"] = 0.0
+        rec = torch.nan_to_num(sub.diagonal() / sub.sum(1), nan=0.0, posinf=0.0)
+        out["recall"] = float(rec.mean()) if n else 0.0
+        if self.keep_probs and self._probs:
+            out["roc_auc"] = self._roc_auc(process_group)
+        if do_reset:
+            self.reset()
+        return out
+
+
+class MultiLabelMeter:
+    """The numbers of the reference's ``MultiLabelClassificationMetrics`` (utils/metrics.py:115-189) from scores kept on the device:
+    sigmoid scores and indicator truths of every batch; ``get_values``: subset accuracy, macro precision / recall / f1 of the
+    thresholded predictions (zero_division = 0), mAP and the mean per-class ROC-AUC of the scores (``mean_roc_auc`` :17-35: a class
+    without positives counts 0.5).  Unrounded."""
+
+    def __init__(self, n_classes: int, device="cuda", act_threshold: float = 0.5):
+        self.C, self.thr = n_classes, act_threshold
+        self._scores, self._truths = [], []
+
+    def reset(self):
+        self._scores, self._truths = [], []
+
+    def add_preds(self, logits: torch.Tensor, truths: torch.Tensor, using_knn: bool = False):
+        self._scores.append(torch.sigmoid(logits.float()))          # (the reference applies the sigmoid to kNN scores too: :137-146)
+        self._truths.append(truths.float().clone())
+
+    def get_values(self, process_group=None, do_reset: bool = True) -> dict:
+        score, truth = torch.cat(self._scores), torch.cat(self._truths)
+        if process_group is not None and torch.distributed.get_world_size(process_group) > 1:
+            world = torch.distributed.get_world_size(process_group)
+            sl, tl = [torch.empty_like(score) for _ in range(world)], [torch.empty_like(truth) for _ in range(world)]
+            torch.distributed.all_gather(sl, score, group=process_group)
+            torch.distributed.all_gather(tl, truth, group=process_group)
+            score, truth = torch.cat(sl), torch.cat(tl)
+        C = truth.shape[1]
+        ap = torch.stack([_average_precision(truth[:, c], score[:, c]) for c in range(C)])
+        auc = torch.stack([_auc(truth[:, c] > 0, score[:, c]) if bool(truth[:, c].sum() > 0) else score.new_tensor(0.5, dtype=torch.float64)
+                           for c in range(C)])
+        pred = (score > self.thr).double()
+        t = truth.double()
+        tp = (pred * t).sum(0)
+        z = lambda v: torch.nan_to_num(v, nan=0.0, posinf=0.0)
+        out = {"accuracy": float((pred == t).all(1).double().mean()), "mAP": float(ap.mean()), "roc_auc": float(auc.mean()),
+               "precision": float(z(tp / pred.sum(0)).mean()), "recall": float(z(tp / t.sum(0)).mean()),
+               "f1": float(z(2 * tp / (pred.sum(0) + t.sum(0))).mean())}
         if do_reset:
             self.reset()
         return out

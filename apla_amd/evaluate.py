@@ -64,7 +64,7 @@ class Evaluator:
         if knn and self.feature_bank is None:
             raise RuntimeError("kNN evaluation needs build_feature_bank() first (trainer.py:171-172)")
         dev = self.eng.device
-        meter = ClassificationMeter(self.C, dev)
+        meter = ClassificationMeter(self.C, dev, keep_probs=True)      # (ROC-AUC up to 64 classes: data.py)
         knn_meter = ClassificationMeter(self.C, dev) if knn else None
         loss_sum, n = torch.zeros((), device=dev), 0
         for images, labels in batches:

@@ -599,6 +599,88 @@ def g5_cfg1():
         json.dump(dict(digests=digests, n_trainable=n_train, torch=torch.__version__), f, indent=1)
 
 
+# ---------------------------------------------------------------- G13: kNN vote and the metric objects
+def _ref_knn_predict():
+    """``Trainer.knn_predict`` (defaults/trainer.py:392-455) as the reference file defines it: the method's own source is taken from
+    the file IN PLACE (ast) and compiled with the names it uses — importing ``defaults.trainer`` itself needs torchvision and wandb,
+    which are not installed (the method touches neither; it does not use ``self``)."""
+    import ast
+    import torch.nn.functional as F
+    src = open(os.path.join(REF_SRC, "defaults/trainer.py")).read()
+    tree = ast.parse(src)
+    fn = next(n for c in tree.body if isinstance(c, ast.ClassDef) and c.name == "Trainer" for n in c.body
+              if isinstance(n, ast.FunctionDef) and n.name == "knn_predict")
+    mod = ast.Module(body=[fn], type_ignores=[])
+    ns = {"torch": torch, "F": F}
+    exec(compile(mod, os.path.join(REF_SRC, "defaults/trainer.py"), "exec"), ns)
+    return ns["knn_predict"]
+
+
+def _ref_metrics():
+    """utils/metrics.py loaded in place; its ``from ._utils import *`` (torchvision, timm) is replaced by the handful of names the
+    file uses, ``easydict`` (not installed) by a dict with attribute access."""
+    import types
+    from copy import deepcopy
+    import _ref_shim
+    ed = types.ModuleType("easydict")
+
+    class EasyDict(dict):
+        __getattr__ = dict.__getitem__
+        __setattr__ = dict.__setitem__
+    ed.EasyDict = EasyDict
+    sys.modules["easydict"] = ed
+    u = types.ModuleType("utils._utils")
+    u.torch, u.np, u.nn, u.deepcopy = torch, np, torch.nn, deepcopy
+    u.synchronize = lambda: None
+    u.dist_gather = lambda x, **_k: [x]
+    u.__all__ = ["torch", "np", "nn", "deepcopy", "synchronize", "dist_gather"]
+    sys.modules["utils._utils"] = u
+    return _ref_shim._load("utils.metrics", os.path.join(REF_SRC, "utils/metrics.py"), package="utils")
+
+
+def g13_knn_metrics():
+    import torch.nn.functional as F
+    knn = _ref_knn_predict()
+    M = _ref_metrics()
+    g = torch.Generator().manual_seed(13)
+    arrs = {}
+    # kNN: single-label and multi-label votes
+    B, D, N, C, Cm, k, t = 16, 32, 200, 7, 5, 20, 0.1
+    feat = F.normalize(torch.randn(B, D, generator=g), dim=1)
+    bank = F.normalize(torch.randn(N, D, generator=g), dim=1).t().contiguous()
+    lab = torch.randint(0, C, (N,), generator=g)
+    labm = (torch.rand(Cm, N, generator=g) < 0.3).float()
+    arrs.update(knn_feature=npy(feat), knn_bank=npy(bank), knn_labels=npy(lab), knn_labels_multi=npy(labm),
+                knn_k=np.array(k), knn_t=np.array(t), knn_classes=np.array(C),
+                knn_scores=npy(knn(None, feat, bank, lab, k, t, classes=C)),
+                knn_scores_multi=npy(knn(None, feat.clone(), bank, labm, k, t, classes=Cm, multi_label=True)))
+    # single-label metric object: three batches of logits
+    for tag, n_cls in (("mc", 7), ("bin", 2)):
+        logits = torch.randn(300, n_cls, generator=g) * 2
+        truths = torch.randint(0, n_cls, (300,), generator=g)
+        logits[torch.arange(300), truths] += 1.5          # better than chance
+        m = M.ClassificationMetrics(n_classes=n_cls, mode="val")
+        for lo in (0, 100, 200):
+            m.add_preds(logits[lo:lo + 100], truths[lo:lo + 100])
+        res = m.get_values(use_dist=False, do_reset=False, return_conf_matrix=True)
+        arrs[f"{tag}_logits"], arrs[f"{tag}_truths"] = npy(logits), npy(truths)
+        arrs[f"{tag}_confusion"] = np.asarray(res["confusion_matrix"])
+        for key in ("accuracy", "mean_per_class_accuracy", "quadratic_kappa", "roc_auc", "recall"):
+            arrs[f"{tag}_{key}"] = np.array(float(res["val_" + key]))
+    # multi-label metric object
+    logits = torch.randn(300, Cm, generator=g) * 2
+    truths = (torch.rand(300, Cm, generator=g) < 0.35).float()
+    logits += (truths * 2 - 1) * 1.0
+    mm = M.MultiLabelClassificationMetrics(n_classes=Cm, mode="val")
+    for lo in (0, 150):
+        mm.add_preds(logits[lo:lo + 150], truths[lo:lo + 150])
+    res = mm.get_value(use_dist=False)
+    arrs["ml_logits"], arrs["ml_truths"] = npy(logits), npy(truths)
+    for key in ("accuracy", "mAP", "precision", "recall", "f1", "roc_auc"):
+        arrs[f"ml_{key}"] = np.array(float(res["val_" + key]))
+    save("g13_knn_metrics.npz", **arrs)
+
+
 if __name__ == "__main__":
     g1()
     g2_g8()
@@ -611,3 +693,4 @@ if __name__ == "__main__":
     g11_ssl_head_koleo()
     g12_ssl_step("apla", 32)
     g12_ssl_step("full", "full")
+    g13_knn_metrics()

@@ -1,5 +1,7 @@
 """Input-side kernel and device metrics: apla_augment_images against the oracle's restatement of ToTensor +
 Normalize + flip + Mixup / CutMix; the device-side confusion matrix against the reference's numpy definition."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -70,3 +72,46 @@ def test_classification_meter_matches_numpy_definition():
     assert abs(vals["accuracy"] - cm.diagonal().sum() / cm.sum()) < 1e-12
     assert abs(vals["mean_per_class_accuracy"] - per.mean()) < 1e-12
     assert int(meter.cm.sum()) == 0   # reset
+
+
+@pytest.mark.gpu
+def test_knn_and_meters_on_device_against_oracle_and_golden():
+    """evaluate.knn_predict, ClassificationMeter and MultiLabelMeter with their state on the GPU: against golden G13 (the reference's
+    own code) and, on fresh random inputs with ties and an absent class, against the oracle restatement (oracle/eval_oracle.py)."""
+    import numpy as np
+    from conftest import GOLDEN
+    from oracle import eval_oracle as E
+    from apla_amd.data import ClassificationMeter, MultiLabelMeter
+    from apla_amd.evaluate import knn_predict
+    dev = "cuda"
+    d = np.load(os.path.join(GOLDEN, "g13_knn_metrics.npz"))
+    k, temp, C = int(d["knn_k"]), float(d["knn_t"]), int(d["knn_classes"])
+    f, bank = torch.tensor(d["knn_feature"], device=dev), torch.tensor(d["knn_bank"], device=dev)
+    got = knn_predict(f, bank, torch.tensor(d["knn_labels"], device=dev), k, temp, C)
+    assert np.abs(got.cpu().numpy() - d["knn_scores"]).max() < 2e-6
+    lm = torch.tensor(d["knn_labels_multi"], device=dev)
+    assert np.abs(knn_predict(f, bank, lm, k, temp, lm.shape[0], multi_label=True).cpu().numpy() - d["knn_scores_multi"]).max() < 2e-6
+    m = ClassificationMeter(7, dev, keep_probs=True)
+    lg, tr = torch.tensor(d["mc_logits"], device=dev), torch.tensor(d["mc_truths"], device=dev)
+    m.add_preds(lg[:150], tr[:150]); m.add_preds(lg[150:], tr[150:])
+    r = m.get_values()
+    for key in ("accuracy", "mean_per_class_accuracy", "quadratic_kappa", "roc_auc", "recall"):
+        assert abs(r[key] - float(d["mc_" + key])) <= 5.01e-4, (key, r[key])
+    # fresh inputs: 9 classes of which one never occurs, coarse logits (ties), two batches
+    g = torch.Generator().manual_seed(77)
+    lg = (torch.randn(500, 9, generator=g) * 2).round() / 2
+    tr = torch.randint(0, 8, (500,), generator=g)
+    lg[torch.arange(500), tr] += 1.0
+    m = ClassificationMeter(9, dev, keep_probs=True)
+    m.add_preds(lg[:200].to(dev), tr[:200].to(dev)); m.add_preds(lg[200:].to(dev), tr[200:].to(dev))
+    r, o = m.get_values(), E.classification_metrics(lg.numpy(), tr.numpy(), 9)
+    for key in ("accuracy", "mean_per_class_accuracy", "quadratic_kappa", "roc_auc", "recall"):
+        assert abs(r[key] - o[key]) < 1e-6, (key, r[key], o[key])
+    lg = (torch.randn(400, 6, generator=g) * 2).round() / 2
+    tr = (torch.rand(400, 6, generator=g) < 0.3).float()
+    tr[:, 5] = 0                                           # a class without positives: ROC-AUC 0.5, precision / recall / f1 0
+    mm = MultiLabelMeter(6, dev)
+    mm.add_preds(lg[:100].to(dev), tr[:100].to(dev)); mm.add_preds(lg[100:].to(dev), tr[100:].to(dev))
+    r, o = mm.get_values(), E.multilabel_metrics(lg.numpy(), tr.numpy())
+    for key in ("accuracy", "precision", "recall", "f1", "roc_auc"):
+        assert abs(r[key] - o[key]) < 1e-6, (key, r[key], o[key])

@@ -446,7 +446,8 @@ def test_main_evaluation_and_knn(tmp_path):
     args = main.parse_arguments(["--params_path", path, "--steps_per_epoch", "3", "--save_dir", str(tmp_path), "--knn"])
     main.main(main.update_params_from_args(main.load_parameters(path), args), args)
     m1 = main.main.last_metrics
-    assert set(m1) == {"val_accuracy", "val_mean_per_class_accuracy", "val_loss", "knn_val_accuracy", "knn_val_mean_per_class_accuracy"}
+    base = {"accuracy", "mean_per_class_accuracy", "quadratic_kappa", "recall"}
+    assert set(m1) == {"val_" + k for k in base | {"roc_auc", "loss"}} | {"knn_val_" + k for k in base}
     assert np.isfinite(m1["val_loss"]) and 0.0 <= m1["val_accuracy"] <= 1.0 and 0.0 <= m1["knn_val_accuracy"] <= 1.0
     args = main.parse_arguments(["--params_path", path, "--test", "--pretrained_path", str(tmp_path / "tiny.pth")])
     main.main(main.update_params_from_args(main.load_parameters(path), args), args)

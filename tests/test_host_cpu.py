@@ -337,6 +337,37 @@ def test_knn_predict_matches_bruteforce_vote():
         assert torch.allclose(got[b], (multi[:, order] * (w / w.sum())).sum(1), atol=1e-6)
 
 
+def test_knn_and_meters_match_reference_golden_g13():
+    """The product's kNN vote and metric meters (plain torch: they run wherever their tensors live) against golden G13 = the
+    reference's own knn_predict source and metric classes; metrics to the three decimals the reference rounds to."""
+    import numpy as np
+    from conftest import GOLDEN
+    from apla_amd.data import ClassificationMeter, MultiLabelMeter
+    from apla_amd.evaluate import knn_predict
+    d = np.load(os.path.join(GOLDEN, "g13_knn_metrics.npz"))
+    k, temp, C = int(d["knn_k"]), float(d["knn_t"]), int(d["knn_classes"])
+    f, bank = torch.tensor(d["knn_feature"]), torch.tensor(d["knn_bank"])
+    assert (knn_predict(f, bank, torch.tensor(d["knn_labels"]), k, temp, C) - torch.tensor(d["knn_scores"])).abs().max() < 1e-6
+    lm = torch.tensor(d["knn_labels_multi"])
+    assert (knn_predict(f, bank, lm, k, temp, lm.shape[0], multi_label=True) - torch.tensor(d["knn_scores_multi"])).abs().max() < 1e-6
+    for tag, n_cls in (("mc", 7), ("bin", 2)):
+        m = ClassificationMeter(n_cls, "cpu", keep_probs=True)
+        lg, tr = torch.tensor(d[tag + "_logits"]), torch.tensor(d[tag + "_truths"])
+        for lo in (0, 100, 200):
+            m.add_preds(lg[lo:lo + 100], tr[lo:lo + 100])
+        assert np.array_equal(m.cm.numpy(), d[tag + "_confusion"].astype(np.int64))
+        r = m.get_values()
+        for key in ("accuracy", "mean_per_class_accuracy", "quadratic_kappa", "roc_auc", "recall"):
+            assert abs(r[key] - float(d[f"{tag}_{key}"])) <= 5.01e-4, (tag, key, r[key])
+    mm = MultiLabelMeter(5, "cpu")
+    lg, tr = torch.tensor(d["ml_logits"]), torch.tensor(d["ml_truths"])
+    for lo in (0, 150):
+        mm.add_preds(lg[lo:lo + 150], tr[lo:lo + 150])
+    r = mm.get_values()
+    for key in ("accuracy", "mAP", "precision", "recall", "f1", "roc_auc"):
+        assert abs(r[key] - float(d["ml_" + key])) <= 5.01e-4, (key, r[key])
+
+
 @pytest.mark.parametrize("name,dinov2,expect", [
     ("cfg1_vit_s16_cifar10_bs8", False, dict(img=224, batch=8, n_classes=10, backbone="vit_small", patch=16, r=64, gpus=1)),
     ("cfg2_vit_b16_bs128", False, dict(img=224, batch=128, n_classes=1000, backbone="vit_base", patch=16, r=192, gpus=1)),

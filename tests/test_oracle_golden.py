@@ -178,3 +178,24 @@ def test_g10_ssl_losses_oracle():
     w = m3.double() / m3.double().sum(-1, keepdim=True).clamp(min=1.0) / m3.shape[0]
     l3, d3 = O.distill_ce(s3.reshape(-1, K), t3.reshape(-1, K), 0.1, w.reshape(-1))
     assert abs(float(l3) - float(g["ibotd.loss"])) < 2e-6 * abs(float(l3)) and rel_err(d3.reshape(s3.shape), g["ibotd.ds"]) < 2e-6
+
+
+# ------------------------------------------------------------------------------------------- G13: kNN vote and metric objects
+def test_g13_knn_vote_and_metrics_oracle():
+    """oracle/eval_oracle.py against the reference's own knn_predict source and metric classes (golden G13): the kNN scores to 1e-6,
+    the metric values to the three decimals the reference rounds to, the confusion matrices exactly."""
+    from oracle import eval_oracle as E
+    d = np.load(os.path.join(GOLDEN, "g13_knn_metrics.npz"))
+    k, t, C = int(d["knn_k"]), float(d["knn_t"]), int(d["knn_classes"])
+    s = E.knn_predict(d["knn_feature"], d["knn_bank"], d["knn_labels"], k, t, C)
+    assert np.abs(s - d["knn_scores"]).max() < 1e-6 and np.allclose(s.sum(1), 1.0)
+    sm = E.knn_predict(d["knn_feature"], d["knn_bank"], d["knn_labels_multi"], k, t, d["knn_labels_multi"].shape[0], True)
+    assert np.abs(sm - d["knn_scores_multi"]).max() < 1e-6
+    for tag, n_cls in (("mc", 7), ("bin", 2)):
+        r = E.classification_metrics(d[tag + "_logits"], d[tag + "_truths"], n_cls)
+        assert np.array_equal(r["confusion_matrix"], d[tag + "_confusion"])
+        for key in ("accuracy", "mean_per_class_accuracy", "quadratic_kappa", "roc_auc", "recall"):
+            assert abs(r[key] - float(d[f"{tag}_{key}"])) <= 5.01e-4, (tag, key, r[key], float(d[f"{tag}_{key}"]))
+    r = E.multilabel_metrics(d["ml_logits"], d["ml_truths"])
+    for key in ("accuracy", "mAP", "precision", "recall", "f1", "roc_auc"):
+        assert abs(r[key] - float(d["ml_" + key])) <= 5.01e-4, (key, r[key], float(d["ml_" + key]))
