@@ -74,6 +74,7 @@ class GradExchanger:
         self.world = self.world_of(process_group)
         self.active = self.world > 1 or (always and dist.is_initialized() and process_group is not None)
         self._comm = torch.cuda.Stream() if (flat_grads.is_cuda and self.active) else None
+        self._wait_events = None    # timing of wait(): see time_waits()
         covered = sorted(self.chunks)
         assert covered[0][0] == 0 and covered[-1][1] == flat_grads.numel() and all(
             covered[i][1] == covered[i + 1][0] for i in range(len(covered) - 1)), "chunks must tile the flat buffer"
@@ -104,7 +105,27 @@ class GradExchanger:
     def wait(self):
         """Make the compute stream wait for all outstanding chunks (before clip/AdamW)."""
         if self._comm is not None:
+            if self._wait_events is not None:       # two events on the compute stream around the wait: what the exchange costs the step
+                cur = torch.cuda.current_stream()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(cur)
+                cur.wait_stream(self._comm)
+                e1.record(cur)
+                self._wait_events.append((e0, e1))
+                return
             torch.cuda.current_stream().wait_stream(self._comm)
+
+    def time_waits(self, on: bool = True):
+        """Start (or stop) recording how long the compute stream is held at wait(): the part of the gradient exchange that the
+        backward did not cover.  bench.py reports it per rank so that a scaling curve explains itself (exchange_wait_ms)."""
+        self._wait_events = [] if (on and self._comm is not None) else None
+
+    def mean_wait_ms(self):
+        """Mean duration of the recorded waits in ms (after a synchronize); None when nothing was recorded."""
+        if not self._wait_events:
+            return None
+        ts = [a.elapsed_time(b) for a, b in self._wait_events]
+        return sum(ts) / len(ts)
 
     @property
     def grad_scale(self) -> float:

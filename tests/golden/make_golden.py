@@ -599,6 +599,27 @@ def g5_cfg1():
         json.dump(dict(digests=digests, n_trainable=n_train, torch=torch.__version__), f, indent=1)
 
 
+def g5_cfg1_seeds(seeds=(1, 2, 3, 4, 5, 6, 7)):
+    """The same BASELINE config-1 model (weights under torch.manual_seed(0), as g5_cfg1) on further input batches: reference logits
+    and loss per input seed, so that the 16-bit parity numbers of the product are a maximum over batches, not one sample."""
+    torch.manual_seed(0)
+    model = vit.vit_small(pretrained=False, img_size=[224], patch_size=16, pretrained_type="dinov2",
+                          is_memory_efficient=True, block_conf=Cfg(has_layerscale=True, layerscale_init_values=1.0))
+    model = avit.build_apla(Cfg(partial_size=64), model, "apla_attn")
+    model.fc = torch.nn.Identity()
+    fc = torch.nn.Linear(384, 10)
+    logits, losses = [], []
+    with torch.no_grad():
+        for sd in seeds:
+            g = torch.Generator().manual_seed(sd)
+            images = torch.randn(8, 3, 224, 224, generator=g)
+            labels = torch.randint(0, 10, (8,), generator=g)
+            out = fc(model(images))
+            logits.append(npy(out))
+            losses.append(npy(torch.nn.functional.cross_entropy(out, labels)))
+    save("g5_cfg1_seeds.npz", seeds=np.array(seeds), logits=np.stack(logits), loss=np.stack(losses))
+
+
 # ---------------------------------------------------------------- G13: kNN vote and the metric objects (SURVEY 8f rank 4)
 def _ref_knn_predict():
     """``Trainer.knn_predict`` (defaults/trainer.py:392-455) as the reference file defines it: the method's own source is taken from
@@ -688,6 +709,7 @@ if __name__ == "__main__":
     g4()
     g5_tiny()
     g5_cfg1()
+    g5_cfg1_seeds()
     g9_lr_schedule()
     g10_ssl_losses()
     g11_ssl_head_koleo()

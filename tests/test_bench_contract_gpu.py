@@ -35,6 +35,28 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert cb["kind"] == "port" and cb["unit"] == "images/s" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     par = d["parity"]      # config 1 through the same build and dtype, against the reference's CPU logits
     assert par["dtype"] == "bf16" and par["tol_asserted"] == 8e-3 and par["logits_rel_vs_reference_cfg1"] < par["tol_asserted"]
+    assert par["n_batches"] == 8 and par["logits_rel_mean_over_batches"] <= par["logits_rel_max_over_batches"] < par["tol_asserted"]
+    p16, f16 = d["parity_fp16"], d["fp16"]      # the configuration that meets the north-star's 1e-3: parity AND throughput in the line
+    assert p16["dtype"] == "fp16" and p16["logits_rel_max_over_batches"] < p16["tol_asserted"] == 1e-3
+    assert f16["steps"] == 3 and f16["ms_per_step"] > 0 and abs(f16["images_per_sec"] - 128 / (f16["ms_per_step"] * 1e-3)) < 0.01 * f16["images_per_sec"]
+    rk = d["ranks"]                              # a one-rank run has no exchange: nothing waited for
+    assert rk["ms_per_step"] == [rk["ms_per_step_min"]] == [rk["ms_per_step_max"]] and rk["exchange_wait_ms"] == [None] and rk["exchange_chunks"] == 0
+
+
+def test_bench_reports_the_exchange_wait_on_the_forced_exchange_path():
+    """APLA_FORCE_EXCHANGE=1: the world > 1 code path (four graph segments, an RCCL all-reduce per gradient chunk on the side stream,
+    reserved CUs) on ONE rank — the bench line must then carry what a scaling run needs to explain itself: the time the compute stream
+    stood at GradExchanger.wait(), every rank's own step time, and the RCCL / CU budget in force."""
+    env = dict(os.environ, APLA_FORCE_EXCHANGE="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2", "--no-cpu-baseline",
+                        "--no-parity", "--no-peak-probe", "--no-fp16-leg"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    rk = d["ranks"]
+    assert rk["exchange_chunks"] == 4 and rk["reserved_cus"] == 8 and len(rk["exchange_wait_ms"]) == 1
+    assert rk["exchange_wait_ms"][0] is not None and 0.0 <= rk["exchange_wait_ms"][0] < d["ms_per_step"]
+    assert rk["env"]["NCCL_MAX_NCHANNELS"] == "8" and rk["env"]["APLA_RESERVE_CUS"] == "8" and rk["env"]["APLA_FORCE_EXCHANGE"] == "1"
+    assert abs(rk["ms_per_step"][0] - d["ms_per_step"]) < 0.2 * d["ms_per_step"]
 
 
 def test_bench_selflaunch_two_ranks():

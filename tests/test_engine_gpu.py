@@ -226,6 +226,35 @@ def test_engine_cfg1_matches_reference_golden():
         assert float((sd[nm].cpu() - ref_after).abs().max()) < 2.5e-4
 
 
+def cfg1_logit_errors_over_seeds(compute_dtype=None, loss_scale=1.0):
+    """max|logits - reference| / max|reference| of BASELINE config 1 for every input batch of golden g5_cfg1_seeds (seven batches,
+    the reference's own fp32 CPU logits) and for the batch of g5_cfg1_vits: eight numbers."""
+    from apla_amd.engine import AplaTrainEngine, OptimConfig
+    gs, g0 = load_golden("g5_cfg1_seeds.npz"), load_golden("g5_cfg1_vits.npz")
+    tp = dict(img_size=[224], patch_size=16, pretrained_type="dinov2", is_memory_efficient=True,
+              block_conf=dict(has_layerscale=True, layerscale_init_values=1.0))
+    model = build_classifier("vit_small", 64, 10, tp, seed=0)
+    kw = {} if compute_dtype is None else dict(compute_dtype=compute_dtype, loss_scale=loss_scale)
+    eng = AplaTrainEngine(model, 8, 224, optim=OptimConfig(lr=1e-4, weight_decay=1e-5, grad_clipping=1.0), **kw)
+    errs, loss_errs = [], []
+    for sd, ref, ref_loss in [(0, g0["logits"], g0["loss"])] + [(int(s_), gs["logits"][i], gs["loss"][i]) for i, s_ in enumerate(gs["seeds"])]:
+        gen = torch.Generator().manual_seed(sd)
+        images = torch.randn(8, 3, 224, 224, generator=gen)
+        labels = torch.randint(0, 10, (8,), generator=gen)
+        logits, _, loss = eng.forward_only(images.cuda(), labels.cuda())
+        torch.cuda.synchronize()
+        errs.append(rel_err(logits.cpu(), ref))
+        loss_errs.append(abs(float(loss) - float(ref_loss)))
+    return errs, loss_errs
+
+
+def test_engine_cfg1_logits_over_eight_batches():
+    """The bf16 parity number is a maximum over eight input batches, not one sample (VERDICT r03 #4b)."""
+    errs, loss_errs = cfg1_logit_errors_over_seeds()
+    print("cfg1 bf16 logits rel err per batch:", " ".join(f"{e:.2e}" for e in errs), f"max {max(errs):.3e} mean {sum(errs) / len(errs):.3e}")
+    assert max(errs) < CFG1_LOGIT_TOL and max(loss_errs) < 5e-3
+
+
 def test_session_checkpoint_interchange_with_torch_adamw():
     """a session dict exported from the engine has the reference layout (defaults/bases.py:456-464) and its
     'optimizer' entry loads into a real torch.optim.AdamW over get_params_groups(model) (defaults/wrappers.py:186-221);

@@ -7,7 +7,7 @@ import torch
 
 from conftest import load_golden, rel_err, t
 from oracle import apla_oracle as O
-from test_engine_gpu import build_classifier, rel_l2
+from test_engine_gpu import build_classifier, cfg1_logit_errors_over_seeds, rel_l2
 
 pytestmark = pytest.mark.gpu
 
@@ -131,3 +131,11 @@ def test_fp16_engine_dynamic_loss_scale_recovers_from_overflow():
         losses.append(float(eng.train_step(images, labels)))
     assert float(eng.scaler[7]) == 0.0 and float(eng.scaler[6]) < 2.0 ** 30
     assert losses[-1] < losses[0] - 0.2
+
+
+def test_fp16_cfg1_logits_within_1e3_over_eight_batches():
+    """The north-star tolerance (logits within 1e-3 of the CPU reference) as a maximum over eight input batches of BASELINE
+    config 1, not one sample (VERDICT r03 #4b)."""
+    errs, loss_errs = cfg1_logit_errors_over_seeds(torch.float16, 1024.0)
+    print("cfg1 fp16 logits rel err per batch:", " ".join(f"{e:.2e}" for e in errs), f"max {max(errs):.3e} mean {sum(errs) / len(errs):.3e}")
+    assert max(errs) < LOGIT_TOL_F16 and max(loss_errs) < 1e-3

@@ -78,6 +78,22 @@ def test_oracle_reproduces_reference_cfg1_step(cfg1_model):
         assert rel_err(p[nm], g["after." + nm]) < 1e-5
 
 
+def test_oracle_reproduces_reference_cfg1_logits_on_further_batches(cfg1_model):
+    """Golden g5_cfg1_seeds: the reference's logits / loss for seven more input batches of config 1 (the 16-bit parity numbers of
+    the product are a maximum over these); the fp32 oracle reproduces each."""
+    gs = load_golden("g5_cfg1_seeds.npz")
+    p = {(k[len("backbone."):] if k.startswith("backbone.") else k): v.detach().clone() for k, v in cfg1_model.state_dict().items()}
+    cfg = dict(patch=16, depth=12, heads=6, r=64)
+    for i, sd in enumerate(gs["seeds"][:3]):       # (three of the seven: the CPU suite stays short)
+        gen = torch.Generator().manual_seed(int(sd))
+        images = torch.randn(8, 3, 224, 224, generator=gen)
+        labels = torch.randint(0, 10, (8,), generator=gen)
+        logits, _ = O.vit_forward(images, p, cfg)
+        assert rel_err(logits, gs["logits"][i]) < 2e-5
+        loss, _ = O.cross_entropy_fwd_bwd(logits, labels)
+        assert abs(float(loss) - float(gs["loss"][i])) < 1e-5
+
+
 def test_build_apla_rules(tmp_path):
     from apla_amd import vit
     from apla_amd.apla import APLA_Attention, APLA_MemEffAttention, build_apla
