@@ -9,7 +9,8 @@
 
 namespace {
 
-constexpr int MAXC = 8;  // row chunks of 4 elements per lane: D <= 64*4*MAXC = 2048 (kernels are instantiated per chunk count)
+constexpr int MAXC = 6;  // row chunks of 4 elements per lane: D <= 64*4*MAXC = 1536 = ViT-g, the widest BASELINE model (kernels are instantiated
+                         // per chunk count; an 8-chunk backward spilled 448-896 registers to scratch and no configuration used it)
 #ifndef APLA_LN_ROWS
 #define APLA_LN_ROWS 4
 #endif
@@ -246,7 +247,7 @@ extern "C" int apla_layernorm_fwd(const void* x, int res_dtype, long x_row_strid
                                   const float* beta, void* y, int y_dtype, int ldy, float* mean, float* rstd, int M,
                                   int D, float eps, const void* add_in, long add_row_stride, void* x_out,
                                   long x_out_row_stride, hipStream_t stream) {
-  APLA_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 256 * MAXC, "apla_layernorm_fwd: need D%%4==0 and D<=2048 (D=%d)", D);
+  APLA_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 256 * MAXC, "apla_layernorm_fwd: need D%%4==0 and D<=1536 (D=%d)", D);
   APLA_REQUIRE(x && y && mean && rstd && ((gamma == nullptr) == (beta == nullptr)), "apla_layernorm_fwd: null pointer (gamma and beta are given together or not at all)");
   APLA_REQUIRE(x_row_stride % 4 == 0 && ldy % 4 == 0 && x_row_stride >= D && ldy >= D, "apla_layernorm_fwd: strides must be >= D and multiples of 4");
   APLA_REQUIRE(apla_aligned16(x) && (gamma == nullptr || (apla_aligned16(gamma) && apla_aligned16(beta))) && (((uintptr_t)y) & 7) == 0, "apla_layernorm_fwd: alignment");
@@ -260,8 +261,7 @@ extern "C" int apla_layernorm_fwd(const void* x, int res_dtype, long x_row_strid
     else if (nc_ == 2) LN_FWD_NC(T, Y, 2);              \
     else if (nc_ == 3) LN_FWD_NC(T, Y, 3);              \
     else if (nc_ == 4) LN_FWD_NC(T, Y, 4);              \
-    else if (nc_ <= 6) LN_FWD_NC(T, Y, 6);              \
-    else LN_FWD_NC(T, Y, 8);                            \
+    else LN_FWD_NC(T, Y, 6);                            \
   } while (0)
   if (res_dtype == APLA_F32 && y_dtype == APLA_H16) LN_FWD(float, bf16);
   else if (res_dtype == APLA_F32 && y_dtype == APLA_F32) LN_FWD(float, float);
@@ -282,7 +282,7 @@ extern "C" int apla_layernorm_bwd_ex(const void* dy, int dy_dtype, int lddy, con
                                      int dres_row_period, void* dx_out, int grad_dtype, long dx_row_stride, void* dx_bf16_copy,
                                      long copy_row_stride, const int32_t* inds, int r, void* gather_out, int M, int D,
                                      hipStream_t stream) {
-  APLA_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 256 * MAXC, "apla_layernorm_bwd: need D%%4==0 and D<=2048 (D=%d)", D);
+  APLA_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 256 * MAXC, "apla_layernorm_bwd: need D%%4==0 and D<=1536 (D=%d)", D);
   APLA_REQUIRE(dy && x && rstd && dx_out && dres_row_period >= 0, "apla_layernorm_bwd: null pointer");
   APLA_REQUIRE(lddy % 4 == 0 && x_row_stride % 4 == 0 && dx_row_stride % 4 == 0 && lddy >= D && x_row_stride >= D && dx_row_stride >= D, "apla_layernorm_bwd: bad strides");
   APLA_REQUIRE(dx_bf16_copy == nullptr || (copy_row_stride % 4 == 0 && copy_row_stride >= D), "apla_layernorm_bwd: bad copy stride");
@@ -325,8 +325,7 @@ extern "C" int apla_layernorm_bwd_ex(const void* dy, int dy_dtype, int lddy, con
     else if (nc_ == 2) LN_BWD_NC(X, Y, G, GA, 2);       \
     else if (nc_ == 3) LN_BWD_NC(X, Y, G, GA, 3);       \
     else if (nc_ == 4) LN_BWD_NC(X, Y, G, GA, 4);       \
-    else if (nc_ <= 6) LN_BWD_NC(X, Y, G, GA, 6);       \
-    else LN_BWD_NC(X, Y, G, GA, 8);                     \
+    else LN_BWD_NC(X, Y, G, GA, 6);                     \
   } while (0)
 #define LN_BWD_G(X, Y, G) do { if (gather) LN_BWD(X, Y, G, true); else LN_BWD(X, Y, G, false); } while (0)
 #define LN_BWD_Y(X, G)                                           \
