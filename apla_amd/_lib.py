@@ -95,6 +95,8 @@ SIGNATURES = {
                                     c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "apla_assemble_tokens": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                      c_void_p]),
+    "apla_assemble_tokens_masked": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                            c_int, c_void_p]),
     "apla_sgemm_small": (c_int, [c_void_p, c_long, c_long, c_void_p, c_long, c_long, c_void_p, c_void_p, c_long, c_int,
                                  c_int, c_int, c_int, c_void_p]),
     "apla_cross_entropy": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),

@@ -28,5 +28,6 @@ class APLA_MemEffAttention(APLA_Attention):
         if x.ndim != 3 or x.shape[0] != 1 or x.shape[1] != attn_bias.total:
             raise ValueError(f"a packed batch must be [1, {attn_bias.total}, C]; got {tuple(x.shape)}")
         qkv = AF.linear(x, self.qkv.weight, self.qkv.bias)
-        o = AF.attention_core_varlen(qkv, attn_bias.cu_seqlens(x.device), attn_bias.max_seqlen, self.num_heads, self.scale)
+        o = AF.attention_core_varlen(qkv, attn_bias.cu_seqlens(x.device), attn_bias.max_seqlen, self.num_heads, self.scale,
+                                        runs=attn_bias.runs())
         return self._project(o, ls_gamma).to(x.dtype)

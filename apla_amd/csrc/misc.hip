@@ -49,13 +49,17 @@ template <typename ResT>
 __global__ __launch_bounds__(256) void assemble_tokens_kernel(const bf16* __restrict__ patches, int ldp,
                                                               const float* __restrict__ cls,
                                                               const float* __restrict__ pos, ResT* __restrict__ tok,
-                                                              int Np, int D) {
+                                                              int Np, int D, const uint8_t* __restrict__ masked,
+                                                              const float* __restrict__ mask_token) {
   const int row = blockIdx.x;  // b*(Np+1) + n
   const int N = Np + 1;
   const int b = row / N, n = row - b * N;
+  // iBOT (dinov2_vits.py:213-214): a masked patch is replaced by the mask token BEFORE the position embedding is added
+  const bool use_mask_token = masked != nullptr && n > 0 && masked[(size_t)b * Np + n - 1] != 0;
   for (int c4 = threadIdx.x; c4 < D / 4; c4 += 256) {
     f32x4 v = *(const f32x4*)(pos + (size_t)n * D + c4 * 4);
     if (n == 0) v += *(const f32x4*)(cls + c4 * 4);
+    else if (use_mask_token) v += *(const f32x4*)(mask_token + c4 * 4);
     else v += Vec4IO<bf16>::load(patches + ((size_t)b * Np + n - 1) * ldp + c4 * 4);
     Vec4IO<ResT>::store(tok + (size_t)row * D + c4 * 4, v);
   }
@@ -283,19 +287,27 @@ extern "C" int apla_patchify(const float* images, void* cols, int B, int S, int 
   return APLA_OK;
 }
 
-extern "C" int apla_assemble_tokens(const void* patches, int ldp, const float* cls_token, const float* pos_embed,
-                                    void* tokens, int res_dtype, int B, int Np, int D, hipStream_t stream) {
+extern "C" int apla_assemble_tokens_masked(const void* patches, int ldp, const float* cls_token, const float* pos_embed,
+                                           const uint8_t* masked, const float* mask_token, void* tokens, int res_dtype, int B,
+                                           int Np, int D, hipStream_t stream) {
   APLA_REQUIRE(patches && cls_token && pos_embed && tokens && B > 0 && Np > 0 && D % 4 == 0 && ldp % 4 == 0, "apla_assemble_tokens: bad arguments");
+  APLA_REQUIRE((masked == nullptr) == (mask_token == nullptr), "apla_assemble_tokens: the mask and the mask token come together");
+  APLA_REQUIRE((long)B * (Np + 1) < (1L << 31), "apla_assemble_tokens: too many rows for one launch");
   if (res_dtype == APLA_F32)
-    hipLaunchKernelGGL(assemble_tokens_kernel<float>, dim3(B * (Np + 1)), dim3(256), 0, stream, (const bf16*)patches, ldp, cls_token, pos_embed, (float*)tokens, Np, D);
+    hipLaunchKernelGGL(assemble_tokens_kernel<float>, dim3(B * (Np + 1)), dim3(256), 0, stream, (const bf16*)patches, ldp, cls_token, pos_embed, (float*)tokens, Np, D, masked, mask_token);
   else if (res_dtype == APLA_H16)
-    hipLaunchKernelGGL(assemble_tokens_kernel<bf16>, dim3(B * (Np + 1)), dim3(256), 0, stream, (const bf16*)patches, ldp, cls_token, pos_embed, (bf16*)tokens, Np, D);
+    hipLaunchKernelGGL(assemble_tokens_kernel<bf16>, dim3(B * (Np + 1)), dim3(256), 0, stream, (const bf16*)patches, ldp, cls_token, pos_embed, (bf16*)tokens, Np, D, masked, mask_token);
   else {
     apla_set_error("apla_assemble_tokens: bad res_dtype %d", res_dtype);
     return APLA_ENOSYS;
   }
   APLA_CHECK_LAUNCH("apla_assemble_tokens");
   return APLA_OK;
+}
+
+extern "C" int apla_assemble_tokens(const void* patches, int ldp, const float* cls_token, const float* pos_embed,
+                                    void* tokens, int res_dtype, int B, int Np, int D, hipStream_t stream) {
+  return apla_assemble_tokens_masked(patches, ldp, cls_token, pos_embed, nullptr, nullptr, tokens, res_dtype, B, Np, D, stream);
 }
 
 // ---- self-distillation losses (DINO CLS-token loss, iBOT patch loss): rows of K prototypes (65 536 in the shipped config) ----

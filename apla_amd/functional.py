@@ -16,7 +16,9 @@ import torch
 from . import ops
 from ._lib import AplaHipError
 
-_BF = torch.bfloat16
+def _h():
+    """The 16-bit operand dtype of the loaded library build (bf16, or fp16 inside ``ops.use_half(torch.float16)``)."""
+    return ops.half()
 
 
 def require_no_dropout(drop_module, training: bool):
@@ -33,13 +35,13 @@ def _require_cuda(x: torch.Tensor, what: str):
 
 # ------------------------------------------------------------------------------------------------ weight cache
 class _WeightCache:
-    """bf16 (and transposed bf16) copies of parameters keyed by identity + version."""
+    """16-bit (and transposed 16-bit) copies of parameters keyed by identity + version + the operand dtype in force."""
 
     def __init__(self):
         self._store = {}
 
     def get(self, p: torch.Tensor, kind: str, make):
-        key = (id(p), kind)
+        key = (id(p), kind, ops.half())
         ent = self._store.get(key)
         ver = p._version
         if ent is not None and ent[0] == ver and ent[1]() is p and ent[2].device == p.device:
@@ -56,11 +58,11 @@ CACHE = _WeightCache()
 
 
 def w_bf16(p):
-    return CACHE.get(p, "bf16", lambda: p.detach().to(_BF).contiguous())
+    return CACHE.get(p, "bf16", lambda: p.detach().to(_h()).contiguous())
 
 
 def w_bf16_t(p):
-    return CACHE.get(p, "bf16_t", lambda: p.detach().t().to(_BF).contiguous())
+    return CACHE.get(p, "bf16_t", lambda: p.detach().t().to(_h()).contiguous())
 
 
 def b_f32(p):
@@ -80,7 +82,7 @@ def _img(p, kind: str, make, M: int):
 
 
 def _as2d_bf16(x):
-    return x.reshape(-1, x.shape[-1]).to(_BF).contiguous()
+    return x.reshape(-1, x.shape[-1]).to(_h()).contiguous()
 
 
 # ------------------------------------------------------------------------------------------------ LayerNorm
@@ -91,7 +93,7 @@ class _LayerNormFn(torch.autograd.Function):
         if weight.requires_grad or bias.requires_grad:
             raise NotImplementedError("trainable LayerNorm affine is outside the APLA path (all norms are frozen)")
         x2 = x.reshape(-1, x.shape[-1])
-        x2 = x2 if x2.dtype in (torch.float32, _BF) else x2.float()
+        x2 = x2 if x2.dtype in (torch.float32, _h()) else x2.float()
         x2 = x2.contiguous()
         y, mean, rstd = ops.layernorm_fwd(x2, b_f32(weight), b_f32(bias), eps)
         ctx.save_for_backward(x2, mean, rstd, weight)
@@ -121,7 +123,7 @@ class _AddLayerNormFn(torch.autograd.Function):
         if weight.requires_grad or bias.requires_grad:
             raise NotImplementedError("trainable LayerNorm affine is outside the APLA path (all norms are frozen)")
         x2 = x.reshape(-1, x.shape[-1])
-        x2 = (x2 if x2.dtype in (torch.float32, _BF) else x2.float()).contiguous()
+        x2 = (x2 if x2.dtype in (torch.float32, _h()) else x2.float()).contiguous()
         b2 = _as2d_bf16(branch)
         x_new = torch.empty_like(x2)
         y, mean, rstd = ops.layernorm_fwd(x2, b_f32(weight), b_f32(bias), eps, add=b2, x_out=x_new)
@@ -136,10 +138,10 @@ class _AddLayerNormFn(torch.autograd.Function):
             d = dx_new.reshape(x_new.shape)
         else:
             dres = None if dx_new is None else dx_new.reshape(x_new.shape).to(x_new.dtype).contiguous()
-            if ctx.bdtype == _BF and x_new.dtype == torch.float32:
+            if ctx.bdtype == _h() and x_new.dtype == torch.float32:
                 # the branch gradient is the 16-bit copy of the same rows: written by the kernel in the same pass instead of a
                 # cast over the whole [tokens, dim] stream afterwards (1.4 ms per self-supervised iteration at config 4)
-                db = torch.empty(x_new.shape, device=x_new.device, dtype=_BF)
+                db = torch.empty(x_new.shape, device=x_new.device, dtype=_h())
                 d, _ = ops.layernorm_bwd(_as2d_bf16(dy), x_new, b_f32(weight), mean, rstd, dres=dres, out_bf16=db)
                 return d.reshape(ctx.shape), db.reshape(ctx.shape), None, None, None
             d, _ = ops.layernorm_bwd(_as2d_bf16(dy), x_new, b_f32(weight), mean, rstd, dres=dres)
@@ -161,7 +163,7 @@ class _LinearFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         _require_cuda(x, "linear")
         x2 = _as2d_bf16(x)
-        y = ops.gemm_nt(x2, _img(weight, "bf16", lambda: weight.detach().to(_BF).contiguous(), x2.shape[0]), b_f32(bias))
+        y = ops.gemm_nt(x2, _img(weight, "bf16", lambda: weight.detach().to(_h()).contiguous(), x2.shape[0]), b_f32(bias))
         ctx.save_for_backward(x2, weight, bias if bias is not None else torch.empty(0))
         ctx.has_bias = bias is not None
         ctx.shape = x.shape
@@ -173,7 +175,7 @@ class _LinearFn(torch.autograd.Function):
         dy2 = _as2d_bf16(dy)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = ops.gemm_nt(dy2, _img(weight, "bf16_t", lambda: weight.detach().t().to(_BF).contiguous(), dy2.shape[0])).reshape(ctx.shape)
+            dx = ops.gemm_nt(dy2, _img(weight, "bf16_t", lambda: weight.detach().t().to(_h()).contiguous(), dy2.shape[0])).reshape(ctx.shape)
         dW = db = None
         if weight.requires_grad:
             dW = torch.empty(weight.shape, device=dy.device, dtype=torch.float32)
@@ -200,7 +202,7 @@ class _LinearGeluFn(torch.autograd.Function):
         w = w_bf16(weight)      # cached against the parameter's version counter (FlatAdamW increments it)
         train = any(ctx.needs_input_grad)   # (grad mode itself is off inside Function.forward)
         if train:
-            g = torch.empty(x2.shape[0], weight.shape[0], device=x2.device, dtype=_BF)
+            g = torch.empty(x2.shape[0], weight.shape[0], device=x2.device, dtype=_h())
             h = ops.gemm_nt(x2, w, b_f32(bias), epilogue=ops.EPI_GELU, aux_out=g)
             ctx.save_for_backward(x2, g, weight, bias if bias is not None else torch.empty(0))
         else:
@@ -230,7 +232,7 @@ class _LinearGeluFn(torch.autograd.Function):
 def linear_gelu(x, weight, bias=None):
     """GELU(linear(x)) in one launch (needs out_features % 128 == 0 and in_features % 64 == 0, else falls back to two steps)."""
     if weight.shape[0] % 128 or weight.shape[1] % 64:
-        return torch.nn.functional.gelu(linear(x, weight, bias).float()).to(_BF)
+        return torch.nn.functional.gelu(linear(x, weight, bias).float()).to(_h())
     return _LinearGeluFn.apply(x, weight, bias)
 
 
@@ -274,12 +276,55 @@ class _AttnVarlenFn(torch.autograd.Function):
         return dqkv.reshape(shape), None, None, None, None
 
 
-def attention_core_varlen(qkv, cu_seqlens, max_n, H, scale):
-    """qkv [..., total, 3*H*64] with all leading dims of size 1 (a packed batch); cu_seqlens int32[S+1] on qkv's device."""
+class _AttnRunsFn(torch.autograd.Function):
+    """The same block-diagonal attention for a packed batch made of a FEW runs of equal-length sequences (the multi-crop batch:
+    global crops then local crops): one uniform launch per run on its slice of the packed rows.  Each run then gets the kernel and
+    the workgroup size of its own length (the packed launch sizes every workgroup and its LDS for the longest sequence: at config 4
+    512 of the 640 sequences are 50 tokens long next to 257) and the persistent backward where it applies."""
+
+    @staticmethod
+    def forward(ctx, qkv, runs, H, scale):
+        shape = qkv.shape
+        qkv2 = qkv.reshape(-1, shape[-1]).contiguous()
+        o = torch.empty(qkv2.shape[0], H * 64, device=qkv.device, dtype=_h())
+        lses, a = [], 0
+        for cnt, n in runs:
+            b = a + cnt * n
+            lses.append(ops.attn_fwd(qkv2[a:b], cnt, n, H, scale, o=o[a:b])[1])
+            a = b
+        ctx.save_for_backward(qkv2, o, *lses)
+        ctx.dims = (shape, runs, H, scale)
+        return o.reshape(*shape[:-1], H * 64)
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv2, o, *lses = ctx.saved_tensors
+        shape, runs, H, scale = ctx.dims
+        do2 = _as2d_bf16(do)
+        dqkv = torch.empty_like(qkv2)
+        a = 0
+        for (cnt, n), lse in zip(runs, lses):
+            b = a + cnt * n
+            ops.attn_bwd(qkv2[a:b], o[a:b], do2[a:b], lse, cnt, n, H, scale, dqkv=dqkv[a:b])
+            a = b
+        return dqkv.reshape(shape), None, None, None
+
+
+MAX_ATTN_RUNS = 4   # more runs than this: one packed launch over the offsets instead
+
+
+def attention_core_varlen(qkv, cu_seqlens, max_n, H, scale, runs=None):
+    """qkv [..., total, 3*H*64] with all leading dims of size 1 (a packed batch); cu_seqlens int32[S+1] on qkv's device.
+    ``runs``: the host-side description of the same offsets as (count, length) pairs of consecutive equal-length sequences
+    (BlockDiagonalMask.runs()); with a few runs each goes through the uniform-batch kernels on its slice."""
     if qkv.shape[-1] != 3 * H * 64:
         raise NotImplementedError(f"the HIP attention kernel needs head_dim 64 (got {qkv.shape[-1] // (3 * H)})")
     if qkv.numel() != qkv.shape[-2] * qkv.shape[-1]:
         raise ValueError("a packed (block-diagonal) batch must have batch size 1: [1, total, 3*dim]")
+    if runs is not None and len(runs) <= MAX_ATTN_RUNS:
+        if sum(c * n for c, n in runs) != qkv.shape[-2]:
+            raise ValueError("runs do not cover the packed batch")
+        return _AttnRunsFn.apply(qkv, tuple(runs), H, scale)
     return _AttnVarlenFn.apply(qkv, cu_seqlens, max_n, H, scale)
 
 
@@ -326,8 +371,8 @@ class AplaProjState:
                 Wn *= self.gamma[:, None]
                 bn *= self.gamma
                 self.gamma_r = self.gamma[idx[:(r + 63) // 64 * 64]].contiguous()   # row scales of the dW step (padded rank)
-            self.Wnat = Wn.to(_BF)
-            self.WnatT = Wn.t().contiguous().to(_BF)
+            self.Wnat = Wn.to(_h())
+            self.WnatT = Wn.t().contiguous().to(_h())
             self.bnat = bn
             self.inds32 = idx.int().contiguous()
             self.key = key
@@ -376,12 +421,12 @@ def apla_projection(o, W1, b1, W2, b2, inds, state: AplaProjState, gamma=None):
 
 # ------------------------------------------------------------------------------------------------ MLPs
 def _scaled_w(w, gamma):      # gamma[:, None] * w  as bf16 (frozen LayerScale folded into the producing Linear)
-    return CACHE.get(w, f"bf16_g{id(gamma)}_{gamma._version}", lambda: (w.detach().float() * gamma.detach().float()[:, None]).to(_BF).contiguous())
+    return CACHE.get(w, f"bf16_g{id(gamma)}_{gamma._version}", lambda: (w.detach().float() * gamma.detach().float()[:, None]).to(_h()).contiguous())
 
 
 def _scaled_w_t(w, gamma):
     return CACHE.get(w, f"bf16_gt{id(gamma)}_{gamma._version}",
-                     lambda: (w.detach().float() * gamma.detach().float()[:, None]).t().to(_BF).contiguous())
+                     lambda: (w.detach().float() * gamma.detach().float()[:, None]).t().to(_h()).contiguous())
 
 
 def _scaled_b(b, gamma):
@@ -392,15 +437,15 @@ def _hidden_buffer(M, F, n_next, epilogue, device):
     """Output buffer of the MLP's first GEMM of a pass ([M, F], epilogue GELU / GELU_FWD / MUL) whose only reader is a plain-store
     GEMM with n_next outputs: a K-panel image [F/32, M, 32] where the producing epilogue can write one and the consumer reads one."""
     if _IMAGES and ops.gemm_out_image_ok(M, F, n_next, epilogue) and ops.gemm_panel_ok(M, n_next, F):
-        return torch.empty(F // 32, M, 32, device=device, dtype=_BF)
-    return torch.empty(M, F, device=device, dtype=_BF)
+        return torch.empty(F // 32, M, 32, device=device, dtype=_h())
+    return torch.empty(M, F, device=device, dtype=_h())
 
 
 def _fc2_weight(w2, gamma, M):
     if gamma is None:
-        return _img(w2, "bf16", lambda: w2.detach().to(_BF).contiguous(), M)
+        return _img(w2, "bf16", lambda: w2.detach().to(_h()).contiguous(), M)
     return _img(w2, f"bf16_g{id(gamma)}_{gamma._version}",
-                lambda: (w2.detach().float() * gamma.detach().float()[:, None]).to(_BF).contiguous(), M)
+                lambda: (w2.detach().float() * gamma.detach().float()[:, None]).to(_h()).contiguous(), M)
 
 
 class _MlpGeluFn(torch.autograd.Function):
@@ -409,7 +454,7 @@ class _MlpGeluFn(torch.autograd.Function):
         _require_cuda(x, "mlp")
         x2 = _as2d_bf16(x)
         M, F = x2.shape[0], w1.shape[0]
-        gp = torch.empty(M, F, device=x.device, dtype=_BF)
+        gp = torch.empty(M, F, device=x.device, dtype=_h())
         h = _hidden_buffer(M, F, w2.shape[0], ops.EPI_GELU, x.device)   # a K-panel image where fc1's epilogue can write one
         w1h = w_bf16(w1)
         if _IMAGES and ops.gemm_panel_ok(M, F, w1.shape[1], ops.EPI_GELU):   # the two-output GELU above 40 000 rows: ping-pong kernel
@@ -429,7 +474,7 @@ class _MlpGeluFn(torch.autograd.Function):
         M, F = gp.shape
         da = _hidden_buffer(M, F, w1.shape[1], ops.EPI_MUL, dy.device)
         ops.gemm_nt(_as2d_bf16(dy), w2t, epilogue=ops.EPI_MUL, aux_in=gp, out=da)
-        dx = ops.gemm_nt(da, _img(w1, "bf16_t", lambda: w1.detach().t().to(_BF).contiguous(), M))
+        dx = ops.gemm_nt(da, _img(w1, "bf16_t", lambda: w1.detach().t().to(_h()).contiguous(), M))
         return dx.reshape(ctx.shape), None, None, None, None, None
 
 
@@ -457,9 +502,9 @@ class _MlpSwigluFn(torch.autograd.Function):
     def forward(ctx, x, w12, b12, w3, b3):
         _require_cuda(x, "mlp")
         x2 = _as2d_bf16(x)
-        w12i = CACHE.get(w12, "il", lambda: _interleave_rows(w12.detach()).to(_BF))
+        w12i = CACHE.get(w12, "il", lambda: _interleave_rows(w12.detach()).to(_h()))
         b12i = None if b12 is None else CACHE.get(b12, "il", lambda: _interleave_rows(b12.detach().float()))
-        saved = torch.empty(x2.shape[0], w12.shape[0], device=x.device, dtype=_BF)
+        saved = torch.empty(x2.shape[0], w12.shape[0], device=x.device, dtype=_h())
         h = ops.gemm_nt(x2, w12i, b12i, epilogue=ops.EPI_SWIGLU, aux_out=saved)
         y = ops.gemm_nt(h, w_bf16(w3), b_f32(b3))
         ctx.save_for_backward(saved, w12, w3)
@@ -472,7 +517,7 @@ class _MlpSwigluFn(torch.autograd.Function):
         if w12.requires_grad or w3.requires_grad:
             raise NotImplementedError("trainable MLP weights are outside the APLA path")
         dx12 = ops.gemm_nt(_as2d_bf16(dy), w_bf16_t(w3), epilogue=ops.EPI_SWIGLU_BWD, aux_in=saved)
-        w12it = CACHE.get(w12, "il_t", lambda: _interleave_rows(w12.detach()).t().contiguous().to(_BF))
+        w12it = CACHE.get(w12, "il_t", lambda: _interleave_rows(w12.detach()).t().contiguous().to(_h()))
         dx = ops.gemm_nt(dx12, w12it)
         return dx.reshape(ctx.shape), None, None, None, None
 
@@ -495,7 +540,7 @@ def patch_embed(images, conv_w, conv_b, patch: int):
     def make():
         w = torch.zeros(D, Kp, device=conv_w.device, dtype=torch.float32)
         w[:, :K] = conv_w.detach().reshape(D, K).float()
-        return w.to(_BF)
+        return w.to(_h())
 
     wp = CACHE.get(conv_w, f"pe{Kp}", make)
     cols = ops.patchify(images.float().contiguous(), patch, Kp)

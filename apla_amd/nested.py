@@ -69,6 +69,19 @@ class BlockDiagonalMask:
         return out
 
     # -- what the kernels need ----------------------------------------------------------------------------------------
+    def runs(self) -> List[Tuple[int, int]]:
+        """Consecutive sequences of equal length as (count, length) pairs: a multi-crop batch is two such runs (global crops,
+        local crops), each a uniform batch the dense attention kernels take at their own block size."""
+        if getattr(self, "_runs", None) is None:
+            out: List[Tuple[int, int]] = []
+            for n in self.seqlens:
+                if out and out[-1][1] == n:
+                    out[-1] = (out[-1][0] + 1, n)
+                else:
+                    out.append((1, n))
+            self._runs = out
+        return self._runs
+
     def cu_seqlens(self, device) -> torch.Tensor:
         device = torch.device(device)
         if device not in self._cu:

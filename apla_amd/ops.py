@@ -720,15 +720,31 @@ def patchify(images: torch.Tensor, patch: int, Kp: int, out: Optional[torch.Tens
 
 
 def assemble_tokens(patches: torch.Tensor, cls_token: torch.Tensor, pos: torch.Tensor, B: int, Np: int,
-                    res_dtype=torch.float32, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                    res_dtype=torch.float32, out: Optional[torch.Tensor] = None, masked: Optional[torch.Tensor] = None,
+                    mask_token: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """tokens[b] = [cls + pos[0] | patches[b] + pos[1:]] in the residual dtype; with ``masked`` (bool / uint8 [B, Np]) the masked
+    patches are replaced by ``mask_token`` (fp32 [D]) first (iBOT).  ``out`` [B*(Np+1), D] may be a row slice of a larger buffer."""
     _req(patches, half(), "patches", 2), _req(cls_token, torch.float32, "cls"), _req(pos, torch.float32, "pos", 2)
     D = patches.shape[1]
-    if patches.shape[0] != B * Np or cls_token.numel() != D or tuple(pos.shape) != (Np + 1, D) or not pos.is_contiguous():
+    if patches.shape[0] != B * Np or cls_token.numel() != D or tuple(pos.shape) != (Np + 1, D) or not pos.is_contiguous() \
+            or not cls_token.is_contiguous():
         raise ValueError("assemble_tokens: shape mismatch")
     if out is None:
         out = torch.empty(B * (Np + 1), D, device=patches.device, dtype=res_dtype)
-    check(lib().apla_assemble_tokens(patches.data_ptr(), patches.stride(0), cls_token.data_ptr(), pos.data_ptr(),
-                                     out.data_ptr(), _DT[out.dtype], B, Np, D, _stream()), "apla_assemble_tokens")
+    _req(out, None, "out", 2)
+    if tuple(out.shape) != (B * (Np + 1), D) or not out.is_contiguous() or out.dtype not in (torch.float32, half()):
+        raise ValueError("assemble_tokens: bad out buffer")
+    if (masked is None) != (mask_token is None):
+        raise ValueError("assemble_tokens: masked and mask_token come together")
+    if masked is not None:
+        if masked.dtype == torch.bool:
+            masked = masked.view(torch.uint8)
+        _req(masked, torch.uint8, "masked"), _req(mask_token, torch.float32, "mask_token")
+        if masked.numel() != B * Np or not masked.is_contiguous() or mask_token.numel() != D or not mask_token.is_contiguous():
+            raise ValueError("assemble_tokens: masked must be [B, Np], mask_token [D]")
+    check(lib().apla_assemble_tokens_masked(patches.data_ptr(), patches.stride(0), cls_token.data_ptr(), pos.data_ptr(), _ptr(masked),
+                                            _ptr(mask_token), out.data_ptr(), _DT[out.dtype], B, Np, D, _stream()),
+          "apla_assemble_tokens")
     return out
 
 

@@ -61,13 +61,18 @@ class FlatAdamW:
         """Global gradient norm before clipping, as left on the device by the last step (a 0-d tensor; no host sync)."""
         return self.norm_ws[1]
 
-    def step(self, max_norm: float = 0.0, grad_scale: float = 1.0, skip: Sequence[str] = ()):
+    def step(self, max_norm: float = 0.0, grad_scale: float = 1.0, skip: Sequence[str] = (), check_finite: bool = False) -> bool:
         """clip_grad_norm_(all trainable tensors, max_norm) then AdamW on every tensor whose name contains none of `skip`
-        (utils/_utils.py:418-421 ``cancel_gradients`` matches by substring)."""
+        (utils/_utils.py:418-421 ``cancel_gradients`` matches by substring).  With ``check_finite`` (fp16 under a loss scale,
+        whose inverse the caller folds into ``grad_scale``) the step is GradScaler.step: if the norm of the unscaled gradients
+        is not finite nothing is updated, no step count advances and False is returned (one host read, as GradScaler does)."""
         L = lib()
         n = self.flat.numel()
         s = _stream()
         check(L.apla_grad_sumsq(self.grads.data_ptr(), n, float(grad_scale), self.norm_ws.data_ptr(), s), "apla_grad_sumsq")
+        if check_finite and not bool(torch.isfinite(self.norm_ws[2:258].sum()).item()):
+            self.norm_ws[1] = float("inf")
+            return False
         active = [not any(k in name for k in skip) for name in self.names]
         for i, on in enumerate(active):
             if on:
@@ -87,10 +92,18 @@ class FlatAdamW:
                                      int(self.steps[i]), float(max_norm), float(grad_scale), self.norm_ws.data_ptr(), s),
                   "apla_adamw_apply")
             i = j + 1
-        # the kernels wrote through raw pointers: tell the bf16 weight cache (keyed by tensor version) that values changed
+        if not all(active) and (max_norm > 0.0 or grad_scale != 1.0):
+            # clip_grad_norm_ / unscale_ rescale EVERY gradient, also those of the tensors the update leaves out (the reference drops
+            # them afterwards): the same coefficient the kernel derived, from the norm it left in norm_ws[1]
+            coef = float(grad_scale) if max_norm <= 0.0 else (max_norm / (self.norm_ws[1] + 1e-6)).clamp(max=1.0) * float(grad_scale)
+            for i, on in enumerate(active):
+                if not on:
+                    self.grads[self.offsets[i]:self.offsets[i + 1]].mul_(coef)
+        # the kernels wrote through raw pointers: tell the 16-bit weight cache (keyed by tensor version) that values changed
         for p, on in zip(self.params, active):
             if on:
                 torch.autograd.graph.increment_version(p)
+        return True
 
     # -- torch.optim-compatible state, for the reference's session layout (bases.py:456-467) ---------------------------
     def state_dict(self):

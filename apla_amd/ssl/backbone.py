@@ -14,6 +14,7 @@ import torch
 from torch import nn
 
 from .. import functional as AF
+from .. import ops
 from ..apla.appla_attn_mem_eff import APLA_MemEffAttention
 from ..nested import BlockDiagonalMask
 from ..vit import Attention, VisionTransformer
@@ -33,7 +34,8 @@ class MemEffAttention(Attention):
         if x.ndim != 3 or x.shape[0] != 1 or x.shape[1] != attn_bias.total:
             raise ValueError(f"a packed batch must be [1, {attn_bias.total}, C]; got {tuple(x.shape)}")
         qkv = AF.linear(x, self.qkv.weight, self.qkv.bias)
-        o = AF.attention_core_varlen(qkv, attn_bias.cu_seqlens(x.device), attn_bias.max_seqlen, self.num_heads, self.scale)
+        o = AF.attention_core_varlen(qkv, attn_bias.cu_seqlens(x.device), attn_bias.max_seqlen, self.num_heads, self.scale,
+                                        runs=attn_bias.runs())
         return AF.linear(o, self.proj.weight, self.proj.bias).to(x.dtype)
 
 
@@ -78,9 +80,38 @@ class DinoVisionTransformer(VisionTransformer):
         x = torch.cat((self.cls_token.expand(x.shape[0], -1, -1).to(x.dtype), x), dim=1)
         return x + self.interpolate_pos_encoding(x.shape[1] - 1).to(x.dtype)
 
+    def pack_tokens(self, x_list: List[torch.Tensor], masks_list: List[Optional[torch.Tensor]]):
+        """prepare_tokens_with_masks of every crop group + the packing of dinov2 block.py:204-217 in one pass per group: the patch
+        GEMM's 16-bit rows, the class token, the mask token and the resized position table are combined in fp32 straight into the
+        group's rows of the packed residual stream (apla_assemble_tokens_masked) — the torch route is where + cat + add + cat, four
+        passes and a 16-bit position add.  Needs the class / mask tokens and the table frozen (they are under APLA)."""
+        groups = []
+        for x in x_list:
+            if x.shape[-1] % self.patch_size or x.shape[-2] != x.shape[-1]:
+                raise ValueError(f"square crops with sides divisible by {self.patch_size} expected, got {tuple(x.shape)}")
+            groups.append((x.shape[0], (x.shape[-1] // self.patch_size) ** 2))
+        mask = BlockDiagonalMask([n + 1 for b, n in groups for _ in range(b)])
+        mask._batch_sizes = [b for b, _ in groups]
+        D = self.embed_dim
+        packed = torch.empty(1, mask.total, D, device=x_list[0].device, dtype=torch.float32)
+        cls = self.cls_token.detach().reshape(-1).float().contiguous()
+        row = 0
+        for x, m, (b, n) in zip(x_list, masks_list, groups):
+            patches = self.patch_embed(x).reshape(b * n, D)
+            pos = self.interpolate_pos_encoding(n).detach().reshape(n + 1, D).float().contiguous()
+            ops.assemble_tokens(patches, cls, pos, b, n, out=packed[0, row:row + b * (n + 1)],
+                                masked=None if m is None else m.reshape(b, n).contiguous(),
+                                mask_token=None if m is None else self.mask_token.detach().reshape(-1).float().contiguous())
+            row += b * (n + 1)
+        return mask, packed
+
     def forward_features_list(self, x_list: List[torch.Tensor], masks_list: List[Optional[torch.Tensor]]):
-        toks = [self.prepare_tokens_with_masks(x, m) for x, m in zip(x_list, masks_list)]
-        attn_bias, x = BlockDiagonalMask.from_tensor_list(toks)
+        if x_list[0].is_cuda and not (self.cls_token.requires_grad or self.pos_embed.requires_grad or self.mask_token.requires_grad
+                                      or any(p.requires_grad for p in self.patch_embed.parameters())):
+            attn_bias, x = self.pack_tokens(x_list, masks_list)
+        else:
+            toks = [self.prepare_tokens_with_masks(x, m) for x, m in zip(x_list, masks_list)]
+            attn_bias, x = BlockDiagonalMask.from_tensor_list(toks)
         for blk in self.blocks:
             if not isinstance(blk.attn, (APLA_MemEffAttention, MemEffAttention)):   # block.py:249
                 raise NotImplementedError("the packed forward needs (APLA_)MemEffAttention blocks (build_apla(..., 'apla_attn_mem_eff'))")

@@ -33,51 +33,27 @@ def softmax_center(x: torch.Tensor, center: torch.Tensor, temp: float) -> torch.
     return out.reshape(x.shape)
 
 
-class _DistillCE(torch.autograd.Function):
-    """sum_r w_r * CE(t_r, softmax(s_r / temp)) with the gradient wrt s produced in the same pass."""
-
-    @staticmethod
-    def forward(ctx, s, t, temp, row_weight, weight):
-        K = s.shape[-1]
-        s2, t2 = s.reshape(-1, K), t.reshape(-1, K)
-        s2 = s2 if s2.stride(-1) == 1 else s2.contiguous()
-        t2 = (t2 if t2.dtype == torch.float32 else t2.float())
-        t2 = t2 if t2.stride(-1) == 1 else t2.contiguous()
-        ops._req(s2, None, "student", 2), ops._req(t2, torch.float32, "teacher", 2)
-        R = s2.shape[0]
-        if t2.shape != s2.shape:
-            raise ValueError(f"distill_ce: student {tuple(s2.shape)} vs teacher {tuple(t2.shape)}")
-        rw = None
-        if row_weight is not None:
-            rw = row_weight.reshape(-1).float().contiguous()
-            if rw.numel() != R:
-                raise ValueError("distill_ce: one weight per row expected")
-        # the gradient in the student's own dtype (what backward returns anyway): a 16-bit student saves the fp32 round trip of a
-        # [rows, 65 536] tensor (iBOT: 1.3 GB written, re-read, scaled and cast per iteration)
-        g16 = s2.dtype == ops.half() and K % 8 == 0 and s2.stride(0) % 8 == 0 and t2.stride(0) % 4 == 0
-        ds = torch.empty(R, K, device=s.device, dtype=s2.dtype if g16 else torch.float32) if s.requires_grad else None
-        row_loss = torch.empty(R, device=s.device, dtype=torch.float32)
-        check(lib().apla_distill_ce_ex(s2.data_ptr(), ops._DT[s2.dtype], s2.stride(0), t2.data_ptr(), t2.stride(0), 1.0 / float(temp),
-                                       ops._ptr(rw), float(weight), ops._ptr(ds), ops._DT[ds.dtype] if ds is not None else ops._DT[torch.float32],
-                                       K, 0, row_loss.data_ptr(), R, K, ops._stream()),
-              "apla_distill_ce")
-        ctx.save_for_backward(ds)
-        ctx.meta = (s.shape, s.dtype)
-        return row_loss.sum()
-
-    @staticmethod
-    def backward(ctx, g):
-        (ds,) = ctx.saved_tensors
-        shape, dtype = ctx.meta
-        if ds.dtype == dtype:   # same-dtype product (a bf16 tensor times an fp32 0-dim tensor takes torch's slow mixed-type kernel)
-            return (ds * g.to(dtype)).reshape(shape), None, None, None, None
-        return (ds * g).reshape(shape).to(dtype), None, None, None, None
+# fp16 only: the factor the trainer will multiply the loss by before backward (its loss scale).  The cross-entropy kernels write the
+# gradient with respect to the student logits in the student's 16-bit type during FORWARD; entries of that gradient are weight / rows
+# times a probability difference — most of them below fp16's smallest normal number — so they are written pre-multiplied by this factor
+# (what GradScaler's scaled backward would have produced) and backward multiplies by (upstream gradient / factor), exactly 1 when the
+# trainer's scale is the hint.  1.0 (bf16, fp32) changes nothing.
+_PRESCALE = 1.0
 
 
-def distill_ce(student, teacher_probs, temp, row_weight=None, weight=1.0):
-    if isinstance(teacher_probs, CenteredTeacher):
-        return _DistillCECentered.apply(student, teacher_probs, temp, row_weight, weight)
-    return _DistillCE.apply(student, teacher_probs, temp, row_weight, weight)
+class grad_prescale:
+    def __init__(self, factor: float):
+        self.factor = float(factor)
+
+    def __enter__(self):
+        global _PRESCALE
+        self._old, _PRESCALE = _PRESCALE, self.factor
+        return self
+
+    def __exit__(self, *exc):
+        global _PRESCALE
+        _PRESCALE = self._old
+        return False
 
 
 class CenteredTeacher:
@@ -104,42 +80,81 @@ class CenteredTeacher:
         return logits.is_cuda and logits.dtype in (ops.half(), torch.float32) and K % 8 == 0 and logits.stride(-1) == 1
 
 
-class _DistillCECentered(torch.autograd.Function):
-    """_DistillCE with the teacher given as (logits, centre, temperature): one kernel, no [rows, K] probability tensor."""
+def launch_distill_ce(s, target, temp, row_weight, weight, want_grad, ds=None):
+    """One launch of the fused cross-entropy over the rows of `s` ([..., K], 16-bit or fp32): `target` is a probability tensor of the
+    same shape or a CenteredTeacher.  Returns (row_loss fp32 [R], ds or None); ds[r, :] = d(sum_r row_loss) / d s[r, :], in the student's
+    16-bit type when it has one (written into `ds` if given: a [R, K] row slice of a larger buffer), else fp32."""
+    K = s.shape[-1]
+    s2 = s.reshape(-1, K)
+    s2 = s2 if s2.stride(-1) == 1 else s2.contiguous()
+    ops._req(s2, None, "student", 2)
+    R = s2.shape[0]
+    rw = None
+    if row_weight is not None:
+        rw = row_weight.reshape(-1).float().contiguous()
+        if rw.numel() != R:
+            raise ValueError("distill_ce: one weight per row expected")
+    centered = isinstance(target, CenteredTeacher)
+    if centered:
+        t2 = target.logits.reshape(-1, K)
+        ops._req(t2, None, "teacher logits", 2)
+        g16 = s2.dtype == ops.half()
+    else:
+        t2 = target.reshape(-1, K)
+        t2 = t2 if t2.dtype == torch.float32 else t2.float()
+        t2 = t2 if t2.stride(-1) == 1 else t2.contiguous()
+        ops._req(t2, torch.float32, "teacher", 2)
+        # the gradient in the student's own dtype (what backward returns anyway): a 16-bit student saves the fp32 round trip of a
+        # [rows, 65 536] tensor (iBOT: 1.3 GB written, re-read, scaled and cast per iteration)
+        g16 = s2.dtype == ops.half() and K % 8 == 0 and s2.stride(0) % 8 == 0 and t2.stride(0) % 4 == 0
+    if t2.shape != s2.shape:
+        raise ValueError(f"distill_ce: student {tuple(s2.shape)} vs teacher {tuple(t2.shape)}")
+    if ds is not None:
+        if not g16 or ds.dtype != s2.dtype or tuple(ds.shape) != (R, K) or ds.stride(1) != 1:
+            raise ValueError("distill_ce: the caller's gradient rows need the student's 16-bit type and shape")
+    elif want_grad:
+        ds = torch.empty(R, K, device=s.device, dtype=s2.dtype if g16 else torch.float32)
+    row_loss = torch.empty(R, device=s.device, dtype=torch.float32)
+    ds_dt = ops._DT[ds.dtype] if ds is not None else ops._DT[torch.float32]
+    ld_ds = ds.stride(0) if ds is not None else K
+    if centered:
+        c = target.center.reshape(-1).float().contiguous()
+        check(lib().apla_distill_ce_centered(s2.data_ptr(), ops._DT[s2.dtype], s2.stride(0), t2.data_ptr(), ops._DT[t2.dtype], t2.stride(0),
+                                             c.data_ptr(), 1.0 / float(temp), 1.0 / target.temp, ops._ptr(rw), float(weight), ops._ptr(ds),
+                                             ds_dt, ld_ds, row_loss.data_ptr(), R, K, ops._stream()), "apla_distill_ce_centered")
+    else:
+        check(lib().apla_distill_ce_ex(s2.data_ptr(), ops._DT[s2.dtype], s2.stride(0), t2.data_ptr(), t2.stride(0), 1.0 / float(temp),
+                                       ops._ptr(rw), float(weight), ops._ptr(ds), ds_dt, ld_ds, 0, row_loss.data_ptr(), R, K, ops._stream()),
+              "apla_distill_ce")
+    return row_loss, ds
+
+
+class _DistillCE(torch.autograd.Function):
+    """sum_r w_r * CE(t_r, softmax(s_r / temp)) with the gradient wrt s produced in the same pass; `t` a probability tensor or a
+    CenteredTeacher (then one kernel, no [rows, K] probability tensor)."""
 
     @staticmethod
-    def forward(ctx, s, teacher, temp, row_weight, weight):
-        K = s.shape[-1]
-        s2, x2 = s.reshape(-1, K), teacher.logits.reshape(-1, K)
-        s2 = s2 if s2.stride(-1) == 1 else s2.contiguous()
-        ops._req(s2, None, "student", 2), ops._req(x2, None, "teacher logits", 2)
-        R = s2.shape[0]
-        if x2.shape != s2.shape:
-            raise ValueError(f"distill_ce: student {tuple(s2.shape)} vs teacher {tuple(x2.shape)}")
-        c = teacher.center.reshape(-1).float().contiguous()
-        rw = None
-        if row_weight is not None:
-            rw = row_weight.reshape(-1).float().contiguous()
-            if rw.numel() != R:
-                raise ValueError("distill_ce: one weight per row expected")
-        g16 = s2.dtype == ops.half()
-        ds = torch.empty(R, K, device=s.device, dtype=s2.dtype if g16 else torch.float32) if s.requires_grad else None
-        row_loss = torch.empty(R, device=s.device, dtype=torch.float32)
-        check(lib().apla_distill_ce_centered(s2.data_ptr(), ops._DT[s2.dtype], s2.stride(0), x2.data_ptr(), ops._DT[x2.dtype], x2.stride(0),
-                                             c.data_ptr(), 1.0 / float(temp), 1.0 / teacher.temp, ops._ptr(rw), float(weight), ops._ptr(ds),
-                                             ops._DT[ds.dtype] if ds is not None else ops._DT[torch.float32], K, row_loss.data_ptr(), R, K,
-                                             ops._stream()), "apla_distill_ce_centered")
+    def forward(ctx, s, t, temp, row_weight, weight):
+        P = _PRESCALE
+        row_loss, ds = launch_distill_ce(s, t, temp, row_weight, weight * P, s.requires_grad)
         ctx.save_for_backward(ds)
-        ctx.meta = (s.shape, s.dtype)
-        return row_loss.sum()
+        ctx.meta = (s.shape, s.dtype, P)
+        total = row_loss.sum()
+        return total if P == 1.0 else total / P
 
     @staticmethod
     def backward(ctx, g):
         (ds,) = ctx.saved_tensors
-        shape, dtype = ctx.meta
-        if ds.dtype == dtype:
+        shape, dtype, P = ctx.meta
+        if P != 1.0:
+            g = g / P
+        if ds.dtype == dtype:   # same-dtype product (a bf16 tensor times an fp32 0-dim tensor takes torch's slow mixed-type kernel)
             return (ds * g.to(dtype)).reshape(shape), None, None, None, None
         return (ds * g).reshape(shape).to(dtype), None, None, None, None
+
+
+def distill_ce(student, teacher_probs, temp, row_weight=None, weight=1.0):
+    return _DistillCE.apply(student, teacher_probs, temp, row_weight, weight)
 
 
 class _CenteredLoss(nn.Module):

@@ -23,7 +23,7 @@ from torch import nn
 from ..apla import build_apla
 from ..models import AttrDict
 from .backbone import DinoVisionTransformer
-from .heads import DINOHead, KoLeoLoss
+from .heads import DINOHead, KoLeoLoss, proto_losses
 from .losses import DINOLoss, iBOTPatchLoss
 
 _GEOMETRY = {"vit_small": (384, 12, 6, False), "vit_base": (768, 12, 12, False), "vit_large": (1024, 24, 16, False),
@@ -103,6 +103,7 @@ class DINOv2(nn.Module):
         self.do_koleo = dino_p.koleo_loss_weight > 0
         self.do_ibot = ibot_p.loss_weight > 0
         self.ibot_separate_head = ibot_p.separate_head
+        self.unfused_losses = False   # True: the module-by-module route of the reference (head, split, one loss object per term)
         if self.ibot_separate_head:
             raise NotImplementedError("ibot.separate_head is false in the shipped config (models.py:160-171 reads an undefined "
                                       "`params.ibot` there)")
@@ -182,9 +183,35 @@ class DINOv2(nn.Module):
             pbuf = s_glob_cls.new_zeros(upper, s_glob_cls.shape[-1])
             pbuf[:n_masked] = sg["x_norm_patchtokens"].flatten(0, 1).index_select(0, idx)
             head_in.append(pbuf)
-        outs = self.student.dino_head(torch.cat(head_in)).split([t.shape[0] for t in head_in])
-        o_loc, o_glob = outs[0], outs[1]
         loss_dict, total = {}, 0
+        loss_scales = 2   # both global crops go through together
+        head = self.student.dino_head
+        if (do_dino and do_ibot and n_local > 0 and centering == "centering" and isinstance(head, DINOHead) and not self.unfused_losses):
+            # one autograd node from the bottleneck features to the three cross-entropy sums (heads._ProtoLosses): same kernels, same
+            # values as the module route below, the [rows, K] gradient written once and read by the two GEMMs only
+            Bc, off = s_loc_cls.shape[0] // n_local, s_loc_cls.shape[0]
+            tsum = t_dino[0].float() + t_dino[1].float()                     # DINOLoss.forward: the targets of one student view add up
+            terms = [(0, i * Bc, (i + 1) * Bc, tsum, self.dino_loss.student_temp, None, 1.0 / Bc) for i in range(n_local)]
+            terms.append((1, off, off + s_glob_cls.shape[0], t_dino.flatten(0, 1), self.dino_loss.student_temp, None, 1.0 / s_glob_cls.shape[0]))
+            off += s_glob_cls.shape[0]
+            terms.append((2, off, off + n_masked, t_ibot[:n_masked], self.ibot_patch_loss.student_temp, masks_weight, 1.0 / masks.shape[0]))
+            sums = proto_losses(head.bottleneck(torch.cat(head_in)), head.prototype_weight(), 3, terms)
+            l = sums[0] / (n_global_terms + n_local_terms)
+            loss_dict["dino_local_crops_loss"] = l
+            total = total + self.dino_loss_weight * l
+            l = sums[1] * loss_scales / (n_global_terms + n_local_terms)
+            loss_dict["dino_global_crops_loss"] = l
+            total = total + self.dino_loss_weight * l
+            if self.do_koleo:
+                kl = self.model_params.dinov2.dino.koleo_loss_weight * sum(self.koleo_loss(p) for p in s_glob_cls.chunk(2))
+                total = total + kl
+                loss_dict["koleo_loss"] = kl / loss_scales
+            l = sums[2] * loss_scales * (1.0 / n_global)
+            loss_dict["ibot_loss"] = l / 2
+            total = total + self.ibot_loss_weight * l
+            return total, loss_dict
+        outs = head(torch.cat(head_in)).split([t.shape[0] for t in head_in])
+        o_loc, o_glob = outs[0], outs[1]
         if do_dino and n_local > 0:
             l = self.dino_loss(student_output_list=o_loc.chunk(n_local), teacher_out_softmaxed_centered_list=t_dino) \
                 / (n_global_terms + n_local_terms)

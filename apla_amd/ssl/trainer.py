@@ -9,16 +9,22 @@ What changes against the reference's loop is where things run, not what they com
 * data parallel: the reference wraps the model in DistributedDataParallel (wrappers.py:73-78).  The trainable set here is
   one flat buffer, so the exchange is ONE all-reduce of it (RCCL, sum; the mean is folded into ``grad_scale``), plus the
   centre all-reduces the losses already issue (losses.py).  No per-step barrier;
-* mixed precision: bf16 operands with fp32 accumulation inside the kernels — no GradScaler (``use_mixed_precision`` with
-  fp16 + dynamic scaling is implemented for the classification step only).
+* mixed precision: 16-bit operands with fp32 accumulation inside the kernels.  ``compute_dtype=torch.bfloat16`` (default) needs
+  no loss scale.  ``compute_dtype=torch.float16`` is the reference's ``use_mixed_precision`` branch (trainer.py:124-135,
+  autocast + GradScaler): the loss is multiplied by the scale before backward, the optimizer unscales inside its norm pass,
+  an iteration whose gradients are not finite leaves parameters, moments and step counts untouched and halves the scale, and
+  ``growth_interval`` finite iterations in a row double it — torch.cuda.amp.GradScaler's defaults and, like it, one host read
+  of the found-inf flag per iteration.
 """
 from typing import Dict, Optional
 
 import torch
 import torch.distributed as dist
 
+from .. import ops
 from ..optim import FlatAdamW
 from .collate import build_schedulers
+from .losses import grad_prescale
 from .models import DINOv2
 
 
@@ -26,7 +32,16 @@ class Dinov2Trainer:
     def __init__(self, model: DINOv2, *, iters_per_epoch: int, epochs: int, lr: float = 1e-4, weight_decay: float = 1e-5,
                  eta_min: float = 1e-6, warmup_epochs: int = 0, grad_clipping: float = 0.0, freeze_last_layer_epochs: int = 0,
                  momentum_teacher: float = 0.994, final_momentum_teacher: float = 1.0, warmup_teacher_temp: float = 0.04,
-                 teacher_temp: float = 0.07, warmup_teacher_temp_epochs: int = 30, schedules=None, process_group=None):
+                 teacher_temp: float = 0.07, warmup_teacher_temp_epochs: int = 30, schedules=None, process_group=None,
+                 compute_dtype=torch.bfloat16, init_scale: float = 65536.0, growth_factor: float = 2.0, backoff_factor: float = 0.5,
+                 growth_interval: int = 2000):
+        if compute_dtype not in (torch.bfloat16, torch.float16):
+            raise TypeError("compute_dtype must be torch.bfloat16 or torch.float16")
+        self.compute_dtype = compute_dtype
+        # GradScaler state (fp16 only): torch.cuda.amp.GradScaler defaults, bases.py / defaults/trainer.py:50-51
+        self.loss_scale = float(init_scale) if compute_dtype == torch.float16 else 1.0
+        self.growth_factor, self.backoff_factor, self.growth_interval = growth_factor, backoff_factor, growth_interval
+        self.growth_tracker, self.skipped_steps = 0, 0
         self.model = model
         self.iters_per_epoch, self.total_iters = iters_per_epoch, iters_per_epoch * epochs
         self.grad_clipping, self.freeze_last_for = grad_clipping, freeze_last_layer_epochs
@@ -51,12 +66,25 @@ class Dinov2Trainer:
         opt = self.optimizer
         opt.lr, opt.weight_decay = lr, wd     # apply_optim_scheduler: one lr for both groups, wd on the regularised group
         opt.zero_grad()
-        loss, loss_dict = self.model(images=batch["images"], teacher_temp=teacher_temp)
-        loss.backward()
+        fp16 = self.compute_dtype == torch.float16
+        with ops.use_half(self.compute_dtype), grad_prescale(self.loss_scale):
+            loss, loss_dict = self.model(images=batch["images"], teacher_temp=teacher_temp)
+            (loss * self.loss_scale if fp16 else loss).backward()      # scaler.scale(loss).backward() (:125)
         if self.world > 1:
             dist.all_reduce(opt.grads, op=dist.ReduceOp.SUM, group=self.pg)
         skip = ("dino_head.last_layer", "ibot_head.last_layer") if (self.freeze_last_for and self.epoch <= self.freeze_last_for) else ()
-        opt.step(max_norm=self.grad_clipping or 0.0, grad_scale=1.0 / self.world, skip=skip)
+        # unscale_ + clip_grad_norm_ + cancel + scaler.step (:126-134): one norm pass with 1/(world * scale) folded in
+        applied = opt.step(max_norm=self.grad_clipping or 0.0, grad_scale=1.0 / (self.world * self.loss_scale), skip=skip,
+                           check_finite=fp16)
+        if fp16:                                                        # scaler.update() (:135)
+            if not applied:
+                self.loss_scale *= self.backoff_factor
+                self.growth_tracker, self.skipped_steps = 0, self.skipped_steps + 1
+            else:
+                self.growth_tracker += 1
+                if self.growth_tracker >= self.growth_interval:
+                    self.loss_scale *= self.growth_factor
+                    self.growth_tracker = 0
         self.model.update_teacher(mom)
         self.loss, self.loss_dict = loss.detach(), {k: v.detach() for k, v in loss_dict.items()}
         self.iters += 1

@@ -324,6 +324,12 @@ int apla_adamw_step_dynamic(float* params, float* grads, float* exp_avg, float* 
 int apla_patchify(const float* images, void* cols, int B, int S, int patch, int Kp, hipStream_t stream);
 int apla_assemble_tokens(const void* patches, int ldp, const float* cls_token, const float* pos_embed, void* tokens,
                          int res_dtype, int B, int Np, int D, hipStream_t stream);
+/* The same with iBOT masking (self_supervised/dinov2/dinov2_vits.py:210-222, prepare_tokens_with_masks): masked uint8 [B, Np]
+ * (non-zero = masked), mask_token fp32 [D]; tokens[b,1+t] = (masked[b,t] ? mask_token : patches[b,t]) + pos[1+t].  Both NULL =
+ * apla_assemble_tokens.  `tokens` may point into a larger buffer (the packed multi-crop batch): rows are written densely. */
+int apla_assemble_tokens_masked(const void* patches, int ldp, const float* cls_token, const float* pos_embed,
+                                const uint8_t* masked, const float* mask_token, void* tokens, int res_dtype, int B, int Np,
+                                int D, hipStream_t stream);
 
 /* Self-distillation losses of the DINOv2-APLA step (dinov2/loss/dino_clstoken_loss.py,
  * dinov2/loss/ibot_patch_loss.py) over rows of K prototype logits (K = 65 536 in the shipped config):

@@ -140,6 +140,7 @@ def test_block_diagonal_mask_api():
     back = mask.split(packed)
     assert all(torch.equal(a, b) for a, b in zip(xs, back))
     m2 = BlockDiagonalMask.from_seqlens([5, 5, 2, 2, 2])
+    assert m2.runs() == [(2, 5), (3, 2)] and BlockDiagonalMask([3, 4, 3]).runs() == [(1, 3), (1, 4), (1, 3)]
     assert [t.shape for t in m2.split(packed)] == [(2, 5, 3), (3, 2, 3)]   # grouping by equal consecutive lengths
     assert mask.cu_seqlens("cpu").dtype == torch.int32 and mask.cu_seqlens("cpu").tolist() == mask.seqstart_py
     dense = mask.materialize()

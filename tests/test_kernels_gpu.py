@@ -288,6 +288,43 @@ def test_attention_block_diagonal_packed(ops, attn_variant, seqlens, H):
         assert torch.equal(o2, o) and torch.equal(lse2.permute(1, 0, 2).reshape(H, total), lse)
 
 
+@pytest.mark.parametrize("half", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("runs,H", [([(6, 257), (24, 50)], 2), ([(3, 197)], 3), ([(2, 33), (260, 50), (1, 300)], 1)])
+def test_attention_packed_as_runs_of_uniform_batches(ops, runs, H, half):
+    """The multi-crop batch as the backbone runs it (functional.attention_core_varlen with the mask's runs): one uniform launch per
+    run of equal-length sequences (260 x 50 tokens takes the persistent backward).  Forward and the three gradients against the
+    oracle's per-sequence attention, and against the one-launch packed kernels on the same operands."""
+    from apla_amd import functional as AF
+    from apla_amd import ops as OPS
+    from apla_amd.nested import BlockDiagonalMask
+    seqlens = [n for c, n in runs for _ in range(c)]
+    mask = BlockDiagonalMask(seqlens)
+    assert mask.runs() == [tuple(r) for r in runs]
+    D, total, scale = 64 * H, sum(seqlens), 64 ** -0.5
+    x = rnd(total, 3 * D, seed=37)
+    dox = rnd(total, D, seed=38)
+    with OPS.use_half(half):
+        qkv = x.to(half)
+        qkvd = qkv.double()
+        oref, lref = O.attention_varlen_fwd(qkvd, seqlens, H, scale)
+        q = dev(qkv).reshape(1, total, 3 * D).requires_grad_(True)
+        o = AF.attention_core_varlen(q, mask.cu_seqlens("cuda"), mask.max_seqlen, H, scale, runs=mask.runs())
+        tol_o = BF16_OUT if half == torch.bfloat16 else BF16_OUT / 8
+        assert o.shape == (1, total, D) and rel_err(o[0].cpu(), oref) < tol_o
+        do = dox.to(half)
+        dref = O.attention_varlen_bwd(do.double(), qkvd, o[0].detach().cpu().double(), lref, seqlens, H, scale)
+        o.backward(dev(do).reshape(1, total, D))
+        got = q.grad[0].cpu()
+        for i, nm in enumerate(("dq", "dk", "dv")):
+            e = rel_err(got[:, i * D:(i + 1) * D], dref[:, i * D:(i + 1) * D])
+            assert e < (2e-2 if half == torch.bfloat16 else 3e-3), (nm, e)
+        # the packed one-launch path on the same operands: same forward bits (same kernel body per sequence)
+        q2 = dev(qkv).reshape(1, total, 3 * D).requires_grad_(True)
+        o2 = AF.attention_core_varlen(q2, mask.cu_seqlens("cuda"), mask.max_seqlen, H, scale)
+        if max(seqlens) <= 288:
+            assert torch.equal(o2, o)
+
+
 @pytest.mark.parametrize("attn_variant", [0, 1], indirect=True)
 def test_attention_online_softmax_rescale_branch(ops, attn_variant):
     """Force the running max to jump at a later key block (guide rule 26): one key spikes against every query."""

@@ -81,6 +81,42 @@ def test_packed_multicrop_forward_equals_one_pass_per_resolution():
     assert not bb.mask_token.requires_grad     # build_apla freezes everything but the selected projection rows (apla_vit.py:51-59)
 
 
+@pytest.mark.parametrize("half", [torch.bfloat16, torch.float16])
+def test_packed_tokens_kernel_against_the_torch_route(half):
+    """pack_tokens (apla_assemble_tokens_masked into the packed residual stream) against prepare_tokens_with_masks of the reference
+    (dinov2_vits.py:210-222: mask-token replacement, class token, resized position table) evaluated in fp32 on the kernel's own
+    16-bit patch rows — exact up to fp32 rounding; and the mask bookkeeping of the packed batch."""
+    from apla_amd import ops as OPS
+    bb = _student()
+    with torch.no_grad():
+        bb.cls_token.normal_(std=0.3)
+        bb.pos_embed.normal_(std=0.3)
+    g = torch.Generator().manual_seed(2)
+    glob, loc = torch.randn(3, 3, 64, 64, generator=g).cuda(), torch.randn(5, 3, 32, 32, generator=g).cuda()
+    masks = (torch.rand(3, 16, generator=g) < 0.5).cuda()
+    masks[1] = False
+    with OPS.use_half(half), torch.no_grad():
+        mask, packed = bb.pack_tokens([glob, loc], [masks, None])
+        assert packed.dtype == torch.float32 and packed.shape == (1, 3 * 17 + 5 * 5, 128)
+        assert mask.seqlens == [17] * 3 + [5] * 5 and mask.runs() == [(3, 17), (5, 5)] and mask._batch_sizes == [3, 5]
+        row = 0
+        for x, m in ((glob, masks), (loc, None)):
+            pt = bb.patch_embed(x).float()
+            if m is not None:
+                pt = torch.where(m.unsqueeze(-1), bb.mask_token.float().unsqueeze(0), pt)
+            ref = torch.cat((bb.cls_token.float().expand(x.shape[0], -1, -1), pt), dim=1) + bb.interpolate_pos_encoding(pt.shape[1]).float()
+            got = packed[0, row:row + ref.shape[0] * ref.shape[1]].reshape(ref.shape)
+            assert float((got - ref).abs().max()) < 1e-6
+            row += ref.shape[0] * ref.shape[1]
+        # the list forward takes this route when the tokens are frozen (they are under APLA), the torch route otherwise
+        outs = bb.forward_features_list([glob, loc], [masks, None])
+        bb.cls_token.requires_grad_(True)
+        outs2 = bb.forward_features_list([glob, loc], [masks, None])
+        bb.cls_token.requires_grad_(False)
+        for a, b in zip(outs, outs2):
+            assert rel_err(a["x_norm_patchtokens"].float().cpu(), b["x_norm_patchtokens"].double().cpu()) < (2e-2 if half == torch.bfloat16 else 3e-3)
+
+
 def test_update_teacher_ema_touches_only_trainable_tensors():
     from apla_amd.ssl import update_teacher
     student = _student(seed=0)

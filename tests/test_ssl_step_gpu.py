@@ -47,8 +47,16 @@ def build_from_golden(g, tag):
     return model.cuda().train()
 
 
-@pytest.mark.parametrize("tag", ["apla", "full"])
-def test_two_iterations_match_reference(tag):
+# bounds per operand dtype: (loss, loss terms rel, grad norm rel, gradients, update mismatch, teacher, centres)
+BOUNDS = {torch.bfloat16: dict(loss=2e-2, term=2e-2, gnorm=3e-2, grad=4e-2, upd=0.15, teacher=5e-3, center=2e-2),
+          torch.float16: dict(loss=5e-4, term=1.5e-3, gnorm=5e-3, grad=8e-3, upd=0.012, teacher=5e-3, center=2e-3)}
+# measured (r4j): bf16 loss 2.9e-4, gnorm 9.3e-3, grad 1.9e-2, upd 4.2e-2, centre 5.2e-3; fp16 loss 5.7e-5, term 3.5e-4, gnorm 2.2e-3,
+# grad 4.5e-3, upd 4.0e-3, centre 5.3e-4.  The teacher deviation (1.7e-3 / 2.7e-3) does not depend on the operand type: it is the EMA of
+# Adam's first, sign-like steps.
+
+
+def run_two_iterations(tag, half, **trainer_kw):
+    """Two iterations on golden G12's inputs; returns the worst relative deviation of every compared quantity."""
     from apla_amd.ssl import CosineScheduler, Dinov2Trainer
     g = load_golden(f"g12_ssl_step_{tag}.npz")
     model = build_from_golden(g, tag)
@@ -57,8 +65,10 @@ def test_two_iterations_match_reference(tag):
     sched = (CosineScheduler(base_value=1e-3, final_value=1e-6, total_iters=6, warmup_iters=2, start_warmup_value=0),
              CosineScheduler(base_value=0.04, final_value=1e-4, total_iters=6), CosineScheduler(base_value=0.9, final_value=1.0, total_iters=6),
              CosineScheduler(base_value=0.07, final_value=0.07, total_iters=3, warmup_iters=3, start_warmup_value=0.04), None)
-    tr = Dinov2Trainer(model, iters_per_epoch=1, epochs=6, grad_clipping=3.0, freeze_last_layer_epochs=1, schedules=sched)
+    tr = Dinov2Trainer(model, iters_per_epoch=1, epochs=6, grad_clipping=3.0, freeze_last_layer_epochs=1, schedules=sched,
+                       compute_dtype=half, **trainer_kw)
     sp, tp = dict(model.student.named_parameters()), dict(model.teacher.named_parameters())
+    worst = dict(loss=0.0, term=0.0, gnorm=0.0, grad=0.0, upd=0.0, teacher=0.0, center=0.0)
     for it in (1, 2):
         images = {"collated_global_crops": t(g[f"it{it}.glob"]), "collated_local_crops": t(g[f"it{it}.loc"]),
                   "collated_masks": t(g[f"it{it}.masks"]), "mask_indices_list": t(g[f"it{it}.mask_indices"]),
@@ -67,14 +77,14 @@ def test_two_iterations_match_reference(tag):
         before_last = {n: p.detach().clone() for n, p in sp.items() if "last_layer" in n}
         loss = tr.global_step({"images": images})
         torch.cuda.synchronize()
-        assert abs(float(loss) - float(g[f"it{it}.loss"])) < 2e-2 * float(g[f"it{it}.loss"])
+        worst["loss"] = max(worst["loss"], abs(float(loss) - float(g[f"it{it}.loss"])) / float(g[f"it{it}.loss"]))
         for k, v in tr.loss_dict.items():
             ref = float(g[f"it{it}.ld.{k}"])
-            assert abs(float(v) - ref) < 2e-2 * abs(ref) + 2e-3, (k, float(v), ref)
+            worst["term"] = max(worst["term"], max(abs(float(v) - ref) - 2e-3 * (half == torch.bfloat16), 0.0) / abs(ref))
         gn = float(tr.optimizer.grad_norm())
-        assert abs(gn - float(g[f"it{it}.gnorm"])) < 3e-2 * float(g[f"it{it}.gnorm"])
+        worst["gnorm"] = max(worst["gnorm"], abs(gn - float(g[f"it{it}.gnorm"])) / float(g[f"it{it}.gnorm"]))
         for n in trainable:     # the optimizer leaves the clipped gradients in place, like clip_grad_norm_
-            assert rel_err(sp[n].grad.cpu(), g[f"it{it}.g.{n}"]) < 4e-2, (it, n)
+            worst["grad"] = max(worst["grad"], rel_err(sp[n].grad.cpu(), g[f"it{it}.g.{n}"]))
         for n in trainable:
             # Adam's first steps move every element by ~lr whatever the gradient's size: compare the UPDATE, loosely
             ref_new, ref_old = t(g[f"it{it}.student.{n}"]), (t(g[f"it{it - 1}.student.{n}"]) if it > 1 else t(g["init." + n]))
@@ -82,12 +92,89 @@ def test_two_iterations_match_reference(tag):
             if it == 1 and "last_layer" in n:   # frozen for the first epoch: untouched
                 assert torch.equal(sp[n].detach(), before_last[n]) and float(ref_upd.abs().max()) == 0.0
                 continue
-            assert float((upd - ref_upd).abs().mean() / (ref_upd.abs().mean() + 1e-12)) < 0.15, (it, n)
-            assert rel_err(tp[n].detach().cpu(), g[f"it{it}.teacher.{n}"]) < 5e-3, (it, n)   # (1 - m) x a few sign-flipped lr steps
+            worst["upd"] = max(worst["upd"], float((upd - ref_upd).abs().mean() / (ref_upd.abs().mean() + 1e-12)))
+            worst["teacher"] = max(worst["teacher"], rel_err(tp[n].detach().cpu(), g[f"it{it}.teacher.{n}"]))   # (1 - m) x a few sign-flipped lr steps
     model.dino_loss.apply_center_update()
     model.ibot_patch_loss.apply_center_update()
-    assert rel_err(model.dino_loss.center.cpu(), g["dino.center"]) < 2e-2
-    assert rel_err(model.ibot_patch_loss.center.cpu(), g["ibot.center"]) < 2e-2
+    worst["center"] = max(rel_err(model.dino_loss.center.cpu(), g["dino.center"]), rel_err(model.ibot_patch_loss.center.cpu(), g["ibot.center"]))
+    return worst, tr
+
+
+@pytest.mark.parametrize("half", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("tag", ["apla", "full"])
+def test_two_iterations_match_reference(tag, half):
+    """bf16: no loss scale.  fp16: the reference's ``use_mixed_precision`` branch (GradScaler; an initial scale the two iterations do
+    not overflow at) — the same comparison within bounds 5-40x tighter than bf16's (fp16 rounds 8x finer)."""
+    worst, tr = run_two_iterations(tag, half, **({"init_scale": 1024.0} if half == torch.float16 else {}))
+    print(f"G12 {tag} {half}: " + ", ".join(f"{k} {v:.2e}" for k, v in worst.items()))
+    if half == torch.float16:
+        assert tr.skipped_steps == 0 and tr.loss_scale == 1024.0 and tr.growth_tracker == 2
+    bad = {k: (v, BOUNDS[half][k]) for k, v in worst.items() if not v < BOUNDS[half][k]}
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("half", [torch.bfloat16, torch.float16])
+def test_fused_head_losses_equal_the_module_route(half):
+    """DINOv2.forward's one-node route from the bottleneck features to the three cross-entropy sums (heads._ProtoLosses) against the
+    reference-shaped route (head -> split -> DINOLoss / iBOTPatchLoss objects): identical loss values (same kernels on the same
+    rows), gradients equal up to the place the upstream scalar is applied (rows of the [rows, 256] operands instead of the [rows, K]
+    gradient)."""
+    from apla_amd import ops as OPS
+    from apla_amd.ssl.losses import grad_prescale
+    g = load_golden("g12_ssl_step_apla.npz")
+    images = {"collated_global_crops": t(g["it1.glob"]), "collated_local_crops": t(g["it1.loc"]), "collated_masks": t(g["it1.masks"]),
+              "mask_indices_list": t(g["it1.mask_indices"]), "masks_weight": t(g["it1.masks_weight"]), "upperbound": int(g["it1.upperbound"]),
+              "n_masked_patches": torch.tensor([len(g["it1.mask_indices"])])}
+    res = {}
+    for unfused in (True, False):
+        model = build_from_golden(g, "apla")
+        model.unfused_losses = unfused
+        scale = 256.0 if half == torch.float16 else 1.0
+        with OPS.use_half(half), grad_prescale(scale):
+            loss, ld = model(images=images, teacher_temp=0.05)
+            (loss * scale).backward()
+        res[unfused] = (float(loss), {k: float(v) for k, v in ld.items()},
+                        {n: p.grad.detach().float().cpu() / scale for n, p in model.student.named_parameters() if p.requires_grad})
+    assert res[True][0] == res[False][0] and res[True][1] == res[False][1]
+    for n, ga in res[True][2].items():
+        assert rel_err(res[False][2][n], ga) < (2e-2 if half == torch.bfloat16 else 3e-3), n
+
+
+def test_fp16_dynamic_loss_scale_skips_and_backs_off():
+    """GradScaler semantics (self_supervised/dinov2/trainer.py:124-135): a scale the fp16 gradients overflow at must leave
+    parameters, moments and step counts untouched, halve the scale and reset the growth counter; iterations then resume and
+    `growth_interval` finite ones in a row double the scale."""
+    from apla_amd.ssl import CosineScheduler, Dinov2Trainer
+    g = load_golden("g12_ssl_step_apla.npz")
+    model = build_from_golden(g, "apla")
+    sched = (CosineScheduler(base_value=1e-3, final_value=1e-3, total_iters=80), CosineScheduler(base_value=0.04, final_value=0.04, total_iters=80),
+             CosineScheduler(base_value=0.9, final_value=0.9, total_iters=80), CosineScheduler(base_value=0.07, final_value=0.07, total_iters=80), None)
+    tr = Dinov2Trainer(model, iters_per_epoch=80, epochs=1, grad_clipping=3.0, schedules=sched, compute_dtype=torch.float16,
+                       init_scale=2.0 ** 40, growth_interval=3)
+    images = {"collated_global_crops": t(g["it1.glob"]), "collated_local_crops": t(g["it1.loc"]), "collated_masks": t(g["it1.masks"]),
+              "mask_indices_list": t(g["it1.mask_indices"]), "masks_weight": t(g["it1.masks_weight"]), "upperbound": int(g["it1.upperbound"]),
+              "n_masked_patches": torch.tensor([len(g["it1.mask_indices"])])}
+    before = tr.optimizer.flat.clone()
+    scales, skipped, applied = [], 0, 0
+    for i in range(70):
+        s0, k0 = tr.loss_scale, tr.skipped_steps
+        tr.global_step({"images": images})
+        if tr.skipped_steps > k0:                       # overflow: nothing moved, scale halved, growth counter reset
+            skipped += 1
+            assert tr.loss_scale == s0 * 0.5 and tr.growth_tracker == 0
+            if skipped == i + 1:                        # nothing applied so far: state exactly as built
+                assert torch.equal(tr.optimizer.flat, before) and float(tr.optimizer.exp_avg.abs().max()) == 0.0
+                assert all(st == 0 for st in tr.optimizer.steps)
+        else:
+            applied += 1
+        scales.append(tr.loss_scale)
+        if applied >= 7:
+            break
+    assert skipped >= 5 and tr.skipped_steps == skipped          # 2^40 overflows fp16 gradients for sure
+    assert applied == 7 and max(tr.optimizer.steps) == applied   # only applied iterations count (bias corrections)
+    assert not torch.equal(tr.optimizer.flat, before) and bool(torch.isfinite(tr.optimizer.flat).all())
+    assert any(b == 2 * a for a, b in zip(scales, scales[1:]))   # three finite iterations in a row doubled the scale
+    assert np.isfinite(float(tr.loss))
 
 
 def test_flat_adamw_matches_torch_adamw():
