@@ -349,6 +349,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
 // every wave walks the keys on its own — no per-block staging through registers, no further barriers.  Two workgroups
 // per CU (56 KB of LDS each at N = 197).
 constexpr int SMALL_MAX_ROWS = 288;   // up to nine 32-row blocks: also the 257-token sequences of ViT-*/14 at 224 px
+constexpr int TINY_MAX_ROWS = 64;       // two 32-row blocks: the fused backward at two waves and 17 KB of LDS
 constexpr int SMALL_MAX_ROWS_BWD = 288;  // the fused backward also takes the 257-token sequences of ViT-*/14 at 224 px (9 blocks of 32 rows)
 
 __global__ __launch_bounds__(576, 4) void attn_fwd_small_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
@@ -756,11 +757,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __rest
 //            to the caller's buffer), then the dQ body (S^T, dP^T, dQ^T += K^T dS^T) over the resident key tiles;
 //   phase 2  the SAME LDS buffer is refilled with Q, dO; each wave, for its key blocks: the dK/dV body (S, dP,
 //            dV^T += dO^T P, dK^T += Q^T dS) over the resident query tiles.
+// MAXR = rows the LDS layout holds, NW = waves per workgroup.  <288, 4> is the general form; <64, 2> the one for sequences of at
+// most 64 tokens (the 50-token local crops of the multi-crop batch: 17 KB of LDS and two waves, four workgroups per CU, where the
+// general form would hold 76 KB and leave two of its four waves without a block).
 // Four waves per workgroup, wave w owns the 32-row blocks w, w+4 (and w+8): 58 KB of LDS at N = 197 and 256 threads, so TWO
 // workgroups share a CU and one's loads / stores run under the other's products (a first version with one 7-wave workgroup
 // per CU and all four tiles resident, 116 KB, serialised them: 139 us; the split kernels: 150 us).  Same seven products in
 // the same order as the split kernels: bitwise equal to them.
-__global__ __launch_bounds__(256, 2) void attn_bwd_small_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
+template <int MAXR, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void attn_bwd_small_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
                                                                 const bf16* __restrict__ dout, const float* __restrict__ lse,
                                                                 float* __restrict__ delta, bf16* __restrict__ dqkv, int Nmax,
                                                                 int H, float scale, const int32_t* __restrict__ cu, int total,
@@ -782,11 +787,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_small_kernel(const bf16* __re
   const bf16* base = qkv + (long)sq.start * ld + h * 64;
   const bf16* dobase = dout + (long)sq.start * D + h * 64;
   const float c = scale * LOG2E;
-  constexpr int TB_OFF = SMALL_MAX_ROWS_BWD * 128;   // byte distance TA -> TB
+  constexpr int TB_OFF = MAXR * 128;   // byte distance TA -> TB
   char* TA = smem;            // K, later Q
   char* TB = smem + TB_OFF;   // V, later dO
   float* lses2 = (float*)(smem + 2 * TB_OFF);
-  float* dls = lses2 + SMALL_MAX_ROWS_BWD;
+  float* dls = lses2 + MAXR;
   const int nt = (N + 31) / 32;   // 32-row blocks of this sequence
   const int npc = NP / 8;         // 1 KB pieces (8 rows x 128 B) per tile
   const FragOffs fo = frag_offs(lane);
@@ -796,7 +801,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_small_kernel(const bf16* __re
   // both tiles of a phase: 2 * npc pieces, dealt round-robin to the four waves; swizzle on the source column (the LDS side
   // of a DMA is lane-linear)
   auto stage = [&](const bf16* srcA, long ldA, const bf16* srcB, long ldB) {
-    for (int pc = wave; pc < 2 * npc; pc += 4) {     // wave-uniform
+    for (int pc = wave; pc < 2 * npc; pc += NW) {     // wave-uniform
       const bool isb = pc >= npc;
       const int pr = isb ? pc - npc : pc;
       const int row = pr * 8 + (lane >> 3);
@@ -810,7 +815,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_small_kernel(const bf16* __re
 
   // ================================================================ phase 1: K, V resident; delta and dQ per query block
   stage(base + D, ld, base + 2 * D, ld);
-  for (int blk = wave, first = 1; blk < SMALL_MAX_ROWS_BWD / 32 + 3; blk += 4, first = 0) {   // the barrier below is reached by every wave exactly once
+  for (int blk = wave, first = 1; blk < MAXR / 32 + NW - 1; blk += NW, first = 0) {   // the barrier below is reached by every wave exactly once
     const bool active = blk < nt;
     int r = blk * 32 + (lane & 31);
     const bool rvalid = active && r < N;
@@ -892,7 +897,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_small_kernel(const bf16* __re
 
   // ================================================================ phase 2: Q, dO resident; dK and dV per key block
   stage(base, ld, dobase, D);
-  for (int blk = wave, first = 1; blk < SMALL_MAX_ROWS_BWD / 32 + 3; blk += 4, first = 0) {
+  for (int blk = wave, first = 1; blk < MAXR / 32 + NW - 1; blk += NW, first = 0) {
     const bool active = blk < nt;
     int r = blk * 32 + (lane & 31);
     const bool rvalid = active && r < N;
@@ -1506,7 +1511,7 @@ static int launch_attn_bwd(const void* qkv, const void* o, const void* d_o, cons
   // uniform batch of short sequences with at least one head per CU: the persistent kernel (every load one phase ahead of its use);
   // variant 2 pins the one-workgroup-per-head kernel below, variant 3 the persistent one wherever it applies (tests, A/B timing)
   if (cu == nullptr && N <= PERSIST_MAX_ROWS && g_attn_variant != 1 && g_attn_variant != 2 &&
-      (g_attn_variant == 3 || (long)B * H >= apla_num_cus())) {
+      (g_attn_variant == 3 || ((long)B * H >= apla_num_cus() && N > TINY_MAX_ROWS))) {
     const int NP = (N + 31) / 32 * 32, BH = B * H;
     const int nt = NP / 32;
     const bool staged = nt <= 7;       // 4 tiles + 2 KB + 8 x 4 KB of store buffers: 162 KB at eight blocks, one CU has 160
@@ -1528,12 +1533,20 @@ static int launch_attn_bwd(const void* qkv, const void* o, const void* d_o, cons
     APLA_CHECK_LAUNCH(who);
     return APLA_OK;
   }
+  if (N <= TINY_MAX_ROWS && g_attn_variant != 1) {       // the same kernel at 64 rows and two waves (see the kernel)
+    const int NP = (N + 31) / 32 * 32;
+    const size_t lds = (size_t)TINY_MAX_ROWS * (2 * 128 + 8);
+    hipLaunchKernelGGL((attn_bwd_small_kernel<TINY_MAX_ROWS, 2>), dim3(H, B), dim3(128), lds, stream, (const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse, delta, (bf16*)dqkv, N, H, scale, cu, total, NP);
+    APLA_CHECK_LAUNCH(who);
+    return APLA_OK;
+  }
   if (N <= SMALL_MAX_ROWS_BWD && g_attn_variant != 1) {  // one workgroup per head, operands read from HBM once (see the kernel)
     const int NP = (N + 31) / 32 * 32;
     const size_t lds = (size_t)SMALL_MAX_ROWS_BWD * (2 * 128 + 8);   // two tiles at a fixed distance + lse*log2e + delta
     static std::atomic<unsigned long long> lds_ok{0};   // > 64 KB of dynamic LDS
-    apla_allow_lds(lds_ok, (const void*)attn_bwd_small_kernel, (int)lds);
-    hipLaunchKernelGGL(attn_bwd_small_kernel, dim3(H, B), dim3(256), lds, stream, (const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse, delta, (bf16*)dqkv, N, H, scale, cu, total, NP);
+    auto kern = attn_bwd_small_kernel<SMALL_MAX_ROWS_BWD, 4>;
+    apla_allow_lds(lds_ok, (const void*)kern, (int)lds);
+    hipLaunchKernelGGL(kern, dim3(H, B), dim3(256), lds, stream, (const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse, delta, (bf16*)dqkv, N, H, scale, cu, total, NP);
     APLA_CHECK_LAUNCH(who);
     return APLA_OK;
   }

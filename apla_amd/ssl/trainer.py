@@ -6,8 +6,11 @@ What changes against the reference's loop is where things run, not what they com
 * clip + AdamW: ``FlatAdamW`` (apla_grad_sumsq / apla_adamw_apply over one flat buffer) instead of ``clip_grad_norm_`` +
   ``torch.optim.AdamW`` walking a dozen tensors; ``possibly_cancel_last_layer_grads`` (trainer.py:84-90) becomes the
   optimizer's ``skip=`` list — same effect: the prototype layer is left out of the update but not out of the norm;
-* data parallel: the reference wraps the model in DistributedDataParallel (wrappers.py:73-78).  The trainable set here is
-  one flat buffer, so the exchange is ONE all-reduce of it (RCCL, sum; the mean is folded into ``grad_scale``), plus the
+* data parallel: the reference wraps the model in DistributedDataParallel (wrappers.py:73-78), whose buckets are reduced while
+  backward still runs.  The trainable set here is one flat buffer (97 MB at config 4, 92 MB of it the head); it is exchanged in
+  chunks of at most ``exchange_chunk_mb`` of consecutive tensors, each all-reduce (RCCL, sum; the mean is folded into
+  ``grad_scale``) issued on a side stream by the hook of the chunk's last gradient — the prototype layer's 67 MB leave as soon
+  as the head's backward has produced them and travel under the backbone's backward — and joined before the norm pass; plus the
   centre all-reduces the losses already issue (losses.py).  No per-step barrier;
 * mixed precision: 16-bit operands with fp32 accumulation inside the kernels.  ``compute_dtype=torch.bfloat16`` (default) needs
   no loss scale.  ``compute_dtype=torch.float16`` is the reference's ``use_mixed_precision`` branch (trainer.py:124-135,
@@ -22,6 +25,7 @@ import torch
 import torch.distributed as dist
 
 from .. import ops
+from ..dist import GradExchanger
 from ..optim import FlatAdamW
 from .collate import build_schedulers
 from .losses import grad_prescale
@@ -34,7 +38,7 @@ class Dinov2Trainer:
                  momentum_teacher: float = 0.994, final_momentum_teacher: float = 1.0, warmup_teacher_temp: float = 0.04,
                  teacher_temp: float = 0.07, warmup_teacher_temp_epochs: int = 30, schedules=None, process_group=None,
                  compute_dtype=torch.bfloat16, init_scale: float = 65536.0, growth_factor: float = 2.0, backoff_factor: float = 0.5,
-                 growth_interval: int = 2000):
+                 growth_interval: int = 2000, exchange_chunk_mb: float = 32.0, force_exchange: bool = False):
         if compute_dtype not in (torch.bfloat16, torch.float16):
             raise TypeError("compute_dtype must be torch.bfloat16 or torch.float16")
         self.compute_dtype = compute_dtype
@@ -53,10 +57,51 @@ class Dinov2Trainer:
             iters_per_epoch=iters_per_epoch, total_iters=self.total_iters)
         self.optimizer = FlatAdamW(model.student.named_parameters(), lr=lr, weight_decay=weight_decay)
         self.pg = process_group
-        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.world = GradExchanger.world_of(process_group)
+        self._setup_exchange(exchange_chunk_mb, force_exchange)
         self.iters, self.epoch = 1, 1    # the reference counts from 1 (bases.py; trainer.py:96-99 indexes the schedules with it)
         self.loss: Optional[torch.Tensor] = None
         self.loss_dict: Dict[str, torch.Tensor] = {}
+
+    def _setup_exchange(self, chunk_mb: float, force: bool):
+        """Chunks of consecutive tensors of the flat gradient buffer (a tensor larger than the budget is a chunk of its own) and one
+        post-accumulate hook per tensor: the hook of the last tensor of a chunk to receive its gradient starts the chunk's all-reduce."""
+        opt = self.optimizer
+        budget, chunks, owner = int(chunk_mb * 2 ** 20 / 4), [], []
+        lo = 0
+        for i, (a, b) in enumerate(zip(opt.offsets[:-1], opt.offsets[1:])):
+            if b - lo > budget and a > lo:
+                chunks.append((lo, a))
+                lo = a
+            owner.append(len(chunks))
+        chunks.append((lo, opt.offsets[-1]))
+        self.exchanger = GradExchanger(opt.grads, chunks, self.pg, always=force)
+        self._chunk_size = [owner.count(k) for k in range(len(chunks))]
+        self._chunk_seen, self._chunk_sent = [0] * len(chunks), [False] * len(chunks)
+        if not self.exchanger.active:
+            return
+
+        def make_hook(k):
+            def hook(_param):
+                self._chunk_seen[k] += 1
+                if self._chunk_seen[k] == self._chunk_size[k] and not self._chunk_sent[k]:
+                    self._chunk_sent[k] = True
+                    self.exchanger.launch_chunk(k)
+            return hook
+        for p, k in zip(opt.params, owner):
+            p.register_post_accumulate_grad_hook(make_hook(k))
+
+    def _finish_exchange(self):
+        """After backward: chunks whose tensors did not all receive a gradient this iteration (none in the shipped configuration) go
+        now; then the compute stream waits for the side stream."""
+        ex = self.exchanger
+        if not ex.active:
+            return
+        for k, sent in enumerate(self._chunk_sent):
+            if not sent:
+                ex.launch_chunk(k)
+        ex.wait()
+        self._chunk_seen, self._chunk_sent = [0] * len(ex.chunks), [False] * len(ex.chunks)
 
     def global_step(self, batch) -> torch.Tensor:
         """``batch`` is the collate's dictionary (``batch['images']`` holds the crops and the mask bookkeeping)."""
@@ -70,8 +115,7 @@ class Dinov2Trainer:
         with ops.use_half(self.compute_dtype), grad_prescale(self.loss_scale):
             loss, loss_dict = self.model(images=batch["images"], teacher_temp=teacher_temp)
             (loss * self.loss_scale if fp16 else loss).backward()      # scaler.scale(loss).backward() (:125)
-        if self.world > 1:
-            dist.all_reduce(opt.grads, op=dist.ReduceOp.SUM, group=self.pg)
+        self._finish_exchange()
         skip = ("dino_head.last_layer", "ibot_head.last_layer") if (self.freeze_last_for and self.epoch <= self.freeze_last_for) else ()
         # unscale_ + clip_grad_norm_ + cancel + scaler.step (:126-134): one norm pass with 1/(world * scale) folded in
         applied = opt.step(max_norm=self.grad_clipping or 0.0, grad_scale=1.0 / (self.world * self.loss_scale), skip=skip,

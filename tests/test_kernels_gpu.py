@@ -239,7 +239,7 @@ def attn_variant(request):
 
 @pytest.mark.parametrize("attn_variant", [0, 1, 2, 3], indirect=True)
 @pytest.mark.parametrize("B,N,H", [(2, 197, 2), (1, 64, 1), (3, 300, 3), (1, 1, 1), (2, 129, 2), (1, 1370, 1), (2, 256, 3),
-                                   (1, 33, 2), (2, 224, 1), (2, 257, 2), (3, 288, 1), (5, 225, 2)])
+                                   (1, 33, 2), (2, 224, 1), (2, 257, 2), (3, 288, 1), (5, 225, 2), (7, 50, 3), (3, 32, 1), (2, 65, 1)])
 def test_attention_fwd_bwd(ops, attn_variant, B, N, H):
     D = 64 * H
     scale = 64 ** -0.5

@@ -133,7 +133,7 @@ def test_fused_head_losses_equal_the_module_route(half):
         with OPS.use_half(half), grad_prescale(scale):
             loss, ld = model(images=images, teacher_temp=0.05)
             (loss * scale).backward()
-        res[unfused] = (float(loss), {k: float(v) for k, v in ld.items()},
+        res[unfused] = (float(loss.detach()), {k: float(v.detach()) for k, v in ld.items()},
                         {n: p.grad.detach().float().cpu() / scale for n, p in model.student.named_parameters() if p.requires_grad})
     assert res[True][0] == res[False][0] and res[True][1] == res[False][1]
     for n, ga in res[True][2].items():
