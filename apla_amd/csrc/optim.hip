@@ -7,14 +7,42 @@
 namespace {
 constexpr int NPART = 256;
 
+// One thread's share of sum (g[i] * scale)^2 over [0, n): 16-byte loads, four of them in flight per trip (a one-float-per-trip loop
+// is a chain of dependent HBM round trips: 146 us for the 97 MB of the self-supervised step's gradients, 0.66 TB/s).  The order of
+// the additions is fixed by (n, grid), so the result is deterministic.
+__device__ inline float sumsq_strided(const float* __restrict__ g, long n, float scale) {
+  const long tid = (long)blockIdx.x * 256 + threadIdx.x, nthr = (long)NPART * 256;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  long n4 = 0;
+  if ((reinterpret_cast<uintptr_t>(g) & 15) == 0) {
+    n4 = n / 4;
+    const f32x4* g4 = reinterpret_cast<const f32x4*>(g);
+    long i = tid;
+    for (; i + 3 * nthr < n4; i += 4 * nthr) {
+      const f32x4 a = g4[i], b = g4[i + nthr], c = g4[i + 2 * nthr], d = g4[i + 3 * nthr];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float va = a[e] * scale, vb = b[e] * scale, vc = c[e] * scale, vd = d[e] * scale;
+        s0 += va * va; s1 += vb * vb; s2 += vc * vc; s3 += vd * vd;
+      }
+    }
+    for (; i < n4; i += nthr) {
+      const f32x4 a = g4[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float v = a[e] * scale; s0 += v * v; }
+    }
+  }
+  for (long i = n4 * 4 + tid; i < n; i += nthr) {
+    const float v = g[i] * scale;
+    s1 += v * v;
+  }
+  return (s0 + s1) + (s2 + s3);
+}
+
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n, float grad_scale,
                                                     float* __restrict__ ws) {
   __shared__ float red[4];
-  float s = 0.f;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)NPART * 256) {
-    const float v = g[i] * grad_scale;
-    s += v * v;
-  }
+  float s = sumsq_strided(g, n, grad_scale);
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
@@ -83,11 +111,7 @@ __global__ __launch_bounds__(256) void sumsq_dyn_kernel(const float* __restrict_
                                                         float* __restrict__ ws) {
   __shared__ float red[4];
   const float gs = grad_scale / scaler[3 * parity];
-  float s = 0.f;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)NPART * 256) {
-    const float v = g[i] * gs;
-    s += v * v;
-  }
+  float s = sumsq_strided(g, n, gs);
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
