@@ -11,7 +11,7 @@ python -m pytest tests -m gpu -q -p no:cacheprovider > $O/pytest_gpu.txt 2>&1; t
 tools/mfma_peak 1.0 > $O/mfma_peak.json 2>&1
 [ -x tools/dma_probe ] && tools/dma_probe > $O/dma_probe.txt 2>&1
 python bench.py > $O/bench.json 2> $O/bench.err; tail -c 1500 $O/bench.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-parity --no-peak-probe > $O/trace_bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-parity --no-peak-probe --no-fp16-leg > $O/trace_bench.log 2>&1
 python3 tools/summarize_prof.py $(find $O/trace -name "*kernel_stats.csv") 14 --cfg2 > $O/kernel_stats.md
 cp $(find $O/trace -name "*kernel_stats.csv") $O/kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do
