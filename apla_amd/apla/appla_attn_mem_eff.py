@@ -15,9 +15,11 @@ from ..nested import BlockDiagonalMask
 
 
 class APLA_MemEffAttention(APLA_Attention):
-    def forward(self, x, attn_bias=None, ls_gamma=None):
+    def forward(self, x, attn_bias=None, ls_gamma=None, rows=None):
         """``ls_gamma`` (extension): the block's frozen LayerScale vector; when given the result is ls1(attention(x)), the
-        scale being folded into the projection GEMM (apla_amd/ssl/backbone.py uses it on the packed path)."""
+        scale being folded into the projection GEMM (apla_amd/ssl/backbone.py uses it on the packed path).
+        ``rows`` (extension, packed path): int64 row indices; only those token rows of the attention output are projected and
+        returned ([1, len(rows), C]) — the last block of a backbone whose consumers read a subset of its tokens."""
         if attn_bias is None:
             y, _ = super().forward(x, ls_gamma)
             return y
@@ -30,4 +32,6 @@ class APLA_MemEffAttention(APLA_Attention):
         qkv = AF.linear(x, self.qkv.weight, self.qkv.bias)
         o = AF.attention_core_varlen(qkv, attn_bias.cu_seqlens(x.device), attn_bias.max_seqlen, self.num_heads, self.scale,
                                         runs=attn_bias.runs())
+        if rows is not None:
+            o = o.index_select(1, rows)
         return self._project(o, ls_gamma).to(x.dtype)

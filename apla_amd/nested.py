@@ -88,6 +88,13 @@ class BlockDiagonalMask:
             self._cu[device] = torch.tensor(self.seqstart_py, dtype=torch.int32, device=device)
         return self._cu[device]
 
+    def seq_starts(self, device) -> torch.Tensor:
+        """int64 [S]: first packed row of every sequence (the row of its class token), on `device`."""
+        key = ("starts", torch.device(device))
+        if key not in self._cu:
+            self._cu[key] = torch.tensor(self.seqstart_py[:-1], dtype=torch.long, device=device)
+        return self._cu[key]
+
     def materialize(self, dtype=torch.float32, device="cpu") -> torch.Tensor:
         """Dense additive bias [total, total] (0 inside a block, -inf outside): for tests and the CPU oracle only."""
         m = torch.full((self.total, self.total), float("-inf"), dtype=dtype, device=device)

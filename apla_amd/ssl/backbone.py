@@ -25,7 +25,7 @@ class MemEffAttention(Attention):
     the module the backbone keeps when ``partial_size: full`` leaves the projection un-split (apla_vit.py:66-75: the whole
     ``attn.proj`` Linear is trainable; its dW runs on the same TN MFMA kernel with r = D)."""
 
-    def forward(self, x, attn_bias=None):
+    def forward(self, x, attn_bias=None, rows=None):
         if attn_bias is None:
             return super().forward(x)[0]
         if not isinstance(attn_bias, BlockDiagonalMask):
@@ -36,6 +36,8 @@ class MemEffAttention(Attention):
         qkv = AF.linear(x, self.qkv.weight, self.qkv.bias)
         o = AF.attention_core_varlen(qkv, attn_bias.cu_seqlens(x.device), attn_bias.max_seqlen, self.num_heads, self.scale,
                                         runs=attn_bias.runs())
+        if rows is not None:
+            o = o.index_select(1, rows)
         return AF.linear(o, self.proj.weight, self.proj.bias).to(x.dtype)
 
 
@@ -121,6 +123,33 @@ class DinoVisionTransformer(VisionTransformer):
             outs.append({"x_norm_clstoken": x_norm[:, 0], "x_norm_regtokens": x_norm[:, 1:1], "x_norm_patchtokens": x_norm[:, 1:],
                          "x_prenorm": xi, "masks": masks})
         return outs
+
+    def forward_cls_and_masked(self, x_list: List[torch.Tensor], masks_list: List[Optional[torch.Tensor]],
+                               masked_idx: Optional[torch.Tensor] = None):
+        """What the DINOv2 meta-architecture reads of ``forward_features_list`` (models.py:231-347): the normalised class token of
+        every crop, and the normalised patch tokens of the FIRST crop group at ``masked_idx`` (int64 indices into its
+        [crops * patches] patch tokens: the collate's ``mask_indices_list``).  Same values; the last block's projection, MLP and
+        both LayerNorms around it run on those rows only (every token still attends and is attended to: the block's K / V are
+        dense), forward and backward — 5 519 of the student's 58 496 and 5 007 of the teacher's 32 896 rows at config 4.
+        Returns ([cls of group 0, cls of group 1, ...], masked patch tokens or None)."""
+        if x_list[0].is_cuda and not (self.cls_token.requires_grad or self.pos_embed.requires_grad or self.mask_token.requires_grad
+                                      or any(p.requires_grad for p in self.patch_embed.parameters())):
+            attn_bias, x = self.pack_tokens(x_list, masks_list)
+        else:
+            attn_bias, x = BlockDiagonalMask.from_tensor_list([self.prepare_tokens_with_masks(x, m) for x, m in zip(x_list, masks_list)])
+        for blk in self.blocks:
+            if not isinstance(blk.attn, (APLA_MemEffAttention, MemEffAttention)):
+                raise NotImplementedError("the packed forward needs (APLA_)MemEffAttention blocks (build_apla(..., 'apla_attn_mem_eff'))")
+        rows, counts = [attn_bias.seq_starts(x.device)], list(attn_bias._batch_sizes)
+        if masked_idx is not None and masked_idx.numel():
+            n0 = attn_bias.seqlens[0] - 1                                   # patches per crop of group 0
+            rows.append(masked_idx + torch.div(masked_idx, n0, rounding_mode="floor") + 1)    # crop s, patch t -> row s (n0 + 1) + 1 + t
+        rows = torch.cat(rows)
+        _, x_norm = self.run_blocks(x, attn_bias, last_rows=rows)
+        x_norm = x_norm[0]
+        n_cls = sum(counts)
+        cls = list(x_norm[:n_cls].split(counts))
+        return cls, (x_norm[n_cls:] if len(rows) > n_cls else None)
 
     def forward_features_dict(self, x, masks=None):
         if isinstance(x, (list, tuple)):

@@ -103,6 +103,7 @@ class DINOv2(nn.Module):
         self.do_koleo = dino_p.koleo_loss_weight > 0
         self.do_ibot = ibot_p.loss_weight > 0
         self.ibot_separate_head = ibot_p.separate_head
+        self.sparse_last_block = True  # False: every block on every token, as the reference runs it (forward_features_list)
         self.unfused_losses = False   # True: the module-by-module route of the reference (head, split, one loss object per term)
         if self.ibot_separate_head:
             raise NotImplementedError("ibot.separate_head is false in the shipped config (models.py:160-171 reads an undefined "
@@ -145,15 +146,21 @@ class DINOv2(nn.Module):
         centering = self.model_params.dinov2.centering
         do_dino, do_ibot = self.do_dino, self.do_ibot
 
+        sparse = self.sparse_last_block and hasattr(self.teacher.backbone, "forward_cls_and_masked")
         with torch.no_grad():   # ---- teacher (models.py:231-300)
-            tout = self.teacher.backbone(glob, is_training=True)
-            a, b = tout["x_norm_clstoken"].chunk(n_global)
+            if sparse:   # the same tokens, the last block's token-wise part on the rows read here only (backbone.forward_cls_and_masked)
+                (t_cls_tok,), t_masked = self.teacher.backbone.forward_cls_and_masked([glob], [None], idx if do_ibot else None)
+            else:
+                tout = self.teacher.backbone(glob, is_training=True)
+                t_cls_tok = tout["x_norm_clstoken"]
+                t_masked = tout["x_norm_patchtokens"].flatten(0, 1).index_select(0, idx) if do_ibot else None
+            a, b = t_cls_tok.chunk(n_global)
             tcls = torch.cat((b, a))     # swapped halves: crop A's student is matched with crop B's teacher
             n_cls = tcls.shape[0]
             if do_ibot:
                 buf = tcls.new_zeros(upper + n_cls, tcls.shape[-1])
                 buf[:n_cls] = tcls
-                buf[n_cls:n_cls + n_masked] = tout["x_norm_patchtokens"].flatten(0, 1).index_select(0, idx)
+                buf[n_cls:n_cls + n_masked] = t_masked
                 after = self.teacher.dino_head(buf)
                 tcls_h, tpatch_h = after[:n_cls], after[n_cls:n_cls + n_masked]
             else:
@@ -176,12 +183,16 @@ class DINOv2(nn.Module):
                 raise NotImplementedError(centering)
 
         # ---- student: one packed pass over both resolutions (models.py:306-308), one head pass (models.py:326-347)
-        sg, sl = self.student.backbone([glob, loc], masks=[masks, None], is_training=True)
-        s_loc_cls, s_glob_cls = sl["x_norm_clstoken"], sg["x_norm_clstoken"]
+        if sparse:
+            (s_glob_cls, s_loc_cls), s_masked = self.student.backbone.forward_cls_and_masked([glob, loc], [masks, None], idx if do_ibot else None)
+        else:
+            sg, sl = self.student.backbone([glob, loc], masks=[masks, None], is_training=True)
+            s_loc_cls, s_glob_cls = sl["x_norm_clstoken"], sg["x_norm_clstoken"]
+            s_masked = sg["x_norm_patchtokens"].flatten(0, 1).index_select(0, idx) if do_ibot else None
         head_in = [s_loc_cls, s_glob_cls]
         if do_ibot:
             pbuf = s_glob_cls.new_zeros(upper, s_glob_cls.shape[-1])
-            pbuf[:n_masked] = sg["x_norm_patchtokens"].flatten(0, 1).index_select(0, idx)
+            pbuf[:n_masked] = s_masked
             head_in.append(pbuf)
         loss_dict, total = {}, 0
         loss_scales = 2   # both global crops go through together

@@ -197,21 +197,30 @@ class VisionTransformer(nn.Module):
                                          recompute_scale_factor=False)
         return torch.cat((pe[:, :1], grid.permute(0, 2, 3, 1).reshape(1, -1, dim)), dim=1)
 
-    def run_blocks(self, x, attn_bias=None):
+    def run_blocks(self, x, attn_bias=None, last_rows=None):
         """All blocks + the final norm on a token tensor ([B, N, D], or packed [1, total, D] with a BlockDiagonalMask):
         x += ls1(attn(norm1 x)); x += ls2(mlp(norm2 x)) (vit.py:279-288).  The residual stream is kept in fp32, every residual
         add is fused into the LayerNorm that follows it (AF.add_layer_norm: one pass forward, one pass backward) and frozen
         LayerScale vectors are folded into the GEMM that produces the branch (APLA projection / fc2) — what the fused engine
         does, here for the autograd path.  Blocks whose attention / MLP are not the modules of this package, or whose
-        LayerScale is trainable, go through their own forward.  Returns (x_prenorm fp32, x_norm bf16)."""
+        LayerScale is trainable, go through their own forward.  Returns (x_prenorm fp32, x_norm bf16).
+        ``last_rows`` (packed batches): int64 row indices the caller will read of the result.  Everything behind the last block's
+        attention product is token-wise, so that block projects, normalises and runs its MLP on those rows only and the result is
+        [1, len(last_rows), D]; autograd scatters the two gradients (attention output, residual stream) back into zero rows."""
         res, branch = x.float(), None
-        for blk in self.blocks:
+        n_blocks = len(self.blocks)
+        for bi, blk in enumerate(self.blocks):
             if branch is None:
                 h = AF.layer_norm(res, blk.norm1)
             else:
                 res, h = AF.add_layer_norm(res, branch, blk.norm1)
             g1, g2 = getattr(blk.ls1, "gamma", None), getattr(blk.ls2, "gamma", None)
             kw = {} if attn_bias is None else {"attn_bias": attn_bias}
+            if last_rows is not None and bi == n_blocks - 1:
+                if attn_bias is None:
+                    raise ValueError("last_rows needs a packed batch")
+                kw["rows"] = last_rows
+                res = res.index_select(1, last_rows)
             if hasattr(blk.attn, "_project") and (g1 is None or not g1.requires_grad):   # APLA attention: scale folded into the projection
                 y = blk.attn(h, ls_gamma=g1, **kw)
                 y = y[0] if isinstance(y, tuple) else y

@@ -140,6 +140,31 @@ def test_fused_head_losses_equal_the_module_route(half):
         assert rel_err(res[False][2][n], ga) < (2e-2 if half == torch.bfloat16 else 3e-3), n
 
 
+def test_sparse_last_block_equals_the_dense_forward():
+    """DINOv2.forward with the last block's token-wise part on the rows the losses read (class tokens + masked patches:
+    backbone.forward_cls_and_masked) against every block on every token: same losses and gradients up to the 16-bit rounding of
+    GEMMs that run at another row count (another kernel schedule), for the student and through the teacher's targets."""
+    g = load_golden("g12_ssl_step_apla.npz")
+    images = {"collated_global_crops": t(g["it1.glob"]), "collated_local_crops": t(g["it1.loc"]), "collated_masks": t(g["it1.masks"]),
+              "mask_indices_list": t(g["it1.mask_indices"]), "masks_weight": t(g["it1.masks_weight"]), "upperbound": int(g["it1.upperbound"]),
+              "n_masked_patches": torch.tensor([len(g["it1.mask_indices"])])}
+    res = {}
+    for sparse in (False, True):
+        model = build_from_golden(g, "apla")
+        model.sparse_last_block = sparse
+        loss, ld = model(images=images, teacher_temp=0.05)
+        loss.backward()
+        res[sparse] = (float(loss.detach()), {k: float(v.detach()) for k, v in ld.items()},
+                       {n: p.grad.detach().float().cpu() for n, p in model.student.named_parameters() if p.requires_grad})
+    assert abs(res[True][0] - res[False][0]) < 2e-3 * abs(res[False][0])
+    for k, v in res[False][1].items():
+        assert abs(res[True][1][k] - v) < 3e-3 * abs(v) + 1e-4, k
+    for n, ga in res[False][2].items():
+        assert rel_err(res[True][2][n], ga) < 3e-2, n
+    # block 0 .. depth-2 see the scattered gradients: their trainable rows must have received something everywhere
+    assert all(float(gr.abs().max()) > 0 for gr in res[True][2].values())
+
+
 def test_fp16_dynamic_loss_scale_skips_and_backs_off():
     """GradScaler semantics (self_supervised/dinov2/trainer.py:124-135): a scale the fp16 gradients overflow at must leave
     parameters, moments and step counts untouched, halve the scale and reset the growth counter; iterations then resume and
