@@ -243,24 +243,25 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
 }
 
 // 16-bit input, many rows (the iBOT centre: the column mean of a [~5000, 65536] teacher output): 256 columns per workgroup,
-// four per lane and access, its four waves take the rows i = w, w + 4, ... four at a time; fp32 sums, combined in wave order
-__global__ __launch_bounds__(256) void colsum16_kernel(const bf16* __restrict__ X, long ld, float* __restrict__ out, int M, int N) {
-  __shared__ f32x4 red[4][64];
+// four per lane and access; its sixteen waves take the rows i = w, w + 16, ... eight at a time (a CU holds one workgroup per
+// column group: 16 waves x 8 loads of 512 B keep 64 KB in flight per CU); fp32 sums, combined in wave order
+__global__ __launch_bounds__(1024) void colsum16_kernel(const bf16* __restrict__ X, long ld, float* __restrict__ out, int M, int N) {
+  __shared__ f32x4 red[16][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = blockIdx.x * 256 + lane * 4;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   if (j < N) {
     int i = wave;
-    for (; i + 12 < M; i += 16) {
-      bf16x4 v[4];
+    for (; i + 7 * 16 < M; i += 8 * 16) {
+      bf16x4 v[8];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = *(const bf16x4*)(X + (long)(i + 4 * u) * ld + j);
+      for (int u = 0; u < 8; ++u) v[u] = *(const bf16x4*)(X + (long)(i + 16 * u) * ld + j);
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < 8; ++u)
 #pragma unroll
         for (int e = 0; e < 4; ++e) s[e] += (float)v[u][e];
     }
-    for (; i < M; i += 4) {
+    for (; i < M; i += 16) {
       const bf16x4 v = *(const bf16x4*)(X + (long)i * ld + j);
 #pragma unroll
       for (int e = 0; e < 4; ++e) s[e] += (float)v[e];
@@ -268,7 +269,12 @@ __global__ __launch_bounds__(256) void colsum16_kernel(const bf16* __restrict__ 
   }
   red[wave][lane] = s;
   __syncthreads();
-  if (wave == 0 && j < N) *(f32x4*)(out + j) = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+  if (wave == 0 && j < N) {
+    f32x4 t = red[0][lane];
+#pragma unroll
+    for (int v = 1; v < 16; ++v) t += red[v][lane];
+    *(f32x4*)(out + j) = t;
+  }
 }
 
 }  // namespace
@@ -597,6 +603,89 @@ __global__ __launch_bounds__(256) void distill_ce_centered_kernel(const ST* __re
   }
 }
 
+// The same for 16-bit rows of at most 65 536 logits, ONE pass over HBM: a workgroup of 16 waves holds its row of student and
+// teacher logits in registers (eight 16-byte pieces of each per thread) between the statistics and the gradient.  The two-pass
+// kernel above re-reads both rows for the gradient; at iBOT's 4 879 x 65 536 the second read misses every cache (1.2 GB of rows
+// in flight): 640 KB per row and 638 us, against 384 KB here.
+template <typename HT>
+__global__ __launch_bounds__(1024) void distill_ce_centered_row_kernel(const HT* __restrict__ s, long lds, const HT* __restrict__ x, long ldx,
+                                                                       const float* __restrict__ center, float inv_temp_s, float inv_temp_t,
+                                                                       const float* __restrict__ row_weight, float weight,
+                                                                       HT* __restrict__ ds, long ldds, float* __restrict__ row_loss, int K) {
+  __shared__ float red[5][16];
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const HT* sr = s + (long)r * lds;
+  const HT* xr = x + (long)r * ldx;
+  const float w = row_weight != nullptr ? row_weight[r] * weight : weight;
+  typedef HT h16x8 __attribute__((ext_vector_type(8)));
+  h16x8 sv[8], xv[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = (j * 1024 + tid) * 8;
+    if (k < K) { sv[j] = *(const h16x8*)(sr + k); xv[j] = *(const h16x8*)(xr + k); }
+  }
+  float ms = -INFINITY, ss = 0.f, mt = -INFINITY, st = 0.f, dt = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = (j * 1024 + tid) * 8;
+    if (k >= K) continue;
+    float z[8], y[8], c[8];
+    ld8f<float>(center + k, c);
+    float vs = -INFINITY, vt = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      z[e] = (float)sv[j][e] * inv_temp_s;
+      y[e] = ((float)xv[j][e] - c[e]) * inv_temp_t;
+      vs = fmaxf(vs, z[e]); vt = fmaxf(vt, y[e]);
+    }
+    if (vs > ms) { ss *= __expf(ms - vs); ms = vs; }
+    if (vt > mt) { const float f = __expf(mt - vt); st *= f; dt *= f; mt = vt; }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      ss += __expf(z[e] - ms);
+      const float pe = __expf(y[e] - mt);
+      st += pe;
+      dt += pe * z[e];
+    }
+  }
+  // workgroup statistics: per wave, then the sixteen wave results in wave order (deterministic)
+  {
+    const float wms = wave_max(ms), wmt = wave_max(mt);
+    const float fs = ms == -INFINITY ? 0.f : __expf(ms - wms), ft = mt == -INFINITY ? 0.f : __expf(mt - wmt);
+    const float wss = wave_sum(ss * fs), wst = wave_sum(st * ft), wdt = wave_sum(dt * ft);
+    if (lane == 0) { red[0][wave] = wms; red[1][wave] = wss; red[2][wave] = wmt; red[3][wave] = wst; red[4][wave] = wdt; }
+    __syncthreads();
+    ms = red[0][0]; mt = red[2][0];
+#pragma unroll
+    for (int v = 1; v < 16; ++v) { ms = fmaxf(ms, red[0][v]); mt = fmaxf(mt, red[2][v]); }
+    ss = 0.f; st = 0.f; dt = 0.f;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const float a = red[0][v] == -INFINITY ? 0.f : __expf(red[0][v] - ms), b = red[2][v] == -INFINITY ? 0.f : __expf(red[2][v] - mt);
+      ss += red[1][v] * a; st += red[3][v] * b; dt += red[4][v] * b;
+    }
+  }
+  const float lse = ms + __logf(ss), inv_t = 1.0f / st;
+  if (tid == 0) row_loss[r] = w * (lse - dt * inv_t);
+  if (ds == nullptr) return;
+  HT* dr = ds + (long)r * ldds;
+  const float cw = w * inv_temp_s;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = (j * 1024 + tid) * 8;
+    if (k >= K) continue;
+    float c[8];
+    ld8f<float>(center + k, c);
+    f32x4 g0, g1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      g0[e] = cw * (__expf((float)sv[j][e] * inv_temp_s - lse) - __expf(((float)xv[j][e] - c[e]) * inv_temp_t - mt) * inv_t);
+      g1[e] = cw * (__expf((float)sv[j][4 + e] * inv_temp_s - lse) - __expf(((float)xv[j][4 + e] - c[4 + e]) * inv_temp_t - mt) * inv_t);
+    }
+    st8f<HT>(dr + k, g0, g1, false);
+  }
+}
+
 // workgroups per row: enough of them to fill the chip when the call has few rows; a slice is a multiple of one workgroup pass
 static inline int wide_row_split(int R, int K, int* slice) {
   int S = R >= 512 ? 1 : (1024 + R - 1) / R;
@@ -672,6 +761,12 @@ extern "C" int apla_distill_ce_centered(const void* student, int s_dtype, long l
   APLA_REQUIRE(apla_aligned16(student) && apla_aligned16(teacher_logits) && apla_aligned16(center) && lds % (s_dtype == APLA_F32 ? 4 : 8) == 0 &&
                ldx % (x_dtype == APLA_F32 ? 4 : 8) == 0 && (dstudent == nullptr || (apla_aligned16(dstudent) && ldds % (g16 ? 8 : 4) == 0)),
                "apla_distill_ce_centered: rows must be 16-byte aligned");
+  if (s_dtype == APLA_H16 && x_dtype == APLA_H16 && (dstudent == nullptr || g16) && K >= 8192 && K <= 65536 && R >= 256) {
+    hipLaunchKernelGGL(distill_ce_centered_row_kernel<bf16>, dim3(R), dim3(1024), 0, stream, (const bf16*)student, lds, (const bf16*)teacher_logits, ldx,
+                       center, inv_temp_s, inv_temp_t, row_weight, weight, (bf16*)dstudent, ldds, row_loss, K);
+    APLA_CHECK_LAUNCH("apla_distill_ce_centered");
+    return APLA_OK;
+  }
   int slice = K;
   const int S = dstudent != nullptr ? wide_row_split(R, K, &slice) : 1;
 #define DCC(ST, XT, GT) hipLaunchKernelGGL((distill_ce_centered_kernel<ST, XT, GT>), dim3(S, R), dim3(256), 0, stream, (const ST*)student, lds, (const XT*)teacher_logits, ldx, center, inv_temp_s, inv_temp_t, row_weight, weight, (GT*)dstudent, ldds, row_loss, K, slice)
@@ -779,7 +874,7 @@ extern "C" int apla_colsum(const float* X, long ld, float* out, int M, int N, hi
 extern "C" int apla_colsum_h16(const void* X, long ld, float* out, int M, int N, hipStream_t stream) {
   APLA_REQUIRE(X && out && M > 0 && N > 0 && N % 4 == 0 && ld % 4 == 0 && ld >= N && (((uintptr_t)X) & 7) == 0 && apla_aligned16(out),
                "apla_colsum_h16: [M, N] 16-bit matrix with N %% 4 == 0 and 8-byte aligned rows");
-  hipLaunchKernelGGL(colsum16_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, (const bf16*)X, ld, out, M, N);
+  hipLaunchKernelGGL(colsum16_kernel, dim3((N + 255) / 256), dim3(1024), 0, stream, (const bf16*)X, ld, out, M, N);
   APLA_CHECK_LAUNCH("apla_colsum_h16");
   return APLA_OK;
 }

@@ -84,6 +84,7 @@ def test_distill_ce_at_shipped_width_and_16bit_student():
 
 
 @pytest.mark.parametrize("R,K,sdt,xdt", [(24, 65536, torch.bfloat16, torch.bfloat16), (700, 1024, torch.float32, torch.float32),
+                                         (300, 65536, torch.bfloat16, torch.bfloat16), (260, 9000, torch.bfloat16, torch.bfloat16),   # one-pass row kernel
                                          (5, 512, torch.bfloat16, torch.float32)])
 def test_centered_teacher_inside_the_cross_entropy(R, K, sdt, xdt):
     """iBOT's targets left as (teacher logits, centre, temperature) and computed inside the cross-entropy kernel
