@@ -34,8 +34,10 @@ constexpr int APLA_GEMM_TAGS = 9;   // tags 0 .. 8 (1 is not used: the profiler'
 // 8-wave ping-pong kernel (gemm_pp2.hip); returns APLA_ENOSYS when the shape / (epilogue, dtype) is not covered there
 int apla_gemm_pp2_launch(const GemmParams& p, int epilogue, int out_dtype, hipStream_t stream);
 bool apla_gemm_pp2_covers(int M, int N, int K, long lda, long ldw, int epilogue, int out_dtype);
+int apla_gemm_pp2_tile_rows(int M, int N, int epilogue, int out_dtype, int exp, int reserve);   // 320, or 256 where that takes fewer tile-rows of work
 int apla_gemm_w4_launch(const GemmParams& p, int epilogue, int out_dtype, hipStream_t stream);   // gemm_w4.hip
 bool apla_gemm_w4_covers(int M, int N, int K, long lda, long ldw, int epilogue, int out_dtype);
+int apla_gemm_w4_tile_rows(int M, int N, int epilogue, int out_dtype, int exp, int reserve);    // 160, or 128
 int apla_gemm_tp_launch(const GemmParams& p, int epilogue, int out_dtype, hipStream_t stream);   // gemm_tp.hip
 bool apla_gemm_tp_covers(int M, int N, int K, long lda, long ldw, int epilogue, int out_dtype, int w_panel);
 
@@ -391,8 +393,8 @@ __device__ __forceinline__ void gelu8_fwd(f32x4 lo, f32x4 hi, bf16x8& h) {
 // r at chunk c ^ (r >> 1): conflict-free both ways) so that a store instruction writes 8 rows x 128 B = whole cache lines.
 // In the MFMA layout a wave instruction covers 16 rows x 64 B, and a CU then stores at ~23 GB/s whatever the rest of the
 // chip does; with whole lines one CU reaches ~80 GB/s and only the chip-wide HBM rate bounds it (tools/store_probe.hip).
-template <int EPI, typename OutT>
-__device__ __forceinline__ void wide_epilogue(const GemmParams& p, f32x4 (&acc)[5][8], const float* bias_lds, char* tbuf,
+template <int EPI, typename OutT, int MI = 5>   // MI: 16-row fragments per wave (wave tile 16 MI x 128)
+__device__ __forceinline__ void wide_epilogue(const GemmParams& p, f32x4 (&acc)[MI][8], const float* bias_lds, char* tbuf,
                                               int m0, int n0, int wm, int wn, int lane, bool full_tile) {
   using E = WideEpi<EPI, OutT>;
   using AuxT = typename E::AuxT;
@@ -406,7 +408,7 @@ __device__ __forceinline__ void wide_epilogue(const GemmParams& p, f32x4 (&acc)[
     for (int u = 0; u < 4; ++u) {
       const f32x4 blo = *(const f32x4*)(bias_lds + ncol + 32 * u), bhi = *(const f32x4*)(bias_lds + ncol + 32 * u + 4);
 #pragma unroll
-      for (int i = 0; i < 5; ++i) { acc[i][2 * u] += blo; acc[i][2 * u + 1] += bhi; }
+      for (int i = 0; i < MI; ++i) { acc[i][2 * u] += blo; acc[i][2 * u + 1] += bhi; }
     }
   }
   if constexpr (E::LINES) {
@@ -415,7 +417,7 @@ __device__ __forceinline__ void wide_epilogue(const GemmParams& p, f32x4 (&acc)[
     const int rrow = lane >> 3, rc = lane & 7;
     const char* rd0 = tbuf + rrow * 128 + ((rc ^ (rrow >> 1)) << 4);
     const char* rd1 = tbuf + (rrow + 8) * 128 + ((rc ^ ((rrow + 8) >> 1)) << 4);
-    const int mbase = m0 + wm * 80 + rrow;
+    const int mbase = m0 + wm * (16 * MI) + rrow;
     const size_t cbase = (size_t)n0 + wn * 128 + rc * 8;
     // One buffer, software-pipelined: LDS serves a wave's operations in order, so the writes of step k+1 may be issued
     // right behind the reads of step k; the global stores of step k go out while step k+1's round trip is in flight.
@@ -443,7 +445,7 @@ __device__ __forceinline__ void wide_epilogue(const GemmParams& p, f32x4 (&acc)[
     auto run = [&](auto FULL) {
       if constexpr (EPI == APLA_EPI_GELU_FWD) {   // like GELU below, one output: no cross-step registers
 #pragma unroll
-        for (int k = 0; k < 10; ++k) {
+        for (int k = 0; k < 2 * MI; ++k) {
           const int i = k >> 1, h = k & 1;
           bf16x8 hc0, hc1, n0_, n1_;
           gelu8_fwd(acc[i][4 * h], acc[i][4 * h + 1], hc0);
@@ -455,17 +457,17 @@ __device__ __forceinline__ void wide_epilogue(const GemmParams& p, f32x4 (&acc)[
       } else if constexpr (EPI == APLA_EPI_STORE) {
         bf16x8 p0, p1;  // step k-1, read back and waiting to be stored
 #pragma unroll
-        for (int k = 0; k <= 10; ++k) {
+        for (int k = 0; k <= 2 * MI; ++k) {
           const int i = k >> 1, h = k & 1;
           bf16x8 n0_, n1_;
-          if (k < 10)
+          if (k < 2 * MI)
             stage(Vec8IO<bf16>::pack(acc[i][4 * h], acc[i][4 * h + 1]), Vec8IO<bf16>::pack(acc[i][4 * h + 2], acc[i][4 * h + 3]), n0_, n1_);
           if (k > 0) commit(FULL, (bf16*)p.C, p.ldc, false, (k - 1) >> 1, (k - 1) & 1, p0, p1);
           p0 = n0_; p1 = n1_;
         }
       } else {  // GELU: the two outputs of a step overlap each other; no cross-step registers (the kernel has none to spare)
 #pragma unroll
-        for (int k = 0; k < 10; ++k) {
+        for (int k = 0; k < 2 * MI; ++k) {
           const int i = k >> 1, h = k & 1;
           bf16x8 hc0, gc0, hc1, gc1, n0_, n1_, m0_, m1_;
           gelu8(acc[i][4 * h], acc[i][4 * h + 1], hc0, gc0);
@@ -487,7 +489,7 @@ __device__ __forceinline__ void wide_epilogue(const GemmParams& p, f32x4 (&acc)[
   }
   AuxRegs<AuxT> aux[2][4];  // two rows in flight
   auto row_ptr = [&](int i) {
-    int mr = m0 + wm * 80 + i * 16 + frow;
+    int mr = m0 + wm * (16 * MI) + i * 16 + frow;
     mr = mr < p.M ? mr : p.M - 1;
     return (const AuxT*)p.aux_in + (size_t)mr * p.ld_aux_in + n0 + ncol;
   };
@@ -496,12 +498,12 @@ __device__ __forceinline__ void wide_epilogue(const GemmParams& p, f32x4 (&acc)[
     asm_load_row4<AuxT>(aux[1], row_ptr(1));
   }
 #pragma unroll
-  for (int i = 0; i < 5; ++i) {
+  for (int i = 0; i < MI; ++i) {
     if constexpr (E::HAS_AUX) {
       // operations issued after row i's loads: row i+1's loads (if any) and, from i >= 1, the stores of row i-1
       constexpr int LN = E::L, SN = E::S;
       if (i == 0) wait_vmcnt<LN>();
-      else if (i < 4) { if (full_tile) wait_vmcnt<LN + SN>(); else wait_vmcnt<LN>(); }
+      else if (i < MI - 1) { if (full_tile) wait_vmcnt<LN + SN>(); else wait_vmcnt<LN>(); }
       else { if (full_tile) wait_vmcnt<SN>(); else wait_vmcnt<0>(); }
 #pragma unroll
       for (int u = 0; u < 4; ++u) asm_wait_pin<AuxT>(aux[i & 1][u]);
@@ -513,7 +515,7 @@ __device__ __forceinline__ void wide_epilogue(const GemmParams& p, f32x4 (&acc)[
         else { acc[i][2 * u] += alo; acc[i][2 * u + 1] += ahi; }
       }
     }
-    const int m = m0 + wm * 80 + i * 16 + frow;
+    const int m = m0 + wm * (16 * MI) + i * 16 + frow;
     if (m < p.M) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -534,7 +536,7 @@ __device__ __forceinline__ void wide_epilogue(const GemmParams& p, f32x4 (&acc)[
     }
     asm volatile("" ::: "memory");
     if constexpr (E::HAS_AUX) {
-      if (i + 2 < 5) asm_load_row4<AuxT>(aux[i & 1], row_ptr(i + 2));
+      if (i + 2 < MI) asm_load_row4<AuxT>(aux[i & 1], row_ptr(i + 2));
     }
   }
 }

@@ -517,7 +517,7 @@ extern "C" int apla_gemm_nt_kernel_name(int M, int N, int K, int epilogue, int o
   APLA_REQUIRE(buf && buflen >= 48 && M > 0 && N > 0 && K > 0, "apla_gemm_nt_kernel_name: bad arguments");
   static const char* const epi_names[] = {"STORE", "GELU", "RESIDUAL", "MUL", "SWIGLU", "SWIGLU_BWD", "GELU_FWD"};
   APLA_REQUIRE(epilogue >= 0 && epilogue <= 6, "apla_gemm_nt_kernel_name: unknown epilogue %d", epilogue);
-  const int v = (flags >> 8) & 0xff, w_panel = (flags >> 16) & 15;
+  const int v = (flags >> 8) & 0xff, w_panel = (flags >> 16) & 15, reserve = (flags >> 20) & 0xff, exp = (flags >> 28) & 7;
   const Sched sc = pick_schedule(epilogue, out_dtype, M, N, K, (w_panel & 2) ? 32 : K, (w_panel & 1) ? 32 : K, w_panel, v == 0 ? 4 : (v == 1 ? 0 : v));
 #if defined(APLA_FP16)
   const char* ot = out_dtype == APLA_F32 ? "float" : "f16";
@@ -525,7 +525,9 @@ extern "C" int apla_gemm_nt_kernel_name(int M, int N, int K, int epilogue, int o
   const char* ot = out_dtype == APLA_F32 ? "float" : "bf16";
 #endif
   if (sc.kind == 4) snprintf(buf, buflen, "gemm_tp_kernel<%s,%s>", epi_names[epilogue], ot);
+  else if (sc.kind == 3 && apla_gemm_w4_tile_rows(M, N, epilogue, out_dtype, exp, reserve) == 128) snprintf(buf, buflen, "gemm_w4_kernel<%s,%s,128 rows>", epi_names[epilogue], ot);
   else if (sc.kind == 3) snprintf(buf, buflen, "gemm_w4_kernel<%s,%s>", epi_names[epilogue], ot);
+  else if (sc.kind == 2 && apla_gemm_pp2_tile_rows(M, N, epilogue, out_dtype, exp, reserve) == 256) snprintf(buf, buflen, "gemm_pp2_kernel<%s,%s,256 rows>", epi_names[epilogue], ot);
   else if (sc.kind == 2) snprintf(buf, buflen, "gemm_pp2_kernel<%s,%s>", epi_names[epilogue], ot);
   else if (sc.kind == 1) snprintf(buf, buflen, "gemm_persist_kernel<%s,%s,%d>", epi_names[epilogue], ot, sc.mi);
   else snprintf(buf, buflen, "gemm_nt_kernel<%s,%s>", epi_names[epilogue], ot);

@@ -23,18 +23,24 @@ extern "C" int apla_abl_clock_pp2(unsigned long long* dst) { return (int)hipMemc
 
 namespace {
 
-constexpr int QBM = 320, QBN = 256, QBK = 32;
-constexpr int QA_BYTES = QBM * QBK * 2;  // 20 KB
+constexpr int QBN = 256, QBK = 32;
 constexpr int QW_BYTES = QBN * QBK * 2;  // 16 KB
-constexpr int QSTG = QA_BYTES + QW_BYTES;
 constexpr int QNS = 4;
-constexpr int QGRP = 5;  // LDS-DMA pieces per wave per K-step: 36 real (20 A + 16 W) + 4 duplicates over 8 waves
 constexpr int QAHEAD = 3;
 
-// TAG: profiling tag only (see GemmParams::tag) — the instantiations of one (EPI, OutT) are the same code under different names
-template <int EPI, typename OutT, int TAG = 0>
+// TAG: profiling tag only (see GemmParams::tag) — the instantiations of one (EPI, OutT) are the same code under different names.
+// MI: 16-row fragments per wave.  5 = the 320-row tile described above; 4 = a 256-row tile (wave tile 64 x 128, 128 accumulator
+// registers, 32 pieces per K-step and no duplicates) for problems whose tile count falls just past a multiple of the CU count: the
+// launch then takes the same number of rounds of tiles that are a fifth smaller (the self-supervised step's M = 58 496, N = 768:
+// 549 tiles of 320 rows = 2.14 rounds -> 3; 687 tiles of 256 rows = 2.68 -> 3 rounds at 0.8 of the tile).
+template <int EPI, typename OutT, int TAG = 0, int MI = 5>
 __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmParams p, int tiles_m) {
   using E = WideEpi<EPI, OutT>;
+  constexpr int QBM = 64 * MI;                 // 320 / 256
+  constexpr int QA_BYTES = QBM * QBK * 2;      // 20 / 16 KB
+  constexpr int QSTG = QA_BYTES + QW_BYTES;
+  constexpr int QGRP = MI;                     // LDS-DMA pieces per wave per K-step: MI = 5: 36 real (20 A + 16 W) + 4 duplicates over 8 waves
+  constexpr int NPC = 4 * MI + 16;             // real pieces of a stage
   __shared__ __attribute__((aligned(16))) char smem[QNS * QSTG + 2048 + 4 * 2048];  // + two bias pieces (256 floats each) + four 2 KB epilogue line buffers
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -59,7 +65,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmParams p, int tile
   // tile; only a tile that hangs over the M edge recomputes clamped row offsets (keeps VGPRs for the accumulators).
   const int srow = lane >> 2;
   const int koff = ((lane & 3) ^ ((-(srow >> 2)) & 3)) * 8;
-  // waves 0-3 stream the 20 A pieces (c = 5*wave + it), waves 4-7 the 16 W pieces (+ 4 duplicates of the last one)
+  // waves 0-3 stream the 4 MI A pieces (c = MI * wave + it), waves 4-7 the 16 W pieces (MI = 5: + 4 duplicates of the last one)
   const bool a_wave = wave < 4;
   const unsigned wrow = (p.w_panel & 1) ? 32u : (unsigned)p.ldw;   // elements between consecutive W rows
   const size_t wkstep = (p.w_panel & 1) ? (size_t)p.N * 64 : (size_t)QBK * 2;  // bytes between consecutive K-steps of W
@@ -74,10 +80,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmParams p, int tile
 #pragma unroll
   for (int it = 0; it < QGRP; ++it) {
     int c = wave * QGRP + it;
-    c = c < 36 ? c : 35;
-    // W piece pw = c-20 fills LDS rows 16*pw + srow = (wn'=pw>>3)*128 + (j=pw&7)*16 + srow, which hold W row
+    c = c < NPC ? c : NPC - 1;
+    // W piece pw = c - 4 MI fills LDS rows 16*pw + srow = (wn'=pw>>3)*128 + (j=pw&7)*16 + srow, which hold W row
     //   wn'*128 + 32*(j>>1) + 8*(srow>>2) + 4*(j&1) + (srow&3)     (MFMA order, see gemm_common.h)
-    const int pw = c - 20, j = pw & 7;
+    const int pw = c - 4 * MI, j = pw & 7;
     poff[it] = a_wave ? (unsigned)(c * 16) * arow * 2u
                       : (unsigned)((pw >> 3) * 128 + 32 * (j >> 1) + 4 * (j & 1)) * wrow * 2u;
   }
@@ -102,7 +108,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmParams p, int tile
 #pragma unroll
       for (int it = 0; it < QGRP; ++it) {
         int c = wave * QGRP + it;
-        c = c < 36 ? c : 35;
+        c = c < NPC ? c : NPC - 1;
         char* dst = a_wave ? base + it * 1024 : base + c * 1024;
         __builtin_amdgcn_global_load_lds(GLBP(tbase + kb + poff[it] + lane_off), LDSP(dst), 16, 0, 0);
       }
@@ -124,10 +130,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmParams p, int tile
   };
 
   // ------------------------------------------------------------------ fragments / accumulators
-  bf16x8 af[5], wf[8];
-  f32x4 acc[5][8];
+  bf16x8 af[MI], wf[8];
+  f32x4 acc[MI][8];
   const int foff = frow * 64 + ((fq ^ ((-(frow >> 2)) & 3)) << 4);
-  const int a_off = (grp * 160 + wm * 80) * 64 + foff;
+  const int a_off = (grp * (32 * MI) + wm * (16 * MI)) * 64 + foff;
   const int w_off = QA_BYTES + (wn * 128) * 64 + foff;
   int r_slot = 0;  // ring slot of the next K-step to read
   auto read_frags = [&]() {
@@ -137,20 +143,20 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmParams p, int tile
     if (r_slot != 1 || d_step > 8) return;
 #endif
 #pragma unroll
-    for (int i = 0; i < 5; ++i) af[i] = *(const bf16x8*)(st + a_off + i * 1024);
+    for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(st + a_off + i * 1024);
 #pragma unroll
     for (int j = 0; j < 8; ++j) wf[j] = *(const bf16x8*)(st + w_off + j * 1024);
   };
   auto frags_landed = [&]() {  // fragment reads complete BEFORE the barrier: their stage is re-filled from the next phase on
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int i = 0; i < 5; ++i) asm volatile("" : "+v"(af[i]));
+    for (int i = 0; i < MI; ++i) asm volatile("" : "+v"(af[i]));
 #pragma unroll
     for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(wf[j]));
   };
   auto zero_acc = [&]() {
 #pragma unroll
-    for (int i = 0; i < 5; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   };
@@ -159,7 +165,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmParams p, int tile
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int i = 0; i < 5; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[i][j] = MFMA_F32_16x16x32_H16(wf[j], af[i], acc[i][j]);
     __builtin_amdgcn_s_setprio(0);
@@ -170,9 +176,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmParams p, int tile
     const int tile = xbeg + slot + ordinal * slots;
     int tm, tn;
     tile_coords(tile, tiles_m, tiles_n, p.ngrp, tm, tn);
-    const int m0 = tm * QBM + grp * 160, n0 = tn * QBN;
-    const bool full = m0 + 160 <= p.M;
-    wide_epilogue<EPI, OutT>(p, acc, (const float*)(smem + QNS * QSTG + (ordinal & 1) * 1024), smem + QNS * QSTG + 2048 + lw * 2048,
+    const int m0 = tm * QBM + grp * (32 * MI), n0 = tn * QBN;
+    const bool full = m0 + 32 * MI <= p.M;
+    wide_epilogue<EPI, OutT, MI>(p, acc, (const float*)(smem + QNS * QSTG + (ordinal & 1) * 1024), smem + QNS * QSTG + 2048 + lw * 2048,
                               m0, n0, wm, wn, lane, full);
     asm volatile("" ::: "memory");
     zero_acc();
@@ -184,7 +190,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmParams p, int tile
   // K-step being waited for in the (in-order) vmcnt queue and may stay in flight too.
   auto end_even_phase = [&](int s) {
     if (s + 3 < s_total) {
-      if (relaxed > 0) wait_vmcnt<2 * QGRP + E::NST>(); else wait_vmcnt<2 * QGRP>();
+      if (relaxed > 0) wait_vmcnt<2 * QGRP + MI * E::S>(); else wait_vmcnt<2 * QGRP>();
     } else if (s + 2 < s_total) {
       wait_vmcnt<QGRP>();
     } else {
@@ -267,15 +273,28 @@ bool apla_gemm_pp2_covers(int M, int N, int K, long lda, long ldw, int epilogue,
   return (epilogue == APLA_EPI_GELU || epilogue == APLA_EPI_GELU_FWD) && out_dtype == APLA_H16;
 }
 
+// Tile height (bf16 STORE only): 320 rows unless 256-row tiles finish in fewer tile-rows of work — rounds over the CUs x height, with
+// 4 % charged to the smaller tile for its leaner wave tile (12 fragment reads per 32 products instead of 13 per 40).
+// GemmParams::exp 5 / 6 force 256 / 320 (A/B runs and tests).
+int apla_gemm_pp2_tile_rows(int M, int N, int epilogue, int out_dtype, int exp, int reserve) {
+  if (epilogue != APLA_EPI_STORE || out_dtype != APLA_H16 || exp == 6) return 320;
+  if (exp == 5) return 256;
+  const int cus = 256 - (reserve > 0 && reserve < 192 ? reserve : 0);
+  auto rounds = [&](int qbm) { return ((long)((M + qbm - 1) / qbm) * (N / QBN) + cus - 1) / cus; };
+  return (double)rounds(256) * 256 * 1.04 < (double)rounds(320) * 320 ? 256 : 320;
+}
+
 int apla_gemm_pp2_launch(const GemmParams& p_in, int epilogue, int out_dtype, hipStream_t stream) {
   // (operands given as K-panel images are addressed with a row pitch of 32 elements: the offset limit applies to that pitch)
   if (!apla_gemm_pp2_covers(p_in.M, p_in.N, p_in.K, (p_in.w_panel & 2) ? 32 : p_in.lda, (p_in.w_panel & 1) ? 32 : p_in.ldw, epilogue, out_dtype))
     return APLA_ENOSYS;
   GemmParams p = p_in;
   p.ngrp = pick_ngrp(p.N / QBN, QBN, p.K);
+  const int cus = 256 - (p.reserve > 0 && p.reserve < 192 ? p.reserve : 0);
+  const int QBM = apla_gemm_pp2_tile_rows(p.M, p.N, epilogue, out_dtype, p.exp, p.reserve);
+  const bool small_tile = QBM == 256;
   const int tiles_m = (p.M + QBM - 1) / QBM;
   const int total = tiles_m * (p.N / QBN);
-  const int cus = 256 - (p.reserve > 0 && p.reserve < 192 ? p.reserve : 0);
   const int G = total < cus ? total : cus;
 #define PP2_LAUNCH(E, T)                                                                                 \
   do {                                                                                                   \
@@ -287,6 +306,12 @@ int apla_gemm_pp2_launch(const GemmParams& p_in, int epilogue, int out_dtype, hi
   switch (epilogue) {
     case APLA_EPI_STORE:
       if (out_dtype == APLA_F32) PP2_LAUNCH(APLA_EPI_STORE, float);
+      if (small_tile) {
+        hipLaunchKernelGGL((gemm_pp2_kernel<APLA_EPI_STORE, bf16, 0, 4>), dim3(G), dim3(512), 0, stream, p, tiles_m);
+        hipError_t e__ = hipGetLastError();
+        if (e__ != hipSuccess) { apla_set_error("apla_gemm_nt[pp2]: launch failed: %s", hipGetErrorString(e__)); return APLA_EIO; }
+        return APLA_OK;
+      }
       switch (p.tag) {   // bf16 STORE: the step's six call-site shapes run through this one kernel
 #define PP2_TAGGED(T)                                                                                                 \
         case T:                                                                                                        \

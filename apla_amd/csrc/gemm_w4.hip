@@ -18,11 +18,8 @@ extern "C" int apla_abl_clock_w4(unsigned long long* dst) { return (int)hipMemcp
 
 namespace {
 
-constexpr int VBM = 160, VBN = 256, VBK = 32;
-constexpr int VA_BYTES = VBM * VBK * 2;  // 10 KB
+constexpr int VBN = 256, VBK = 32;
 constexpr int VW_BYTES = VBN * VBK * 2;  // 16 KB
-constexpr int VSTG = VA_BYTES + VW_BYTES;
-constexpr int VGRP = 7;                  // LDS-DMA issues per wave and K-step (26 pieces over four waves: two duplicates)
 
 // VNS: stages of the ring (LDS-DMA runs VNS - 1 K-steps ahead).  3: 78 KB + two 1 KB bias pieces = exactly 80 KB, two workgroups
 // fill a CU's 160 KB and the epilogue's four 2 KB line buffers live in the stage that was read last; 2: 62 KB with line buffers of
@@ -32,9 +29,16 @@ constexpr int VGRP = 7;                  // LDS-DMA issues per wave and K-step (
 // KSPLIT: the K axis is cut into `ksplit` equal parts and the work items are (tile, part) pairs, part fastest; part s writes its fp32
 // partial tile into slice s of a workspace [ksplit][M][ldc] (p.C), summed afterwards in a fixed order (apla_gemm_nt_splitk: few
 // tiles and a long K — the prototype layer's input gradient of the self-supervised step is 35 tiles x 2 048 K-steps).
-template <int EPI, typename OutT, bool PRIO, int VNS, int TAG = 0, bool KSPLIT = false>
+// MI: 16-row fragments per wave: 5 = the 160-row tile; 4 = a 128-row tile (wave tile 64 x 128; 24 pieces per K-step, two A pieces per
+// wave) for problems whose tile count falls just past a multiple of the resident workgroups (gemm_pp2.hip has the same choice).
+template <int EPI, typename OutT, bool PRIO, int VNS, int TAG = 0, bool KSPLIT = false, int MI = 5>
 __global__ __launch_bounds__(256, 2) void gemm_w4_kernel(GemmParams p, int tiles_m, int ksplit) {
   using E = WideEpi<EPI, OutT>;
+  constexpr int VBM = 32 * MI;               // 160 / 128
+  constexpr int VA_BYTES = VBM * VBK * 2;    // 10 / 8 KB
+  constexpr int VSTG = VA_BYTES + VW_BYTES;
+  constexpr int VGRP = MI == 5 ? 7 : 6;      // LDS-DMA issues per wave and K-step (MI = 5: 26 pieces over four waves, two duplicates)
+  static_assert(MI == 5 || (MI == 4 && VNS == 2), "the 128-row tile is built for the two-stage ring");
   constexpr int VBIAS = VNS * VSTG;
   constexpr bool OWN_TBUF = VNS < 3;
   __shared__ __attribute__((aligned(16))) char smem[VBIAS + 2048 + (OWN_TBUF ? 4 * 2048 : 0)];
@@ -65,7 +69,7 @@ __global__ __launch_bounds__(256, 2) void gemm_w4_kernel(GemmParams p, int tiles
   const size_t akstep = (p.w_panel & 2) ? (size_t)p.M * 64 : (size_t)VBK * 2;
   const unsigned a_lane = ((unsigned)srow * arow + koff) * 2u;
   const unsigned w_lane = ((unsigned)(8 * (srow >> 2) + (srow & 3)) * wrow + koff) * 2u;
-  const int a_first = wave < 2 ? 3 * wave : 6 + 2 * (wave - 2);
+  const int a_first = MI == 4 ? 2 * wave : (wave < 2 ? 3 * wave : 6 + 2 * (wave - 2));
   int d_step = 0, d_k = 0, d_tile = 0, d_slot = 0, d_tm = 0, d_k0 = 0;
   bool d_edge = false;
   const char* a_base = nullptr;
@@ -100,9 +104,9 @@ __global__ __launch_bounds__(256, 2) void gemm_w4_kernel(GemmParams p, int tiles
       __builtin_amdgcn_global_load_lds(GLBP(w_base + kw + off + w_lane), LDSP(base + VA_BYTES + pw * 1024), 16, 0, 0);
     }
 #pragma unroll
-    for (int it = 0; it < 3; ++it) {
+    for (int it = 0; it < (MI == 4 ? 2 : 3); ++it) {
       int c = a_first + it;
-      if (wave >= 2 && it == 2) {   // waves 2 and 3 own two pieces.  The deeper ring counts its waits per wave, so there the third issue
+      if (MI == 5 && wave >= 2 && it == 2) {   // waves 2 and 3 own two pieces.  The deeper ring counts its waits per wave, so there the third issue
         if (VNS < 3) continue;      // repeats the second (same bytes, same place); the two-stage ring waits for everything: no repeat
         c -= 1;
       }
@@ -120,14 +124,14 @@ __global__ __launch_bounds__(256, 2) void gemm_w4_kernel(GemmParams p, int tiles
   };
 
   // ---- fragments / accumulators
-  bf16x8 af[5], wf[8];
-  f32x4 acc[5][8];
+  bf16x8 af[MI], wf[8];
+  f32x4 acc[MI][8];
   const int foff = frow * 64 + ((fq ^ ((-(frow >> 2)) & 3)) << 4);
-  const int a_off = (wm * 80) * 64 + foff;
+  const int a_off = (wm * (16 * MI)) * 64 + foff;
   const int w_off = VA_BYTES + (wn * 128) * 64 + foff;
   auto zero_acc = [&]() {
 #pragma unroll
-    for (int i = 0; i < 5; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   };
@@ -145,7 +149,7 @@ __global__ __launch_bounds__(256, 2) void gemm_w4_kernel(GemmParams p, int tiles
     // flight, and so may a full tile's epilogue stores, which were issued after the shares of the next tile's first VNS - 1 K-steps
     constexpr int YOUNGER = (VNS - 2) * VGRP;
     if (s + VNS - 2 >= s_total) wait_vmcnt<0>();
-    else if (relaxed > 0) wait_vmcnt<YOUNGER + E::NST>();
+    else if (relaxed > 0) wait_vmcnt<YOUNGER + MI * E::S>();
     else if (VNS > 2 && kk == nk - 1 && has_bias) wait_vmcnt<YOUNGER + 1>();
     else wait_vmcnt<YOUNGER>();
     --relaxed;
@@ -158,19 +162,19 @@ __global__ __launch_bounds__(256, 2) void gemm_w4_kernel(GemmParams p, int tiles
 #endif
     {
 #pragma unroll
-      for (int i = 0; i < 5; ++i) af[i] = *(const bf16x8*)(st + a_off + i * 1024);
+      for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(st + a_off + i * 1024);
 #pragma unroll
       for (int j = 0; j < 8; ++j) wf[j] = *(const bf16x8*)(st + w_off + j * 1024);
     }
 #if defined(APLA_ABL_NOREAD)
 #pragma unroll
-    for (int i = 0; i < 5; ++i) asm volatile("" : "+v"(af[i]));
+    for (int i = 0; i < MI; ++i) asm volatile("" : "+v"(af[i]));
 #pragma unroll
     for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(wf[j]));
 #endif
     if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int i = 0; i < 5; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[i][j] = MFMA_F32_16x16x32_H16(wf[j], af[i], acc[i][j]);
     if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
@@ -192,9 +196,9 @@ __global__ __launch_bounds__(256, 2) void gemm_w4_kernel(GemmParams p, int tiles
       if constexpr (KSPLIT) {
         GemmParams q = p;
         q.C = (char*)p.C + (size_t)part * p.M * p.ldc * sizeof(OutT);
-        wide_epilogue<EPI, OutT>(q, acc, (const float*)(smem + VBIAS + (ord & 1) * 1024), tbuf, m0, n0, wm, wn, lane, full);
+        wide_epilogue<EPI, OutT, MI>(q, acc, (const float*)(smem + VBIAS + (ord & 1) * 1024), tbuf, m0, n0, wm, wn, lane, full);
       } else {
-        wide_epilogue<EPI, OutT>(p, acc, (const float*)(smem + VBIAS + (ord & 1) * 1024), tbuf, m0, n0, wm, wn, lane, full);
+        wide_epilogue<EPI, OutT, MI>(p, acc, (const float*)(smem + VBIAS + (ord & 1) * 1024), tbuf, m0, n0, wm, wn, lane, full);
       }
       asm volatile("" ::: "memory");
       zero_acc();
@@ -219,14 +223,27 @@ bool apla_gemm_w4_covers(int M, int N, int K, long lda, long ldw, int epilogue, 
   return (epilogue == APLA_EPI_GELU || epilogue == APLA_EPI_GELU_FWD || epilogue == APLA_EPI_STORE) && out_dtype == APLA_H16;
 }
 
+// Tile height (bf16 STORE only): 160 rows unless 128-row tiles finish in fewer tile-rows of work (rounds over the resident workgroups x
+// height, 4 % charged to the smaller tile), as in gemm_pp2.hip; GemmParams::exp 5 / 6 force 128 / 160 (7 and 4 are this kernel's other
+// A/B selectors and keep 160).
+int apla_gemm_w4_tile_rows(int M, int N, int epilogue, int out_dtype, int exp, int reserve) {
+  if (epilogue != APLA_EPI_STORE || out_dtype != APLA_H16 || exp == 6 || exp == 7 || exp == 4) return 160;
+  if (exp == 5) return 128;
+  const int resident = 512 - 2 * (reserve > 0 && reserve < 192 ? reserve : 0);
+  auto rounds = [&](int vbm) { return ((long)((M + vbm - 1) / vbm) * (N / VBN) + resident - 1) / resident; };
+  return (double)rounds(128) * 128 * 1.04 < (double)rounds(160) * 160 ? 128 : 160;
+}
+
 int apla_gemm_w4_launch(const GemmParams& p_in, int epilogue, int out_dtype, hipStream_t stream) {
   if (!apla_gemm_w4_covers(p_in.M, p_in.N, p_in.K, (p_in.w_panel & 2) ? 32 : p_in.lda, (p_in.w_panel & 1) ? 32 : p_in.ldw, epilogue, out_dtype))
     return APLA_ENOSYS;
   GemmParams p = p_in;
   p.ngrp = pick_ngrp(p.N / VBN, VBN, p.K);
+  const int resident = 512 - 2 * (p.reserve > 0 && p.reserve < 192 ? p.reserve : 0);
+  const int VBM = apla_gemm_w4_tile_rows(p.M, p.N, epilogue, out_dtype, p.exp, p.reserve);
+  const bool small_tile = VBM == 128;
   const int tiles_m = (p.M + VBM - 1) / VBM;
   const int total = tiles_m * (p.N / VBN);
-  const int resident = 512 - 2 * (p.reserve > 0 && p.reserve < 192 ? p.reserve : 0);
   const int G = total < resident ? total : resident;
   // GemmParams::exp (A/B runs, tools/gemm_bench.py): 0 = the default; 7 = no priority; 4 = the three-stage ring
 #define W4_LAUNCH(...) hipLaunchKernelGGL((gemm_w4_kernel<__VA_ARGS__>), dim3(G), dim3(256), 0, stream, p, tiles_m, 1)
@@ -241,6 +258,7 @@ int apla_gemm_w4_launch(const GemmParams& p_in, int epilogue, int out_dtype, hip
     case APLA_EPI_GELU_FWD: W4_AB(APLA_EPI_GELU_FWD); break;
     case APLA_EPI_STORE:
       if (p.exp == 7 || p.exp == 4) { W4_AB(APLA_EPI_STORE); break; }
+      if (small_tile) { W4_LAUNCH(APLA_EPI_STORE, bf16, true, 2, 0, false, 4); break; }
       switch (p.tag) {   // the step's call sites run through this one kernel under different names
         case 2: W4_LAUNCH(APLA_EPI_STORE, bf16, true, 2, 2); break;
         case 3: W4_LAUNCH(APLA_EPI_STORE, bf16, true, 2, 3); break;
@@ -277,7 +295,7 @@ __global__ __launch_bounds__(256) void w4_splitk_reduce_kernel(const float* __re
 }
 // parts of the K axis: enough work items for two workgroups per CU, each part a whole number of 32-wide K-steps and at least 8 of them
 inline int w4_pick_split(int M, int N, int K) {
-  const long tiles = (long)((M + VBM - 1) / VBM) * (N / VBN);
+  const long tiles = (long)((M + 160 - 1) / 160) * (N / VBN);
   int S = (int)((512 + tiles - 1) / tiles);
   S = S > 64 ? 64 : S;
   while (S > 1 && ((K / VBK) % S != 0 || K / VBK / S < 8)) --S;
@@ -303,7 +321,7 @@ extern "C" int apla_gemm_nt_splitk(const void* A, int lda, const void* W, int ld
   APLA_REQUIRE(workspace_bytes >= (long)S * M * N * (long)sizeof(float), "apla_gemm_nt_splitk: workspace too small (ask apla_gemm_nt_splitk_workspace_bytes)");
   GemmParams p{(const bf16*)A, lda, (const bf16*)W, ldw, nullptr, workspace, N, nullptr, 0, nullptr, 0, M, N, K, N / 128, 0, 0, 0, 0, 0};
   p.ngrp = pick_ngrp(p.N / VBN, VBN, p.K);
-  const int tiles_m = (M + VBM - 1) / VBM;
+  const int tiles_m = (M + 160 - 1) / 160;
   const long items = (long)tiles_m * (N / VBN) * S;
   const int G = items < 512 ? (int)items : 512;
   hipLaunchKernelGGL((gemm_w4_kernel<APLA_EPI_STORE, float, true, 2, 0, true>), dim3(G), dim3(256), 0, stream, p, tiles_m, S);

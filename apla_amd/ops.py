@@ -294,7 +294,7 @@ def gemm_kernel_name(M: int, N: int, K: int, epilogue: int = EPI_STORE, out_dtyp
     import ctypes
     buf = ctypes.create_string_buffer(96)
     panel = (4 if out_image else 0) | (8 if aux_image else 0)
-    check(lib().apla_gemm_nt_kernel_name(M, N, K, epilogue, _DT[out_dtype or half()], (_GEMM_VARIANT << 8) | (panel << 16), buf, 96),
+    check(lib().apla_gemm_nt_kernel_name(M, N, K, epilogue, _DT[out_dtype or half()], (_GEMM_VARIANT << 8) | (panel << 16) | (_RESERVED_CUS << 20) | (_GEMM_EXP << 28), buf, 96),
           "apla_gemm_nt_kernel_name")
     return buf.value.decode()
 

@@ -706,6 +706,42 @@ def test_gemm_tile_alternating_kernel(ops, M, N, K):
         ops.set_gemm_variant(old)
 
 
+@pytest.mark.parametrize("M,N,K", [(27400, 768, 1536), (27400, 768, 768), (1000, 256, 2304), (130, 512, 256), (257, 256, 3072)])
+def test_gemm_small_row_tiles(ops, M, N, K):
+    """The 256-row tile of the ping-pong kernel and the 128-row tile of the wide 4-wave kernel (bf16 STORE; chosen where the tile count
+    falls just past a multiple of the CU count — the first two shapes: 86 x 3 tiles of 320 rows = 258 -> two rounds; the self-supervised
+    step's N = 768 launches): forced on and off on every shape (row tails, fewer rows than a tile), row-major and image operands, with
+    and without bias, CUs reserved — the bits of the tall tiles and of the 4-wave kernel."""
+    a, ad = bf(rnd(M, K, seed=151))
+    w, wd = bf(rnd(N, K, scale=K ** -0.5, seed=152))
+    bias = dev(rnd(N, seed=153))
+    A, W = dev(a), dev(w)
+    old = ops.set_gemm_variant(15)
+    try:
+        ref, ref_nb = ops.gemm_nt(A, W, bias).clone(), ops.gemm_nt(A, W, None).clone()
+        assert rel_err(ref.cpu(), ad @ wd.t() + bias.cpu().double()) < BF16_OUT
+        for variant, small in ((9, "gemm_pp2_kernel<STORE,bf16,256 rows>"), (16, "gemm_w4_kernel<STORE,bf16,128 rows>")):
+            ops.set_gemm_variant(variant)
+            for exp in (5, 6):
+                ops._GEMM_EXP = exp
+                assert (ops.gemm_kernel_name(M, N, K) == small) == (exp == 5)
+                for Ai, Wi in ((A, W), (A, ops.k_panels(W)), (ops.k_panels(A), ops.k_panels(W))):
+                    for rep in range(2):
+                        assert torch.equal(ops.gemm_nt(Ai, Wi, bias), ref), (variant, exp, rep)
+                assert torch.equal(ops.gemm_nt(A, W, None), ref_nb)
+                with ops.reserved_cus(150):
+                    assert torch.equal(ops.gemm_nt(A, W, bias), ref)
+            ops._GEMM_EXP = 0
+        ops.set_gemm_variant(0)
+        if M == 27400:   # the automatic rule takes the small tile here, on whichever of the two kernels it picks
+            assert ops.gemm_kernel_name(M, N, K) == ("gemm_w4_kernel<STORE,bf16,128 rows>" if K <= 1024 else "gemm_pp2_kernel<STORE,bf16,256 rows>")
+            assert ops.gemm_kernel_name(25216, 768, 3072) == "gemm_pp2_kernel<STORE,bf16>" and ops.gemm_kernel_name(25216, 2304, 768) == "gemm_w4_kernel<STORE,bf16>"
+            assert torch.equal(ops.gemm_nt(A, W, bias), ref)
+    finally:
+        ops._GEMM_EXP = 0
+        ops.set_gemm_variant(old)
+
+
 @pytest.mark.parametrize("M,N,K", [(5581, 256, 8192), (300, 512, 4096), (161, 256, 256)])
 def test_gemm_split_k(ops, M, N, K):
     """apla_gemm_nt_splitk (few tiles, long K: the prototype layer's input gradient of the self-supervised step): the K axis cut into
