@@ -206,5 +206,6 @@ def update_teacher(student: nn.Module, teacher: nn.Module, m: float):
             t_list.append(tp)
             s_list.append(sp[name].detach())
     if t_list:
-        torch._foreach_lerp_(t_list, s_list, 1.0 - m)    # t + (1 - m) (s - t): one pass over the trainable set instead of mul_ then add_
+        torch._foreach_mul_(t_list, m)
+        torch._foreach_add_(t_list, s_list, alpha=1 - m)
     return len(t_list)

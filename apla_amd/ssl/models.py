@@ -256,7 +256,8 @@ class DINOv2(nn.Module):
                 if ps.requires_grad:
                     t_list.append(pt)
                     s_list.append(ps.detach())
-        torch._foreach_lerp_(t_list, s_list, 1.0 - m)    # t + (1 - m) (s - t): one pass over the trainable set instead of mul_ then add_
+        torch._foreach_mul_(t_list, m)
+        torch._foreach_add_(t_list, s_list, alpha=1 - m)
         return len(t_list)
 
     def train(self, train_mode=True):
