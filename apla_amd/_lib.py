@@ -5,7 +5,7 @@ returns an error, an exception is raised.  Nothing here imports the CPU oracle.
 """
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_long, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_long, c_ulonglong, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 # bf16 operands (default).  APLA_LIB=<path> substitutes another build of the library (tools/build_ablations.sh: A/B timing)
@@ -95,6 +95,9 @@ SIGNATURES = {
                                     c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "apla_assemble_tokens": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                      c_void_p]),
+    "apla_dropout_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_long, c_float, c_ulonglong, c_ulonglong, c_void_p]),
+    "apla_dropout_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_long, c_float, c_void_p]),
+    "apla_scale_samples": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_long, c_long, c_void_p]),
     "apla_assemble_tokens_masked": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                             c_int, c_void_p]),
     "apla_sgemm_small": (c_int, [c_void_p, c_long, c_long, c_void_p, c_long, c_long, c_void_p, c_void_p, c_long, c_int,

@@ -64,10 +64,11 @@ class APLA_Attention(nn.Module):
     def forward(self, x, ls_gamma=None):
         """``ls_gamma`` (extension, used by VisionTransformer.run_blocks): the block's frozen LayerScale vector; when given,
         x is ls1(attention(x)) with the scale folded into the projection GEMM."""
-        AF.require_no_dropout(self.attn_drop, self.training), AF.require_no_dropout(self.proj_drop, self.training)
+        AF.require_no_dropout(self.attn_drop, self.training)
         B, N, _ = x.shape
         qkv, o, lse = self._attend(x)
-        y = self._project(o, ls_gamma).to(x.dtype)
+        # proj_drop (appla_attn.py:82) commutes with the LayerScale vector folded into the projection: both are element-wise
+        y = AF.dropout(self._project(o, ls_gamma).to(x.dtype), self.proj_drop, self.training)
         attn = None
         if self.return_attn_matrix:
             attn = ops.attn_probs(qkv.detach().reshape(B * N, -1), lse, B, N, self.num_heads, self.scale)

@@ -26,7 +26,7 @@ class APLA_MemEffAttention(APLA_Attention):
         if not isinstance(attn_bias, BlockDiagonalMask):
             raise TypeError("attn_bias must be an apla_amd.nested.BlockDiagonalMask (the xformers mask class the reference "
                             f"uses is not a dependency of this package); got {type(attn_bias).__name__}")
-        AF.require_no_dropout(self.attn_drop, self.training), AF.require_no_dropout(self.proj_drop, self.training)
+        AF.require_no_dropout(self.attn_drop, self.training)
         if x.ndim != 3 or x.shape[0] != 1 or x.shape[1] != attn_bias.total:
             raise ValueError(f"a packed batch must be [1, {attn_bias.total}, C]; got {tuple(x.shape)}")
         qkv = AF.linear(x, self.qkv.weight, self.qkv.bias)
@@ -34,4 +34,4 @@ class APLA_MemEffAttention(APLA_Attention):
                                         runs=attn_bias.runs())
         if rows is not None:
             o = o.index_select(1, rows)
-        return self._project(o, ls_gamma).to(x.dtype)
+        return AF.dropout(self._project(o, ls_gamma).to(x.dtype), self.proj_drop, self.training)

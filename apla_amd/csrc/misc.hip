@@ -879,6 +879,115 @@ extern "C" int apla_colsum_h16(const void* X, long ld, float* out, int M, int N,
   return APLA_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ dropout / stochastic depth
+// nn.Dropout (vit.py:152-168 Mlp.drop, appla_attn.py:82 proj_drop, pos_drop) and DropPath (vit.py:74-93) for the module path.  All
+// shipped configurations use 0; main.py:101-111 can set them.  The keep decision of element i is word (i & 3) of
+// Philox4x32-10(counter = {i >> 2 (64 bit), offset (64 bit)}, key = seed (64 bit)) compared with p * 2^32: counter-based, so the mask
+// does not depend on the launch geometry and the oracle (oracle/apla_oracle.py:philox_keep_mask) reproduces it bit for bit.
+__device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, unsigned k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0], p1 = (unsigned long long)0xCD9E8D57u * c[2];
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1;
+    c[1] = (unsigned)p1; c[3] = (unsigned)p0; c[0] = n0; c[2] = n2;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+
+// y = keep ? x / (1 - p) : 0, keep bytes written for the backward.  One thread = 8 consecutive elements (two Philox blocks).
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, uint8_t* __restrict__ keep, long n,
+                                                          unsigned threshold, float inv_keep, unsigned long long seed,
+                                                          unsigned long long offset) {
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 8;
+  if (i >= n) return;
+  float v[8];
+  ld8f<T>(x + i, v);
+  unsigned char kb[8];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const unsigned long long blk = (unsigned long long)(i >> 2) + h;
+    unsigned c[4] = {(unsigned)blk, (unsigned)(blk >> 32), (unsigned)offset, (unsigned)(offset >> 32)};
+    philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const bool k = c[e] >= threshold;
+      kb[4 * h + e] = k ? 1 : 0;
+      v[4 * h + e] = k ? v[4 * h + e] * inv_keep : 0.f;
+    }
+  }
+  f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+  st8f<T>(y + i, a, b, false);
+  *(unsigned long long*)(keep + i) = *(const unsigned long long*)kb;
+}
+
+// dx = keep ? dy / (1 - p) : 0
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ keep, T* __restrict__ dx,
+                                                          long n, float inv_keep) {
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 8;
+  if (i >= n) return;
+  float v[8];
+  ld8f<T>(dy + i, v);
+  const unsigned long long kw = *(const unsigned long long*)(keep + i);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = ((kw >> (8 * e)) & 0xff) ? v[e] * inv_keep : 0.f;
+  f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+  st8f<T>(dx + i, a, b, false);
+}
+
+// y[s, :] = x[s, :] * scale[s] over S samples of `per` elements each (DropPath: scale[s] = floor(keep_prob + u_s) / keep_prob)
+template <typename T>
+__global__ __launch_bounds__(256) void scale_samples_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ scale,
+                                                            long per, long n) {
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 8;
+  if (i >= n) return;
+  float v[8];
+  ld8f<T>(x + i, v);
+  const float sc = scale[i / per];   // per % 8 == 0: the eight elements belong to one sample
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] *= sc;
+  f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+  st8f<T>(y + i, a, b, false);
+}
+
+extern "C" int apla_dropout_fwd(const void* x, int dtype, void* y, uint8_t* keep, long n, float p, unsigned long long seed,
+                                unsigned long long offset, hipStream_t stream) {
+  APLA_REQUIRE(x && y && keep && n > 0 && n % 8 == 0 && p >= 0.f && p < 1.f, "apla_dropout_fwd: need n %% 8 == 0 and 0 <= p < 1 (n=%ld p=%f)", n, (double)p);
+  APLA_REQUIRE(apla_aligned16(x) && apla_aligned16(y) && (((uintptr_t)keep) & 7) == 0, "apla_dropout_fwd: pointers must be 16-byte (keep: 8-byte) aligned");
+  const double t = (double)p * 4294967296.0;
+  const unsigned threshold = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+  const unsigned blocks = (unsigned)((n / 8 + 255) / 256);
+  if (dtype == APLA_F32) hipLaunchKernelGGL(dropout_fwd_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)x, (float*)y, keep, n, threshold, 1.0f / (1.0f - p), seed, offset);
+  else if (dtype == APLA_H16) hipLaunchKernelGGL(dropout_fwd_kernel<bf16>, dim3(blocks), dim3(256), 0, stream, (const bf16*)x, (bf16*)y, keep, n, threshold, 1.0f / (1.0f - p), seed, offset);
+  else { apla_set_error("apla_dropout_fwd: unsupported dtype %d", dtype); return APLA_ENOSYS; }
+  APLA_CHECK_LAUNCH("apla_dropout_fwd");
+  return APLA_OK;
+}
+
+extern "C" int apla_dropout_bwd(const void* dy, int dtype, const uint8_t* keep, void* dx, long n, float p, hipStream_t stream) {
+  APLA_REQUIRE(dy && dx && keep && n > 0 && n % 8 == 0 && p >= 0.f && p < 1.f, "apla_dropout_bwd: need n %% 8 == 0 and 0 <= p < 1");
+  APLA_REQUIRE(apla_aligned16(dy) && apla_aligned16(dx) && (((uintptr_t)keep) & 7) == 0, "apla_dropout_bwd: pointers must be 16-byte (keep: 8-byte) aligned");
+  const unsigned blocks = (unsigned)((n / 8 + 255) / 256);
+  if (dtype == APLA_F32) hipLaunchKernelGGL(dropout_bwd_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)dy, keep, (float*)dx, n, 1.0f / (1.0f - p));
+  else if (dtype == APLA_H16) hipLaunchKernelGGL(dropout_bwd_kernel<bf16>, dim3(blocks), dim3(256), 0, stream, (const bf16*)dy, keep, (bf16*)dx, n, 1.0f / (1.0f - p));
+  else { apla_set_error("apla_dropout_bwd: unsupported dtype %d", dtype); return APLA_ENOSYS; }
+  APLA_CHECK_LAUNCH("apla_dropout_bwd");
+  return APLA_OK;
+}
+
+extern "C" int apla_scale_samples(const void* x, int dtype, void* y, const float* scale, long samples, long per_sample, hipStream_t stream) {
+  APLA_REQUIRE(x && y && scale && samples > 0 && per_sample > 0 && per_sample % 8 == 0, "apla_scale_samples: need per_sample %% 8 == 0");
+  APLA_REQUIRE(apla_aligned16(x) && apla_aligned16(y), "apla_scale_samples: pointers must be 16-byte aligned");
+  const long n = samples * per_sample;
+  const unsigned blocks = (unsigned)((n / 8 + 255) / 256);
+  if (dtype == APLA_F32) hipLaunchKernelGGL(scale_samples_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)x, (float*)y, scale, per_sample, n);
+  else if (dtype == APLA_H16) hipLaunchKernelGGL(scale_samples_kernel<bf16>, dim3(blocks), dim3(256), 0, stream, (const bf16*)x, (bf16*)y, scale, per_sample, n);
+  else { apla_set_error("apla_scale_samples: unsupported dtype %d", dtype); return APLA_ENOSYS; }
+  APLA_CHECK_LAUNCH("apla_scale_samples");
+  return APLA_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ K-panel operand image
 // dst[(k / 32) * rows + r][k % 32] = src[r][k]: the image apla_gemm_nt_ex reads with flags bit 16 (W) / bit 17 (A).  One thread
 // moves 16 bytes; a frozen weight is converted once, a trainable one by its own pack kernel.

@@ -89,6 +89,10 @@ class AplaTrainEngine:
         self.D, self.L, self.H = bb.embed_dim, bb.depth, bb.num_heads
         if self.D != 64 * self.H:
             raise NotImplementedError("HIP attention kernel needs head_dim == 64")
+        for name, mod in model.named_modules():   # the captured launch sequence has no dropout / stochastic depth: never ignore one silently
+            if (isinstance(mod, nn.Dropout) and mod.p > 0.0) or (getattr(mod, "drop_prob", None) or 0.0) > 0.0:
+                raise NotImplementedError(f"{name}: dropout / stochastic depth > 0 is implemented on the module path only "
+                                          "(apla_amd.vit / apla_amd.functional), not in the fused step; every shipped APLA config uses 0")
         self.Np = (img_size // self.patch) ** 2
         self.N = self.Np + 1
         self.M = self.B * self.N

@@ -22,10 +22,75 @@ def _h():
 
 
 def require_no_dropout(drop_module, training: bool):
-    """Dropouts are 0 in every shipped APLA config (SURVEY §5 hazard 14); the HIP path asserts that."""
+    """Dropout INSIDE the fused softmax (attn_drop, appla_attn.py:58) is not implemented: 0 in every shipped APLA config."""
     p = getattr(drop_module, "p", 0.0)
     if training and p and p > 0.0:
-        raise NotImplementedError(f"dropout p={p} is not supported on the HIP path (all shipped APLA configs use 0)")
+        raise NotImplementedError(f"attention-probability dropout p={p} is not supported on the HIP path (it would sit inside the fused "
+                                  "softmax; all shipped APLA configs use 0); proj_drop / drop_rate / drop_path_rate are")
+
+
+class _DropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        _require_cuda(x, "dropout")
+        x2 = x.contiguous()
+        if x2.dtype not in (torch.float32, _h()):
+            x2 = x2.float()
+        y, keep = ops.dropout_fwd(x2, p, seed)
+        ctx.save_for_backward(keep)
+        ctx.p, ctx.dtype = p, x.dtype
+        return y.to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (keep,) = ctx.saved_tensors
+        d = dy.contiguous()
+        if d.dtype not in (torch.float32, _h()):
+            d = d.float()
+        return ops.dropout_bwd(d, keep, ctx.p).to(ctx.dtype), None, None
+
+
+def dropout(x, drop, training: bool):
+    """nn.Dropout on the HIP path (Mlp.drop vit.py:152-168, proj_drop appla_attn.py:82, pos_drop vit.py:395): ``drop`` is the module or
+    its p.  The mask comes from a counter-based generator (apla_dropout_fwd) keyed by one 63-bit draw from torch's default CPU
+    generator per call, so ``torch.manual_seed`` makes a run repeatable; it is not torch's own CUDA mask stream."""
+    p = float(getattr(drop, "p", drop) or 0.0)
+    if not training or p == 0.0:
+        return x
+    if p >= 1.0:
+        return torch.zeros_like(x)
+    seed = int(torch.empty((), dtype=torch.int64).random_())
+    return _DropoutFn.apply(x, p, seed)
+
+
+class _ScaleSamplesFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, scale):
+        _require_cuda(x, "drop_path")
+        x2 = x.contiguous()
+        if x2.dtype not in (torch.float32, _h()):
+            x2 = x2.float()
+        ctx.save_for_backward(scale)
+        ctx.dtype = x.dtype
+        return ops.scale_samples(x2, scale).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (scale,) = ctx.saved_tensors
+        d = dy.contiguous()
+        if d.dtype not in (torch.float32, _h()):
+            d = d.float()
+        return ops.scale_samples(d, scale).to(ctx.dtype), None
+
+
+def drop_path(x, drop_prob: float, training: bool):
+    """Stochastic depth per sample (utils/transformers/vit.py:74-82): x / keep_prob * floor(keep_prob + u_b), one u per sample of the
+    leading dimension (drawn with torch on the device: B numbers), applied by apla_scale_samples forward and backward."""
+    if not drop_prob or not training:
+        return x
+    keep = 1.0 - float(drop_prob)
+    scale = torch.floor(keep + torch.rand(x.shape[0], device=x.device, dtype=torch.float32)) / keep
+    return _ScaleSamplesFn.apply(x, scale)
 
 
 def _require_cuda(x: torch.Tensor, what: str):

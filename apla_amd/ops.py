@@ -748,6 +748,39 @@ def assemble_tokens(patches: torch.Tensor, cls_token: torch.Tensor, pos: torch.T
     return out
 
 
+def dropout_fwd(x: torch.Tensor, p: float, seed: int, offset: int = 0):
+    """(y, keep) of include/apla_hip.h:apla_dropout_fwd for a contiguous fp32 / 16-bit tensor whose size is a multiple of 8."""
+    _req(x, None, "x")
+    if x.dtype not in (torch.float32, half()) or not x.is_contiguous() or x.numel() % 8 or not 0.0 <= p < 1.0:
+        raise ValueError("dropout_fwd: contiguous fp32 / 16-bit tensor with numel % 8 == 0 and 0 <= p < 1 expected")
+    y = torch.empty_like(x)
+    keep = torch.empty(x.numel(), device=x.device, dtype=torch.uint8)
+    check(lib().apla_dropout_fwd(x.data_ptr(), _DT[x.dtype], y.data_ptr(), keep.data_ptr(), x.numel(), float(p), int(seed) & (2 ** 64 - 1),
+                                 int(offset) & (2 ** 64 - 1), _stream()), "apla_dropout_fwd")
+    return y, keep
+
+
+def dropout_bwd(dy: torch.Tensor, keep: torch.Tensor, p: float) -> torch.Tensor:
+    _req(dy, None, "dy"), _req(keep, torch.uint8, "keep", 1)
+    if dy.dtype not in (torch.float32, half()) or not dy.is_contiguous() or keep.numel() != dy.numel() or dy.numel() % 8:
+        raise ValueError("dropout_bwd: dy must match the forward's tensor")
+    dx = torch.empty_like(dy)
+    check(lib().apla_dropout_bwd(dy.data_ptr(), _DT[dy.dtype], keep.data_ptr(), dx.data_ptr(), dy.numel(), float(p), _stream()), "apla_dropout_bwd")
+    return dx
+
+
+def scale_samples(x: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
+    """y[s] = x[s] * scale[s] over the leading dimension (include/apla_hip.h:apla_scale_samples)."""
+    _req(x, None, "x"), _req(scale, torch.float32, "scale", 1)
+    S = x.shape[0]
+    per = x.numel() // max(S, 1)
+    if x.dtype not in (torch.float32, half()) or not x.is_contiguous() or scale.numel() != S or per % 8 or not scale.is_contiguous():
+        raise ValueError("scale_samples: contiguous [S, ...] tensor with a multiple of 8 elements per sample and S scales expected")
+    y = torch.empty_like(x)
+    check(lib().apla_scale_samples(x.data_ptr(), _DT[x.dtype], y.data_ptr(), scale.data_ptr(), S, per, _stream()), "apla_scale_samples")
+    return y
+
+
 def sgemm_small(A: torch.Tensor, Bm: torch.Tensor, *, trans_a=False, trans_b=False, bias=None, out=None,
                 accumulate=False) -> torch.Tensor:
     """fp32: out[M,N] (+)= op(A) @ op(Bm) (+bias); op = transpose when trans_* is set."""

@@ -30,7 +30,7 @@ class MemEffAttention(Attention):
             return super().forward(x)[0]
         if not isinstance(attn_bias, BlockDiagonalMask):
             raise TypeError(f"attn_bias must be an apla_amd.nested.BlockDiagonalMask, got {type(attn_bias).__name__}")
-        AF.require_no_dropout(self.attn_drop, self.training), AF.require_no_dropout(self.proj_drop, self.training)
+        AF.require_no_dropout(self.attn_drop, self.training)
         if x.ndim != 3 or x.shape[0] != 1 or x.shape[1] != attn_bias.total:
             raise ValueError(f"a packed batch must be [1, {attn_bias.total}, C]; got {tuple(x.shape)}")
         qkv = AF.linear(x, self.qkv.weight, self.qkv.bias)
@@ -38,7 +38,7 @@ class MemEffAttention(Attention):
                                         runs=attn_bias.runs())
         if rows is not None:
             o = o.index_select(1, rows)
-        return AF.linear(o, self.proj.weight, self.proj.bias).to(x.dtype)
+        return AF.dropout(AF.linear(o, self.proj.weight, self.proj.bias).to(x.dtype), self.proj_drop, self.training)
 
 
 class DinoVisionTransformer(VisionTransformer):

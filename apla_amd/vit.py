@@ -49,7 +49,9 @@ class Mlp(nn.Module):
         self.drop = nn.Dropout(drop)
 
     def forward(self, x):
-        AF.require_no_dropout(self.drop, self.training)
+        if self.training and self.drop.p > 0.0:   # fc1 -> act -> drop -> fc2 -> drop (vit.py:162-168): the one-node MLP has no place for the first
+            h = AF.dropout(AF.linear_gelu(x, self.fc1.weight, self.fc1.bias), self.drop, True)
+            return AF.dropout(AF.linear(h, self.fc2.weight, self.fc2.bias), self.drop, True)
         return AF.mlp_gelu(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)
 
 
@@ -83,9 +85,21 @@ class Attention(nn.Module):
         self.return_attn_matrix = False
 
     def forward(self, x):
-        AF.require_no_dropout(self.attn_drop, self.training), AF.require_no_dropout(self.proj_drop, self.training)
-        return AF.attention_module_forward(x, self.qkv.weight, self.qkv.bias, self.proj.weight, self.proj.bias,
-                                           self.num_heads, self.scale, self.return_attn_matrix)
+        AF.require_no_dropout(self.attn_drop, self.training)
+        y, attn = AF.attention_module_forward(x, self.qkv.weight, self.qkv.bias, self.proj.weight, self.proj.bias,
+                                              self.num_heads, self.scale, self.return_attn_matrix)
+        return AF.dropout(y, self.proj_drop, self.training), attn
+
+
+class DropPath(nn.Module):
+    """Stochastic depth per sample (utils/transformers/vit.py:85-93)."""
+
+    def __init__(self, drop_prob=None):
+        super().__init__()
+        self.drop_prob = drop_prob
+
+    def forward(self, x):
+        return AF.drop_path(x, self.drop_prob, self.training)
 
 
 class Block(nn.Module):
@@ -94,12 +108,10 @@ class Block(nn.Module):
     def __init__(self, dim, num_heads, mlp_ratio=4.0, qkv_bias=False, qk_scale=None, drop=0.0, attn_drop=0.0,
                  drop_path=0.0, norm_layer=nn.LayerNorm, conf=None, use_swiglu=False):
         super().__init__()
-        if drop_path > 0.0:
-            raise NotImplementedError("stochastic depth is 0 in every shipped APLA config; not supported on the HIP path")
         self.norm1 = norm_layer(dim)
         self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop,
                               proj_drop=drop)
-        self.drop_path = nn.Identity()
+        self.drop_path = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()   # vit.py:257
         self.norm2 = norm_layer(dim)
         hidden = int(dim * mlp_ratio)
         self.mlp = SwiGLUFFNFused(dim, hidden, drop=drop) if use_swiglu else Mlp(dim, hidden, drop=drop)
@@ -124,8 +136,8 @@ class Block(nn.Module):
         y = self.ls1(y)
         if return_attention and not return_intermediate:
             return attn
-        x = x + y
-        x = x + self.ls2(self.mlp(AF.layer_norm(x, self.norm2)))
+        x = x + self.drop_path(y)
+        x = x + self.drop_path(self.ls2(self.mlp(AF.layer_norm(x, self.norm2))))
         return (x, attn) if return_intermediate else x
 
 
@@ -227,12 +239,18 @@ class VisionTransformer(nn.Module):
             else:
                 y = blk.attn(h, **kw)
                 y = blk.ls1(y[0] if isinstance(y, tuple) else y)
+            stochastic = self.training and isinstance(blk.drop_path, DropPath) and blk.drop_path.drop_prob > 0.0
+            if stochastic:
+                if attn_bias is not None:
+                    raise NotImplementedError("stochastic depth on a packed batch (its samples are not the leading dimension) is not supported")
+                y = blk.drop_path(y)
             res, h = AF.add_layer_norm(res, y, blk.norm2)
-            if isinstance(blk.mlp, Mlp) and (g2 is None or not g2.requires_grad):
-                AF.require_no_dropout(blk.mlp.drop, self.training)
+            if isinstance(blk.mlp, Mlp) and (g2 is None or not g2.requires_grad) and not (self.training and blk.mlp.drop.p > 0.0):
                 branch = AF.mlp_gelu(h, blk.mlp.fc1.weight, blk.mlp.fc1.bias, blk.mlp.fc2.weight, blk.mlp.fc2.bias, gamma=g2)
             else:
                 branch = blk.ls2(blk.mlp(h))
+            if stochastic:
+                branch = blk.drop_path(branch)
         return AF.add_layer_norm(res, branch, self.norm)
 
     def forward_features(self, x):
@@ -240,7 +258,7 @@ class VisionTransformer(nn.Module):
         B = x.shape[0]
         x = torch.cat((self.cls_token.expand(B, -1, -1).to(x.dtype), x), dim=1)
         x = x + self.interpolate_pos_encoding(x.shape[1] - 1).to(x.dtype)
-        AF.require_no_dropout(self.pos_drop, self.training)
+        x = AF.dropout(x, self.pos_drop, self.training)
         _, x = self.run_blocks(x)
         return x[:, 0]
 

@@ -331,6 +331,19 @@ int apla_assemble_tokens_masked(const void* patches, int ldp, const float* cls_t
                                 const uint8_t* masked, const float* mask_token, void* tokens, int res_dtype, int B, int Np,
                                 int D, hipStream_t stream);
 
+/* Dropout and stochastic depth of the module path (utils/transformers/vit.py:74-93 DropPath, :152-168 Mlp.drop; apla/appla_attn.py:82
+ * proj_drop; all shipped configurations use 0, main.py:101-111 can set them).
+ *   apla_dropout_fwd : y = keep ? x / (1 - p) : 0 and keep[i] (one byte per element, for the backward).  Element i keeps iff word
+ *                      (i & 3) of Philox4x32-10(counter {i >> 2, offset}, key seed) >= p * 2^32 — counter-based: independent of the
+ *                      launch geometry, reproduced bit for bit by the oracle.  n % 8 == 0; dtype fp32 or the build's 16-bit type.
+ *   apla_dropout_bwd : dx = keep ? dy / (1 - p) : 0
+ *   apla_scale_samples: y[s, :] = x[s, :] * scale[s] (DropPath: scale[s] = floor(keep_prob + u_s) / keep_prob, drawn by the caller —
+ *                      one number per sample); the same call is its backward. */
+int apla_dropout_fwd(const void* x, int dtype, void* y, uint8_t* keep, long n, float p, unsigned long long seed,
+                     unsigned long long offset, hipStream_t stream);
+int apla_dropout_bwd(const void* dy, int dtype, const uint8_t* keep, void* dx, long n, float p, hipStream_t stream);
+int apla_scale_samples(const void* x, int dtype, void* y, const float* scale, long samples, long per_sample, hipStream_t stream);
+
 /* Self-distillation losses of the DINOv2-APLA step (dinov2/loss/dino_clstoken_loss.py,
  * dinov2/loss/ibot_patch_loss.py) over rows of K prototype logits (K = 65 536 in the shipped config):
  *   apla_softmax_center : out[r,:] = softmax((x[r,:] - center[:]) * inv_temp)    teacher centering + sharpening

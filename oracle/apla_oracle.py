@@ -485,3 +485,41 @@ def train_step(images: Tensor, labels: Tensor, p: Dict[str, Tensor], cfg: Dict, 
     gnorm = clip_grad_norm(grads, clip) if clip else None
     adamw_step(p, grads, opt_state, lr, wd)
     return logits, loss, grads, gnorm
+
+
+# ---------------------------------------------------------------------------------------------- dropout / stochastic depth
+def philox4x32_10(counter, key):
+    """Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11; the Random123 reference implementation):
+    counter [..., 4] and key [..., 2] uint32 arrays -> [..., 4] uint32.  Pinned by the Random123 known-answer vectors
+    (tests/test_oracle_golden.py::test_philox_known_answers)."""
+    import numpy as np
+    c = np.array(counter, dtype=np.uint64) & 0xFFFFFFFF
+    k = np.array(key, dtype=np.uint64) & 0xFFFFFFFF
+    c0, c1, c2, c3 = (c[..., i].copy() for i in range(4))
+    k0, k1 = k[..., 0].copy(), k[..., 1].copy()
+    for _ in range(10):
+        p0, p1 = 0xD2511F53 * c0, 0xCD9E8D57 * c2
+        n0 = ((p1 >> 32) ^ c1 ^ k0) & 0xFFFFFFFF
+        n2 = ((p0 >> 32) ^ c3 ^ k1) & 0xFFFFFFFF
+        c1, c3, c0, c2 = p1 & 0xFFFFFFFF, p0 & 0xFFFFFFFF, n0, n2
+        k0, k1 = (k0 + 0x9E3779B9) & 0xFFFFFFFF, (k1 + 0xBB67AE85) & 0xFFFFFFFF
+    return np.stack([c0, c1, c2, c3], axis=-1).astype(np.uint32)
+
+
+def philox_keep_mask(n, p, seed, offset=0):
+    """keep[i] of apla_dropout_fwd (include/apla_hip.h): word (i & 3) of Philox4x32-10(counter {i >> 2, offset}, key seed) >= p * 2^32.
+    nn.Dropout semantics (utils/transformers/vit.py:152-168 Mlp.drop; appla_attn.py:82): y = keep ? x / (1 - p) : 0."""
+    import numpy as np
+    blk = np.arange((n + 3) // 4, dtype=np.uint64)
+    ctr = np.stack([blk & 0xFFFFFFFF, blk >> 32, np.full_like(blk, offset & 0xFFFFFFFF), np.full_like(blk, (offset >> 32) & 0xFFFFFFFF)], axis=-1)
+    key = np.stack([np.full_like(blk, seed & 0xFFFFFFFF), np.full_like(blk, (seed >> 32) & 0xFFFFFFFF)], axis=-1)
+    words = philox4x32_10(ctr, key).reshape(-1)[:n].astype(np.uint64)
+    t = float(np.float32(p)) * 4294967296.0
+    threshold = 4294967295 if t >= 4294967295.0 else int(t)
+    return words >= threshold
+
+
+def drop_path(x, u, drop_prob):
+    """utils/transformers/vit.py:74-82 with the uniform numbers u [B] given: x / keep_prob * floor(keep_prob + u)."""
+    keep = 1.0 - drop_prob
+    return x / keep * torch.floor(keep + u).reshape((-1,) + (1,) * (x.ndim - 1))

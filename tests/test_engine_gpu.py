@@ -583,3 +583,19 @@ def test_cross_entropy_rejects_out_of_range_labels():
     torch.cuda.synchronize()
     assert torch.isnan(rl[1]) and torch.isnan(rl[2]) and torch.isfinite(rl[0]) and torch.isfinite(rl[3]) and torch.isnan(loss[0])
     assert float(dl[1].abs().max()) == 0.0 and float(dl[2].abs().max()) == 0.0 and float(dl[0].abs().max()) > 0
+
+
+def test_fused_step_refuses_dropout():
+    """The captured launch sequence has no dropout / stochastic depth: a model that asks for one must not be trained as if it did not."""
+    from apla_amd.engine import AplaTrainEngine
+    from apla_amd.vit import DropPath
+    model = small_vit(depth=2)
+    model.backbone.blocks[1].mlp.drop.p = 0.1
+    with pytest.raises(NotImplementedError, match="module path only"):
+        AplaTrainEngine(model, 4, 32)
+    model.backbone.blocks[1].mlp.drop.p = 0.0
+    model.backbone.blocks[1].drop_path = DropPath(0.2)
+    with pytest.raises(NotImplementedError, match="module path only"):
+        AplaTrainEngine(model, 4, 32)
+    model.backbone.blocks[1].drop_path = torch.nn.Identity()
+    AplaTrainEngine(model, 4, 32)

@@ -1089,3 +1089,29 @@ def test_gemm_gelu_forward_only_epilogue(ops, M, N, K, variant):
     assert torch.equal(h, h_ref)
     r = (a.double() @ w.double().t() + bias.double()).float()
     assert rel_err(h.float().cpu(), (r * 0.5 * (1 + torch.erf(r / math.sqrt(2)))).cpu()) < 6e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("p,n", [(0.1, 8 * 1237), (0.5, 3 * 197 * 768), (0.0, 64)])
+def test_dropout_kernels_and_the_oracle_mask(ops, dtype, p, n):
+    """apla_dropout_fwd / _bwd: the keep mask is the oracle's counter-based mask bit for bit (Philox4x32-10 pinned by the Random123
+    vectors), y = keep ? x / (1 - p) : 0 in the tensor's own rounding, the backward applies the same mask and scale."""
+    import numpy as np
+    x = rnd(n, seed=161).to(dtype)
+    seed, offset = 0x1234_5678_9ABC_DEF0, 3
+    y, keep = ops.dropout_fwd(dev(x), p, seed, offset)
+    want = torch.from_numpy(O.philox_keep_mask(n, p, seed, offset))
+    assert torch.equal(keep.cpu().bool(), want)
+    inv = torch.tensor(1.0, dtype=torch.float32) / (torch.tensor(1.0, dtype=torch.float32) - torch.tensor(p, dtype=torch.float32))
+    ref = torch.where(want, (x.float() * inv), torch.zeros(())).to(dtype)
+    assert torch.equal(y.cpu(), ref)
+    dy = rnd(n, seed=162).to(dtype)
+    dx = ops.dropout_bwd(dev(dy), keep, p)
+    assert torch.equal(dx.cpu(), torch.where(want, dy.float() * inv, torch.zeros(())).to(dtype))
+    if p > 0:
+        assert abs(float(want.float().mean()) - (1 - p)) < 0.02
+        y2, keep2 = ops.dropout_fwd(dev(x), p, seed, offset + 1)
+        assert not torch.equal(keep2, keep)            # another offset, another mask
+    sc = torch.tensor([0.0, 2.0, 1.0], device="cuda")
+    xs = dev(rnd(3, 5, 64, seed=163).to(dtype))
+    assert torch.equal(ops.scale_samples(xs, sc).float().cpu(), (xs.float() * sc[:, None, None]).to(dtype).float().cpu())

@@ -146,3 +146,58 @@ def test_fused_block_loop_equals_block_by_block():
     assert set(f[3]) == set(p[3]) and len(f[3]) == 6
     for n in f[3]:
         assert rel_err(f[3][n].cpu(), p[3][n].double().cpu()) < GRAD_TOL, n
+
+
+def test_dropout_and_stochastic_depth_on_the_module_path():
+    """drop_rate / drop_path_rate > 0 (main.py:101-111 can set them; utils/transformers/vit.py:74-93, 152-168, 257-288): the ViT's
+    module path applies pos_drop, proj_drop, both Mlp dropouts and per-sample DropPath through the HIP kernels; eval mode is the
+    deterministic network; a seed repeats a training pass; gradients flow through the masks; attention-probability dropout and the fused
+    step refuse."""
+    from apla_amd import functional as AF
+    from apla_amd.vit import Block, DropPath, VisionTransformer
+    torch.manual_seed(0)
+    kw = dict(img_size=[32], patch_size=16, embed_dim=128, depth=3, num_heads=2, qkv_bias=True)
+    vit = VisionTransformer(drop_rate=0.2, drop_path_rate=0.3, **kw).cuda()
+    ref = VisionTransformer(**kw).cuda()
+    ref.load_state_dict(vit.state_dict())
+    for net in (vit, ref):          # the APLA situation: everything frozen but the attention projections
+        for n, p_ in net.named_parameters():
+            p_.requires_grad_(".attn.proj." in n)
+    assert isinstance(vit.blocks[2].drop_path, DropPath) and abs(vit.blocks[2].drop_path.drop_prob - 0.3) < 1e-6
+    assert isinstance(vit.blocks[0].drop_path, torch.nn.Identity)          # linspace(0, rate, depth)[0] = 0
+    x = torch.randn(6, 3, 32, 32, device="cuda")
+    vit.eval(), ref.eval()
+    with torch.no_grad():
+        assert torch.equal(vit(x), ref(x))                                  # eval: every dropout is the identity
+    vit.train()
+    torch.manual_seed(5)
+    a = vit(x)
+    torch.manual_seed(5)
+    b = vit(x)
+    c = vit(x)
+    assert torch.equal(a, b) and not torch.equal(a, c)                      # the masks follow torch's seed
+    with torch.no_grad():
+        e = ref(x)
+    assert not torch.equal(a.detach(), e) and float((a.detach().float() - e.float()).abs().mean()) < float(e.float().abs().mean())
+    vit(x).float().square().mean().backward()
+    got = [p_.grad for n, p_ in vit.named_parameters() if ".attn.proj.weight" in n]
+    assert len(got) == 3 and all(g_ is not None and bool(torch.isfinite(g_).all()) and float(g_.abs().max()) > 0 for g_ in got)
+
+    # DropPath per sample: the branch of a sample is either dropped or scaled by 1 / keep_prob (vit.py:74-82)
+    t = torch.randn(64, 5, 128, device="cuda")
+    y = AF.drop_path(t, 0.25, True)
+    ratio = (y / t).reshape(64, -1)
+    per = ratio[:, 0]
+    assert bool(((per == 0) | ((per - 1 / 0.75).abs() < 1e-6)).all()) and 0 < int((per == 0).sum()) < 64
+    assert float((ratio - per[:, None]).abs().max()) < 1e-6
+    assert AF.drop_path(t, 0.25, False) is t and AF.dropout(t, 0.5, False) is t
+
+    # the expectation is preserved: mean over many draws of dropout(x) ~ x
+    acc = torch.zeros_like(t)
+    for _ in range(200):
+        acc += AF.dropout(t, 0.5, True)
+    assert float((acc / 200 - t).abs().mean()) < 0.12 * float(t.abs().mean()) + 0.05
+
+    blk = Block(128, 2, attn_drop=0.1).cuda().train()
+    with pytest.raises(NotImplementedError):
+        blk(torch.randn(2, 5, 128, device="cuda"))

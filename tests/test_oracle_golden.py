@@ -199,3 +199,18 @@ def test_g13_knn_vote_and_metrics_oracle():
     r = E.multilabel_metrics(d["ml_logits"], d["ml_truths"])
     for key in ("accuracy", "mAP", "precision", "recall", "f1", "roc_auc"):
         assert abs(r[key] - float(d["ml_" + key])) <= 5.01e-4, (key, r[key], float(d["ml_" + key]))
+
+
+def test_philox_known_answers():
+    """The oracle's Philox4x32-10 (the generator behind apla_dropout_fwd's keep mask) against the Random123 known-answer vectors
+    (kat_vectors: philox4x32 10)."""
+    import numpy as np
+    from oracle import apla_oracle as O
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        got = O.philox4x32_10(np.array(ctr, dtype=np.uint64), np.array(key, dtype=np.uint64))
+        assert tuple(int(v) for v in got) == want, (ctr, [hex(int(v)) for v in got])
+    m = O.philox_keep_mask(100000, 0.25, seed=12345, offset=7)
+    assert abs(m.mean() - 0.75) < 5e-3 and m[:8].tolist() != m[8:16].tolist()
