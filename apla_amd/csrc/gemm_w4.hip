@@ -4,7 +4,7 @@
 // epilogue arithmetic runs under the other's MFMAs (gemm_nt.hip's 4-wave kernel); the matrix pipes want a large wave tile, so that
 // a K-step costs few LDS-DMA issues and fragment reads per MFMA (gemm_pp2.hip).  gemm_nt.hip's wave tile is 80 x 64: per 40 MFMAs
 // a wave issues 9 LDS-DMA pieces and 18 fragment reads and the tile does 71 FLOP per staged byte, which puts the CU's LDS fill
-// path beside its matrix pipes (DESIGN.md 0c).  Here every wave owns 80 x 128 outputs (5 x 8 MFMA tiles, 160 accumulator registers,
+// path beside its matrix pipes (DESIGN.md appendix A).  Here every wave owns 80 x 128 outputs (5 x 8 MFMA tiles, 160 accumulator registers,
 // as in gemm_pp2.hip): per 40 MFMAs 6.5 pieces and 13 reads, 98 FLOP per staged byte; a 32-wide K-step keeps a stage at 26 KB, so
 // a 3-stage ring (LDS-DMA two K-steps ahead) + two bias pieces are exactly 80 KB: two workgroups fill a CU's 160 KB (the epilogue's
 // line buffers live in the stage that was read last).  The LDS image of a stage, the fragment

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Diagnostic builds of the library for ablation timing (see DESIGN.md §4 "Where the time goes"): each variant compiles ONE
+# Diagnostic builds of the library for ablation timing (see DESIGN.md appendix C.1 "Where the GEMM time goes"): each variant compiles ONE
 # source with a -DAPLA_ABL_* switch and links it with the product objects into apla_amd/build/exp/libapla_<variant>.so.
 # Results of these builds are WRONG by construction; they exist to be timed (tools/gemm_bench.py / tools/dw_bench.py with
 # APLA_LIB=<path>).  Run after `python -m apla_amd.build`.
