@@ -12,6 +12,10 @@ OUT_F16 = os.path.join(HERE, "libapla_hip_f16.so")  # same sources with -DAPLA_F
 SOURCES = ["errors.cpp", "gemm_nt.hip", "gemm_pp2.hip", "gemm_w4.hip", "gemm_tp.hip", "gemm_small.hip", "layernorm.hip", "attention.hip", "apla_dw.hip", "optim.hip", "misc.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"]
+# Sources whose kernels count their own s_waitcnt (LDS-DMA rings, ds_read_tr pipelines, asm operand loads): a register spill puts scratch
+# loads and stores into the same in-order vmcnt queue and silently breaks those counts (round 4: the fused attention backward at
+# three waves per SIMD spilled 74 registers and returned wrong gradients).  Their objects are only accepted spill-free.
+NO_SPILL = ("gemm_nt.hip", "gemm_pp2.hip", "gemm_w4.hip", "gemm_tp.hip", "attention.hip", "apla_dw.hip", "layernorm.hip")
 
 
 def _stale(obj, src):
@@ -57,6 +61,21 @@ def audit_gemm_tp(defines=(), verbose: bool = True) -> dict:
     return meta
 
 
+def spilled_kernels(remarks: str) -> dict:
+    """{kernel: spilled VGPRs} for every kernel of a `-Rpass-analysis=kernel-resource-usage` listing that spills vector registers
+    (spilled SGPRs go to VGPR lanes by v_writelane: no memory operation, harmless for the wait counts)."""
+    import re
+    out, name = {}, None
+    for line in remarks.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+        m = re.search(r"VGPRs Spill: (\d+)", line)
+        if m and name and int(m.group(1)) > 0:
+            out[name] = out.get(name, 0) + int(m.group(1))
+    return out
+
+
 def build(force: bool = False, verbose: bool = True, fp16: bool = True) -> str:
     """Compile libapla_hip.so and (fp16=True) libapla_hip_f16.so."""
     _build_one(OUT, "build", [], force, verbose)
@@ -73,7 +92,8 @@ def _build_one(out, objsub, defines, force, verbose):
         src = os.path.join(CSRC, s)
         obj = os.path.join(objdir, s.rsplit(".", 1)[0] + ".o")
         if force or _stale(obj, src):
-            cmd = [HIPCC] + FLAGS + defines + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", src, "-o", obj]
+            cmd = [HIPCC] + FLAGS + defines + (["-x", "hip"] if s.endswith(".cpp") else []) + \
+                  (["-Rpass-analysis=kernel-resource-usage"] if s in NO_SPILL else []) + ["-c", src, "-o", obj]
             jobs.append(cmd)
     def run(cmd):
         if verbose:
@@ -81,6 +101,11 @@ def _build_one(out, objsub, defines, force, verbose):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed:\n{r.stdout}\n{r.stderr}")
+        if "-Rpass-analysis=kernel-resource-usage" in cmd:
+            spilled = spilled_kernels(r.stderr)
+            if spilled:
+                os.remove(cmd[-1])      # never link an object whose hand-counted waits cannot be trusted
+                raise RuntimeError(f"{os.path.basename(cmd[-3])}: register spills in kernels that count their own waits: {spilled}")
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
     if any("gemm_tp.hip" in " ".join(j) for j in jobs):

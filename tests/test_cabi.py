@@ -88,3 +88,18 @@ def test_gemm_tp_register_audit():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     gen = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_tp_asm.py")], capture_output=True, text=True, check=True).stdout
     assert gen == open(os.path.join(root, "apla_amd", "csrc", "gemm_tp_asm.inc")).read()
+
+
+def test_build_rejects_vector_register_spills_in_hand_waited_kernels():
+    """apla_amd/build.py compiles the sources whose kernels count their own s_waitcnt with the resource-usage remarks on and refuses
+    an object in which any kernel spills vector registers (scratch traffic shares the in-order vmcnt queue with the LDS-DMA the
+    counts are about).  The parser, on a listing in hipcc's format."""
+    from apla_amd.build import NO_SPILL, spilled_kernels
+    txt = ("x.hip:1:1: remark: Function Name: kA [-Rpass-analysis=kernel-resource-usage]\n"
+           "x.hip:1:1: remark:     SGPRs Spill: 8 [-Rpass-analysis=kernel-resource-usage]\n"
+           "x.hip:1:1: remark:     VGPRs Spill: 0 [-Rpass-analysis=kernel-resource-usage]\n"
+           "x.hip:1:1: remark: Function Name: kB [-Rpass-analysis=kernel-resource-usage]\n"
+           "x.hip:1:1: remark:     SGPRs Spill: 0 [-Rpass-analysis=kernel-resource-usage]\n"
+           "x.hip:1:1: remark:     VGPRs Spill: 74 [-Rpass-analysis=kernel-resource-usage]\n")
+    assert spilled_kernels(txt) == {"kB": 74}
+    assert {"attention.hip", "gemm_pp2.hip", "gemm_w4.hip", "gemm_tp.hip", "gemm_nt.hip"} <= set(NO_SPILL)
