@@ -387,10 +387,20 @@ def main(params, args):
         if pretrained and is_rank0():
             print("\033[93m[main] model_params.pretrained is true but there is no network and no --pretrained_path: random initialisation\033[0m")
     hdt = torch.float16 if args.dtype == "fp16" else torch.bfloat16
-    eng = AplaTrainEngine(model, run["batch"], run["img"], device=dev, process_group=dist.group.WORLD if world > 1 else None,
-                          optim=OptimConfig(lr=run["lr"], weight_decay=run["wd"], grad_clipping=run["grad_clipping"]),
-                          compute_dtype=hdt, loss_scale="dynamic" if hdt == torch.float16 else 1.0,
-                          soft_targets=run["soft_targets"])
+    from apla_amd.module_trainer import ModulePathTrainer, wants_dropout
+    module_path = wants_dropout(model)
+    if module_path:
+        # --dr / --dpr (main.py:101-111): the fused step has no dropout / stochastic depth; train on the drop-in module path
+        if is_rank0():
+            print("[main] drop_rate / drop_path_rate > 0: training on the module path (apla_amd.module_trainer), not the fused step", flush=True)
+        eng = ModulePathTrainer(model.to(dev), lr=run["lr"], weight_decay=run["wd"], grad_clipping=run["grad_clipping"],
+                                process_group=dist.group.WORLD if world > 1 else None, compute_dtype=hdt,
+                                loss_scale=1024.0 if hdt == torch.float16 else 1.0, soft_targets=run["soft_targets"])
+    else:
+        eng = AplaTrainEngine(model, run["batch"], run["img"], device=dev, process_group=dist.group.WORLD if world > 1 else None,
+                              optim=OptimConfig(lr=run["lr"], weight_decay=run["wd"], grad_clipping=run["grad_clipping"]),
+                              compute_dtype=hdt, loss_scale="dynamic" if hdt == torch.float16 else 1.0,
+                              soft_targets=run["soft_targets"])
     data = TensorBatches(run, rank, world, dev, args.steps_per_epoch)
     sched = make_schedule(run, data.steps)
     epochs = 0 if args.test else (1 if args.dry else run["epochs"])   # --test: evaluate the loaded weights only (main.py:219-222)
@@ -423,9 +433,14 @@ def main(params, args):
     if is_rank0() and run["save_dir"] and not (args.dry or args.debug or args.test):
         os.makedirs(run["save_dir"], exist_ok=True)
         path = os.path.join(run["save_dir"], run["model_name"] + ".pth")
-        torch.save(ckpt.session_dict(eng, iters=iters, epoch=epochs, parameters=params), path)
+        if module_path:   # the reference's session layout (bases.py:456-464) with FlatAdamW's torch.optim-shaped state
+            torch.save({"iters": iters, "state_dict": {k: v.detach().cpu().clone() for k, v in eng.model.state_dict().items()},
+                        "original_state": None, "optimizer": eng.optimizer.state_dict(), "epoch": epochs, "parameters": params,
+                        "best_val_target": 0.0}, path)
+        else:
+            torch.save(ckpt.session_dict(eng, iters=iters, epoch=epochs, parameters=params), path)
         print(f"[main] saved {path}")
-    if (args.test or args.knn or tp_knn) and is_rank0() and not soft_engine:
+    if (args.test or args.knn or tp_knn) and is_rank0() and not soft_engine and not module_path:
         # Trainer.test / evaluate (defaults/trainer.py:162-345) on rank 0: loss + accuracy on the evaluation batches, optionally
         # kNN metrics against a feature bank of the training batches (the evaluation split of a TensorFile is its
         # `val_images` / `val_labels` entries when present, else the training tensors; synthetic data otherwise)

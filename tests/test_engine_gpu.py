@@ -81,6 +81,11 @@ def small_vit(depth=2, r=64, swiglu=False, ls=True, dim=128, heads=2, img=32, pa
             self.backbone = bb
             self.backbone.fc = nn.Identity()
             self.fc = nn.Linear(dim, classes)
+
+        def forward(self, x, return_embedding=False):   # defaults/models.py:81-92
+            emb = self.backbone(x)
+            out = self.fc(emb.float())
+            return (out, emb) if return_embedding else out
     return Net()
 
 
@@ -314,6 +319,37 @@ def test_main_entry_point_trains_on_synthetic_data(tmp_path):
     assert sess["iters"] == 12 and "backbone.blocks.0.attn.proj_weight1" in sess["state_dict"]
     assert tuple(sess["state_dict"]["backbone.blocks.0.attn.proj_weight1"].shape) == (8, 384)
     assert float(sess["optimizer"]["state"][0]["step"]) == 12.0
+
+
+def test_main_entry_point_with_dropout_trains_on_the_module_path(tmp_path):
+    """main.py --dr / --dpr (the reference's main.py:101-111 overrides): the fused step refuses dropout, so the entry point trains on
+    the module path (apla_amd.module_trainer: autograd over the HIP kernels + FlatAdamW) — the loss must fall on a repeated synthetic
+    batch, the session file keeps the reference layout, and a run without the flags still takes the fused step."""
+    import main
+    from apla_amd.module_trainer import ModulePathTrainer, wants_dropout
+    path = os.path.join(os.path.dirname(__file__), "params", "tiny", "apla.yml")
+    args = main.parse_arguments(["--params_path", path, "--steps_per_epoch", "6", "--save_dir", str(tmp_path), "--lr", "0.002",
+                                 "--dr", "0.1", "--dpr", "0.1"])
+    params = main.update_params_from_args(main.load_parameters(path), args)
+    assert params["model_params"]["transformers_params"]["drop_rate"] == 0.1
+    loss = main.main(params, args)
+    assert np.isfinite(loss)
+    sess = torch.load(tmp_path / "tiny.pth", weights_only=False)
+    assert sess["iters"] == 12 and tuple(sess["state_dict"]["backbone.blocks.0.attn.proj_weight1"].shape) == (8, 384)
+    assert float(sess["optimizer"]["state"][0]["step"]) == 12.0
+    # the trainer itself: the step of the reference's loop on a fixed batch learns it
+    model = small_vit(depth=2)
+    model.backbone.blocks[1].mlp.drop.p = 0.1
+    assert wants_dropout(model)
+    tr = ModulePathTrainer(model, lr=2e-3, weight_decay=0.0, grad_clipping=1.0)
+    g = torch.Generator().manual_seed(0)
+    x, y = torch.randn(4, 3, 32, 32, generator=g).cuda(), torch.randint(0, 10, (4,), generator=g).cuda()
+    first = float(tr.train_step(x, y))
+    for _ in range(30):
+        last = float(tr.train_step(x, y))
+    assert last < 0.5 * first and float(tr.grad_norm) > 0
+    logits, emb, l_eval = tr.forward_only(x, y)
+    assert logits.shape == (4, 10) and np.isfinite(float(l_eval)) and tr.model.training
 
 
 def test_engine_soft_targets_step():
