@@ -91,3 +91,48 @@ def test_two_rank_ssl_iteration(tmp_path, same_data):
         upd = torch.from_numpy(named[n]) - t(g["init." + n])
         assert float((upd - ref_upd).abs().mean() / (ref_upd.abs().mean() + 1e-12)) < 0.2, n
     assert rel_err(torch.from_numpy(np.load(tmp_path / "center_0.npy")), g["dino.center"]) < 2e-2
+
+
+def _rccl_worker(outdir):
+    """One rank, backend nccl (= RCCL): the trainer's hook-driven chunked exchange with real RCCL calls on the side stream."""
+    import torch.distributed as dist
+    from apla_amd.ssl import CosineScheduler, Dinov2Trainer
+    from conftest import load_golden
+    from test_ssl_step_gpu import build_from_golden
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + os.getpid() % 400))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        g = load_golden("g12_ssl_step_apla.npz")
+        sched = (CosineScheduler(base_value=1e-3, final_value=1e-6, total_iters=6, warmup_iters=2, start_warmup_value=0),
+                 CosineScheduler(base_value=0.04, final_value=1e-4, total_iters=6), CosineScheduler(base_value=0.9, final_value=1.0, total_iters=6),
+                 CosineScheduler(base_value=0.07, final_value=0.07, total_iters=3, warmup_iters=3, start_warmup_value=0.04), None)
+        tr = Dinov2Trainer(build_from_golden(g, "apla"), iters_per_epoch=1, epochs=6, grad_clipping=3.0, freeze_last_layer_epochs=1,
+                           schedules=sched, process_group=dist.group.WORLD, exchange_chunk_mb=0.25, force_exchange=True)
+        assert tr.world == 1 and tr.exchanger.active and len(tr.exchanger.chunks) >= 3
+        for it in (1, 2):
+            tr.global_step(_batch(g, it))
+        torch.cuda.synchronize()
+        np.save(os.path.join(outdir, "rccl_student.npy"), tr.optimizer.flat.cpu().numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_chunked_exchange_on_one_rank(tmp_path):
+    """The RCCL transport under the self-supervised trainer's exchange (chunks started by post-accumulate hooks while backward runs, an
+    all-reduce per chunk on the side stream, the wait before the norm pass), which the two-rank gloo test cannot cover on a one-GPU
+    box: a `nccl` group of ONE rank with the exchange forced on must leave the iteration bit-identical to the plain one."""
+    import torch.multiprocessing as mp
+    from conftest import load_golden
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_rccl_worker, args=(str(tmp_path),))
+    p.start()
+    p.join(300)
+    assert p.exitcode == 0
+    g = load_golden("g12_ssl_step_apla.npz")
+    tr = _trainer(g)
+    assert not tr.exchanger.active
+    for it in (1, 2):
+        tr.global_step(_batch(g, it))
+    torch.cuda.synchronize()
+    assert np.array_equal(np.load(tmp_path / "rccl_student.npy"), tr.optimizer.flat.cpu().numpy())
