@@ -107,16 +107,20 @@ class DinoVisionTransformer(VisionTransformer):
             row += b * (n + 1)
         return mask, packed
 
-    def forward_features_list(self, x_list: List[torch.Tensor], masks_list: List[Optional[torch.Tensor]]):
-        if x_list[0].is_cuda and not (self.cls_token.requires_grad or self.pos_embed.requires_grad or self.mask_token.requires_grad
-                                      or any(p.requires_grad for p in self.patch_embed.parameters())):
-            attn_bias, x = self.pack_tokens(x_list, masks_list)
-        else:
-            toks = [self.prepare_tokens_with_masks(x, m) for x, m in zip(x_list, masks_list)]
-            attn_bias, x = BlockDiagonalMask.from_tensor_list(toks)
+    def _packed_input(self, x_list, masks_list):
+        """(mask, packed tokens [1, total, D]) of a list of crop groups: one assemble kernel per group when the token parameters are
+        frozen (they are under APLA), the reference's torch route (prepare_tokens_with_masks + concatenation) otherwise."""
         for blk in self.blocks:
             if not isinstance(blk.attn, (APLA_MemEffAttention, MemEffAttention)):   # block.py:249
                 raise NotImplementedError("the packed forward needs (APLA_)MemEffAttention blocks (build_apla(..., 'apla_attn_mem_eff'))")
+        frozen = not (self.cls_token.requires_grad or self.pos_embed.requires_grad or self.mask_token.requires_grad
+                      or any(p.requires_grad for p in self.patch_embed.parameters()))
+        if x_list[0].is_cuda and frozen:
+            return self.pack_tokens(x_list, masks_list)
+        return BlockDiagonalMask.from_tensor_list([self.prepare_tokens_with_masks(x, m) for x, m in zip(x_list, masks_list)])
+
+    def forward_features_list(self, x_list: List[torch.Tensor], masks_list: List[Optional[torch.Tensor]]):
+        attn_bias, x = self._packed_input(x_list, masks_list)
         x_pre, x_nrm = self.run_blocks(x, attn_bias)     # LayerNorm is token-wise: normalise packed, split afterwards
         outs = []
         for xi, x_norm, masks in zip(attn_bias.split(x_pre), attn_bias.split(x_nrm), masks_list):
@@ -132,14 +136,7 @@ class DinoVisionTransformer(VisionTransformer):
         both LayerNorms around it run on those rows only (every token still attends and is attended to: the block's K / V are
         dense), forward and backward — 5 519 of the student's 58 496 and 5 007 of the teacher's 32 896 rows at config 4.
         Returns ([cls of group 0, cls of group 1, ...], masked patch tokens or None)."""
-        if x_list[0].is_cuda and not (self.cls_token.requires_grad or self.pos_embed.requires_grad or self.mask_token.requires_grad
-                                      or any(p.requires_grad for p in self.patch_embed.parameters())):
-            attn_bias, x = self.pack_tokens(x_list, masks_list)
-        else:
-            attn_bias, x = BlockDiagonalMask.from_tensor_list([self.prepare_tokens_with_masks(x, m) for x, m in zip(x_list, masks_list)])
-        for blk in self.blocks:
-            if not isinstance(blk.attn, (APLA_MemEffAttention, MemEffAttention)):
-                raise NotImplementedError("the packed forward needs (APLA_)MemEffAttention blocks (build_apla(..., 'apla_attn_mem_eff'))")
+        attn_bias, x = self._packed_input(x_list, masks_list)
         rows, counts = [attn_bias.seq_starts(x.device)], list(attn_bias._batch_sizes)
         if masked_idx is not None and masked_idx.numel():
             n0 = attn_bias.seqlens[0] - 1                                   # patches per crop of group 0

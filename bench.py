@@ -370,6 +370,11 @@ def main():
     sync()
     torch.cuda.reset_peak_memory_stats()
     eng.exchanger.time_waits(True)     # (two event records per step on the compute stream; nothing when there is no exchange)
+    from apla_amd import telemetry
+    hwmon = telemetry.find_hwmon()     # what the socket draws during the timed steps (driver's hwmon files; None where they are missing)
+    sampler = telemetry.Sampler(hwmon, period=0.01) if hwmon else None
+    if sampler:
+        sampler.start()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # per-step durations for the median
     t0 = time.perf_counter()
     marks[0].record()
@@ -378,6 +383,12 @@ def main():
         marks[k + 1].record()
     sync()
     elapsed = time.perf_counter() - t0
+    power = None
+    if sampler:
+        sampler.stop()
+        power = sampler.summary(since=t0)
+        if power is not None:
+            power["cap_w"] = telemetry.power_cap_w(hwmon)
     loss = float(eng.loss)
     per_step = torch.tensor([marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps)], dtype=torch.float64)
     # what a scaling curve needs to explain itself: every rank's own step time and the time its compute stream was held waiting for
@@ -385,7 +396,7 @@ def main():
     wait_ms = eng.exchanger.mean_wait_ms()
     eng.exchanger.time_waits(False)
     rank_ms = float(per_step.mean()) if args.steps else 0.0
-    per_rank = [[rank_ms, -1.0 if wait_ms is None else wait_ms]]
+    per_rank = [[rank_ms, -1.0 if wait_ms is None else wait_ms, -1.0 if power is None else power["mean_w"]]]
     if world > 1:
         mine = torch.tensor(per_rank[0], device="cuda", dtype=torch.float64)
         allr = [torch.empty_like(mine) for _ in range(world)]
@@ -475,9 +486,13 @@ def main():
                       # mean time per step the compute stream stood at GradExchanger.wait(): null = no exchange in this run
                       "exchange_wait_ms": [None if r[1] < 0 else round(r[1], 4) for r in per_rank],
                       "exchange_chunks": len(eng.chunks) if eng.exchanger.active else 0,
+                      # what each rank's socket drew during the timed steps (driver hwmon, 10 ms samples); null where not readable
+                      "socket_w": [None if (len(r) < 3 or r[2] < 0) else round(r[2], 1) for r in per_rank],
                       "reserved_cus": eng.reserve_cus,
                       "env": {k: os.environ.get(k) for k in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS", "APLA_RESERVE_CUS", "APLA_FORCE_EXCHANGE")}},
             "final_loss": round(loss, 4),
+            # rank 0's socket during the timed steps: the GEMM launches of the step run AT the cap (tools/power_probe.py)
+            "power": power,
             "roofline": {"bound": "mfma", "kernel": f"{dom_kernel} (apla_gemm_nt, fc1+activation launch) M={M} N={Fdim} K={bb.embed_dim}",
                          "achieved": round(k_tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(k_tf / PEAK_BF16_TFLOPS, 4),

@@ -42,6 +42,11 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert f16["steps"] == 3 and f16["ms_per_step"] > 0 and abs(f16["images_per_sec"] - 128 / (f16["ms_per_step"] * 1e-3)) < 0.01 * f16["images_per_sec"]
     rk = d["ranks"]                              # a one-rank run has no exchange: nothing waited for
     assert rk["ms_per_step"] == [rk["ms_per_step_min"]] == [rk["ms_per_step_max"]] and rk["exchange_wait_ms"] == [None] and rk["exchange_chunks"] == 0
+    pw = d["power"]                              # socket telemetry of the timed steps (null only where the driver's hwmon files are missing)
+    assert len(rk["socket_w"]) == 1
+    if pw is not None:
+        assert pw["samples"] >= 1 and 100.0 < pw["mean_w"] <= pw["max_w"] <= 1.1 * pw["cap_w"] and 500 <= pw["sclk_mhz"] <= 2600
+        assert rk["socket_w"] == [pw["mean_w"]]
 
 
 def test_bench_reports_the_exchange_wait_on_the_forced_exchange_path():
