@@ -15,22 +15,27 @@ import torch.distributed as dist
 
 from . import ops
 from .dist import GradExchanger
-from .optim import FlatAdamW
+from .optim import DynamicLossScale, FlatAdamW
 
 
 class ModulePathTrainer:
     def __init__(self, model, *, lr: float = 1e-4, weight_decay: float = 1e-5, grad_clipping: float = 0.0, process_group=None,
-                 compute_dtype=torch.bfloat16, loss_scale: float = 1.0, soft_targets: bool = False, label_smoothing: float = 0.0):
+                 compute_dtype=torch.bfloat16, loss_scale=1.0, soft_targets: bool = False, label_smoothing: float = 0.0):
+        """``loss_scale``: a float (static) or "dynamic" (GradScaler semantics, fp16 only: defaults/trainer.py:129-138)."""
         if compute_dtype not in (torch.bfloat16, torch.float16):
             raise TypeError("compute_dtype must be torch.bfloat16 or torch.float16")
         self.model = model.cuda().train()
-        self.compute_dtype, self.loss_scale = compute_dtype, float(loss_scale)
+        self.compute_dtype = compute_dtype
+        dyn = loss_scale == "dynamic"
+        self.scaler = DynamicLossScale(enabled=dyn) if dyn else DynamicLossScale(init_scale=float(loss_scale), growth_interval=1 << 62)
+        if not dyn:
+            self.scaler.backoff_factor = 1.0     # a static scale stays what it is; a non-finite step is still skipped and counted
         self.grad_clipping, self.soft_targets = float(grad_clipping or 0.0), soft_targets
         self.optimizer = FlatAdamW(self.model.named_parameters(), lr=lr, weight_decay=weight_decay)
         self.exchanger = GradExchanger(self.optimizer.grads, [(0, self.optimizer.grads.numel())], process_group)
         self.world = self.exchanger.world
         self.criterion = torch.nn.CrossEntropyLoss(label_smoothing=0.0 if soft_targets else label_smoothing)
-        self.step_count, self.skipped_steps = 0, 0
+        self.step_count = 0
 
     @property
     def grad_norm(self) -> torch.Tensor:
@@ -44,15 +49,19 @@ class ModulePathTrainer:
         with ops.use_half(self.compute_dtype):
             logits = self.model(images).float()
             loss = self.criterion(logits, labels if self.soft_targets else labels.long())
-            (loss * self.loss_scale if self.loss_scale != 1.0 else loss).backward()
+            scale = self.scaler.scale
+            (loss * scale if scale != 1.0 else loss).backward()
         if self.exchanger.active:
             self.exchanger.launch_chunk(0)
             self.exchanger.wait()
-        applied = opt.step(max_norm=self.grad_clipping, grad_scale=1.0 / (self.world * self.loss_scale),
+        applied = opt.step(max_norm=self.grad_clipping, grad_scale=1.0 / (self.world * scale),
                            check_finite=self.compute_dtype == torch.float16)
+        self.scaler.update(applied)
         self.step_count += 1
-        self.skipped_steps += 0 if applied else 1
         return loss.detach()
+
+    loss_scale = property(lambda self: self.scaler.scale)
+    skipped_steps = property(lambda self: self.scaler.skipped_steps)
 
     @torch.no_grad()
     def forward_only(self, images, labels=None):

@@ -18,6 +18,39 @@ from ._lib import check, lib
 from .ops import _stream
 
 
+class DynamicLossScale:
+    """torch.cuda.amp.GradScaler's scale bookkeeping (scaler.update(), defaults/trainer.py:129-138; self_supervised/dinov2/
+    trainer.py:124-135) for loops whose optimizer reports whether the step was applied (``FlatAdamW.step(check_finite=True)``):
+    a skipped step multiplies the scale by ``backoff_factor`` and resets the growth counter, ``growth_interval`` applied steps in a row
+    multiply it by ``growth_factor``.  ``enabled=False`` is the constant 1 (bf16)."""
+
+    def __init__(self, init_scale: float = 65536.0, growth_factor: float = 2.0, backoff_factor: float = 0.5, growth_interval: int = 2000,
+                 enabled: bool = True):
+        self.enabled = enabled
+        self.scale = float(init_scale) if enabled else 1.0
+        self.growth_factor, self.backoff_factor, self.growth_interval = growth_factor, backoff_factor, growth_interval
+        self.growth_tracker, self.skipped_steps = 0, 0
+
+    def update(self, applied: bool):
+        if not self.enabled:
+            return
+        if not applied:
+            self.scale *= self.backoff_factor
+            self.growth_tracker, self.skipped_steps = 0, self.skipped_steps + 1
+            return
+        self.growth_tracker += 1
+        if self.growth_tracker >= self.growth_interval:
+            self.scale *= self.growth_factor
+            self.growth_tracker = 0
+
+    def state_dict(self):   # GradScaler.state_dict() layout (defaults/bases.py:465-466)
+        return {"scale": self.scale, "growth_factor": self.growth_factor, "backoff_factor": self.backoff_factor,
+                "growth_interval": self.growth_interval, "_growth_tracker": self.growth_tracker}
+
+    def load_state_dict(self, sd):
+        self.scale, self.growth_tracker = float(sd.get("scale", self.scale)), int(sd.get("_growth_tracker", 0))
+
+
 class FlatAdamW:
     def __init__(self, named_params: Iterable[Tuple[str, torch.nn.Parameter]], lr=1e-4, weight_decay=1e-5, betas=(0.9, 0.999),
                  eps=1e-8):

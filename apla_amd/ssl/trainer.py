@@ -26,7 +26,7 @@ import torch.distributed as dist
 
 from .. import ops
 from ..dist import GradExchanger
-from ..optim import FlatAdamW
+from ..optim import DynamicLossScale, FlatAdamW
 from .collate import build_schedulers
 from .losses import grad_prescale
 from .models import DINOv2
@@ -43,9 +43,7 @@ class Dinov2Trainer:
             raise TypeError("compute_dtype must be torch.bfloat16 or torch.float16")
         self.compute_dtype = compute_dtype
         # GradScaler state (fp16 only): torch.cuda.amp.GradScaler defaults, bases.py / defaults/trainer.py:50-51
-        self.loss_scale = float(init_scale) if compute_dtype == torch.float16 else 1.0
-        self.growth_factor, self.backoff_factor, self.growth_interval = growth_factor, backoff_factor, growth_interval
-        self.growth_tracker, self.skipped_steps = 0, 0
+        self.scaler = DynamicLossScale(init_scale, growth_factor, backoff_factor, growth_interval, enabled=compute_dtype == torch.float16)
         self.model = model
         self.iters_per_epoch, self.total_iters = iters_per_epoch, iters_per_epoch * epochs
         self.grad_clipping, self.freeze_last_for = grad_clipping, freeze_last_layer_epochs
@@ -103,6 +101,11 @@ class Dinov2Trainer:
         ex.wait()
         self._chunk_seen, self._chunk_sent = [0] * len(ex.chunks), [False] * len(ex.chunks)
 
+    # the scaler's state under the names the trainer has always exposed
+    loss_scale = property(lambda self: self.scaler.scale)
+    growth_tracker = property(lambda self: self.scaler.growth_tracker)
+    skipped_steps = property(lambda self: self.scaler.skipped_steps)
+
     def global_step(self, batch) -> torch.Tensor:
         """``batch`` is the collate's dictionary (``batch['images']`` holds the crops and the mask bookkeeping)."""
         it = self.iters
@@ -120,15 +123,7 @@ class Dinov2Trainer:
         # unscale_ + clip_grad_norm_ + cancel + scaler.step (:126-134): one norm pass with 1/(world * scale) folded in
         applied = opt.step(max_norm=self.grad_clipping or 0.0, grad_scale=1.0 / (self.world * self.loss_scale), skip=skip,
                            check_finite=fp16)
-        if fp16:                                                        # scaler.update() (:135)
-            if not applied:
-                self.loss_scale *= self.backoff_factor
-                self.growth_tracker, self.skipped_steps = 0, self.skipped_steps + 1
-            else:
-                self.growth_tracker += 1
-                if self.growth_tracker >= self.growth_interval:
-                    self.loss_scale *= self.growth_factor
-                    self.growth_tracker = 0
+        self.scaler.update(applied)                                     # scaler.update() (:135)
         self.model.update_teacher(mom)
         self.loss, self.loss_dict = loss.detach(), {k: v.detach() for k, v in loss_dict.items()}
         self.iters += 1

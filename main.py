@@ -395,7 +395,7 @@ def main(params, args):
             print("[main] drop_rate / drop_path_rate > 0: training on the module path (apla_amd.module_trainer), not the fused step", flush=True)
         eng = ModulePathTrainer(model.to(dev), lr=run["lr"], weight_decay=run["wd"], grad_clipping=run["grad_clipping"],
                                 process_group=dist.group.WORLD if world > 1 else None, compute_dtype=hdt,
-                                loss_scale=1024.0 if hdt == torch.float16 else 1.0, soft_targets=run["soft_targets"])
+                                loss_scale="dynamic" if hdt == torch.float16 else 1.0, soft_targets=run["soft_targets"])
     else:
         eng = AplaTrainEngine(model, run["batch"], run["img"], device=dev, process_group=dist.group.WORLD if world > 1 else None,
                               optim=OptimConfig(lr=run["lr"], weight_decay=run["wd"], grad_clipping=run["grad_clipping"]),

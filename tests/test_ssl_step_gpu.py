@@ -232,6 +232,45 @@ def test_flat_adamw_matches_torch_adamw():
     assert fopt.steps == [4, 4, 2, 4]
 
 
+def test_dynamic_loss_scale_matches_torch_gradscaler():
+    """DynamicLossScale + FlatAdamW.step(check_finite=True) against the real thing the reference uses — torch.amp.GradScaler +
+    clip_grad_norm_ + torch.optim.AdamW (defaults/trainer.py:129-138; self_supervised/dinov2/trainer.py:124-135) — on the same scaled
+    gradient sequence with overflows injected: the same scale trajectory, the same skipped steps, the same parameters."""
+    from apla_amd.optim import DynamicLossScale, FlatAdamW
+    torch.manual_seed(1)
+    shapes = {"a.weight": (33, 17), "a.bias": (33,), "b.weight": (40, 8)}
+    mine = {n: torch.nn.Parameter(torch.randn(s, device="cuda")) for n, s in shapes.items()}
+    ref = {n: torch.nn.Parameter(p.detach().clone()) for n, p in mine.items()}
+    reg = [p for n, p in ref.items() if not (n.endswith(".bias") or p.ndim == 1)]
+    noreg = [p for n, p in ref.items() if n.endswith(".bias") or p.ndim == 1]
+    topt = torch.optim.AdamW([{"params": reg}, {"params": noreg, "weight_decay": 0.0}], lr=1e-2, weight_decay=0.05)
+    tsc = torch.amp.GradScaler("cuda", init_scale=2.0 ** 12, growth_factor=2.0, backoff_factor=0.5, growth_interval=3)
+    fopt = FlatAdamW(mine.items(), lr=1e-2, weight_decay=0.05)
+    fsc = DynamicLossScale(init_scale=2.0 ** 12, growth_factor=2.0, backoff_factor=0.5, growth_interval=3)
+    overflow_at = {1, 2, 7}
+    for step in range(12):
+        assert fsc.scale == float(tsc.scale(torch.ones((), device="cuda")))   # scaler.scale(loss): also what creates GradScaler's lazy state
+        fopt.zero_grad()
+        topt.zero_grad()
+        for n in shapes:
+            gr = torch.randn(shapes[n], device="cuda") * (3.0 if step % 2 else 0.1)
+            if step in overflow_at and n == "b.weight":
+                gr[3, 5] = float("inf") if step != 2 else float("nan")
+            mine[n].grad.add_(gr * fsc.scale)            # what a backward of (loss * scale) leaves
+            ref[n].grad = gr * float(tsc.get_scale())
+        tsc.unscale_(topt)
+        torch.nn.utils.clip_grad_norm_(list(ref.values()), 1.0)
+        tsc.step(topt)
+        tsc.update()
+        applied = fopt.step(max_norm=1.0, grad_scale=1.0 / fsc.scale, check_finite=True)
+        fsc.update(applied)
+        assert applied == (step not in overflow_at)
+        for n in shapes:
+            assert torch.allclose(mine[n].detach(), ref[n].detach(), rtol=2e-5, atol=2e-6), (step, n)
+    assert fsc.scale == float(tsc.get_scale()) and fsc.skipped_steps == 3 and fopt.steps == [9, 9, 9]
+    assert fsc.state_dict()["_growth_tracker"] == tsc.state_dict()["_growth_tracker"]
+
+
 def test_main_dinov2_entry_point(tmp_path):
     """python main.py --dinov2 --params_path <pretraining apla.yml>: ViT-S/14 student + teacher, 2 x 224 + 8 x 98 synthetic crops,
     host collate with iBOT masks, three epochs of two iterations; writes the session file."""
