@@ -56,7 +56,8 @@ def ssl_flops(batch, D, depth, heads, n_glob_tok, n_loc_tok, n_local, rank, n_ma
     return f
 
 
-def build_cfg4(batch=64, backbone="vit_base", partial_size="128", prototypes=65536, seed=0, dtype=torch.bfloat16):
+def build_cfg4(batch=64, backbone="vit_base", partial_size="128", prototypes=65536, seed=0, dtype=torch.bfloat16, process_group=None,
+               force_exchange=False):
     """The trainer and ONE collated batch (on the GPU) at the shape of BASELINE config 4; deterministic in `seed`."""
     from apla_amd.ssl import DINOv2, Dinov2Trainer, MaskingGenerator, collate_data_and_cast
     from apla_amd.ssl.collate import synthetic_samples
@@ -84,7 +85,7 @@ def build_cfg4(batch=64, backbone="vit_base", partial_size="128", prototypes=655
         crops_params=dict(n_global_crops=2, n_local_crops=8), system_params=dict(which_GPUs=gpus))
     model = DINOv2(params).cuda().train()
     tr = Dinov2Trainer(model, iters_per_epoch=1000, epochs=10, lr=1e-3, weight_decay=1e-5, grad_clipping=3.0, freeze_last_layer_epochs=1,
-                       warmup_teacher_temp_epochs=1, compute_dtype=dtype)
+                       warmup_teacher_temp_epochs=1, compute_dtype=dtype, process_group=process_group, force_exchange=force_exchange)
     mg = MaskingGenerator(input_size=(16, 16), max_num_patches=0.5 * 16 * 16)
     gen = torch.Generator().manual_seed(seed + 1)
     batch_ = collate_data_and_cast(synthetic_samples(batch, 224, 98, 8, gen), n_global_crops=2, n_local_crops=8,
@@ -104,10 +105,20 @@ def main():
     ap.add_argument("--partial-size", default="128")
     ap.add_argument("--prototypes", type=int, default=65536)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"], help="fp16 runs under the dynamic loss scale (GradScaler semantics)")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="one-rank nccl group with the chunked gradient exchange forced on: the RCCL calls of the world > 1 path on one GPU")
     args = ap.parse_args()
     from apla_amd.ssl.models import _GEOMETRY
+    pg = None
+    if args.force_exchange:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 400))
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        pg = dist.group.WORLD
     tr, batch = build_cfg4(args.batch, args.backbone, args.partial_size, args.prototypes,
-                           dtype=torch.float16 if args.dtype == "fp16" else torch.bfloat16)
+                           dtype=torch.float16 if args.dtype == "fp16" else torch.bfloat16, process_group=pg, force_exchange=args.force_exchange)
     model = tr.model
     for _ in range(args.warmup):
         tr.global_step(batch)
@@ -133,11 +144,16 @@ def main():
                       "unit": "images/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 2),
                       "dtype": args.dtype, "data": "synthetic", "roofline": roofline,
                       **({"loss_scale": tr.loss_scale, "skipped_steps": tr.skipped_steps} if args.dtype == "fp16" else {}),
+                      **({"exchange": {"chunks_mb": [round((b - a) * 4 / 2 ** 20, 1) for a, b in tr.exchanger.chunks], "backend": "nccl, one rank"}}
+                         if args.force_exchange else {}),
                       "config": {"workload": f"{args.backbone}/14 student+teacher, 2x224 + 8x98 crops, bs={args.batch}, partial_size={args.partial_size}, "
                                              f"{args.prototypes} prototypes, masked patches {int(batch['images']['n_masked_patches'])} "
                                              f"(upperbound {batch['images']['upperbound']})", "trainable_params": n_train},
                       "loss": round(float(tr.loss), 4), "loss_terms": {k: round(float(v), 4) for k, v in tr.loss_dict.items()},
                       "peak_mem_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}), flush=True)
+    if args.force_exchange:
+        import torch.distributed as dist
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
