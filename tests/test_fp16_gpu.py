@@ -55,6 +55,37 @@ def test_fp16_gemm_epilogues(M, N, K):
             assert torch.equal(ops.gemm_nt(a.cuda(), w.cuda(), bias.cuda(), epilogue=ops.EPI_GELU_FWD), h)
 
 
+@pytest.mark.parametrize("M,N,K", [(9000, 768, 1536), (9000, 768, 768)])
+def test_fp16_gemm_schedules_of_round_4(M, N, K):
+    """The fp16 build of the round-4 kernels: the 256- / 128-row tiles of the two plain-store schedules and the tile-alternating
+    kernel give the bits of the 4-wave kernel, as in the bf16 build."""
+    from apla_amd import ops
+    a, ad = hf(rnd(M, K, seed=11))
+    w, wd = hf(rnd(N, K, scale=K ** -0.5, seed=12))
+    bias = rnd(N, seed=13).cuda()
+    with ops.use_half(torch.float16):
+        A, W = a.cuda(), w.cuda()
+        old = ops.set_gemm_variant(15)
+        try:
+            ref = ops.gemm_nt(A, W, bias).clone()
+            href = ops.gemm_nt(A, W, bias, epilogue=ops.EPI_GELU_FWD).clone()
+            assert rel_err(ref.cpu(), ad @ wd.t() + bias.cpu().double()) < F16_OUT
+            for variant in (9, 16):
+                ops.set_gemm_variant(variant)
+                for exp in (5, 6):
+                    ops._GEMM_EXP = exp
+                    assert torch.equal(ops.gemm_nt(A, ops.k_panels(W), bias), ref), (variant, exp)
+                ops._GEMM_EXP = 0
+            ops.set_gemm_variant(17)
+            if K >= 704:
+                assert ops.gemm_kernel_name(M, N, K, ops.EPI_GELU_FWD).startswith("gemm_tp_kernel<GELU_FWD,f16")
+                assert torch.equal(ops.gemm_nt(A, ops.k_panels(W), bias, epilogue=ops.EPI_GELU_FWD), href)
+                assert torch.equal(ops.gemm_nt(A, W, bias), ref)
+        finally:
+            ops._GEMM_EXP = 0
+            ops.set_gemm_variant(old)
+
+
 def test_fp16_attention_and_layernorm():
     from apla_amd import ops
     B, N, H = 2, 197, 2
