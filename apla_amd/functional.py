@@ -11,6 +11,8 @@ The fused whole-step path (apla_amd/engine.py) does not use autograd at all.
 import os
 import weakref
 
+from typing import Optional
+
 import torch
 
 from . import ops
@@ -217,6 +219,85 @@ class _AddLayerNormFn(torch.autograd.Function):
 def add_layer_norm(x, branch, norm_module):
     """Returns (x + branch [dtype of x], LayerNorm(x + branch) [bf16])."""
     return _AddLayerNormFn.apply(x, branch, norm_module.weight, norm_module.bias, norm_module.eps)
+
+
+# ------------------------------------------------------------------------------------------------ residual stream with a 16-bit gradient
+class ResidualStream:
+    """The fp32 residual stream of VisionTransformer.run_blocks together with a 16-bit autograd PROXY for it.
+
+    autograd hands a tensor a gradient of the tensor's own dtype, so an fp32 stream means an fp32 gradient stream: 16 bytes per
+    element and LayerNorm backward (read dy, x, the incoming stream; write the stream and its 16-bit copy for the branch).  The fused
+    engine keeps the gradient stream in 16 bits.  Here the VALUES stay fp32 and outside the graph; what the graph
+    carries from block to block is an uninitialised 16-bit tensor of the stream's shape whose only role is to own the gradient:
+    every ``stream_add_layer_norm`` takes the proxy in and gives a new one out, its backward reads and writes the 16-bit gradient
+    (10 bytes per element, one output that serves the stream and the branch alike).  Values are never read from a proxy."""
+
+    def __init__(self, values: torch.Tensor):
+        self.values = values.detach().float()
+        self.proxy: Optional[torch.Tensor] = None
+
+    def select_rows(self, rows: torch.Tensor):
+        """Keep the token rows `rows` of a packed stream [1, T, D] (the last block of a backbone whose consumers read a subset)."""
+        self.values = self.values.index_select(1, rows)
+        if self.proxy is not None:
+            self.proxy = self.proxy.index_select(1, rows)      # backward: the 16-bit gradient scattered into zero rows
+
+    def exit(self) -> torch.Tensor:
+        """The stream as an ordinary fp32 tensor that still carries gradient into the blocks (x_prenorm of the reference's API)."""
+        if self.proxy is None or not self.proxy.requires_grad:
+            return self.values
+        return _StreamExitFn.apply(self.proxy, self.values)
+
+
+class _StreamExitFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, proxy, values):
+        return values.view_as(values)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(_h()), None
+
+
+class _StreamAddLayerNormFn(torch.autograd.Function):
+    """stream += branch; y = LayerNorm(stream) (vit.py:284-285 fused into the following norm), the gradient of the stream carried by
+    its 16-bit proxy: d(stream_in) = d(branch) = d(stream_out) + LN_bwd(dy), ONE 16-bit tensor."""
+
+    @staticmethod
+    def forward(ctx, proxy_in, branch, weight, bias, stream, eps):
+        _require_cuda(branch, "add_layer_norm")
+        if weight.requires_grad or bias.requires_grad:
+            raise NotImplementedError("trainable LayerNorm affine is outside the APLA path (all norms are frozen)")
+        shape = stream.values.shape
+        x2 = stream.values.reshape(-1, shape[-1]).contiguous()
+        b2 = _as2d_bf16(branch)
+        x_new = torch.empty_like(x2)
+        y, mean, rstd = ops.layernorm_fwd(x2, b_f32(weight), b_f32(bias), eps, add=b2, x_out=x_new)
+        stream.values = x_new.reshape(shape)
+        ctx.save_for_backward(x_new, mean, rstd, weight)
+        ctx.shape, ctx.bdtype = shape, branch.dtype
+        return torch.empty(shape, device=branch.device, dtype=_h()), y.reshape(shape)
+
+    @staticmethod
+    def backward(ctx, d_proxy, dy):
+        x_new, mean, rstd, weight = ctx.saved_tensors
+        dres = None if d_proxy is None else d_proxy.reshape(x_new.shape).to(_h()).contiguous()
+        if dy is None:
+            d = dres
+        else:
+            out = torch.empty(x_new.shape, device=x_new.device, dtype=_h())
+            d, _ = ops.layernorm_bwd(_as2d_bf16(dy), x_new, b_f32(weight), mean, rstd, dres=dres, out=out)
+        if d is None:
+            return None, None, None, None, None, None
+        d = d.reshape(ctx.shape)
+        return (d if ctx.needs_input_grad[0] else None), (d if ctx.bdtype == d.dtype else d.to(ctx.bdtype)), None, None, None, None
+
+
+def stream_add_layer_norm(stream: ResidualStream, branch, norm_module):
+    """stream += branch, returns LayerNorm(stream) in 16 bits; ``stream`` is updated in place (values and proxy)."""
+    proxy, y = _StreamAddLayerNormFn.apply(stream.proxy, branch, norm_module.weight, norm_module.bias, stream, norm_module.eps)
+    stream.proxy = proxy
+    return y
 
 
 # ------------------------------------------------------------------------------------------------ Linear

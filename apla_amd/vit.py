@@ -219,6 +219,8 @@ class VisionTransformer(nn.Module):
         ``last_rows`` (packed batches): int64 row indices the caller will read of the result.  Everything behind the last block's
         attention product is token-wise, so that block projects, normalises and runs its MLP on those rows only and the result is
         [1, len(last_rows), D]; autograd scatters the two gradients (attention output, residual stream) back into zero rows."""
+        if x.is_cuda and not x.requires_grad:
+            return self._run_blocks_stream(x, attn_bias, last_rows)
         res, branch = x.float(), None
         n_blocks = len(self.blocks)
         for bi, blk in enumerate(self.blocks):
@@ -226,32 +228,61 @@ class VisionTransformer(nn.Module):
                 h = AF.layer_norm(res, blk.norm1)
             else:
                 res, h = AF.add_layer_norm(res, branch, blk.norm1)
-            g1, g2 = getattr(blk.ls1, "gamma", None), getattr(blk.ls2, "gamma", None)
-            kw = {} if attn_bias is None else {"attn_bias": attn_bias}
             if last_rows is not None and bi == n_blocks - 1:
                 if attn_bias is None:
                     raise ValueError("last_rows needs a packed batch")
-                kw["rows"] = last_rows
+                y, branch_of = self._block_branches(blk, h, attn_bias, last_rows)
                 res = res.index_select(1, last_rows)
-            if hasattr(blk.attn, "_project") and (g1 is None or not g1.requires_grad):   # APLA attention: scale folded into the projection
-                y = blk.attn(h, ls_gamma=g1, **kw)
-                y = y[0] if isinstance(y, tuple) else y
             else:
-                y = blk.attn(h, **kw)
-                y = blk.ls1(y[0] if isinstance(y, tuple) else y)
-            stochastic = self.training and isinstance(blk.drop_path, DropPath) and blk.drop_path.drop_prob > 0.0
-            if stochastic:
-                if attn_bias is not None:
-                    raise NotImplementedError("stochastic depth on a packed batch (its samples are not the leading dimension) is not supported")
-                y = blk.drop_path(y)
+                y, branch_of = self._block_branches(blk, h, attn_bias, None)
             res, h = AF.add_layer_norm(res, y, blk.norm2)
-            if isinstance(blk.mlp, Mlp) and (g2 is None or not g2.requires_grad) and not (self.training and blk.mlp.drop.p > 0.0):
-                branch = AF.mlp_gelu(h, blk.mlp.fc1.weight, blk.mlp.fc1.bias, blk.mlp.fc2.weight, blk.mlp.fc2.bias, gamma=g2)
-            else:
-                branch = blk.ls2(blk.mlp(h))
-            if stochastic:
-                branch = blk.drop_path(branch)
+            branch = branch_of(h)
         return AF.add_layer_norm(res, branch, self.norm)
+
+    def _block_branches(self, blk, h, attn_bias, rows):
+        """(attention branch of a block on the normalised input h, function computing its MLP branch from the second norm's output):
+        LayerScale folded into the producing GEMM where it is frozen, stochastic depth applied to both branches (vit.py:279-288)."""
+        g1, g2 = getattr(blk.ls1, "gamma", None), getattr(blk.ls2, "gamma", None)
+        kw = {} if attn_bias is None else {"attn_bias": attn_bias}
+        if rows is not None:
+            kw["rows"] = rows
+        if hasattr(blk.attn, "_project") and (g1 is None or not g1.requires_grad):   # APLA attention: scale folded into the projection
+            y = blk.attn(h, ls_gamma=g1, **kw)
+            y = y[0] if isinstance(y, tuple) else y
+        else:
+            y = blk.attn(h, **kw)
+            y = blk.ls1(y[0] if isinstance(y, tuple) else y)
+        stochastic = self.training and isinstance(blk.drop_path, DropPath) and blk.drop_path.drop_prob > 0.0
+        if stochastic:
+            if attn_bias is not None:
+                raise NotImplementedError("stochastic depth on a packed batch (its samples are not the leading dimension) is not supported")
+            y = blk.drop_path(y)
+
+        def mlp_branch(h2):
+            if isinstance(blk.mlp, Mlp) and (g2 is None or not g2.requires_grad) and not (self.training and blk.mlp.drop.p > 0.0):
+                b = AF.mlp_gelu(h2, blk.mlp.fc1.weight, blk.mlp.fc1.bias, blk.mlp.fc2.weight, blk.mlp.fc2.bias, gamma=g2)
+            else:
+                b = blk.ls2(blk.mlp(h2))
+            return blk.drop_path(b) if stochastic else b
+        return y, mlp_branch
+
+    def _run_blocks_stream(self, x, attn_bias, last_rows):
+        """run_blocks with the gradient of the residual stream in 16 bits (AF.ResidualStream): the values of the stream stay fp32."""
+        st, branch = AF.ResidualStream(x), None
+        n_blocks = len(self.blocks)
+        for bi, blk in enumerate(self.blocks):
+            # block 0 reads the input tokens, which take no gradient on this path: a plain LayerNorm outside the graph
+            h = AF.layer_norm(st.values, blk.norm1) if branch is None else AF.stream_add_layer_norm(st, branch, blk.norm1)
+            last = last_rows is not None and bi == n_blocks - 1
+            if last and attn_bias is None:
+                raise ValueError("last_rows needs a packed batch")
+            y, branch_of = self._block_branches(blk, h, attn_bias, last_rows if last else None)
+            if last:
+                st.select_rows(last_rows)
+            h = AF.stream_add_layer_norm(st, y, blk.norm2)
+            branch = branch_of(h)
+        h = AF.stream_add_layer_norm(st, branch, self.norm)
+        return st.exit(), h
 
     def forward_features(self, x):
         x = self.patch_embed(x)

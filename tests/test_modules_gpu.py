@@ -201,3 +201,33 @@ def test_dropout_and_stochastic_depth_on_the_module_path():
     blk = Block(128, 2, attn_drop=0.1).cuda().train()
     with pytest.raises(NotImplementedError):
         blk(torch.randn(2, 5, 128, device="cuda"))
+
+
+@pytest.mark.parametrize("half", [torch.bfloat16, torch.float16])
+def test_sixteen_bit_gradient_stream_against_the_fp32_one(half):
+    """run_blocks carries the gradient of the fp32 residual stream in 16 bits through an autograd proxy (AF.ResidualStream; the fused
+    engine's gradient stream); tokens that require grad take the fp32-gradient route.  Same forward bits; gradients of the trainable
+    projection rows equal up to the 16-bit rounding of the stream between blocks; the stream's exit (x_prenorm) still carries gradient."""
+    from apla_amd import ops as OPS
+    from apla_amd.apla import build_apla
+    from apla_amd.models import AttrDict
+    from apla_amd.vit import VisionTransformer
+    torch.manual_seed(0)
+    vit = VisionTransformer(img_size=[32], patch_size=16, embed_dim=128, depth=4, num_heads=2, qkv_bias=True)
+    build_apla(AttrDict(partial_size=64), vit, "apla_attn")
+    vit = vit.cuda().train()
+    tokens = torch.randn(6, 5, 128, device="cuda")
+    res = {}
+    with OPS.use_half(half):
+        for mode in ("stream", "fp32"):
+            vit.zero_grad(set_to_none=True)
+            x = tokens.clone().requires_grad_(mode == "fp32")
+            x_pre, x_norm = vit.run_blocks(x)
+            assert x_pre.dtype == torch.float32 and x_norm.dtype == half
+            (x_norm.float().square().mean() + 0.1 * x_pre.square().mean()).backward()
+            res[mode] = (x_pre.detach().clone(), x_norm.detach().clone(),
+                         {n: p.grad.detach().float().clone() for n, p in vit.named_parameters() if p.grad is not None})
+    assert torch.equal(res["stream"][0], res["fp32"][0]) and torch.equal(res["stream"][1], res["fp32"][1])
+    assert set(res["stream"][2]) == set(res["fp32"][2]) and len(res["stream"][2]) == 8        # proj_weight1 / proj_bias1 of four blocks
+    for n, g_ in res["fp32"][2].items():
+        assert rel_err(res["stream"][2][n].cpu(), g_.double().cpu()) < (2e-2 if half == torch.bfloat16 else 3e-3), n
