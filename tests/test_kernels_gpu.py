@@ -310,7 +310,7 @@ def test_attention_packed_as_runs_of_uniform_batches(ops, runs, H, half):
         q = dev(qkv).reshape(1, total, 3 * D).requires_grad_(True)
         o = AF.attention_core_varlen(q, mask.cu_seqlens("cuda"), mask.max_seqlen, H, scale, runs=mask.runs())
         tol_o = BF16_OUT if half == torch.bfloat16 else BF16_OUT / 8
-        assert o.shape == (1, total, D) and rel_err(o[0].cpu(), oref) < tol_o
+        assert o.shape == (1, total, D) and rel_err(o[0].detach().cpu(), oref) < tol_o
         do = dox.to(half)
         dref = O.attention_varlen_bwd(do.double(), qkvd, o[0].detach().cpu().double(), lref, seqlens, H, scale)
         o.backward(dev(do).reshape(1, total, D))
@@ -323,6 +323,13 @@ def test_attention_packed_as_runs_of_uniform_batches(ops, runs, H, half):
         o2 = AF.attention_core_varlen(q2, mask.cu_seqlens("cuda"), mask.max_seqlen, H, scale)
         if max(seqlens) <= 288:
             assert torch.equal(o2, o)
+        # more runs than MAX_ATTN_RUNS: the packed launch, whatever `runs` says
+        many = [(1, n) for n in seqlens]
+        if len(many) > AF.MAX_ATTN_RUNS:
+            o3 = AF.attention_core_varlen(dev(qkv).reshape(1, total, 3 * D), mask.cu_seqlens("cuda"), mask.max_seqlen, H, scale, runs=many)
+            assert torch.equal(o3, o2)
+        with pytest.raises(ValueError):
+            AF.attention_core_varlen(dev(qkv).reshape(1, total, 3 * D), mask.cu_seqlens("cuda"), mask.max_seqlen, H, scale, runs=[(1, total - 1)])
 
 
 @pytest.mark.parametrize("attn_variant", [0, 1], indirect=True)

@@ -357,12 +357,15 @@ def test_iteration_vs_oracle_at_another_geometry():
         assert rel_err(sp[n].grad.cpu(), ref["grads"][n]) < 4e-2, n
 
 
-def test_full_size_config4_iterations_are_reproducible():
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_full_size_config4_iterations_are_reproducible(dtype):
     """BASELINE config 4 at FULL size on one GPU (ViT-B/14 student + teacher, 64 source images = 128 global crops of 257 tokens +
     512 local crops of 50 tokens packed into one 58 496-token student pass, 65 536 prototypes): the golden G12 fixtures pin the
     iteration at fixture size; here the size-independent properties — two independently built trainers fed the same batch produce
     bit-identical losses, students, teachers and centres over two iterations (no atomics, no run-to-run reduction order: a data-
-    parallel replica stays a replica), the loss terms are finite and positive, and the EMA moved the teacher."""
+    parallel replica stays a replica), the loss terms are finite and positive, and the EMA moved the teacher.  In fp16 (the
+    reference's mixed-precision branch) the loss scale starts at 1 024 so that both iterations are applied; the scale bookkeeping of
+    the two trainers must agree as well, and bf16 and fp16 must agree on the first loss to the rounding of their operands."""
     import importlib.util
     free, _ = torch.cuda.mem_get_info()
     if free < 60 * 2 ** 30:
@@ -372,17 +375,29 @@ def test_full_size_config4_iterations_are_reproducible():
     spec.loader.exec_module(sb)
     runs = []
     for _ in range(2):
-        tr, batch = sb.build_cfg4(batch=64)
+        tr, batch = sb.build_cfg4(batch=64, dtype=dtype)
+        if dtype == torch.float16:
+            tr.scaler.scale = 1024.0
         t0 = torch.cat([p.detach().reshape(-1).float() for p in tr.model.teacher.dino_head.parameters()]).clone()
         losses = [tr.global_step(batch).clone() for _ in range(2)]
         torch.cuda.synchronize()
         t1 = torch.cat([p.detach().reshape(-1).float() for p in tr.model.teacher.dino_head.parameters()])
         runs.append((torch.stack(losses), tr.optimizer.flat.clone(), t1.clone(), tr.model.dino_loss.center.clone(),
-                     {k: float(v) for k, v in tr.loss_dict.items()}))
+                     {k: float(v) for k, v in tr.loss_dict.items()}, (tr.loss_scale, tr.skipped_steps, tr.growth_tracker)))
         assert not torch.equal(t0, t1)                      # the EMA touched the teacher's (trainable) head
         del tr, batch
         torch.cuda.empty_cache()
     a, b = runs
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
     assert all(np.isfinite(v) and v > 0 for k, v in a[4].items() if k != "koleo_loss") and np.isfinite(a[4].get("koleo_loss", 0.0))
-    assert float(a[0][1]) != float(a[0][0])
+    assert float(a[0][1]) != float(a[0][0]) and a[5] == b[5]
+    if dtype == torch.float16:
+        assert a[5] == (1024.0, 0, 2)
+    first = float(a[0][0])
+    _FULL_SIZE_FIRST_LOSS[dtype] = first
+    if len(_FULL_SIZE_FIRST_LOSS) == 2:      # the same batch, the same initial weights: the two operand types see the same loss
+        lo, hi = _FULL_SIZE_FIRST_LOSS[torch.float16], _FULL_SIZE_FIRST_LOSS[torch.bfloat16]
+        assert abs(lo - hi) < 5e-3 * abs(lo), (lo, hi)
+
+
+_FULL_SIZE_FIRST_LOSS = {}
