@@ -368,7 +368,15 @@ def center_ema(center: Tensor, teacher_output: Tensor, momentum: float) -> Tenso
 
 def augment_images(src_u8: Tensor, mean, std, flip=None, perm=None, lam=None, box=None) -> Tensor:
     """ToTensor + Normalize (+ horizontal flip) per sample (defaults/bases.py:69-231) and timm-style Mixup / CutMix against
-    the partner sample perm[b] (utils/_utils.py:424-441): src uint8 [B,3,S,S] -> float64 [B,3,S,S]."""
+    the partner sample perm[b] (utils/_utils.py:424-441): src uint8 [B,3,S,S] -> float64 [B,3,S,S].
+
+    PARITY UNPINNED for the Mixup / CutMix part.  The algorithm lives in a third-party dependency that is neither vendored in the
+    reference nor installed here: ``timm.data.mixup.Mixup`` (utils/_utils.py:426-428; timm is installed unpinned by docker/Dockerfile:137
+    and docker/conda-dinov2.yaml:29), as are torchvision's ToTensor / Normalize / RandomHorizontalFlip.  Restated from the published
+    algorithms: Mixup (Zhang et al., ICLR 2018) x = lam x_i + (1 - lam) x_j with the partner j = perm[i] (timm's batch mode pairs sample
+    i with B-1-i: pass perm = arange(B).flip(0)); CutMix (Yun et al., ICCV 2019) pastes the partner's pixels inside a rectangle
+    whose area fraction is 1 - lam.  The random draws (lam, the rectangle, the flips) are INPUTS here and in the kernel
+    (apla_augment_images): what is checked is the mixing itself, against this definition only."""
     x = src_u8.double() / 255.0
     x = (x - torch.tensor(mean, dtype=torch.float64).view(1, 3, 1, 1)) / torch.tensor(std, dtype=torch.float64).view(1, 3, 1, 1)
     if flip is not None:
