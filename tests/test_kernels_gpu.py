@@ -872,12 +872,21 @@ def test_adamw_dynamic_loss_scaling_matches_gradscaler_semantics(ops):
     m, v = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
     ws = torch.zeros(512, device="cuda")
     st = ops.new_scaler_state("cuda", init_scale=scale)
+    # ... and the real class beside the replay: a torch.amp.GradScaler driving a one-tensor optimizer through the same overflow pattern
+    twin = torch.nn.Parameter(torch.zeros(8, device="cuda"))
+    twin_opt = torch.optim.SGD([twin], lr=0.0)
+    tsc = torch.amp.GradScaler("cuda", init_scale=scale, growth_factor=2.0, backoff_factor=0.5, growth_interval=interval)
     for it in range(9):
         true_grad = torch.randn(n, generator=g) * (3.0 if it % 2 else 0.05)     # some steps clip, some do not
         scaled = true_grad * scale * world                                       # what backward + SUM all-reduce leave behind
         if it in (2, 6):
             scaled[17] = float("inf") if it == 2 else float("nan")
         grads = scaled.clone().cuda()
+        assert float(tsc.scale(torch.ones((), device="cuda"))) == scale
+        twin.grad = torch.full((8,), float("inf") if it == 2 else (float("nan") if it == 6 else 1.0), device="cuda")
+        tsc.unscale_(twin_opt)
+        tsc.step(twin_opt)
+        tsc.update()
         ops.adamw_step_dynamic(params, grads, m, v, decay.to(torch.uint8).cuda(), st, it & 1, lr=1e-2, weight_decay=0.1,
                                max_norm=1.0, grad_scale=1.0 / world, growth_interval=interval, norm_ws=ws)
         # reference
@@ -898,6 +907,7 @@ def test_adamw_dynamic_loss_scaling_matches_gradscaler_semantics(ops):
         ref[decay], ref[~decay] = pr.detach(), pn.detach()
         assert rel_err(params.cpu(), ref) < 1e-5, it
         assert float(st[6]) == scale and float(st[3 * ((it + 1) & 1)]) == scale and float(st[3 * ((it + 1) & 1) + 1]) == tracker
+        assert float(tsc.get_scale()) == scale and int(tsc.state_dict()["_growth_tracker"]) == tracker     # torch's own bookkeeping agrees
 
 
 # ------------------------------------------------------------------------------------------- C-ABI error conventions
