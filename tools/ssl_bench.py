@@ -124,11 +124,22 @@ def main():
         tr.global_step(batch)
     torch.cuda.synchronize()
     torch.cuda.reset_peak_memory_stats()
+    from apla_amd import telemetry
+    hwmon = telemetry.find_hwmon()
+    sampler = telemetry.Sampler(hwmon, period=0.01) if hwmon else None
+    if sampler:
+        sampler.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         tr.global_step(batch)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
+    power = None
+    if sampler:
+        sampler.stop()
+        power = sampler.summary(since=t0)
+        if power is not None:
+            power["cap_w"] = telemetry.power_cap_w(hwmon)
     n_train = sum(p.numel() for p in model.student.parameters() if p.requires_grad)
     D, depth, heads = _GEOMETRY[args.backbone][:3]
     fl = ssl_flops(args.batch, D, depth, heads, 257, 50, 8, args.partial_size, int(batch["images"]["n_masked_patches"]),
@@ -142,7 +153,7 @@ def main():
                 "note": "whole-iteration figure: algorithmic matrix FLOPs (tools/ssl_bench.py:ssl_flops) / wall time of one iteration"}
     print(json.dumps({"metric": "images/sec, DINOv2-APLA self-supervised iteration (side measurement)", "value": round(args.batch / dt, 1),
                       "unit": "images/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 2),
-                      "dtype": args.dtype, "data": "synthetic", "roofline": roofline,
+                      "dtype": args.dtype, "data": "synthetic", "roofline": roofline, "power": power,
                       **({"loss_scale": tr.loss_scale, "skipped_steps": tr.skipped_steps} if args.dtype == "fp16" else {}),
                       **({"exchange": {"chunks_mb": [round((b - a) * 4 / 2 ** 20, 1) for a, b in tr.exchanger.chunks], "backend": "nccl, one rank"}}
                          if args.force_exchange else {}),
