@@ -12,6 +12,22 @@ from typing import List, Sequence, Tuple
 import torch
 
 
+# Offsets of a layout as device tensors, shared by every mask object of that layout: a multi-crop training loop builds a new mask with
+# the same sequence lengths every iteration, and a host -> device copy from pageable memory makes the host wait for the stream — the
+# launch path of the next kernels then starts from zero lead (seen as 40-80 us idle gaps behind every such copy in the kernel trace).
+_INDEX_CACHE = {}
+
+
+def _device_index(kind, values, dtype, device):
+    key = (kind, values, dtype, str(device))
+    t = _INDEX_CACHE.get(key)
+    if t is None:
+        if len(_INDEX_CACHE) >= 64:
+            _INDEX_CACHE.clear()
+        t = _INDEX_CACHE[key] = torch.tensor(values, dtype=dtype, device=device)
+    return t
+
+
 class BlockDiagonalMask:
     def __init__(self, seqlens: Sequence[int]):
         seqlens = [int(n) for n in seqlens]
@@ -85,14 +101,14 @@ class BlockDiagonalMask:
     def cu_seqlens(self, device) -> torch.Tensor:
         device = torch.device(device)
         if device not in self._cu:
-            self._cu[device] = torch.tensor(self.seqstart_py, dtype=torch.int32, device=device)
+            self._cu[device] = _device_index("cu", tuple(self.seqstart_py), torch.int32, device)
         return self._cu[device]
 
     def seq_starts(self, device) -> torch.Tensor:
         """int64 [S]: first packed row of every sequence (the row of its class token), on `device`."""
         key = ("starts", torch.device(device))
         if key not in self._cu:
-            self._cu[key] = torch.tensor(self.seqstart_py[:-1], dtype=torch.long, device=device)
+            self._cu[key] = _device_index("starts", tuple(self.seqstart_py[:-1]), torch.long, torch.device(device))
         return self._cu[key]
 
     def materialize(self, dtype=torch.float32, device="cpu") -> torch.Tensor:
