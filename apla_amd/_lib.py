@@ -95,6 +95,8 @@ SIGNATURES = {
                                     c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "apla_assemble_tokens": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                      c_void_p]),
+    "apla_weight_norm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "apla_weight_norm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "apla_dropout_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_long, c_float, c_ulonglong, c_ulonglong, c_void_p]),
     "apla_dropout_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_long, c_float, c_void_p]),
     "apla_scale_samples": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_long, c_long, c_void_p]),

@@ -879,6 +879,70 @@ extern "C" int apla_colsum_h16(const void* X, long ld, float* out, int M, int N,
   return APLA_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ weight normalisation
+// torch.nn.utils.weight_norm(dim = 0) of the DINO head's prototype layer (dinov2/layers/dino_head.py:27-28): W[i, :] = v[i, :] * g[i] / ||v[i, :]||.
+// One wave per row.  Forward writes W in the GEMM's 16-bit operand type (the fp32 W of the torch route is only ever cast) and the row
+// norms; backward turns dW (fp32, from the dW kernel) into dv = (g / n) (dW - v (dW . v) / n^2) and dg = (dW . v) / n — the formulas
+// of torch's _weight_norm_interface_backward.  torch runs three element-wise kernels forward and about ten backward over the [65 536, 256]
+// matrices of the shipped head.
+__global__ __launch_bounds__(256) void weight_norm_fwd_kernel(const float* __restrict__ v, const float* __restrict__ g, bf16* __restrict__ w,
+                                                              float* __restrict__ norm, int K, int D) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= K) return;
+  const float* vr = v + (size_t)row * D;
+  float ss = 0.f;
+  for (int c = lane * 4; c < D; c += 256) {
+    const f32x4 a = *(const f32x4*)(vr + c);
+    ss += a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3];
+  }
+  const float n = sqrtf(wave_sum(ss));
+  const float sc = g[row] / n;
+  for (int c = lane * 4; c < D; c += 256) {
+    const f32x4 a = *(const f32x4*)(vr + c);
+    Vec4IO<bf16>::store(w + (size_t)row * D + c, a * sc);
+  }
+  if (lane == 0) norm[row] = n;
+}
+
+__global__ __launch_bounds__(256) void weight_norm_bwd_kernel(const float* __restrict__ dw, const float* __restrict__ v, const float* __restrict__ g,
+                                                              const float* __restrict__ norm, float* __restrict__ dv, float* __restrict__ dg,
+                                                              int K, int D) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= K) return;
+  const float* vr = v + (size_t)row * D;
+  const float* dr = dw + (size_t)row * D;
+  float dot = 0.f;
+  for (int c = lane * 4; c < D; c += 256) {
+    const f32x4 a = *(const f32x4*)(vr + c), d = *(const f32x4*)(dr + c);
+    dot += a[0] * d[0] + a[1] * d[1] + a[2] * d[2] + a[3] * d[3];
+  }
+  dot = wave_sum(dot);
+  const float n = norm[row], gi = g[row];
+  const float a1 = gi / n, a2 = gi * dot / (n * n * n);
+  for (int c = lane * 4; c < D; c += 256) {
+    const f32x4 a = *(const f32x4*)(vr + c), d = *(const f32x4*)(dr + c);
+    *(f32x4*)(dv + (size_t)row * D + c) = d * a1 - a * a2;
+  }
+  if (lane == 0 && dg != nullptr) dg[row] = dot / n;
+}
+
+extern "C" int apla_weight_norm_fwd(const float* v, const float* g, void* w_h16, float* norm, int K, int D, hipStream_t stream) {
+  APLA_REQUIRE(v && g && w_h16 && norm && K > 0 && D > 0 && D % 4 == 0, "apla_weight_norm_fwd: need D %% 4 == 0 (K=%d D=%d)", K, D);
+  APLA_REQUIRE(apla_aligned16(v) && apla_aligned16(w_h16), "apla_weight_norm_fwd: pointers must be 16-byte aligned");
+  hipLaunchKernelGGL(weight_norm_fwd_kernel, dim3((K + 3) / 4), dim3(256), 0, stream, v, g, (bf16*)w_h16, norm, K, D);
+  APLA_CHECK_LAUNCH("apla_weight_norm_fwd");
+  return APLA_OK;
+}
+
+extern "C" int apla_weight_norm_bwd(const float* dw, const float* v, const float* g, const float* norm, float* dv, float* dg, int K, int D,
+                                    hipStream_t stream) {
+  APLA_REQUIRE(dw && v && g && norm && dv && K > 0 && D > 0 && D % 4 == 0, "apla_weight_norm_bwd: need D %% 4 == 0 (K=%d D=%d)", K, D);
+  APLA_REQUIRE(apla_aligned16(dw) && apla_aligned16(v) && apla_aligned16(dv), "apla_weight_norm_bwd: pointers must be 16-byte aligned");
+  hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3((K + 3) / 4), dim3(256), 0, stream, dw, v, g, norm, dv, dg, K, D);
+  APLA_CHECK_LAUNCH("apla_weight_norm_bwd");
+  return APLA_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ dropout / stochastic depth
 // nn.Dropout (vit.py:152-168 Mlp.drop, appla_attn.py:82 proj_drop, pos_drop) and DropPath (vit.py:74-93) for the module path.  All
 // shipped configurations use 0; main.py:101-111 can set them.  The keep decision of element i is word (i & 3) of

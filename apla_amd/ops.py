@@ -748,6 +748,31 @@ def assemble_tokens(patches: torch.Tensor, cls_token: torch.Tensor, pos: torch.T
     return out
 
 
+def weight_norm_fwd(v: torch.Tensor, g: torch.Tensor):
+    """(W 16-bit [K, D], row norms fp32 [K]) of torch.nn.utils.weight_norm(dim=0): W = v * g / ||v|| (include/apla_hip.h)."""
+    _req(v, torch.float32, "v", 2), _req(g, torch.float32, "g")
+    K, D = v.shape
+    if not v.is_contiguous() or g.numel() != K or not g.is_contiguous() or D % 4:
+        raise ValueError("weight_norm_fwd: contiguous v [K, D] with D % 4 == 0 and g with K entries expected")
+    w = torch.empty(K, D, device=v.device, dtype=half())
+    norm = torch.empty(K, device=v.device, dtype=torch.float32)
+    check(lib().apla_weight_norm_fwd(v.data_ptr(), g.data_ptr(), w.data_ptr(), norm.data_ptr(), K, D, _stream()), "apla_weight_norm_fwd")
+    return w, norm
+
+
+def weight_norm_bwd(dw: torch.Tensor, v: torch.Tensor, g: torch.Tensor, norm: torch.Tensor, want_dg: bool = True):
+    """(dv [K, D], dg [K] | None) from dW (fp32) — torch's _weight_norm_interface_backward."""
+    _req(dw, torch.float32, "dw", 2), _req(v, torch.float32, "v", 2), _req(g, torch.float32, "g"), _req(norm, torch.float32, "norm", 1)
+    K, D = v.shape
+    if tuple(dw.shape) != (K, D) or not (dw.is_contiguous() and v.is_contiguous() and g.is_contiguous()) or norm.numel() != K or g.numel() != K:
+        raise ValueError("weight_norm_bwd: shape mismatch")
+    dv = torch.empty_like(v)
+    dg = torch.empty(K, device=v.device, dtype=torch.float32) if want_dg else None
+    check(lib().apla_weight_norm_bwd(dw.data_ptr(), v.data_ptr(), g.data_ptr(), norm.data_ptr(), dv.data_ptr(), _ptr(dg), K, D, _stream()),
+          "apla_weight_norm_bwd")
+    return dv, dg
+
+
 def dropout_fwd(x: torch.Tensor, p: float, seed: int, offset: int = 0):
     """(y, keep) of include/apla_hip.h:apla_dropout_fwd for a contiguous fp32 / 16-bit tensor whose size is a multiple of 8."""
     _req(x, None, "x")

@@ -17,36 +17,56 @@ from .. import functional as AF
 from .. import ops
 
 
+def _normed_weight(v, g):
+    """(W 16-bit, row norms | None) of the weight-normalised prototype layer: one kernel (apla_weight_norm_fwd) where it applies."""
+    if v.is_cuda and v.dtype == torch.float32 and v.ndim == 2 and v.shape[1] % 4 == 0 and v.is_contiguous():
+        return ops.weight_norm_fwd(v.detach(), g.detach().reshape(-1).contiguous())
+    W = v.detach() * (g.detach() / v.detach().norm(dim=1, keepdim=True))
+    return W.to(ops.half()).contiguous(), None
+
+
+def _normed_weight_grads(dW, v, g, norm, need_v, need_g):
+    """(dv, dg) from dW = d(loss) / dW (fp32): apla_weight_norm_bwd, or torch's formulas where the kernel does not apply."""
+    if norm is not None:
+        dv, dg = ops.weight_norm_bwd(dW.contiguous(), v.detach(), g.detach().reshape(-1).contiguous(), norm, want_dg=need_g)
+        return (dv if need_v else None), (dg.reshape(g.shape) if need_g else None)
+    vd, gd = v.detach(), g.detach()
+    n = vd.norm(dim=1, keepdim=True)
+    dot = (dW * vd).sum(dim=1, keepdim=True)
+    return ((gd / n) * dW - vd * (gd * dot / n ** 3)) if need_v else None, (dot / n).reshape(g.shape) if need_g else None
+
+
 class _ProtoLinear(torch.autograd.Function):
-    """y = x @ W^T for the [K, 256] prototype matrix: forward and dX on the MFMA GEMM, dW = dy^T x on the TN MFMA kernel."""
+    """y = x @ W^T for the weight-normalised [K, 256] prototype matrix W = v g / ||v||: W built in 16 bits by one kernel, forward and
+    dX on the MFMA GEMM, dW = dy^T x on the TN MFMA kernel, (dv, dg) from dW by one kernel."""
 
     @staticmethod
-    def forward(ctx, x, W):
+    def forward(ctx, x, v, g):
         x2 = AF._as2d_bf16(x)
-        Wh = W.detach().to(ops.half()).contiguous()
+        Wh, norm = _normed_weight(v, g)
         y = ops.gemm_nt(x2, Wh)
-        ctx.save_for_backward(x2, Wh)
+        ctx.save_for_backward(x2, Wh, v, g, norm)
         ctx.shape = x.shape
-        return y.reshape(*x.shape[:-1], W.shape[0])
+        return y.reshape(*x.shape[:-1], Wh.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
-        x2, Wh = ctx.saved_tensors
+        x2, Wh, v, g, norm = ctx.saved_tensors
         dy2 = AF._as2d_bf16(dy)
-        dx = None
+        dx = dv = dg = None
         if ctx.needs_input_grad[0]:   # [rows, 256] = dy [rows, K] W [K, 256]: 35 tiles with a 65 536-long reduction -> split along K
             WhT = Wh.t().contiguous()
             gemm = ops.gemm_nt_splitk if ops.gemm_splitk_wanted(dy2.shape[0], WhT.shape[0], WhT.shape[1]) else ops.gemm_nt
             dx = gemm(dy2, WhT).reshape(ctx.shape)
-        dW = None
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             K, Din = Wh.shape
             if K % 64 == 0 and Din % 128 == 0:
                 dW = torch.empty(K, Din, device=dy2.device, dtype=torch.float32)
                 ops.proj_dw(dy2, x2, dW, torch.empty(K, device=dy2.device, dtype=torch.float32))
             else:   # shapes the TN kernel does not take
                 dW = torch.mm(dy2.float().t(), x2.float())
-        return dx, dW
+            dv, dg = _normed_weight_grads(dW, v, g, norm, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
+        return dx, dv, dg
 
 
 class _ProtoLosses(torch.autograd.Function):
@@ -61,14 +81,14 @@ class _ProtoLosses(torch.autograd.Function):
     Returns a [n_out] fp32 tensor: out[i] = sum of the terms with out_index i."""
 
     @staticmethod
-    def forward(ctx, x, W, n_out, terms):
+    def forward(ctx, x, v, g, n_out, terms):
         from .losses import _PRESCALE, launch_distill_ce
         P = _PRESCALE
         x2 = AF._as2d_bf16(x)
-        Wh = W.detach().to(ops.half()).contiguous()
+        Wh, norm = _normed_weight(v, g)
         y = ops.gemm_nt(x2, Wh)
         rows, K = y.shape
-        need = x.requires_grad or W.requires_grad
+        need = x.requires_grad or v.requires_grad or g.requires_grad
         dy = torch.empty_like(y) if need else None
         spans = []
         out, covered = [0] * n_out, 0
@@ -83,22 +103,22 @@ class _ProtoLosses(torch.autograd.Function):
             covered = b
         if need and covered < rows:
             dy[covered:].zero_()
-        ctx.save_for_backward(x2, Wh, dy, _row_term_index(rows, tuple(spans), y.device))
+        ctx.save_for_backward(x2, Wh, dy, _row_term_index(rows, tuple(spans), y.device), v, g, norm)
         ctx.meta = (x.shape, P)
         res = torch.stack([o if torch.is_tensor(o) else y.new_zeros((), dtype=torch.float32) for o in out])
         return res if P == 1.0 else res / P
 
     @staticmethod
-    def backward(ctx, g):
-        x2, Wh, dy, idx = ctx.saved_tensors
+    def backward(ctx, gout):
+        x2, Wh, dy, idx, v, g, norm = ctx.saved_tensors
         shape, P = ctx.meta
-        r = (g if P == 1.0 else g / P).float().index_select(0, idx).unsqueeze(1)      # [rows, 1]: the upstream scalar of each row's term
-        dx = dW = None
+        r = (gout if P == 1.0 else gout / P).float().index_select(0, idx).unsqueeze(1)   # [rows, 1]: the upstream scalar of each row's term
+        dx = dv = dg = None
         if ctx.needs_input_grad[0]:   # [rows, 256] = dy [rows, K] W [K, 256]: a 65 536-long reduction -> split along K
             WhT = Wh.t().contiguous()
             gemm = ops.gemm_nt_splitk if ops.gemm_splitk_wanted(dy.shape[0], WhT.shape[0], WhT.shape[1]) else ops.gemm_nt
             dx = (gemm(dy, WhT).float() * r).reshape(shape)
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             K, Din = Wh.shape
             xr = (x2.float() * r).to(x2.dtype)
             if K % 64 == 0 and Din % 128 == 0:
@@ -106,7 +126,8 @@ class _ProtoLosses(torch.autograd.Function):
                 ops.proj_dw(dy, xr, dW, torch.empty(K, device=dy.device, dtype=torch.float32))
             else:
                 dW = torch.mm(dy.float().t(), xr.float())
-        return dx, dW, None, None
+            dv, dg = _normed_weight_grads(dW, v, g, norm, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
+        return dx, dv, dg, None, None
 
 
 _ROW_INDEX_CACHE = {}
@@ -127,8 +148,9 @@ def _row_term_index(rows, spans, device):
     return idx
 
 
-def proto_losses(x, W, n_out, terms):
-    return _ProtoLosses.apply(x, W, n_out, tuple(terms))
+def proto_losses(x, v, g, n_out, terms):
+    """``v``, ``g``: the weight-norm parameters of the prototype layer (``last_layer.weight_v`` / ``weight_g``)."""
+    return _ProtoLosses.apply(x, v, g, n_out, tuple(terms))
 
 
 class DINOHead(nn.Module):
@@ -172,7 +194,7 @@ class DINOHead(nn.Module):
         return v * (g / v.norm(dim=1, keepdim=True))           # torch.nn.utils.weight_norm, dim=0
 
     def forward(self, x):
-        return _ProtoLinear.apply(self.bottleneck(x), self.prototype_weight())
+        return _ProtoLinear.apply(self.bottleneck(x), self.last_layer.weight_v, self.last_layer.weight_g)
 
 
 class KoLeoLoss(nn.Module):

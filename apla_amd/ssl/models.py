@@ -206,7 +206,7 @@ class DINOv2(nn.Module):
             terms.append((1, off, off + s_glob_cls.shape[0], t_dino.flatten(0, 1), self.dino_loss.student_temp, None, 1.0 / s_glob_cls.shape[0]))
             off += s_glob_cls.shape[0]
             terms.append((2, off, off + n_masked, t_ibot[:n_masked], self.ibot_patch_loss.student_temp, masks_weight, 1.0 / masks.shape[0]))
-            sums = proto_losses(head.bottleneck(torch.cat(head_in)), head.prototype_weight(), 3, terms)
+            sums = proto_losses(head.bottleneck(torch.cat(head_in)), head.last_layer.weight_v, head.last_layer.weight_g, 3, terms)
             l = sums[0] / (n_global_terms + n_local_terms)
             loss_dict["dino_local_crops_loss"] = l
             total = total + self.dino_loss_weight * l

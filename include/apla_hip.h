@@ -331,6 +331,14 @@ int apla_assemble_tokens_masked(const void* patches, int ldp, const float* cls_t
                                 const uint8_t* masked, const float* mask_token, void* tokens, int res_dtype, int B, int Np,
                                 int D, hipStream_t stream);
 
+/* torch.nn.utils.weight_norm(dim = 0) of the DINO head's prototype layer (self_supervised/dinov2/layers/dino_head.py:27-28):
+ *   apla_weight_norm_fwd : W[i,:] = v[i,:] * g[i] / ||v[i,:]|| written in the build's 16-bit operand type, norm[i] = ||v[i,:]||
+ *   apla_weight_norm_bwd : dv[i,:] = (g[i] / n) (dW[i,:] - v[i,:] (dW[i,:] . v[i,:]) / n^2),  dg[i] = (dW[i,:] . v[i,:]) / n   (dg may be NULL)
+ * v, dW, dv fp32 [K, D] row-major, g / norm / dg fp32 [K]; D % 4 == 0. */
+int apla_weight_norm_fwd(const float* v, const float* g, void* w_h16, float* norm, int K, int D, hipStream_t stream);
+int apla_weight_norm_bwd(const float* dw, const float* v, const float* g, const float* norm, float* dv, float* dg, int K, int D,
+                         hipStream_t stream);
+
 /* Dropout and stochastic depth of the module path (utils/transformers/vit.py:74-93 DropPath, :152-168 Mlp.drop; apla/appla_attn.py:82
  * proj_drop; all shipped configurations use 0, main.py:101-111 can set them).
  *   apla_dropout_fwd : y = keep ? x / (1 - p) : 0 and keep[i] (one byte per element, for the backward).  Element i keeps iff word

@@ -1132,3 +1132,22 @@ def test_dropout_kernels_and_the_oracle_mask(ops, dtype, p, n):
     sc = torch.tensor([0.0, 2.0, 1.0], device="cuda")
     xs = dev(rnd(3, 5, 64, seed=163).to(dtype))
     assert torch.equal(ops.scale_samples(xs, sc).float().cpu(), (xs.float() * sc[:, None, None]).to(dtype).float().cpu())
+
+
+@pytest.mark.parametrize("K,D", [(65536, 256), (515, 64), (3, 1024)])
+def test_weight_norm_kernels(ops, K, D):
+    """apla_weight_norm_fwd / _bwd against torch.nn.utils.weight_norm's own arithmetic in float64 (dinov2 dino_head.py:27-28: the
+    prototype layer W = v g / ||v||, dim = 0): W in the 16-bit operand type, dv and dg from an fp32 dW."""
+    v = rnd(K, D, seed=171) * 0.3
+    g = (rnd(K, 1, seed=172) * 0.1 + 1.0)
+    dW = rnd(K, D, seed=173)
+    vd, gd = v.double().requires_grad_(True), g.double().requires_grad_(True)
+    Wd = vd * (gd / vd.norm(dim=1, keepdim=True))
+    (Wd * dW.double()).sum().backward()
+    W, norm = ops.weight_norm_fwd(dev(v), dev(g).reshape(-1))
+    assert W.dtype == torch.bfloat16 and rel_err(W.cpu(), Wd.detach()) < BF16_OUT
+    assert rel_err(norm.cpu(), v.double().norm(dim=1)) < 1e-6
+    dv, dg = ops.weight_norm_bwd(dev(dW), dev(v), dev(g).reshape(-1), norm)
+    assert rel_err(dv.cpu(), vd.grad) < 2e-5 and rel_err(dg.cpu(), gd.grad.reshape(-1)) < 2e-5
+    dv2, none = ops.weight_norm_bwd(dev(dW), dev(v), dev(g).reshape(-1), norm, want_dg=False)
+    assert none is None and torch.equal(dv2, dv)
