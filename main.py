@@ -334,6 +334,9 @@ def main_dinov2(params, args):
                                           n_global_crops=2, n_local_crops=c["n_local_crops"], mask_ratio_tuple=tuple(ib["mask_ratio_min_max"]),
                                           mask_probability=ib["mask_sample_probability"], dtype=torch.float32, n_tokens=side * side,
                                           mask_generator=mask_gen)
+            for k_, v_ in batch["images"].items():   # page-locked like the reference's DataLoader(pin_memory=True): the model's
+                if torch.is_tensor(v_) and not v_.is_cuda:   # .to(dev, non_blocking=True) then does not make the host wait for the stream
+                    batch["images"][k_] = v_.pin_memory()
             loss = trainer.global_step(batch)
             seen += run["batch"] * world
             it = trainer.iters - 1
