@@ -54,12 +54,25 @@ def main():
         rows[key][0] += 1
         rows[key][1] += dev_us
         total_torch += dev_us
+    copies = collections.defaultdict(lambda: [0, 0.0])
+    for ev in prof.events():
+        if not ev.kernels:
+            continue
+        for k in ev.kernels:
+            if "copyBuffer" in k.name or "Memcpy" in k.name:
+                key = ev.name + " " + str(getattr(ev, "input_shapes", ""))[:90]
+                copies[key][0] += 1
+                copies[key][1] += k.duration
     print(f"torch-launched kernels of one iteration ({args.dtype}, batch {args.batch}): {total_torch / args.steps / 1e3:.3f} ms/step of "
           f"{total_all / args.steps / 1e3:.3f} ms/step attributed device time\n")
     print("| op | launched from | launches/step | device us/step |")
     print("|---|---|---:|---:|")
     for (name, where), (n, us) in sorted(rows.items(), key=lambda kv: -kv[1][1])[:60]:
         print(f"| {name} | {where} | {n / args.steps:.1f} | {us / args.steps:.1f} |")
+    if copies:
+        print("\nruntime device-to-device copies by operator:\n\n| op | copies/step | device us/step |\n|---|---:|---:|")
+        for name, (n, us) in sorted(copies.items(), key=lambda kv: -kv[1][0])[:25]:
+            print(f"| {name} | {n / args.steps:.1f} | {us / args.steps:.1f} |")
 
 
 if __name__ == "__main__":

@@ -49,3 +49,25 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def neighbours(path, needle, skip=0.5, top=20):
+    """Histogram of (kernel before, kernel after) around every kernel whose name contains `needle`."""
+    import collections
+    rows = []
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            rows.append((int(r["Start_Timestamp"]), r["Kernel_Name"][:60]))
+    rows.sort()
+    rows = rows[int(len(rows) * skip):]
+    h = collections.Counter()
+    for i, (_, n) in enumerate(rows):
+        if needle in n and 0 < i < len(rows) - 1:
+            h[(rows[i - 1][1], rows[i + 1][1])] += 1
+    print(f"\nneighbours of '{needle}' ({sum(h.values())} occurrences):")
+    for (a, b), c in h.most_common(top):
+        print(f"  {c:5d}  {a}  ->  [{needle}]  ->  {b}")
+
+
+if __name__ == "__main__" and len(sys.argv) > 4:
+    neighbours(sys.argv[1], sys.argv[4], float(sys.argv[3]))
