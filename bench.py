@@ -32,7 +32,10 @@ STEP_GF_PER_IMG = {("vit_small", 224, 16): 18.76, ("vit_base", 224, 16): 70.99, 
                    ("vit_large", 224, 14): 330.78, ("vit_giant", 518, 14): 7629.5}
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_dominant_kernel.json")  # written by tools/measure_round.sh (separate --pmc passes)
-LOGIT_TOL = {"bf16": 8e-3, "fp16": 1e-3}   # asserted in tests/test_engine_gpu.py / tests/test_fp16_gpu.py on BASELINE config 1
+# the bounds the tests assert on BASELINE config 1 (tests/test_engine_gpu.py, tests/test_fp16_gpu.py): `max` on every one of the eight
+# batches, `mean` on their mean.  The fp16 maximum is 1.2e-3, not the north-star's 1e-3: the operand roundings alone give 1.04e-3
+# on these batches — the line says so instead of quoting the mean's bound beside the maximum
+LOGIT_TOL = {"bf16": {"max": 8e-3, "mean": 8e-3}, "fp16": {"max": 1.2e-3, "mean": 1e-3}}
 
 
 def dominant_kernel_traffic():
@@ -112,9 +115,24 @@ def executed_gflop_per_image(bb, eng, n_classes):
     return round((fwd + bwd - dead) / 1e9, 2)
 
 
-def cpu_baseline(backbone, r, n_classes, img, patch, sample_bs, threads, budget_s=8.0):
-    """The CPU oracle (a port of the reference step) timed on this box's host cores on a bounded sample: one warm-up step,
-    then whole steps until `budget_s` seconds have been spent (at least one)."""
+def usable_cpus():
+    """CPUs this process may really use: its affinity mask, cut by the cgroup's CPU quota (a GPU box hands a one-GPU lease a share
+    of the host — os.cpu_count() reports the whole machine, and 64 threads on a 16-CPU share is why earlier rounds' figure wandered)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            quota, period = open(path).read().split()[:2]
+            if quota != "max":
+                n = min(n, max(1, int(float(quota) / float(period))))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
+def cpu_baseline_child(backbone, r, n_classes, img, patch, sample_bs, threads, steps):
+    """One leg of the CPU baseline, in a process of its own (thread count and binding fixed by its environment, no GPU touched):
+    the fp32 oracle's full training step (a port of the reference step, pinned by the goldens) on a fixed synthetic batch — one
+    warm-up step, then `steps` timed steps; prints their durations."""
     from oracle import apla_oracle as O
     torch.set_num_threads(threads)
     model = build_model(backbone, r, n_classes, img, patch)
@@ -126,12 +144,44 @@ def cpu_baseline(backbone, r, n_classes, img, patch, sample_bs, threads, budget_
     labels = torch.randint(0, n_classes, (sample_bs,), generator=g)
     state = {}
     O.train_step(images, labels, p, cfg, state)  # warm-up
-    t0, n = time.perf_counter(), 0
-    while n < 1 or (time.perf_counter() - t0 < budget_s and n < 20):
+    ts = []
+    for _ in range(steps):
+        t0 = time.perf_counter()
         O.train_step(images, labels, p, cfg, state)
-        n += 1
-    dt = (time.perf_counter() - t0) / n
-    return sample_bs / dt, n, dt
+        ts.append(time.perf_counter() - t0)
+    print(json.dumps({"threads": threads, "torch_threads": torch.get_num_threads(), "step_s": ts}), flush=True)
+
+
+def cpu_baseline(backbone, r, n_classes, img, patch, sample_bs, steps=5):
+    """The CPU oracle timed on this box's host cores: the same model at batch `sample_bs` (16 by default: config 2's
+    shapes at B = 16), MEDIAN of `steps` (>= 5) full steps after one warm-up, once with 8 threads and once with every CPU this
+    process may use (affinity mask and cgroup quota, not os.cpu_count()).  Each leg is a child process started before this one
+    creates its HIP context, with OMP_NUM_THREADS fixed and OMP_PROC_BIND=close / OMP_PLACES=cores so that threads neither migrate
+    nor oversubscribe.  `value` is the better of the two legs; both are reported."""
+    ncpu = usable_cpus()
+    legs = sorted({min(8, ncpu), ncpu})
+    by_threads, best = {}, None
+    for n in legs:
+        env = dict(os.environ, OMP_NUM_THREADS=str(n), MKL_NUM_THREADS=str(n), OMP_PROC_BIND="close", OMP_PLACES="cores",
+                   HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", str(n), "--backbone", backbone, "--partial-size", str(r),
+               "--classes", str(n_classes), "--img", str(img), "--patch", str(patch), "--cpu-sample-bs", str(sample_bs), "--cpu-steps", str(steps)]
+        try:
+            out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+            rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        except (OSError, subprocess.SubprocessError, ValueError, IndexError):
+            continue
+        ts = sorted(rec["step_s"])
+        med = ts[len(ts) // 2] if len(ts) % 2 else 0.5 * (ts[len(ts) // 2 - 1] + ts[len(ts) // 2])
+        by_threads[str(n)] = {"images_per_s": round(sample_bs / med, 2), "median_step_s": round(med, 3), "min_step_s": round(ts[0], 3), "max_step_s": round(ts[-1], 3)}
+        if best is None or sample_bs / med > best[0]:
+            best = (sample_bs / med, n, med)
+    if best is None:
+        return None
+    return {"value": round(best[0], 2), "unit": "images/s", "cores": best[1], "kind": "port", "statistic": "median", "steps": steps,
+            "cpus_usable": ncpu, "os_cpu_count": os.cpu_count(), "by_threads": by_threads, "binding": "OMP_PROC_BIND=close OMP_PLACES=cores",
+            "sample": f"median of {steps} full training steps of the same model at bs={sample_bs} after one warm-up step (fp32 oracle, "
+                      f"{best[2]:.2f} s/step with {best[1]} threads; {ncpu} CPUs usable of os.cpu_count()={os.cpu_count()})"}
 
 
 def measured_mfma_peak():
@@ -167,6 +217,7 @@ def parity_cfg1(hdt, loss_scale):
     eng.set_batch(images.cuda(), labels.cuda())
     eng.forward_backward()
     torch.cuda.synchronize()
+    loss0 = float(eng.loss)     # the seed-0 batch's loss, read BEFORE the forward-only passes below overwrite eng.loss
     ref = torch.from_numpy(g["logits"]).double()
     err = float((eng.logits.cpu().double() - ref).abs().max() / ref.abs().max())
     name = "fp16" if hdt == torch.float16 else "bf16"
@@ -186,10 +237,11 @@ def parity_cfg1(hdt, loss_scale):
             torch.cuda.synchronize()
             r = torch.from_numpy(gs["logits"][i]).double()
             errs.append(float((lg.cpu().double() - r).abs().max() / r.abs().max()))
-    out = {"dtype": name, "logits_rel_vs_reference_cfg1": float(f"{err:.3e}"), "tol_asserted": LOGIT_TOL[name],
+    out = {"dtype": name, "logits_rel_vs_reference_cfg1": float(f"{err:.3e}"), "tol_asserted": LOGIT_TOL[name]["max"],
+           "tol_asserted_on_the_mean": LOGIT_TOL[name]["mean"], "north_star_tol": 1e-3,
            "logits_rel_max_over_batches": float(f"{max(errs):.3e}"), "logits_rel_mean_over_batches": float(f"{sum(errs) / len(errs):.3e}"),
            "n_batches": len(errs),
-           "loss": round(float(eng.loss), 6), "loss_reference": round(float(g["loss"]), 6),
+           "loss": round(loss0, 6), "loss_reference": round(float(g["loss"]), 6),
            "fc_weight_grad_rel_l2_vs_reference": float(f"{gerr:.3e}"),
            "reference": "tests/golden/g5_cfg1_vits.npz (reference code on CPU, fp32)"}
     del eng
@@ -295,10 +347,25 @@ def main():
     ap.add_argument("--no-parity", action="store_true", help="skip the live config-1 parity record")
     ap.add_argument("--no-peak-probe", action="store_true", help="skip tools/mfma_peak (roofline.peak_measured)")
     ap.add_argument("--no-fp16-leg", action="store_true", help="skip the timing of the fp16 build beside a bf16 run")
-    ap.add_argument("--cpu-sample-bs", type=int, default=8)
+    ap.add_argument("--cpu-sample-bs", type=int, default=16, help="batch of the CPU-baseline sample (SURVEY §8d: config 2's shapes at B = 16)")
+    ap.add_argument("--cpu-steps", type=int, default=5, help="timed steps per CPU-baseline leg (median reported)")
+    ap.add_argument("--cpu-baseline-child", type=int, default=0, help=argparse.SUPPRESS)   # one leg of cpu_baseline(): N threads, no GPU
+    ap.add_argument("--exchange-channels", type=int, default=None, help="RCCL channels (= workgroups) the gradient all-reduce may use "
+                    "(NCCL_MAX_NCHANNELS; default 8 = the CUs the GEMM launches leave free); recorded in ranks.env")
+    ap.add_argument("--reserve-cus", type=int, default=None, help="CUs the persistent GEMM launches leave to the collective when "
+                    "world > 1 (APLA_RESERVE_CUS; default = the channel count); recorded in ranks.env")
     ap.add_argument("--launcher-check", action="store_true", help="multi-rank plumbing only (gloo, no GPU); used by the CPU tests")
     args = ap.parse_args()
 
+    if args.cpu_baseline_child:
+        return cpu_baseline_child(args.backbone, args.partial_size, args.classes, args.img, args.patch, args.cpu_sample_bs,
+                                  args.cpu_baseline_child, args.cpu_steps)
+    # A/B switches of the data-parallel path for the first real multi-GPU run: explicit flags win over the defaults of
+    # rccl_channel_budget(), an operator's own environment wins over both defaults (setdefault there)
+    if args.exchange_channels is not None:
+        os.environ["NCCL_MAX_NCHANNELS"] = str(args.exchange_channels)
+    if args.reserve_cus is not None:
+        os.environ["APLA_RESERVE_CUS"] = str(args.reserve_cus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -313,12 +380,7 @@ def main():
     # a single-GPU run only) and the MFMA-peak probe (a child process, before this process creates its HIP context)
     cpu_rec = None
     if world == 1 and not args.no_cpu_baseline:
-        threads = min(64, os.cpu_count() or 1)
-        v, n, dt_s = cpu_baseline(args.backbone, args.partial_size, args.classes, args.img, args.patch, args.cpu_sample_bs, threads)
-        cpu_rec = {"value": round(v, 2), "unit": "images/s", "cores": threads, "kind": "port",
-                   "sample": f"{n} full steps of the same model at bs={args.cpu_sample_bs} after one warm-up step (fp32 oracle, "
-                             f"{dt_s:.2f} s/step, os.cpu_count()={os.cpu_count()})"}
-        torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+        cpu_rec = cpu_baseline(args.backbone, args.partial_size, args.classes, args.img, args.patch, args.cpu_sample_bs, max(5, args.cpu_steps))
     peak_rec = measured_mfma_peak() if (rank == 0 and not args.no_peak_probe) else None
 
     if not torch.cuda.is_available():
