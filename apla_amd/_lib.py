@@ -45,6 +45,7 @@ SIGNATURES = {
                                       c_void_p, c_int, c_void_p, c_int, c_long, c_void_p, c_long, c_void_p, c_int, c_void_p,
                                       c_int, c_int, c_void_p]),
     "apla_gemm_nt_kernel_name": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_char_p, c_int]),
+    "apla_attn_kernel_name": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_char_p, c_int]),
     "apla_probe_occupy": (c_int, [c_int, c_int, c_int, c_int, c_void_p]),
     "apla_gather_cols": (c_int, [c_void_p, c_int, c_long, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     "apla_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),

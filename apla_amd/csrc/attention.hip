@@ -354,12 +354,13 @@ constexpr int SMALL_MAX_ROWS_BWD = 288;  // the fused backward also takes the 25
 
 __global__ __launch_bounds__(576, 4) void attn_fwd_small_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
                                                                 float* __restrict__ lse, int Nmax, int H, float scale,
-    const int32_t* __restrict__ cu, int total) {
+    const int32_t* __restrict__ cu, int total, int xp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // K rows [NP][64] then V rows [NP][64], NP = 32 * waves
   const int tid = threadIdx.x, lane = tid & 63, h2 = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nw = blockDim.x >> 6, NP = nw * 32;
-  const int b = blockIdx.y, h = blockIdx.x;
+  int b = blockIdx.y, h = blockIdx.x;
+  if (xp & 128) { const int i = (b * H + h) & 255; b = i / H; h = i - b * H; }
   const Seq sq = seq_of(cu, b, Nmax, H, total);
   const int N = sq.n;
   if (N <= 0) return;
@@ -459,7 +460,7 @@ __global__ __launch_bounds__(576, 4) void attn_fwd_small_kernel(const bf16* __re
       }
     }
   };
-  const int nfull = N >> 6;   // blocks without a key >= N
+  const int nfull = (xp & 64) ? 0 : N >> 6;   // blocks without a key >= N
 #pragma unroll 1
   for (int kb = 0; kb < nfull; ++kb) block(kb, std::false_type{});
   if (N & 63) block(nfull, std::true_type{});
@@ -468,6 +469,254 @@ __global__ __launch_bounds__(576, 4) void attn_fwd_small_kernel(const bf16* __re
     store_acc_T(acc_o, o + ((long)sq.start + q) * D + h * 64, h2, 1.0f / l_tot);
     if (h2 == 0) lse[sq.stat + (long)h * sq.stat_h + q] = m_run * scale + __logf(l_tot);
   }
+}
+
+// ------------------------------------------------------------------------------------------------ forward, persistent
+// Uniform batches of short sequences (N <= 224) with at least one head per CU.  Ablations of the kernel above (round 5: all heads
+// read from 256 cache-resident ones / key loop cut to its last block) put its 54 us per layer at ~25 us of skeleton — every
+// workgroup issues its whole K / V, waits for it, computes, stores and exits, three rounds of that per CU —, ~12 us of exposed HBM
+// latency and only ~17 us of products and softmax.  Here ONE workgroup per CU walks its heads, and every byte is requested a whole
+// head ahead of its use:
+//   waves  0 .. NT-1 own one 32-row query block each; wave NT is the loader: it issues every LDS-DMA piece (the compute waves issue
+//          no K / V load at all) and waits for them before the head's only barrier.
+//   LDS    K and V double-buffered, [NR rows][64] each with NR = N rounded up to 8, then 24 zero rows (the last 32-row tile of V
+//          reads past NR: zeros times P = 0; the overrun of K lands in the next buffer and its scores are masked by select), then a
+//          4 KB store buffer per compute wave (O leaves as whole lines).
+//   head i barrier (K, V of head i landed; every wave is done with head i - 1) | loader: K, V of head i + 1 into the other buffers |
+//          store O of head i - 1 (deferred, so that no wave ever waits for its own stores) | QK^T of ALL tiles: S stays in 16 * NT
+//          registers, q rows of head i + 1 requested into the registers q just left | ONE row maximum, exp2, row sum, P rounded
+//          to 16 bits | PV of all tiles | wait for the q rows.
+// No online softmax: one maximum per row, no rescale of O.  The results agree with attn_fwd_small_kernel (four 64-key blocks with
+// running maxima) to rounding, not bitwise.
+template <int I, int E, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < E) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, E>(f);
+  }
+}
+struct QRegs { f32x4 q[4]; };
+__device__ __forceinline__ void q_prefetch(QRegs& r, const bf16* qp) {
+  asm volatile(
+      "global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:32\n\t"
+      "global_load_dwordx4 %2, %4, off offset:64\n\tglobal_load_dwordx4 %3, %4, off offset:96"
+      : "=&v"(r.q[0]), "=&v"(r.q[1]), "=&v"(r.q[2]), "=&v"(r.q[3])
+      : "v"(qp)
+      : "memory");
+}
+__device__ __forceinline__ void q_pin(QRegs& r) {
+  asm volatile("" : "+v"(r.q[0]), "+v"(r.q[1]), "+v"(r.q[2]), "+v"(r.q[3]));
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+constexpr int FWDP_PAD_ROWS = 24;
+constexpr int FWDP_MAX_NT = 7;
+template <int NT>
+__global__ __launch_bounds__(64 * (NT + 1), 2) void attn_fwd_persist_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
+                                                                          float* __restrict__ lse, int N, int H, float scale,
+                                                                          int BH, int NR, int xp) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, h2 = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if ((xp & 1) && wave >= 4 && wave < NT) __builtin_amdgcn_s_setprio(1);
+  if ((xp & 2) && wave < 4) __builtin_amdgcn_s_setprio(1);
+  if ((xp & 4) && wave == NT) __builtin_amdgcn_s_setprio(2);
+  const int D = H * 64;
+  const long ld = 3L * D;
+  const float c = scale * LOG2E;
+  const int TB = NR * 128;                 // bytes per buffer; layout K0 | K1 | V0 | V1 | zero rows
+  const int npc = NR >> 3;                 // 1 KB pieces (8 rows x 128 B) per buffer
+  const FragOffs fo = frag_offs(lane);
+  const unsigned k0a = lds_addr(smem), v0a = k0a + 2 * TB;
+
+  // zero rows behind V1, and the first rows of V1 itself: the first head's last V tile overruns V0 into V1 before any DMA has
+  // written there (whatever the LDS held times P = 0 must not be NaN)
+  for (int i = tid; i < FWDP_PAD_ROWS * 8; i += 64 * (NT + 1)) {
+    *(f32x4*)(smem + 4 * TB + i * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+    *(f32x4*)(smem + 3 * TB + i * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  auto base_of = [&](int idx) { const int b = idx / H, h = idx - b * H; return qkv + (long)b * N * ld + h * 64; };
+  // loader wave: K and V of one head, 2 * npc pieces of 8 rows x 128 B; the XOR swizzle of tile_off goes on the source column (the
+  // LDS side of a DMA is lane-linear).  A piece's address is (wave-uniform piece base) + (a 32-bit lane offset that takes two values,
+  // for even and odd pieces): nothing but scalar adds between two DMA instructions (computed per piece, the swizzle and the 64-bit
+  // row products cost ~240 cycles per piece: 11.8k cycles per head, more than the compute waves need for the head itself).  Only
+  // the buffer's last piece can hold rows >= N (they re-read row N - 1) and takes the long way.
+  const int lr = lane >> 3;
+  const int f_even = (((lr >> 1) & 1) << 2) | (lr >> 2);
+  const unsigned loff_even = (unsigned)(lr * (int)ld * 2 + (((lane & 7) ^ f_even) << 4));
+  const unsigned loff_odd = (unsigned)(lr * (int)ld * 2 + (((lane & 7) ^ f_even ^ 2) << 4));
+  const int nfull = N >> 3;   // pieces without a row >= N
+  auto stage_buf = [&](const bf16* src, char* dst) {
+    const char* pb = (const char*)src;
+    const long step = 8L * ld * 2;
+    int pr = 0;
+#pragma unroll 1
+    for (; pr + 1 < nfull; pr += 2) {
+      __builtin_amdgcn_global_load_lds(ATT_GLBP(pb + loff_even), ATT_LDSP(dst + pr * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(ATT_GLBP(pb + step + loff_odd), ATT_LDSP(dst + pr * 1024 + 1024), 16, 0, 0);
+      pb += 2 * step;
+    }
+    for (; pr < npc; ++pr) {   // an odd full piece and / or the ragged last piece
+      const int row = pr * 8 + lr;
+      const int f = (((row >> 1) & 1) << 2) | ((row >> 2) & 3);
+      const int gr = row < N ? row : N - 1;
+      __builtin_amdgcn_global_load_lds(ATT_GLBP(src + (long)gr * ld + (((lane & 7) ^ f) << 3)), ATT_LDSP(dst + pr * 1024), 16, 0, 0);
+    }
+  };
+  auto stage_head = [&](const bf16* hb, int par) {
+    stage_buf(hb + D, smem + par * TB);
+    stage_buf(hb + 2 * D, smem + 2 * TB + par * TB);
+  };
+
+  int idx = blockIdx.x;
+  if (idx >= BH) return;
+  const int G = gridDim.x;
+  STAMP_DECL
+  if (wave == NT) {   // ------------------------------------------------------------------------------ loader wave
+    stage_head(base_of(idx), 0);
+    int par = 0;
+    while (true) {
+      STAMP(0);   // loader: issue
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      STAMP(1);   // loader: wait for the pieces
+      __builtin_amdgcn_s_barrier();
+      STAMP(2);   // loader: barrier
+      const int next = idx + G;
+      if (next >= BH) break;
+      par ^= 1;
+      stage_head(base_of(next), par);
+      idx = next;
+    }
+#if defined(APLA_ATT_STAMPS)
+    if (lane == 0 && blockIdx.x < 512) for (int k_ = 0; k_ < 16; ++k_) apla_att_dbg[(blockIdx.x * 8 + wave) * 16 + k_] = st_acc[k_];
+#endif
+    return;
+  }
+  // ---------------------------------------------------------------------------------------------------- compute waves
+  int q = wave * 32 + (lane & 31);
+  const bool qvalid = q < N;
+  if (!qvalid) q = N - 1;
+  // head coordinates (b, h) advance by G heads per step without a division
+  const int gq = G / H, gr_ = G - gq * H;
+  int hb_ = idx / H, hh_ = idx - hb_ * H;       // current head
+  int pb_ = hb_, ph_ = hh_;                      // previous head (deferred store)
+  const bf16* base = qkv + (long)hb_ * N * ld + hh_ * 64;
+  QRegs qr;
+  q_prefetch(qr, base + (long)q * ld + 8 * h2);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  q_pin(qr);
+  int par = 0, prev = -1;
+  f32x16 acc_o[2];
+  float m_fin = 0.f, l_fin = 1.f;
+  char* wbuf = smem + 4 * TB + FWDP_PAD_ROWS * 128 + wave * 4096;   // this wave's 4 KB store buffer (whole-line stores: store_acc_T_staged)
+  auto store_head = [&]() {   // head (pb_, ph_)
+    const float l_tot = l_fin + __shfl_xor(l_fin, 32, 64);
+    store_acc_T_staged(acc_o, wbuf, o + (long)pb_ * N * D + ph_ * 64, D, wave * 32, N, lane, 1.0f / l_tot);
+    if (qvalid && h2 == 0) lse[((long)pb_ * H + ph_) * N + q] = m_fin * scale + __logf(l_tot);
+  };
+  while (true) {
+    STAMP(5);   // q wait + loop overhead
+    __builtin_amdgcn_s_barrier();   // K, V of head idx are in LDS (the loader waited for them); every wave is done with head prev
+    asm volatile("" ::: "memory");
+    STAMP(0);   // barrier
+    if (prev >= 0) store_head();
+    STAMP(1);   // deferred store
+    const int next = idx + G;
+    const bool has_next = next < BH;
+    int nb_ = hb_ + gq, nh_ = hh_ + gr_;
+    if (nh_ >= H) { nh_ -= H; ++nb_; }
+    const bf16* nbase = has_next ? qkv + (long)nb_ * N * ld + nh_ * 64 : base;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = __builtin_bit_cast(bf16x8, qr.q[ks]);
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // per-head copies of the fragment bases behind an opaque move: every tile is then an instruction immediate away from four
+    // registers; left visible, hipcc hoists one address per (tile, fragment) out of the head loop — 56 lane constants at seven tiles
+    unsigned kr[4], vt[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      kr[k] = k0a + par * TB + fo.rf[k];
+      vt[k] = v0a + par * TB + fo.tr[k];
+      asm volatile("" : "+v"(kr[k]), "+v"(vt[k]));
+    }
+    // ---------------------------------------------------------------- S^T = K Q^T, all tiles
+    f32x16 sc[NT];
+    static_for<0, NT>([&](auto T) {
+      constexpr int t = decltype(T)::value, OFF = t * 4096;
+      sc[t] = MFMA_F32_32x32x16_H16(row_frag_at<OFF>(kr[0]), qf[0], zero);
+#pragma unroll
+      for (int ks = 1; ks < 4; ++ks) sc[t] = MFMA_F32_32x32x16_H16(row_frag_at<OFF>(kr[ks]), qf[ks], sc[t]);
+    });
+    asm volatile("" :: "v"(sc[NT - 1][15]));
+    STAMP(2);   // S products
+    // qf is dead: the q rows of the next head (the last head re-reads its own, never used)
+    q_prefetch(qr, nbase + (long)q * ld + 8 * h2);
+    if (N < 32 * NT) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if ((NT - 1) * 32 + acc_row(i, h2) >= N) sc[NT - 1][i] = -INFINITY;
+    }
+    // ---------------------------------------------------------------- softmax: one maximum per row
+    float mx = sc[0][0];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sc[t][i]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mc = mx * c;
+    float l = 0.f;
+    bf16x8 pp[NT][2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        sc[t][i] = __builtin_amdgcn_exp2f(fmaf(sc[t][i], c, -mc));
+        l += sc[t][i];
+      }
+      pp[t][0] = acc_to_operand(sc[t], 0);
+      pp[t][1] = acc_to_operand(sc[t], 1);
+    }
+    asm volatile("" :: "v"(pp[NT - 1][1]));
+    STAMP(3);   // softmax
+    // ---------------------------------------------------------------- O^T = V^T P^T, all tiles
+    static_for<0, NT>([&](auto T) {
+      constexpr int t = decltype(T)::value, OFF = t * 4096;
+      TrPair tf[4];   // [2 sk + dt]
+      tr_issue_at<OFF>(tf[0], vt[0], vt[1]);
+      tr_issue_at<OFF>(tf[1], vt[2], vt[3]);
+      tr_issue_at<OFF + 2048>(tf[2], vt[0], vt[1]);
+      tr_issue_at<OFF + 2048>(tf[3], vt[2], vt[3]);
+      lds_landed(tf);
+      if constexpr (t == 0) {
+        acc_o[0] = MFMA_F32_32x32x16_H16(tr_join(tf[0]), pp[t][0], zero);
+        acc_o[1] = MFMA_F32_32x32x16_H16(tr_join(tf[1]), pp[t][0], zero);
+      } else {
+        acc_o[0] = MFMA_F32_32x32x16_H16(tr_join(tf[0]), pp[t][0], acc_o[0]);
+        acc_o[1] = MFMA_F32_32x32x16_H16(tr_join(tf[1]), pp[t][0], acc_o[1]);
+      }
+      acc_o[0] = MFMA_F32_32x32x16_H16(tr_join(tf[2]), pp[t][1], acc_o[0]);
+      acc_o[1] = MFMA_F32_32x32x16_H16(tr_join(tf[3]), pp[t][1], acc_o[1]);
+    });
+    asm volatile("" :: "v"(acc_o[0][15]), "v"(acc_o[1][15]));
+    STAMP(4);   // PV
+    m_fin = mx;
+    l_fin = l;
+    // the q rows of the next head: requested a softmax and a PV ago
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    q_pin(qr);
+    prev = idx;
+    pb_ = hb_; ph_ = hh_;
+    if (!has_next) break;
+    idx = next;
+    hb_ = nb_; hh_ = nh_;
+    base = nbase;
+    par ^= 1;
+  }
+  store_head();
+#if defined(APLA_ATT_STAMPS)
+  if (lane == 0 && blockIdx.x < 512) for (int k_ = 0; k_ < 16; ++k_) apla_att_dbg[(blockIdx.x * 8 + wave) * 16 + k_] = st_acc[k_];
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dQ (+delta)
@@ -1489,14 +1738,57 @@ static void apla_allow_lds(std::atomic<unsigned long long>& mask, const void* ke
 // one-workgroup-per-head short-sequence kernels (never the persistent one), 3 = the persistent backward wherever it applies
 
 // B sequences of (at most) N tokens; cu == nullptr: uniform batch, else packed with cu[B+1] token offsets and `total` tokens
+// Which kernel a launch takes (ONE decision code for the launch and for apla_attn_kernel_name).  `packed`: block-diagonal batch.
+enum AttnKernel { ATTN_FWD_BLOCKED, ATTN_FWD_SMALL, ATTN_FWD_PERSIST, ATTN_BWD_SPLIT, ATTN_BWD_SMALL, ATTN_BWD_TINY, ATTN_BWD_PERSIST };
+static const char* const ATTN_KERNEL_NAMES[] = {"attn_fwd_kernel", "attn_fwd_small_kernel", "attn_fwd_persist_kernel", "attn_bwd_dq_kernel + attn_bwd_dkv_kernel",
+                                                "attn_bwd_small_kernel<288,4>", "attn_bwd_small_kernel<64,2>", "attn_bwd_persist_kernel"};
+static AttnKernel attn_fwd_choice(bool packed, int B, int N, int H, int variant) {
+  // uniform batch of short sequences with at least one head per CU: the persistent kernel (variant 2 pins the
+  // one-workgroup-per-head kernel, variant 3 the persistent one wherever it applies)
+  if (!packed && N > TINY_MAX_ROWS && N <= 32 * FWDP_MAX_NT && variant != 1 && variant != 2 && (variant == 3 || (long)B * H >= apla_num_cus()))
+    return ATTN_FWD_PERSIST;
+  return (N <= SMALL_MAX_ROWS && variant != 1) ? ATTN_FWD_SMALL : ATTN_FWD_BLOCKED;
+}
+static AttnKernel attn_bwd_choice(bool packed, int B, int N, int H, int variant) {
+  // uniform batch of short sequences with at least one head per CU: the persistent kernel (every load one phase ahead of its use);
+  // variant 2 pins the one-workgroup-per-head kernels, variant 3 the persistent one wherever it applies (tests, A/B timing)
+  if (!packed && N <= PERSIST_MAX_ROWS && variant != 1 && variant != 2 && (variant == 3 || ((long)B * H >= apla_num_cus() && N > TINY_MAX_ROWS)))
+    return ATTN_BWD_PERSIST;
+  if (N <= TINY_MAX_ROWS && variant != 1) return ATTN_BWD_TINY;
+  if (N <= SMALL_MAX_ROWS_BWD && variant != 1) return ATTN_BWD_SMALL;
+  return ATTN_BWD_SPLIT;
+}
+
 static int launch_attn_fwd(const void* qkv, void* o, float* lse, const int32_t* cu, int total, int B, int N, int H,
                            float scale, int g_attn_variant, hipStream_t stream, const char* who) {
+  const int xp = g_attn_variant >> 8;
+  g_attn_variant &= 0xff;
   APLA_REQUIRE(g_attn_variant >= 0 && g_attn_variant <= 3, "%s: unknown kernel variant %d", who, g_attn_variant);
-  if (N <= SMALL_MAX_ROWS && g_attn_variant != 1) {
+  const AttnKernel kchoice = attn_fwd_choice(cu != nullptr, B, N, H, g_attn_variant);
+  if (kchoice == ATTN_FWD_PERSIST) {
+    const int nt = (N + 31) / 32, BH = B * H, NR = (N + 7) / 8 * 8;
+    const size_t lds = (size_t)(4 * NR + FWDP_PAD_ROWS) * 128 + (size_t)nt * 4096;   // K0 K1 V0 V1, zero rows, per-wave store buffers
+    const int G = BH < apla_num_cus() ? BH : apla_num_cus();
+#define APLA_FWDP_CASE(NTV)                                                                                                          \
+    case NTV: {                                                                                                                      \
+      auto kern = attn_fwd_persist_kernel<NTV>;                                                                                      \
+      static std::atomic<unsigned long long> lds_ok{0};                                                                              \
+      apla_allow_lds(lds_ok, (const void*)kern, (int)lds);                                                                           \
+      hipLaunchKernelGGL(kern, dim3(G), dim3(64 * (NTV + 1)), lds, stream, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, BH, NR, xp); \
+    } break;
+    switch (nt) {
+      APLA_FWDP_CASE(3) APLA_FWDP_CASE(4) APLA_FWDP_CASE(5) APLA_FWDP_CASE(6) APLA_FWDP_CASE(7)
+      default: apla_set_error("%s: bad block count %d", who, nt); return APLA_EINVAL;
+    }
+#undef APLA_FWDP_CASE
+    APLA_CHECK_LAUNCH(who);
+    return APLA_OK;
+  }
+  if (kchoice == ATTN_FWD_SMALL) {
     const int nw = (N + 31) / 32;
     static std::atomic<unsigned long long> lds_ok{0};   // 72 KB of dynamic LDS at nine blocks
     apla_allow_lds(lds_ok, (const void*)attn_fwd_small_kernel, SMALL_MAX_ROWS * 256);
-    hipLaunchKernelGGL(attn_fwd_small_kernel, dim3(H, B), dim3(64 * nw), (size_t)nw * 32 * 256, stream, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, cu, total);
+    hipLaunchKernelGGL(attn_fwd_small_kernel, dim3(H, B), dim3(64 * nw), (size_t)nw * 32 * 256, stream, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, cu, total, xp);
   } else {
     hipLaunchKernelGGL(attn_fwd_kernel, dim3((N + 127) / 128, H, B), dim3(256), 0, stream, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, cu, total);
   }
@@ -1507,11 +1799,10 @@ static int launch_attn_fwd(const void* qkv, void* o, float* lse, const int32_t* 
 static int launch_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv,
                            const int32_t* cu, int total, int B, int N, int H, float scale, int g_attn_variant,
                            hipStream_t stream, const char* who) {
+  g_attn_variant &= 0xff;
   APLA_REQUIRE(g_attn_variant >= 0 && g_attn_variant <= 3, "%s: unknown kernel variant %d", who, g_attn_variant);
-  // uniform batch of short sequences with at least one head per CU: the persistent kernel (every load one phase ahead of its use);
-  // variant 2 pins the one-workgroup-per-head kernel below, variant 3 the persistent one wherever it applies (tests, A/B timing)
-  if (cu == nullptr && N <= PERSIST_MAX_ROWS && g_attn_variant != 1 && g_attn_variant != 2 &&
-      (g_attn_variant == 3 || ((long)B * H >= apla_num_cus() && N > TINY_MAX_ROWS))) {
+  const AttnKernel kchoice = attn_bwd_choice(cu != nullptr, B, N, H, g_attn_variant);
+  if (kchoice == ATTN_BWD_PERSIST) {
     const int NP = (N + 31) / 32 * 32, BH = B * H;
     const int nt = NP / 32;
     const bool staged = nt <= 7;       // 4 tiles + 2 KB + 8 x 4 KB of store buffers: 162 KB at eight blocks, one CU has 160
@@ -1533,14 +1824,14 @@ static int launch_attn_bwd(const void* qkv, const void* o, const void* d_o, cons
     APLA_CHECK_LAUNCH(who);
     return APLA_OK;
   }
-  if (N <= TINY_MAX_ROWS && g_attn_variant != 1) {       // the same kernel at 64 rows and two waves (see the kernel)
+  if (kchoice == ATTN_BWD_TINY) {       // the same kernel at 64 rows and two waves (see the kernel)
     const int NP = (N + 31) / 32 * 32;
     const size_t lds = (size_t)TINY_MAX_ROWS * (2 * 128 + 8);
     hipLaunchKernelGGL((attn_bwd_small_kernel<TINY_MAX_ROWS, 2>), dim3(H, B), dim3(128), lds, stream, (const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse, delta, (bf16*)dqkv, N, H, scale, cu, total, NP);
     APLA_CHECK_LAUNCH(who);
     return APLA_OK;
   }
-  if (N <= SMALL_MAX_ROWS_BWD && g_attn_variant != 1) {  // one workgroup per head, operands read from HBM once (see the kernel)
+  if (kchoice == ATTN_BWD_SMALL) {  // one workgroup per head, operands read from HBM once (see the kernel)
     const int NP = (N + 31) / 32 * 32;
     const size_t lds = (size_t)SMALL_MAX_ROWS_BWD * (2 * 128 + 8);   // two tiles at a fixed distance + lse*log2e + delta
     static std::atomic<unsigned long long> lds_ok{0};   // > 64 KB of dynamic LDS
@@ -1555,6 +1846,15 @@ static int launch_attn_bwd(const void* qkv, const void* o, const void* d_o, cons
   APLA_CHECK_LAUNCH(who);
   hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, stream, (const bf16*)qkv, (const bf16*)d_o, lse, delta, (bf16*)dqkv, N, H, scale, cu, total);
   APLA_CHECK_LAUNCH(who);
+  return APLA_OK;
+}
+
+extern "C" int apla_attn_kernel_name(int backward, int packed, int B, int N, int H, int variant, char* buf, int buflen) {
+  APLA_REQUIRE(buf && buflen > 0 && B > 0 && N > 0 && H > 0, "apla_attn_kernel_name: bad arguments");
+  variant &= 0xff;
+  APLA_REQUIRE(variant >= 0 && variant <= 3, "apla_attn_kernel_name: unknown kernel variant %d", variant);
+  const AttnKernel k = backward ? attn_bwd_choice(packed != 0, B, N, H, variant) : attn_fwd_choice(packed != 0, B, N, H, variant);
+  snprintf(buf, (size_t)buflen, "%s", ATTN_KERNEL_NAMES[k]);
   return APLA_OK;
 }
 

@@ -424,6 +424,14 @@ def gather_cols(src: torch.Tensor, inds: torch.Tensor, r: int) -> torch.Tensor:
     return out
 
 
+def attn_kernel_name(which: str, B: int, N: int, H: int, *, packed: bool = False) -> str:
+    """Name of the kernel apla_attn_fwd / apla_attn_bwd (which = "fwd" | "bwd") dispatch this problem to under the current variant."""
+    import ctypes
+    buf = ctypes.create_string_buffer(96)
+    check(lib().apla_attn_kernel_name(1 if which == "bwd" else 0, 1 if packed else 0, B, N, H, _ATTN_VARIANT & 0xff, buf, 96), "apla_attn_kernel_name")
+    return buf.value.decode()
+
+
 def attn_fwd(qkv: torch.Tensor, B: int, N: int, H: int, scale: float, *, o: Optional[torch.Tensor] = None,
              lse: Optional[torch.Tensor] = None):
     """qkv: [B*N, 3*H*64] bf16 contiguous.  Returns (o [B*N, H*64] bf16, lse [B,H,N] fp32)."""

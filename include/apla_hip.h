@@ -185,13 +185,18 @@ int apla_attn_varlen_bwd(const void* qkv, const void* o, const void* d_o, const 
                          const int32_t* cu_seqlens, int S, int total, int max_n, int H, float scale, hipStream_t stream);
 
 /* The attention entry points with an explicit kernel choice (`variant`; the plain entry points pass 0):
- *   0 = auto: uniform batches of up to 288 tokens use the one-workgroup-per-head forward (whole K / V of a head in LDS) and,
- *       up to 256 tokens with at least one head per CU, the persistent backward (one 8-wave workgroup per CU walking its heads,
- *       every load one phase ahead of its use); packed batches and 257..288 tokens the one-workgroup-per-head backward;
- *       longer sequences the key-/query-blocked kernels;
- *   1 = always the blocked kernels; 2 = the one-workgroup-per-head kernels (never the persistent one); 3 = the persistent
- *       backward wherever it applies.  All compute bitwise the same results (tests/test_kernels_gpu.py). */
+ *   0 = auto: uniform batches of 65..224 tokens with at least one head per CU use the persistent forward (one workgroup per CU
+ *       walking its heads, K / V double-buffered by a loader wave, one row maximum per head) and, up to 256 tokens, the persistent
+ *       backward (every load one phase ahead of its use); other batches of up to 288 tokens the one-workgroup-per-head kernels
+ *       (whole K / V of a head in LDS); longer sequences the key-/query-blocked kernels;
+ *   1 = always the blocked kernels; 2 = the one-workgroup-per-head kernels (never the persistent ones); 3 = the persistent
+ *       kernels wherever they apply.  The backward kernels compute bitwise the same results, and so do the blocked and the
+ *       one-workgroup-per-head forward; the persistent forward takes ONE maximum per row instead of a running one per 64 keys and
+ *       agrees with them to rounding (tests/test_kernels_gpu.py).  Bits 8.. of `variant`: schedule experiments (diagnostics). */
 int apla_attn_fwd_ex(const void* qkv, void* o, float* lse, int B, int N, int H, float scale, int variant, hipStream_t stream);
+/* Name of the kernel an attention launch is dispatched to (the same decision code as the launch itself): backward = 0 | 1,
+ * packed = 1 for the block-diagonal entry points (N = max_n there).  Diagnostics / bench records; no reference counterpart. */
+int apla_attn_kernel_name(int backward, int packed, int B, int N, int H, int variant, char* buf, int buflen);
 int apla_attn_bwd_ex(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv, int B, int N,
                      int H, float scale, int variant, hipStream_t stream);
 int apla_attn_varlen_fwd_ex(const void* qkv, void* o, float* lse, const int32_t* cu_seqlens, int S, int total, int max_n,

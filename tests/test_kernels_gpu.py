@@ -332,6 +332,38 @@ def test_attention_packed_as_runs_of_uniform_batches(ops, runs, H, half):
             AF.attention_core_varlen(dev(qkv).reshape(1, total, 3 * D), mask.cu_seqlens("cuda"), mask.max_seqlen, H, scale, runs=[(1, total - 1)])
 
 
+@pytest.mark.parametrize("B,N,H", [(24, 197, 12), (128, 197, 12), (70, 129, 4), (40, 224, 8), (300, 65, 1)])
+def test_attention_persistent_forward_walks_its_heads(ops, B, N, H):
+    """attn_fwd_persist_kernel with MORE heads than workgroups (one workgroup per CU walks its heads: double-buffered K / V fed by the
+    loader wave, q rows requested a head ahead, O stored one head late) — the small cases of test_attention_fwd_bwd give every
+    workgroup exactly one head.  Against the one-workgroup-per-head kernel (itself checked against the oracle there): one maximum per
+    row instead of four running ones, so equal to rounding — O within 4 ulp of the largest 16-bit output, lse within 2e-6 — and, on a sample
+    of heads spread over the walk, against the fp64 oracle."""
+    from apla_amd import ops as OPS
+    D, scale = 64 * H, 64 ** -0.5
+    qkv, _ = bf(rnd(B * N, 3 * D, seed=39))
+    q = dev(qkv)
+    old = OPS.set_attn_variant(2)
+    try:
+        o_ref, lse_ref = ops.attn_fwd(q, B, N, H, scale)
+        OPS.set_attn_variant(0)
+        assert ops.attn_kernel_name("fwd", B, N, H) == "attn_fwd_persist_kernel"
+        o, lse = ops.attn_fwd(q, B, N, H, scale)
+        o2, lse2 = ops.attn_fwd(q, B, N, H, scale)
+    finally:
+        OPS.set_attn_variant(old)
+    assert torch.equal(o, o2) and torch.equal(lse, lse2)                     # reproducible
+    assert float((lse - lse_ref).abs().max()) < 2e-6 * max(1.0, float(lse_ref.abs().max()))
+    d, top = (o.float() - o_ref.float()).abs(), float(o_ref.float().abs().max())
+    # an output is a sum of ~N rounded products: the two kernels round P against different maxima, so single outputs differ by a few
+    # units in the last place of the LARGEST outputs (not of their own magnitude: small outputs are sums with cancellation)
+    assert float(d.max()) < 4 * 2 ** -9 * top and float(d.mean()) < 2 ** -12 * top and float((d > 0).float().mean()) < 0.4
+    for b in sorted({0, B // 3, B - 1}):                                       # first, middle and last sequences of the walk
+        oref, lref = O.attention_fwd(qkv[b * N:(b + 1) * N].double().reshape(1, N, 3 * D), H, scale)
+        assert rel_err(o[b * N:(b + 1) * N].cpu().reshape(1, N, D), oref) < BF16_OUT
+        assert float((lse[b].cpu().double() - lref[0]).abs().max()) < 2e-4
+
+
 @pytest.mark.parametrize("attn_variant", [0, 1], indirect=True)
 def test_attention_online_softmax_rescale_branch(ops, attn_variant):
     """Force the running max to jump at a later key block (guide rule 26): one key spikes against every query."""
