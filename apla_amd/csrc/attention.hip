@@ -354,13 +354,12 @@ constexpr int SMALL_MAX_ROWS_BWD = 288;  // the fused backward also takes the 25
 
 __global__ __launch_bounds__(576, 4) void attn_fwd_small_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
                                                                 float* __restrict__ lse, int Nmax, int H, float scale,
-    const int32_t* __restrict__ cu, int total, int xp) {
+    const int32_t* __restrict__ cu, int total) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // K rows [NP][64] then V rows [NP][64], NP = 32 * waves
   const int tid = threadIdx.x, lane = tid & 63, h2 = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nw = blockDim.x >> 6, NP = nw * 32;
-  int b = blockIdx.y, h = blockIdx.x;
-  if (xp & 128) { const int i = (b * H + h) & 255; b = i / H; h = i - b * H; }
+  const int b = blockIdx.y, h = blockIdx.x;
   const Seq sq = seq_of(cu, b, Nmax, H, total);
   const int N = sq.n;
   if (N <= 0) return;
@@ -460,7 +459,7 @@ __global__ __launch_bounds__(576, 4) void attn_fwd_small_kernel(const bf16* __re
       }
     }
   };
-  const int nfull = (xp & 64) ? 0 : N >> 6;   // blocks without a key >= N
+  const int nfull = N >> 6;   // blocks without a key >= N
 #pragma unroll 1
   for (int kb = 0; kb < nfull; ++kb) block(kb, std::false_type{});
   if (N & 63) block(nfull, std::true_type{});
@@ -514,13 +513,10 @@ constexpr int FWDP_MAX_NT = 7;
 template <int NT>
 __global__ __launch_bounds__(64 * (NT + 1), 2) void attn_fwd_persist_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
                                                                           float* __restrict__ lse, int N, int H, float scale,
-                                                                          int BH, int NR, int xp) {
+                                                                          int BH, int NR) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, h2 = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  if ((xp & 1) && wave >= 4 && wave < NT) __builtin_amdgcn_s_setprio(1);
-  if ((xp & 2) && wave < 4) __builtin_amdgcn_s_setprio(1);
-  if ((xp & 4) && wave == NT) __builtin_amdgcn_s_setprio(2);
   const int D = H * 64;
   const long ld = 3L * D;
   const float c = scale * LOG2E;
@@ -1347,6 +1343,35 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_persist_kernel(const bf16* __
 #pragma unroll 1
     for (int it = 0; it < nt; ++it) stage_piece(it, srcA, ldA, srcB, ldB, TA, TB);
   };
+  // Up to seven blocks wave 7 owns no block: it is the LOADER and issues every LDS-DMA piece of the kernel, the compute waves none.
+  // (Round 5, stamps of the persistent forward's loader: computed per piece, the swizzle and the 64-bit row products cost ~240 cycles
+  // per piece — here 14 pieces per compute wave and head inside the product loops.)  A piece's address is a wave-uniform piece base
+  // plus a 32-bit lane offset that takes two values (even / odd pieces): scalar adds only between two DMA instructions.  Pieces
+  // that hold rows >= N (they re-read row N - 1) take the long way: at most four per tile.
+  constexpr bool LOADER = NT <= 7;
+  auto stage_tile_fast = [&](const bf16* src, long lds_, char* dst) {
+    const int lr = lane >> 3;
+    const int f_even = (((lr >> 1) & 1) << 2) | (lr >> 2);
+    const unsigned loff_even = (unsigned)(lr * (int)lds_ * 2 + (((lane & 7) ^ f_even) << 4));
+    const unsigned loff_odd = (unsigned)(lr * (int)lds_ * 2 + (((lane & 7) ^ f_even ^ 2) << 4));
+    const int nfull = N >> 3;
+    const char* pb = (const char*)src;
+    const long step = 8L * lds_ * 2;
+    int pr = 0;
+#pragma unroll 1
+    for (; pr + 1 < nfull; pr += 2) {
+      __builtin_amdgcn_global_load_lds(ATT_GLBP(pb + loff_even), ATT_LDSP(dst + pr * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(ATT_GLBP(pb + step + loff_odd), ATT_LDSP(dst + pr * 1024 + 1024), 16, 0, 0);
+      pb += 2 * step;
+    }
+#pragma unroll 1
+    for (; pr < 4 * nt; ++pr) {
+      const int row = pr * 8 + lr;
+      const int f = (((row >> 1) & 1) << 2) | ((row >> 2) & 3);
+      const int gr = row < N ? row : N - 1;
+      __builtin_amdgcn_global_load_lds(ATT_GLBP(src + (long)gr * lds_ + (((lane & 7) ^ f) << 3)), ATT_LDSP(dst + pr * 1024), 16, 0, 0);
+    }
+  };
   struct Head { const bf16* base; const bf16* dobase; const bf16* obase; const float* lsebase; float* dlbase; bf16* outbase; };
   auto head_of = [&](int idx) {
     const int b = idx / H, h = idx - b * H;
@@ -1367,9 +1392,29 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_persist_kernel(const bf16* __
   int idx = blockIdx.x;
   if (idx >= BH) return;
   Head hd = head_of(idx);
+  if constexpr (LOADER) {
+    if (wave == 7) {   // ---------------------------------------------------------------------------- loader wave
+      stage_tile_fast(hd.base + D, ld, KA);
+      stage_tile_fast(hd.base + 2 * D, ld, VA);
+      while (true) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // X: set A landed; every wave is done with set B
+        stage_tile_fast(hd.base, ld, QB);
+        stage_tile_fast(hd.dobase, D, DB);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // Y: set B landed; every wave is done with set A
+        idx += gridDim.x;
+        if (idx >= BH) break;
+        hd = head_of(idx);
+        stage_tile_fast(hd.base + D, ld, KA);
+        stage_tile_fast(hd.base + 2 * D, ld, VA);
+      }
+      return;
+    }
+  }
   RowRegs rr;
   if (active) { prefetch_rows(rr, hd); rows_landed<0>(rr); }   // first head only: the rows are waited for on the spot
-  stage(hd.base + D, ld, hd.base + 2 * D, ld, KA, VA);
+  if constexpr (!LOADER) stage(hd.base + D, ld, hd.base + 2 * D, ld, KA, VA);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   STAMP(0);   // first head: rows + set A
   while (true) {
@@ -1377,7 +1422,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_persist_kernel(const bf16* __
     __builtin_amdgcn_s_barrier();   // every wave is done with set B, lse and delta of the previous head
     asm volatile("" ::: "memory");
     STAMP(1);   // barrier X
-    if (!active) stage(hd.base, ld, hd.dobase, D, QB, DB);   // a wave without a block issues its share of set B in one go
+    if constexpr (!LOADER) { if (!active) stage(hd.base, ld, hd.dobase, D, QB, DB); }   // a wave without a block issues its share of set B in one go
     if (active) {   // ---------------------------------------------- P1: delta and dQ of query block `wave`
       bf16x8 qf[4], dof[4];
       float dl = 0.f;
@@ -1399,7 +1444,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_persist_kernel(const bf16* __
       STAMP(2);   // P1 start: delta
 #pragma unroll 1
       for (int t = 0; t < nt; ++t) {
-        stage_piece(t, hd.base, ld, hd.dobase, D, QB, DB);   // set B, one piece per iteration
+        if constexpr (!LOADER) stage_piece(t, hd.base, ld, hd.dobase, D, QB, DB);   // set B, one piece per iteration
         const unsigned tb = ka0 + t * 4096;
         unsigned ar[4], at[4];
 #pragma unroll
@@ -1451,8 +1496,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_persist_kernel(const bf16* __
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(kf[ks]), "+v"(vf[ks]));
-      // the DMA of set B is older than the dQ stores
-      if constexpr (STAGED) wait_vmcnt_upto4(tile_stores); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      // the DMA of set B is older than the dQ stores (with a loader wave this wave has no DMA to wait for)
+      if constexpr (!LOADER) { if constexpr (STAGED) wait_vmcnt_upto4(tile_stores); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -1465,7 +1510,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_persist_kernel(const bf16* __
     Head hn = hd;
     if (has_next) {
       hn = head_of(next);
-      if (!active) stage(hn.base + D, ld, hn.base + 2 * D, ld, KA, VA);
+      if constexpr (!LOADER) { if (!active) stage(hn.base + D, ld, hn.base + 2 * D, ld, KA, VA); }
     }
     if (active) {   // ---------------------------------------------- P2: dK and dV of key block `wave`
       f32x16 acc_dk[2], acc_dv[2];
@@ -1474,7 +1519,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_persist_kernel(const bf16* __
       STAMP(7);   // P2 start
 #pragma unroll 1
       for (int t = 0; t < nt; ++t) {
-        if (has_next) stage_piece(t, hn.base + D, ld, hn.base + 2 * D, ld, KA, VA);   // set A of the next head, one piece per iteration
+        if constexpr (!LOADER) { if (has_next) stage_piece(t, hn.base + D, ld, hn.base + 2 * D, ld, KA, VA); }   // set A of the next head, one piece per iteration
         const unsigned tb = ka0 + 2 * T_OFF + t * 4096;   // Q tile, row 32t; the dO tile is T_OFF further
         unsigned ar[4], at[4];
 #pragma unroll
@@ -1761,7 +1806,6 @@ static AttnKernel attn_bwd_choice(bool packed, int B, int N, int H, int variant)
 
 static int launch_attn_fwd(const void* qkv, void* o, float* lse, const int32_t* cu, int total, int B, int N, int H,
                            float scale, int g_attn_variant, hipStream_t stream, const char* who) {
-  const int xp = g_attn_variant >> 8;
   g_attn_variant &= 0xff;
   APLA_REQUIRE(g_attn_variant >= 0 && g_attn_variant <= 3, "%s: unknown kernel variant %d", who, g_attn_variant);
   const AttnKernel kchoice = attn_fwd_choice(cu != nullptr, B, N, H, g_attn_variant);
@@ -1774,7 +1818,7 @@ static int launch_attn_fwd(const void* qkv, void* o, float* lse, const int32_t* 
       auto kern = attn_fwd_persist_kernel<NTV>;                                                                                      \
       static std::atomic<unsigned long long> lds_ok{0};                                                                              \
       apla_allow_lds(lds_ok, (const void*)kern, (int)lds);                                                                           \
-      hipLaunchKernelGGL(kern, dim3(G), dim3(64 * (NTV + 1)), lds, stream, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, BH, NR, xp); \
+      hipLaunchKernelGGL(kern, dim3(G), dim3(64 * (NTV + 1)), lds, stream, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, BH, NR);     \
     } break;
     switch (nt) {
       APLA_FWDP_CASE(3) APLA_FWDP_CASE(4) APLA_FWDP_CASE(5) APLA_FWDP_CASE(6) APLA_FWDP_CASE(7)
@@ -1788,7 +1832,7 @@ static int launch_attn_fwd(const void* qkv, void* o, float* lse, const int32_t* 
     const int nw = (N + 31) / 32;
     static std::atomic<unsigned long long> lds_ok{0};   // 72 KB of dynamic LDS at nine blocks
     apla_allow_lds(lds_ok, (const void*)attn_fwd_small_kernel, SMALL_MAX_ROWS * 256);
-    hipLaunchKernelGGL(attn_fwd_small_kernel, dim3(H, B), dim3(64 * nw), (size_t)nw * 32 * 256, stream, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, cu, total, xp);
+    hipLaunchKernelGGL(attn_fwd_small_kernel, dim3(H, B), dim3(64 * nw), (size_t)nw * 32 * 256, stream, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, cu, total);
   } else {
     hipLaunchKernelGGL(attn_fwd_kernel, dim3((N + 127) / 128, H, B), dim3(256), 0, stream, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, cu, total);
   }
@@ -1799,7 +1843,8 @@ static int launch_attn_fwd(const void* qkv, void* o, float* lse, const int32_t* 
 static int launch_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv,
                            const int32_t* cu, int total, int B, int N, int H, float scale, int g_attn_variant,
                            hipStream_t stream, const char* who) {
-  g_attn_variant &= 0xff;
+  g_attn_variant &= 0xff;   // (bits 8.. carried schedule experiments in round 5: static / alternating wave priorities and a half-tile
+                            // stagger of waves 4-7 changed nothing, profiles/r05_attn_experiments.md)
   APLA_REQUIRE(g_attn_variant >= 0 && g_attn_variant <= 3, "%s: unknown kernel variant %d", who, g_attn_variant);
   const AttnKernel kchoice = attn_bwd_choice(cu != nullptr, B, N, H, g_attn_variant);
   if (kchoice == ATTN_BWD_PERSIST) {
