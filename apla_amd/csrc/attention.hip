@@ -216,6 +216,15 @@ __device__ __forceinline__ void store_acc_T_staged(const f32x16 (&acc)[2], char*
   }
 }
 
+// s_waitcnt vmcnt(n) for a wave-uniform run-time even n in 0..8 (odd n wait like n - 1)
+__device__ __forceinline__ void wait_vmcnt_upto8(int n) {
+  n = __builtin_amdgcn_readfirstlane(n);
+  if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (n >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if (n >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if (n >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
 // s_waitcnt vmcnt(n) for a wave-uniform run-time n in 0..4 (the counter is an instruction immediate)
 __device__ __forceinline__ void wait_vmcnt_upto4(int n) {
   n = __builtin_amdgcn_readfirstlane(n);
@@ -1581,18 +1590,19 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_persist_kernel(const bf16* __
         }
       }
       STAMP(8);   // P2 loop
-      // rows of the next head: older than the stores below in the vmcnt queue.  Unconditional (the last head re-reads its own
-      // rows, never used): a conditional definition would keep the previous head's 49 registers alive through P2
-      // (the row loads sit between the dK and the dV stores: once dK has left, its 32 accumulator registers are free for them)
-      if constexpr (STAGED) store_acc_T_staged(acc_dk, wbuf, hd.outbase + D, ld, wave * 32, N, lane, scale);
-      else if (rvalid) store_acc_T(acc_dk, hd.outbase + (long)r * ld + D, h2, scale);
+      // rows of the next head: requested BEFORE the dK / dV stores (since the loader wave took the DMA out of this loop its registers
+      // have room for them), i.e. older than both tiles' stores in the vmcnt queue, and waited for behind them.  Unconditional (the
+      // last head re-reads its own rows, never used): a conditional definition would keep the previous head's 49 registers alive
+      // through P2.
       asm volatile("" ::: "memory");
       prefetch_rows(rr, hn);
+      if constexpr (STAGED) store_acc_T_staged(acc_dk, wbuf, hd.outbase + D, ld, wave * 32, N, lane, scale);
+      else if (rvalid) store_acc_T(acc_dk, hd.outbase + (long)r * ld + D, h2, scale);
       if constexpr (STAGED) store_acc_T_staged(acc_dv, wbuf, hd.outbase + 2 * D, ld, wave * 32, N, lane, 1.0f);
       else if (rvalid) store_acc_T(acc_dv, hd.outbase + (long)r * ld + 2 * D, h2, 1.0f);
       STAMP(9);   // row prefetch + dK / dV stores issued
-      // set A of the next head (older still) and the rows: landed; the dV stores stay in flight
-      if constexpr (STAGED) { wait_vmcnt_upto4(tile_stores); rows_pin(rr); } else rows_landed<8>(rr);
+      // the rows (and, without a loader wave, set A of the next head: older still) have landed; the dK / dV stores stay in flight
+      if constexpr (STAGED) { wait_vmcnt_upto8(2 * tile_stores); rows_pin(rr); } else rows_landed<16>(rr);
       STAMP(10);  // wait for rows / set A
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
