@@ -186,3 +186,19 @@ def load_session(engine, session: dict, load_optimizer: bool = True):
         engine._scaler_calls = 0
         engine._scaler_step0 = steps   # skipped_steps counts from here (engine.skipped_steps)
     return session.get("iters", 0), session.get("epoch", 0)
+
+
+def load_trainer_session(trainer, session: dict, load_optimizer: bool = True):
+    """Resume a ``ModulePathTrainer`` or a ``Dinov2Trainer`` from the session dictionary ``main.py`` writes for them (the reference's
+    layout, bases.py:456-467): model ``state_dict``, ``FlatAdamW`` state, and — written under fp16 — the loss scaler's
+    ``GradScaler.state_dict()`` (bases.py:430-433 restores it the same way), so that an fp16 run resumes at the scale and growth count
+    it stopped with instead of 65 536 / 0.  ``iters`` / ``epoch`` go back into a trainer that counts them."""
+    trainer.model.load_state_dict(session["state_dict"])
+    if load_optimizer and session.get("optimizer") is not None:
+        trainer.optimizer.load_state_dict(session["optimizer"])
+    if session.get("scaler") is not None and getattr(trainer, "scaler", None) is not None:
+        trainer.scaler.load_state_dict(session["scaler"])
+    for k in ("iters", "epoch"):
+        if hasattr(trainer, k) and k in session:
+            setattr(trainer, k, int(session[k]))
+    return trainer

@@ -504,7 +504,7 @@ class AplaProjState:
         D = W1.shape[1]
         r = W1.shape[0]
         key = (W2.data_ptr(), W2._version, b2._version, inds._version, str(W1.device), r, D,
-               None if gamma is None else (gamma.data_ptr(), gamma._version))
+               None if gamma is None else (gamma.data_ptr(), gamma._version), _h())   # (_h(): the 16-bit images are of ONE operand type)
         if key != self.key:
             idx = inds.to(W1.device).long()
             Wn = torch.zeros(D, D, device=W1.device, dtype=torch.float32)

@@ -25,6 +25,7 @@ class ModulePathTrainer:
         if compute_dtype not in (torch.bfloat16, torch.float16):
             raise TypeError("compute_dtype must be torch.bfloat16 or torch.float16")
         self.model = model.cuda().train()
+        self.device = next(self.model.parameters()).device      # (apla_amd.evaluate.Evaluator reads it, as from the fused engine)
         self.compute_dtype = compute_dtype
         dyn = loss_scale == "dynamic"
         self.scaler = DynamicLossScale(enabled=dyn) if dyn else DynamicLossScale(init_scale=float(loss_scale), growth_interval=1 << 62)

@@ -75,31 +75,42 @@ class Dinov2Trainer:
         chunks.append((lo, opt.offsets[-1]))
         self.exchanger = GradExchanger(opt.grads, chunks, self.pg, always=force)
         self._chunk_size = [owner.count(k) for k in range(len(chunks))]
-        self._chunk_seen, self._chunk_sent = [0] * len(chunks), [False] * len(chunks)
+        self._reset_exchange()
         if not self.exchanger.active:
             return
 
+        # Every rank must issue the SAME sequence of collectives on the communicator, whatever order its autograd engine completes the
+        # gradients in (and whichever tensors receive none on that rank): chunks are launched strictly in descending index order —
+        # the order backward fills the flat buffer in, heads first.  A chunk that completes early waits for its successors' launch;
+        # what is still open after backward goes in the same order from _finish_exchange.
         def make_hook(k):
             def hook(_param):
                 self._chunk_seen[k] += 1
-                if self._chunk_seen[k] == self._chunk_size[k] and not self._chunk_sent[k]:
-                    self._chunk_sent[k] = True
-                    self.exchanger.launch_chunk(k)
+                self._launch_ready()
             return hook
         for p, k in zip(opt.params, owner):
             p.register_post_accumulate_grad_hook(make_hook(k))
 
+    def _reset_exchange(self):
+        n = len(self.exchanger.chunks)
+        self._chunk_seen, self._chunk_next = [0] * n, n - 1     # _chunk_next: the one chunk that may be launched now
+
+    def _launch_ready(self):
+        while self._chunk_next >= 0 and self._chunk_seen[self._chunk_next] >= self._chunk_size[self._chunk_next]:
+            self.exchanger.launch_chunk(self._chunk_next)
+            self._chunk_next -= 1
+
     def _finish_exchange(self):
-        """After backward: chunks whose tensors did not all receive a gradient this iteration (none in the shipped configuration) go
-        now; then the compute stream waits for the side stream."""
+        """After backward: the chunks not launched yet (tensors that received no gradient this iteration keep theirs open), in the
+        same descending order; then the compute stream waits for the side stream."""
         ex = self.exchanger
         if not ex.active:
             return
-        for k, sent in enumerate(self._chunk_sent):
-            if not sent:
-                ex.launch_chunk(k)
+        while self._chunk_next >= 0:
+            ex.launch_chunk(self._chunk_next)
+            self._chunk_next -= 1
         ex.wait()
-        self._chunk_seen, self._chunk_sent = [0] * len(ex.chunks), [False] * len(ex.chunks)
+        self._reset_exchange()
 
     # the scaler's state under the names the trainer has always exposed
     loss_scale = property(lambda self: self.scaler.scale)
@@ -114,6 +125,7 @@ class Dinov2Trainer:
         opt = self.optimizer
         opt.lr, opt.weight_decay = lr, wd     # apply_optim_scheduler: one lr for both groups, wd on the regularised group
         opt.zero_grad()
+        self._reset_exchange()      # (a backward that raised leaves its counts behind)
         fp16 = self.compute_dtype == torch.float16
         with ops.use_half(self.compute_dtype), grad_prescale(self.loss_scale):
             loss, loss_dict = self.model(images=batch["images"], teacher_temp=teacher_temp)

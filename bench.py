@@ -129,7 +129,7 @@ def usable_cpus():
     return max(1, n)
 
 
-def cpu_baseline_child(backbone, r, n_classes, img, patch, sample_bs, threads, steps):
+def cpu_baseline_child(backbone, r, n_classes, img, patch, sample_bs, threads, steps, dump=None):
     """One leg of the CPU baseline, in a process of its own (thread count and binding fixed by its environment, no GPU touched):
     the fp32 oracle's full training step (a port of the reference step, pinned by the goldens) on a fixed synthetic batch — one
     warm-up step, then `steps` timed steps; prints their durations."""
@@ -143,7 +143,10 @@ def cpu_baseline_child(backbone, r, n_classes, img, patch, sample_bs, threads, s
     images = torch.randn(sample_bs, 3, img, img, generator=g)
     labels = torch.randint(0, n_classes, (sample_bs,), generator=g)
     state = {}
-    O.train_step(images, labels, p, cfg, state)  # warm-up
+    logits0, loss0, _, _ = O.train_step(images, labels, p, cfg, state)  # warm-up; its forward ran on the initial parameters
+    if dump:   # the checker's logits for the live parity record of this model shape (parity_on_baseline_sample)
+        import numpy as np
+        np.savez(dump, logits=logits0.detach().numpy(), loss=float(loss0), bs=sample_bs)
     ts = []
     for _ in range(steps):
         t0 = time.perf_counter()
@@ -152,7 +155,7 @@ def cpu_baseline_child(backbone, r, n_classes, img, patch, sample_bs, threads, s
     print(json.dumps({"threads": threads, "torch_threads": torch.get_num_threads(), "step_s": ts}), flush=True)
 
 
-def cpu_baseline(backbone, r, n_classes, img, patch, sample_bs, steps=5):
+def cpu_baseline(backbone, r, n_classes, img, patch, sample_bs, steps=5, dump=None):
     """The CPU oracle timed on this box's host cores: the same model at batch `sample_bs` (16 by default: config 2's
     shapes at B = 16), MEDIAN of `steps` (>= 5) full steps after one warm-up, once with 8 threads and once with every CPU this
     process may use (affinity mask and cgroup quota, not os.cpu_count()).  Each leg is a child process started before this one
@@ -166,6 +169,8 @@ def cpu_baseline(backbone, r, n_classes, img, patch, sample_bs, steps=5):
                    HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
         cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", str(n), "--backbone", backbone, "--partial-size", str(r),
                "--classes", str(n_classes), "--img", str(img), "--patch", str(patch), "--cpu-sample-bs", str(sample_bs), "--cpu-steps", str(steps)]
+        if dump and n == legs[-1]:
+            cmd += ["--cpu-dump", dump]
         try:
             out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
             rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
@@ -246,6 +251,42 @@ def parity_cfg1(hdt, loss_scale):
            "reference": "tests/golden/g5_cfg1_vits.npz (reference code on CPU, fp32)"}
     del eng
     torch.cuda.empty_cache()
+    return out
+
+
+def parity_on_baseline_sample(dump, backbone, r, n_classes, img, patch):
+    """Live parity record for the BENCHMARKED model shape (config 2: ViT-B/16, r = 192, C = 1000), both operand dtypes: the forward of
+    the fused engine on the batch the CPU-baseline leg just ran (same seed-built weights, same seed-0 images) against the logits and
+    loss the fp32 oracle produced there — the oracle as the checker; nothing here is timed.  The full batch of 128 against the oracle:
+    tests/test_engine_gpu.py::test_full_size_cfg2_forward_against_the_fp32_oracle_on_the_host (the oracle's forward takes 19 s there)."""
+    import numpy as np
+    from apla_amd.engine import AplaTrainEngine, OptimConfig
+    try:
+        g = np.load(dump)
+    except (OSError, ValueError):
+        return None
+    bs = int(g["bs"])
+    ref = torch.from_numpy(g["logits"]).double()
+    gen = torch.Generator().manual_seed(0)
+    images = torch.randn(bs, 3, img, img, generator=gen)
+    labels = torch.randint(0, n_classes, (bs,), generator=gen)
+    out = {"reference": f"oracle/apla_oracle.py (fp32, host) on the CPU-baseline sample: {backbone}/{patch}, r={r}, C={n_classes}, bs={bs}, seed-0 images",
+           "loss_reference": round(float(g["loss"]), 6)}
+    for name, hdt, ls in (("bf16", torch.bfloat16, 1.0), ("fp16", torch.float16, 1024.0)):
+        model = build_model(backbone, r, n_classes, img, patch, seed=0)
+        eng = AplaTrainEngine(model, bs, img, optim=OptimConfig(lr=1e-4, weight_decay=1e-5, grad_clipping=1.0), use_graphs=False,
+                              compute_dtype=hdt, loss_scale=ls)
+        lg, _, loss = eng.forward_only(images.cuda(), labels.cuda())
+        torch.cuda.synchronize()
+        d = lg.cpu().double() - ref
+        out[name] = {"logits_rel_max": float(f"{float(d.abs().max() / ref.abs().max()):.3e}"),
+                     "logits_rel_l2": float(f"{float(d.norm() / ref.norm()):.3e}"), "loss": round(float(loss), 6)}
+        del eng, model
+        torch.cuda.empty_cache()
+    try:
+        os.remove(dump)
+    except OSError:
+        pass
     return out
 
 
@@ -350,6 +391,7 @@ def main():
     ap.add_argument("--cpu-sample-bs", type=int, default=16, help="batch of the CPU-baseline sample (SURVEY §8d: config 2's shapes at B = 16)")
     ap.add_argument("--cpu-steps", type=int, default=5, help="timed steps per CPU-baseline leg (median reported)")
     ap.add_argument("--cpu-baseline-child", type=int, default=0, help=argparse.SUPPRESS)   # one leg of cpu_baseline(): N threads, no GPU
+    ap.add_argument("--cpu-dump", default=None, help=argparse.SUPPRESS)                    # that leg also writes its first forward's logits here
     ap.add_argument("--exchange-channels", type=int, default=None, help="RCCL channels (= workgroups) the gradient all-reduce may use "
                     "(NCCL_MAX_NCHANNELS; default 8 = the CUs the GEMM launches leave free); recorded in ranks.env")
     ap.add_argument("--reserve-cus", type=int, default=None, help="CUs the persistent GEMM launches leave to the collective when "
@@ -359,7 +401,7 @@ def main():
 
     if args.cpu_baseline_child:
         return cpu_baseline_child(args.backbone, args.partial_size, args.classes, args.img, args.patch, args.cpu_sample_bs,
-                                  args.cpu_baseline_child, args.cpu_steps)
+                                  args.cpu_baseline_child, args.cpu_steps, args.cpu_dump)
     # A/B switches of the data-parallel path for the first real multi-GPU run: explicit flags win over the defaults of
     # rccl_channel_budget(), an operator's own environment wins over both defaults (setdefault there)
     if args.exchange_channels is not None:
@@ -380,7 +422,9 @@ def main():
     # a single-GPU run only) and the MFMA-peak probe (a child process, before this process creates its HIP context)
     cpu_rec = None
     if world == 1 and not args.no_cpu_baseline:
-        cpu_rec = cpu_baseline(args.backbone, args.partial_size, args.classes, args.img, args.patch, args.cpu_sample_bs, max(5, args.cpu_steps))
+        cpu_dump = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"apla_bench_cpu_logits_{os.getpid()}.npz")
+        cpu_rec = cpu_baseline(args.backbone, args.partial_size, args.classes, args.img, args.patch, args.cpu_sample_bs, max(5, args.cpu_steps),
+                               dump=cpu_dump)
     peak_rec = measured_mfma_peak() if (rank == 0 and not args.no_peak_probe) else None
 
     if not torch.cuda.is_available():
@@ -413,6 +457,8 @@ def main():
     parity = parity_cfg1(hdt, loss_scale) if (rank == 0 and not args.no_parity) else None
     # the fp16 build of the same kernels on the same config-1 check (the north-star's 1e-3 is an fp16-operand number)
     parity_f16 = parity_cfg1(torch.float16, 1024.0) if (parity is not None and args.dtype == "bf16") else None
+    parity_shape = (parity_on_baseline_sample(cpu_dump, args.backbone, args.partial_size, args.classes, img, patch)
+                    if (rank == 0 and cpu_rec is not None and not args.no_parity) else None)
     model = build_model(args.backbone, args.partial_size, args.classes, img, patch, seed=0)  # same seed => same indices on all ranks
     eng = AplaTrainEngine(model, args.batch, img, res_dtype=dt[args.res_dtype], grad_dtype=dt[args.grad_dtype],
                           optim=OptimConfig(lr=1e-4, weight_decay=1e-5, grad_clipping=1.0), process_group=pg,
@@ -580,6 +626,8 @@ def main():
             out["parity"] = parity
         if parity_f16 is not None:
             out["parity_fp16"] = parity_f16
+        if parity_shape is not None:
+            out["parity_benchmarked_model"] = parity_shape
         if fp16_rec is not None:
             out["fp16"] = fp16_rec
         if cpu_rec is not None:

@@ -316,7 +316,8 @@ def main_dinov2(params, args):
                             warmup_epochs=run["warmup_epochs"], grad_clipping=run["grad_clipping"], freeze_last_layer_epochs=run["freeze_last"],
                             momentum_teacher=t["momentum_teacher"], final_momentum_teacher=t["final_momentum_teacher"],
                             warmup_teacher_temp=t["warmup_teacher_temp"], teacher_temp=t["teacher_temp"],
-                            warmup_teacher_temp_epochs=t["warmup_teacher_temp_epochs"], process_group=dist.group.WORLD if world > 1 else None)
+                            warmup_teacher_temp_epochs=t["warmup_teacher_temp_epochs"], process_group=dist.group.WORLD if world > 1 else None,
+                            compute_dtype=torch.float16 if args.dtype == "fp16" else torch.bfloat16)
     c, ib = DINOV2_CROPS, p["model_params"]["dinov2"]["ibot"]
     side = c["img_size"] // run["patch"]
     mask_gen = MaskingGenerator(input_size=(side, side), max_num_patches=0.5 * c["img_size"] // run["patch"] * c["img_size"] // run["patch"])
@@ -325,7 +326,8 @@ def main_dinov2(params, args):
     if is_rank0():
         print(f"\033[93m[main] SYNTHETIC crops: {run['batch']} x (2 x {c['global_crops_size']} + 8 x {c['local_crops_size']}) per GPU\033[0m\n"
               f"[main] DINOv2-APLA {p['model_params']['backbone_type']}/{run['patch']}  {world} GPU(s) x bs {run['batch']}  "
-              f"{len(trainer.optimizer.names)} trainable tensors, {trainer.optimizer.flat.numel():,} parameters", flush=True)
+              f"{len(trainer.optimizer.names)} trainable tensors, {trainer.optimizer.flat.numel():,} parameters, operands {args.dtype}"
+              + (f", dynamic loss scale from {trainer.loss_scale:g}" if args.dtype == "fp16" else ""), flush=True)
     epochs = 1 if args.dry else run["epochs"]
     t0, seen, loss = time.perf_counter(), 0, None
     for epoch in range(epochs):
@@ -353,8 +355,11 @@ def main_dinov2(params, args):
     if is_rank0() and run["save_dir"] and not (args.dry or args.debug):
         os.makedirs(run["save_dir"], exist_ok=True)
         path = os.path.join(run["save_dir"], run["model_name"] + ".pth")
-        torch.save({"state_dict": model.state_dict(), "optimizer": trainer.optimizer.state_dict(), "iters": trainer.iters,
-                    "epoch": trainer.epoch, "parameters": params}, path)   # bases.py:456-467 session layout
+        sess = {"state_dict": model.state_dict(), "optimizer": trainer.optimizer.state_dict(), "iters": trainer.iters,
+                "epoch": trainer.epoch, "parameters": params}   # bases.py:456-467 session layout
+        if args.dtype == "fp16":
+            sess["scaler"] = trainer.scaler.state_dict()        # bases.py:465-466
+        torch.save(sess, path)
         print(f"[main] saved {path}")
     return float(loss)
 
@@ -437,13 +442,20 @@ def main(params, args):
         os.makedirs(run["save_dir"], exist_ok=True)
         path = os.path.join(run["save_dir"], run["model_name"] + ".pth")
         if module_path:   # the reference's session layout (bases.py:456-464) with FlatAdamW's torch.optim-shaped state
-            torch.save({"iters": iters, "state_dict": {k: v.detach().cpu().clone() for k, v in eng.model.state_dict().items()},
-                        "original_state": None, "optimizer": eng.optimizer.state_dict(), "epoch": epochs, "parameters": params,
-                        "best_val_target": 0.0}, path)
+            sess = {"iters": iters, "state_dict": {k: v.detach().cpu().clone() for k, v in eng.model.state_dict().items()},
+                    "original_state": None, "optimizer": eng.optimizer.state_dict(), "epoch": epochs, "parameters": params,
+                    "best_val_target": 0.0}
+            if hdt == torch.float16:
+                sess["scaler"] = eng.scaler.state_dict()     # bases.py:465-466: saved under mixed precision
+            torch.save(sess, path)
         else:
             torch.save(ckpt.session_dict(eng, iters=iters, epoch=epochs, parameters=params), path)
         print(f"[main] saved {path}")
-    if (args.test or args.knn or tp_knn) and is_rank0() and not soft_engine and not module_path:
+    if (args.test or args.knn or tp_knn) and is_rank0() and soft_engine:
+        print("\033[93m[main] --test / --knn: an engine built for probability targets has no class-id loss to evaluate with; skipped\033[0m", flush=True)
+    if (args.test or args.knn or tp_knn) and is_rank0() and not soft_engine:
+        # (on the module path too: ModulePathTrainer.forward_only runs the model in eval mode, where every dropout is the identity —
+        # the reference's Trainer.test / evaluate run whatever the dropout rates are)
         # Trainer.test / evaluate (defaults/trainer.py:162-345) on rank 0: loss + accuracy on the evaluation batches, optionally
         # kNN metrics against a feature bank of the training batches (the evaluation split of a TensorFile is its
         # `val_images` / `val_labels` entries when present, else the training tensors; synthetic data otherwise)

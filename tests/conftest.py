@@ -35,6 +35,15 @@ def rel_err(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
 
+def col_err(a, b):
+    """Per-column relative error: for every column (last axis) the largest |a - b| over the column divided by THAT column's own largest
+    |b|; the worst column is returned.  rel_err divides by the largest entry of the whole array and cannot see a wrong column whose
+    entries are small against the others."""
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    a, b = a.reshape(-1, a.shape[-1]), b.reshape(-1, b.shape[-1])
+    return float(((a - b).abs().amax(0) / (b.abs().amax(0) + 1e-30)).max())
+
+
 @pytest.fixture(scope="session")
 def has_gpu():
     return torch.cuda.is_available()

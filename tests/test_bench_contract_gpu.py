@@ -44,6 +44,11 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert p16["dtype"] == "fp16" and p16["tol_asserted"] == 1.2e-3 and p16["tol_asserted_on_the_mean"] == 1e-3 and p16["north_star_tol"] == 1e-3
     assert p16["logits_rel_mean_over_batches"] < p16["tol_asserted_on_the_mean"] and p16["logits_rel_max_over_batches"] < p16["tol_asserted"]
     assert abs(p16["loss"] - p16["loss_reference"]) < 1e-3
+    pm = d["parity_benchmarked_model"]   # the benchmarked model shape itself (ViT-B/16, r = 192, C = 1000) on the CPU-baseline sample, both dtypes
+    assert "vit_base/16" in pm["reference"] and "bs=2" in pm["reference"]
+    assert pm["bf16"]["logits_rel_max"] < 1.2e-2 and pm["bf16"]["logits_rel_l2"] < 1e-2 and abs(pm["bf16"]["loss"] - pm["loss_reference"]) < 5e-3
+    assert pm["fp16"]["logits_rel_max"] < 2.0e-3 and pm["fp16"]["logits_rel_l2"] < 1.5e-3 and abs(pm["fp16"]["loss"] - pm["loss_reference"]) < 1e-3
+    assert pm["fp16"]["logits_rel_max"] < pm["bf16"]["logits_rel_max"]
     assert f16["steps"] == 3 and f16["ms_per_step"] > 0 and abs(f16["images_per_sec"] - 128 / (f16["ms_per_step"] * 1e-3)) < 0.01 * f16["images_per_sec"]
     rk = d["ranks"]                              # a one-rank run has no exchange: nothing waited for
     assert rk["ms_per_step"] == [rk["ms_per_step_min"]] == [rk["ms_per_step_max"]] and rk["exchange_wait_ms"] == [None] and rk["exchange_chunks"] == 0

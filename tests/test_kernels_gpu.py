@@ -6,7 +6,7 @@ import math
 import pytest
 import torch
 
-from conftest import rel_err
+from conftest import col_err, rel_err
 from oracle import apla_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -45,9 +45,9 @@ def test_gemm_store_bias(ops, M, N, K):
     bias = rnd(N, seed=3)
     ref = ad @ wd.t() + bias.double()
     out = ops.gemm_nt(dev(a), dev(w), dev(bias))
-    assert rel_err(out.cpu(), ref) < BF16_OUT
+    assert rel_err(out.cpu(), ref) < BF16_OUT and col_err(out.cpu(), ref) < 1.5 * BF16_OUT
     out32 = ops.gemm_nt(dev(a), dev(w), dev(bias), out_dtype=torch.float32)
-    assert rel_err(out32.cpu(), ref) < F32_OUT
+    assert rel_err(out32.cpu(), ref) < F32_OUT and col_err(out32.cpu(), ref) < 4 * F32_OUT
     nob = ops.gemm_nt(dev(a), dev(w), None, out_dtype=torch.float32)
     assert rel_err(nob.cpu(), ad @ wd.t()) < F32_OUT
 
@@ -60,6 +60,28 @@ def test_gemm_strided_a_and_tail(ops):
     A = dev(big)[:, K:2 * K]
     out = ops.gemm_nt(A, dev(w), None, out_dtype=torch.float32)
     assert rel_err(out.cpu(), bigd[:, K:2 * K] @ wd.t()) < F32_OUT
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 256, 192), (25216, 768, 768), (4096, 3072, 768)])
+def test_gemm_output_columns_of_very_different_magnitude(ops, M, N, K):
+    """Every output column against ITS OWN scale (col_err): the weight rows span four decades, so a column that came out wrong but small
+    would pass the whole-array comparison of the tests above.  Plain store (both output types), GELU + GELU', the MUL epilogue, on
+    whichever schedule the shape dispatches to (25 216 x 768 x 768 = wide 4-wave kernel, 4 096 x 3 072 x 768 = persistent 4-wave kernel)."""
+    a, ad = bf(rnd(M, K, seed=11))
+    decades = 10.0 ** (-4.0 * torch.arange(N).double() / (N - 1))           # column j of the output is scaled by 10^(-4 j / (N-1))
+    w, wd = bf((rnd(N, K, scale=K ** -0.5, seed=12).double() * decades[torch.randperm(N, generator=torch.Generator().manual_seed(13))][:, None]).float())
+    base = ad @ wd.t()
+    out = ops.gemm_nt(dev(a), dev(w), None)
+    assert col_err(out.cpu(), base) < 1.5 * BF16_OUT, col_err(out.cpu(), base)
+    out32 = ops.gemm_nt(dev(a), dev(w), None, out_dtype=torch.float32)
+    assert col_err(out32.cpu(), base) < 4 * F32_OUT, col_err(out32.cpu(), base)
+    g = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    h = ops.gemm_nt(dev(a), dev(w), None, epilogue=ops.EPI_GELU, aux_out=g)
+    # (GELU of a tiny pre-activation is x / 2 and GELU' is 1 / 2: both keep the column's relative scale)
+    assert col_err(h.cpu(), O.gelu_fwd(base)) < 1.5 * BF16_OUT and col_err(g.cpu(), O.gelu_grad(base)) < 1.5 * BF16_OUT
+    gm, gmd = bf(rnd(M, N, seed=14))
+    mul = ops.gemm_nt(dev(a), dev(w), None, epilogue=ops.EPI_MUL, aux_in=dev(gm))
+    assert col_err(mul.cpu(), base * gmd) < 1.5 * BF16_OUT
 
 
 def test_gemm_gelu(ops):
@@ -143,10 +165,10 @@ def test_layernorm_fwd_bwd(ops, res_dtype, M, D):
     xd = x.double()
     yref, mref, rref = O.layernorm_fwd(xd, gamma.double(), beta.double(), 1e-6)
     y, mean, rstd = ops.layernorm_fwd(dev(x), dev(gamma), dev(beta), 1e-6)
-    assert rel_err(y.cpu(), yref) < BF16_OUT
+    assert rel_err(y.cpu(), yref) < BF16_OUT and col_err(y.cpu(), yref) < 1.5 * BF16_OUT
     assert rel_err(mean.cpu(), mref) < 1e-5 and rel_err(rstd.cpu(), rref) < 1e-5
     y32, _, _ = ops.layernorm_fwd(dev(x), dev(gamma), dev(beta), 1e-6, out_dtype=torch.float32)
-    assert rel_err(y32.cpu(), yref) < F32_OUT
+    assert rel_err(y32.cpu(), yref) < F32_OUT and col_err(y32.cpu(), yref) < 4 * F32_OUT
     dy, dyd = bf(rnd(M, D, seed=24))
     dres = rnd(M, D, seed=25).to(res_dtype)
     ref = dres.double() + O.layernorm_bwd_dx(dyd, xd, gamma.double(), mref, rref)
@@ -154,8 +176,8 @@ def test_layernorm_fwd_bwd(ops, res_dtype, M, D):
     inds = torch.randperm(D, generator=torch.Generator().manual_seed(1)).int()
     dx, gathered = ops.layernorm_bwd(dev(dy), dev(x), dev(gamma), mean, rstd, dres=dev(dres), inds=dev(inds), r=r)
     tol = F32_OUT * 5 if res_dtype == torch.float32 else BF16_OUT
-    assert rel_err(dx.cpu(), ref) < tol
-    assert rel_err(gathered.cpu(), ref[:, inds[:r].long()]) < BF16_OUT
+    assert rel_err(dx.cpu(), ref) < tol and col_err(dx.cpu(), ref) < 2 * tol
+    assert rel_err(gathered.cpu(), ref[:, inds[:r].long()]) < BF16_OUT and col_err(gathered.cpu(), ref[:, inds[:r].long()]) < 1.5 * BF16_OUT
     dx2, none = ops.layernorm_bwd(dev(dy), dev(x), dev(gamma), mean, rstd)
     assert none is None
     assert rel_err(dx2.cpu(), ref - dres.double()) < tol
@@ -383,13 +405,15 @@ def test_attention_online_softmax_rescale_branch(ops, attn_variant):
 def test_proj_dw(ops, M, r, D):
     dyg, dygd = bf(rnd(M, r, seed=41))
     x, xd = bf(rnd(M, D, seed=42))
-    scale = 0.5 + torch.rand(r, generator=torch.Generator().manual_seed(43))
+    scale = (0.5 + torch.rand(r, generator=torch.Generator().manual_seed(43))) * 10.0 ** (-3.0 * torch.rand(r, generator=torch.Generator().manual_seed(44)))
     ref_w = scale.double()[:, None] * (dygd.t() @ xd)
     ref_b = scale.double() * dygd.sum(0)
     dW = torch.full((r, D), 7.0, device="cuda")
     db = torch.full((r,), 7.0, device="cuda")
     ops.proj_dw(dev(dyg), dev(x), dW, db, row_scale=dev(scale))
     assert rel_err(dW.cpu(), ref_w) < 5e-5 and rel_err(db.cpu(), ref_b) < 5e-5
+    # every trainable row of dW (a column of dW^T) and every column against its own scale
+    assert col_err(dW.cpu().t(), ref_w.t()) < 2e-4 and col_err(dW.cpu(), ref_w) < 2e-4
     ops.proj_dw(dev(dyg), dev(x), dW, db, row_scale=dev(scale), accumulate=True)
     assert rel_err(dW.cpu(), 2 * ref_w) < 5e-5 and rel_err(db.cpu(), 2 * ref_b) < 5e-5
     # determinism: bitwise identical on a re-run

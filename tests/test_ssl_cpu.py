@@ -91,3 +91,34 @@ def test_ssl_oracle_reproduces_reference_step(tag):
             assert rel_err(st["teacher"][name], g[f"it{it}.teacher.{name}"]) < 1e-3, name
     c = SO.centers(st)
     assert rel_err(c["dino"], g["dino.center"]) < 1e-5 and rel_err(c["ibot"], g["ibot.center"]) < 1e-5
+
+
+def test_chunked_exchange_launch_order_is_rank_invariant():
+    """the chunked gradient exchange of Dinov2Trainer must issue the same sequence of collectives on every rank, whatever
+    order the autograd engine of a rank completes the gradients in and whichever tensors receive none there.  The launch rule
+    (descending chunk index, a complete chunk waits for its successors) on shuffled completion orders, with tensors left out."""
+    import random
+    from apla_amd.ssl.trainer import Dinov2Trainer
+
+    class Recorder:
+        active = True
+        def __init__(self, n): self.chunks, self.order, self.waited = [None] * n, [], 0
+        def launch_chunk(self, k): self.order.append(k)
+        def wait(self): self.waited += 1
+
+    sizes = [3, 1, 4, 2, 5]
+    tensors = [k for k, n in enumerate(sizes) for _ in range(n)]
+    rng = random.Random(0)
+    for trial in range(50):
+        tr = object.__new__(Dinov2Trainer)
+        tr.exchanger, tr._chunk_size = Recorder(len(sizes)), list(sizes)
+        tr._reset_exchange()
+        done = list(tensors)
+        rng.shuffle(done)
+        for k in done[:rng.randrange(len(done) + 1)]:     # some tensors never get a gradient on this "rank"
+            tr._chunk_seen[k] += 1
+            tr._launch_ready()
+            assert tr.exchanger.order == list(range(len(sizes) - 1, len(sizes) - 1 - len(tr.exchanger.order), -1))
+        tr._finish_exchange()
+        assert tr.exchanger.order == [4, 3, 2, 1, 0] and tr.exchanger.waited == 1
+        assert tr._chunk_seen == [0] * 5 and tr._chunk_next == 4
