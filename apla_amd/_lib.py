@@ -5,7 +5,7 @@ returns an error, an exception is raised.  Nothing here imports the CPU oracle.
 """
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_long, c_ulonglong, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_long, c_uint, c_ulonglong, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 # bf16 operands (default).  APLA_LIB=<path> substitutes another build of the library (tools/build_ablations.sh: A/B timing)
@@ -46,6 +46,9 @@ SIGNATURES = {
                                       c_int, c_int, c_void_p]),
     "apla_gemm_nt_kernel_name": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_char_p, c_int]),
     "apla_attn_kernel_name": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_char_p, c_int]),
+    "apla_attn_fwd_dropout": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_ulonglong, c_uint, c_void_p]),
+    "apla_attn_bwd_dropout": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float,
+                                      c_ulonglong, c_uint, c_void_p]),
     "apla_probe_occupy": (c_int, [c_int, c_int, c_int, c_int, c_void_p]),
     "apla_gather_cols": (c_int, [c_void_p, c_int, c_long, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     "apla_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),

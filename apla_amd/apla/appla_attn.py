@@ -54,7 +54,7 @@ class APLA_Attention(nn.Module):
     def _attend(self, x):
         B, N, _ = x.shape
         qkv = AF.linear(x, self.qkv.weight, self.qkv.bias)
-        o, lse = AF.attention_core(qkv, B, N, self.num_heads, self.scale)
+        o, lse = AF.attention_core(qkv, B, N, self.num_heads, self.scale, AF.active_p(self.attn_drop, self.training))   # appla_attn.py:56-60
         return qkv, o, lse
 
     def _project(self, o, gamma=None):
@@ -64,7 +64,6 @@ class APLA_Attention(nn.Module):
     def forward(self, x, ls_gamma=None):
         """``ls_gamma`` (extension, used by VisionTransformer.run_blocks): the block's frozen LayerScale vector; when given,
         x is ls1(attention(x)) with the scale folded into the projection GEMM."""
-        AF.require_no_dropout(self.attn_drop, self.training)
         B, N, _ = x.shape
         qkv, o, lse = self._attend(x)
         # proj_drop (appla_attn.py:82) commutes with the LayerScale vector folded into the projection: both are element-wise

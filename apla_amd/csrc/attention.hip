@@ -246,10 +246,52 @@ __device__ __forceinline__ Seq seq_of(const int32_t* __restrict__ cu, int b, int
   return s;
 }
 
+// One LDS-DMA piece = 8 rows x 128 B of a [rows][64] tile (row stride ld_ elements in global memory), piece `pr` (wave-uniform) to
+// dst + pr KB.  The XOR swizzle of tile_off goes on the source column (the LDS side of a DMA is lane-linear).  For a piece of rows < N the
+// address is (uniform piece base) + (one of two 32-bit lane offsets, by the piece's parity): computed per piece, the swizzle and the
+// 64-bit row product cost ~240 cycles of a wave's time (round 5, stamps of the persistent forward's loader).  Pieces that hold rows >= N
+// (they re-read row N - 1) take the long way.
+struct PieceOffs { unsigned even, odd; };
+__device__ __forceinline__ PieceOffs piece_offs(int lane, long ld_) {
+  const int lr = lane >> 3;
+  const int f_even = (((lr >> 1) & 1) << 2) | (lr >> 2);
+  PieceOffs po;
+  po.even = (unsigned)(lr * (int)ld_ * 2 + (((lane & 7) ^ f_even) << 4));
+  po.odd = (unsigned)(lr * (int)ld_ * 2 + (((lane & 7) ^ f_even ^ 2) << 4));
+  return po;
+}
+__device__ __forceinline__ void dma_piece(const bf16* src, long ld_, int pr, int N, int lane, const PieceOffs& po, char* dst) {
+  if (pr * 8 + 8 <= N) {
+    const char* pb = (const char*)src + (long)pr * 8 * ld_ * 2;
+    __builtin_amdgcn_global_load_lds(ATT_GLBP(pb + ((pr & 1) ? po.odd : po.even)), ATT_LDSP(dst + pr * 1024), 16, 0, 0);
+  } else {
+    const int row = pr * 8 + (lane >> 3);
+    const int f = (((row >> 1) & 1) << 2) | ((row >> 2) & 3);
+    const int gr = row < N ? row : N - 1;
+    __builtin_amdgcn_global_load_lds(ATT_GLBP(src + (long)gr * ld_ + (((lane & 7) ^ f) << 3)), ATT_LDSP(dst + pr * 1024), 16, 0, 0);
+  }
+}
+
+// Attention-probability dropout (appla_attn.py:58 `attn = self.attn_drop(attn)`, settable from main.py:109-111 --adr; 0 in every
+// shipped configuration): attn_d = keep ? attn / (1 - p) : 0 between the softmax and the product with V.  Implemented in the key- /
+// query-blocked kernels only (the module path routes there when attn_drop is active).  keep(row, key) = word (key & 3) of
+// Philox4x32-10(counter {key >> 2, row (64 bit), offset}, key seed) >= p * 2^32 with row = the (b, h, q) index of lse — counter-based:
+// the forward and the two backward kernels regenerate the same mask in their own tilings, nothing is stored, and the oracle
+// (oracle/apla_oracle.py:philox_attn_keep_mask) reproduces it bit for bit.  Backward: with attn_d = attn o M / (1 - p),
+// d attn = (dO V^T) o M / (1 - p), dS = attn o (d attn - delta) with delta = rowsum(dO o O) unchanged, dV = attn_d^T dO.
+struct DropArgs { unsigned threshold; float inv_keep; unsigned long long seed; unsigned offset; };
+// keep flags of keys 4*kg .. 4*kg+3 of one row: bit e = key 4*kg + e is kept
+__device__ __forceinline__ unsigned drop_keep4(const DropArgs& da, unsigned long long row, unsigned kg) {
+  unsigned c[4] = {kg, (unsigned)row, (unsigned)(row >> 32), da.offset};
+  philox4x32_10(c, (unsigned)da.seed, (unsigned)(da.seed >> 32));
+  return (c[0] >= da.threshold ? 1u : 0u) | (c[1] >= da.threshold ? 2u : 0u) | (c[2] >= da.threshold ? 4u : 0u) | (c[3] >= da.threshold ? 8u : 0u);
+}
+
 // ------------------------------------------------------------------------------------------------ forward
+template <bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
                                                        float* __restrict__ lse, int Nmax, int H, float scale,
-    const int32_t* __restrict__ cu, int total) {
+    const int32_t* __restrict__ cu, int total, DropArgs da) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 8192];
   char* Ks = smem;
   char* Vs = smem + 8192;
@@ -330,6 +372,18 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
       }
     l_run = l_run * alpha + rs;
     m_run = m_new;
+    if constexpr (DROP) {   // the row sum above is the softmax's (undropped); the dropped probabilities go into the product with V
+      const unsigned long long row = (unsigned long long)(sq.stat + (long)h * sq.stat_h + q);
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const unsigned keep = drop_keep4(da, row, (unsigned)((kb * 64 + kt * 32 + 8 * g + 4 * h2) >> 2));
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (!((keep >> e) & 1)) s[kt][4 * g + e] = 0.f;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc_o[0][i] *= alpha; acc_o[1][i] *= alpha; }
 #pragma unroll
@@ -346,7 +400,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
   }
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   if (qvalid) {
-    store_acc_T(acc_o, o + ((long)sq.start + q) * D + h * 64, h2, 1.0f / l_tot);
+    store_acc_T(acc_o, o + ((long)sq.start + q) * D + h * 64, h2, (DROP ? da.inv_keep : 1.0f) / l_tot);
     if (h2 == 0) lse[sq.stat + (long)h * sq.stat_h + q] = m_run * scale + __logf(l_tot);
   }
 }
@@ -380,17 +434,13 @@ __global__ __launch_bounds__(576, 4) void attn_fwd_small_kernel(const bf16* __re
   char* Vs = smem + NP * 128;
 
   // pieces: K has NP/8, V has NP/8; wave w issues pieces 8w .. 8w+7 of the combined list (NP/4 = 8 * nw pieces)
+  const PieceOffs po = piece_offs(lane, ld);
 #pragma unroll
   for (int it = 0; it < 8; ++it) {
     const int pc = wave * 8 + it;          // wave-uniform
     const bool isv = pc >= NP / 8;
     const int pr = isv ? pc - NP / 8 : pc;  // piece inside K or V
-    const int row = pr * 8 + (lane >> 3);
-    const int f = (((row >> 1) & 1) << 2) | ((row >> 2) & 3);
-    const int ch = (lane & 7) ^ f;
-    const int gr = row < N ? row : N - 1;
-    const bf16* src = base + (isv ? 2 * D : D) + (long)gr * ld + ch * 8;
-    __builtin_amdgcn_global_load_lds(ATT_GLBP(src), ATT_LDSP((isv ? Vs : Ks) + pr * 1024), 16, 0, 0);
+    dma_piece(base + (isv ? 2 * D : D), ld, pr, N, lane, po, isv ? Vs : Ks);
   }
 
   int q = wave * 32 + (lane & 31);
@@ -725,10 +775,11 @@ __global__ __launch_bounds__(64 * (NT + 1), 2) void attn_fwd_persist_kernel(cons
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dQ (+delta)
+template <bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
                                                           const bf16* __restrict__ dout, const float* __restrict__ lse,
                                                           float* __restrict__ delta, bf16* __restrict__ dqkv, int Nmax, int H, float scale,
-    const int32_t* __restrict__ cu, int total) {
+    const int32_t* __restrict__ cu, int total, DropArgs da) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 16384];  // two (K tile, V tile) buffers filled by LDS-DMA
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h2 = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128;
@@ -818,6 +869,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restr
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) tr_issue(kt_[2 * sk + dt], Ks, kt * 32 + 16 * sk, 32 * dt, lane);
 #endif
+      if constexpr (DROP) {   // d attn = (dO V^T) o M / (1 - p)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const unsigned keep = drop_keep4(da, (unsigned long long)statidx, (unsigned)((kb * 64 + kt * 32 + 8 * g + 4 * h2) >> 2));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dp[4 * g + e] = ((keep >> e) & 1) ? dp[4 * g + e] * da.inv_keep : 0.f;
+        }
+      }
       // dS^T (unscaled).  Only the sequence's last key tile needs the per-key mask: as one predicated loop hipcc emits the
       // compare/select pair for every element of every tile (45 % of this kernel's VALU instructions).
       if (kb * 64 + kt * 32 + 32 <= N) {
@@ -849,11 +908,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restr
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ dout,
+template <bool DROP>
+__global__ __launch_bounds__(256, (DROP ? 1 : 2)) void attn_bwd_dkv_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ dout,
                                                            const float* __restrict__ lse,
                                                            const float* __restrict__ delta, bf16* __restrict__ dqkv,
                                                            int Nmax, int H, float scale,
-    const int32_t* __restrict__ cu, int total) {
+    const int32_t* __restrict__ cu, int total, DropArgs da) {
   // two (Q tile, dO tile) buffers filled by LDS-DMA (no staging registers: the kernel then fits three waves per SIMD),
   // then two (lse, delta) buffers
   __shared__ __attribute__((aligned(16))) char smem[2 * 16384 + 2 * 2 * 64 * 4];
@@ -923,6 +983,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __rest
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
       if (qt == 1 && qb * 64 + 32 >= N) continue;  // fully masked query tile
+      unsigned keepbits = 0;   // DROP: bit i = element i of this tile (this lane's key, query row acc_row(i, h2) of the tile) is kept
+      if constexpr (DROP) {    // (a rolled loop in front of the products: sixteen unrolled Philox blocks beside 240 live registers spill)
+        const long rowbase = sq.stat + (long)h * sq.stat_h + qb * 64 + qt * 32 + 4 * h2;
+#pragma unroll 1
+        for (int i = 0; i < 16; ++i) {
+          const unsigned keep = drop_keep4(da, (unsigned long long)(rowbase + (i & 3) + 8 * (i >> 2)), (unsigned)key >> 2);
+          keepbits |= ((keep >> (key & 3)) & 1u) << i;
+        }
+      }
       f32x16 s, dp;
 #pragma unroll
       for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
@@ -949,6 +1018,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __rest
           tr_issue(tf[4 * sk + 2 + dt], Qs, qt * 32 + 16 * sk, 32 * dt, lane);
         }
 #endif
+      if constexpr (DROP) {   // d attn = (dO V^T) o M / (1 - p)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dp[i] = ((keepbits >> i) & 1) ? dp[i] * da.inv_keep : 0.f;
+      }
       // P and dS (in place of dP).  Only the sequence's last query tile needs the per-row mask (see the dQ kernel).
       if (qb * 64 + qt * 32 + 32 <= N) {
 #pragma unroll
@@ -977,6 +1050,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __rest
             dp[i] = p * (dp[i] - d4[e]);
           }
         }
+      }
+      if constexpr (DROP) {   // dV = attn_d^T dO: the P operand of that product is the dropped, rescaled one
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[i] = ((keepbits >> i) & 1) ? s[i] * da.inv_keep : 0.f;
       }
 #if defined(APLA_ABL_ATT_NOTR)
       acc_dv[0][0] += s[0] + s[7]; acc_dk[0][0] += dp[3] + dp[12];
@@ -1055,15 +1132,10 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_small_kernel(const bf16* 
   // both tiles of a phase: 2 * npc pieces, dealt round-robin to the four waves; swizzle on the source column (the LDS side
   // of a DMA is lane-linear)
   auto stage = [&](const bf16* srcA, long ldA, const bf16* srcB, long ldB) {
+    const PieceOffs poA = piece_offs(lane, ldA), poB = piece_offs(lane, ldB);
     for (int pc = wave; pc < 2 * npc; pc += NW) {     // wave-uniform
-      const bool isb = pc >= npc;
-      const int pr = isb ? pc - npc : pc;
-      const int row = pr * 8 + (lane >> 3);
-      const int f = (((row >> 1) & 1) << 2) | ((row >> 2) & 3);
-      const int ch = (lane & 7) ^ f;
-      const int gr = row < N ? row : N - 1;
-      const bf16* src = isb ? srcB + (long)gr * ldB + ch * 8 : srcA + (long)gr * ldA + ch * 8;
-      __builtin_amdgcn_global_load_lds(ATT_GLBP(src), ATT_LDSP((isb ? TB : TA) + pr * 1024), 16, 0, 0);
+      if (pc >= npc) dma_piece(srcB, ldB, pc - npc, N, lane, poB, TB);
+      else dma_piece(srcA, ldA, pc, N, lane, poA, TA);
     }
   };
 
@@ -1844,7 +1916,7 @@ static int launch_attn_fwd(const void* qkv, void* o, float* lse, const int32_t* 
     apla_allow_lds(lds_ok, (const void*)attn_fwd_small_kernel, SMALL_MAX_ROWS * 256);
     hipLaunchKernelGGL(attn_fwd_small_kernel, dim3(H, B), dim3(64 * nw), (size_t)nw * 32 * 256, stream, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, cu, total);
   } else {
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3((N + 127) / 128, H, B), dim3(256), 0, stream, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, cu, total);
+    hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3((N + 127) / 128, H, B), dim3(256), 0, stream, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, cu, total, DropArgs{});
   }
   APLA_CHECK_LAUNCH(who);
   return APLA_OK;
@@ -1897,9 +1969,9 @@ static int launch_attn_bwd(const void* qkv, const void* o, const void* d_o, cons
     return APLA_OK;
   }
   dim3 grid((N + 127) / 128, H, B);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, stream, (const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse, delta, (bf16*)dqkv, N, H, scale, cu, total);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, grid, dim3(256), 0, stream, (const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse, delta, (bf16*)dqkv, N, H, scale, cu, total, DropArgs{});
   APLA_CHECK_LAUNCH(who);
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, stream, (const bf16*)qkv, (const bf16*)d_o, lse, delta, (bf16*)dqkv, N, H, scale, cu, total);
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, grid, dim3(256), 0, stream, (const bf16*)qkv, (const bf16*)d_o, lse, delta, (bf16*)dqkv, N, H, scale, cu, total, DropArgs{});
   APLA_CHECK_LAUNCH(who);
   return APLA_OK;
 }
@@ -1960,6 +2032,42 @@ extern "C" int apla_attn_varlen_bwd(const void* qkv, const void* o, const void* 
                                     void* dqkv, const int32_t* cu_seqlens, int S, int total, int max_n, int H,
                                     float scale, hipStream_t stream) {
   return apla_attn_varlen_bwd_ex(qkv, o, d_o, lse, delta, dqkv, cu_seqlens, S, total, max_n, H, scale, 0, stream);
+}
+
+static int drop_args(float p, unsigned long long seed, unsigned offset, DropArgs& da, const char* who) {
+  APLA_REQUIRE(p > 0.f && p < 1.f, "%s: dropout probability must be in (0, 1), got %g", who, (double)p);
+  const double t = (double)p * 4294967296.0;
+  da.threshold = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+  da.inv_keep = 1.0f / (1.0f - p);
+  da.seed = seed;
+  da.offset = offset;
+  return APLA_OK;
+}
+extern "C" int apla_attn_fwd_dropout(const void* qkv, void* o, float* lse, int B, int N, int H, float scale, float p,
+                                     unsigned long long seed, unsigned offset, hipStream_t stream) {
+  APLA_REQUIRE(qkv && o && lse && B > 0 && N > 0 && H > 0 && B <= 65535 && H <= 65535, "apla_attn_fwd_dropout: bad arguments");
+  APLA_REQUIRE(apla_aligned16(qkv) && apla_aligned16(o), "apla_attn_fwd_dropout: pointers must be 16-byte aligned");
+  DropArgs da;
+  if (int rc = drop_args(p, seed, offset, da, "apla_attn_fwd_dropout")) return rc;
+  hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3((N + 127) / 128, H, B), dim3(256), 0, stream, (const bf16*)qkv, (bf16*)o, lse, N, H, scale,
+                     (const int32_t*)nullptr, B * N, da);
+  APLA_CHECK_LAUNCH("apla_attn_fwd_dropout");
+  return APLA_OK;
+}
+extern "C" int apla_attn_bwd_dropout(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv, int B,
+                                     int N, int H, float scale, float p, unsigned long long seed, unsigned offset, hipStream_t stream) {
+  APLA_REQUIRE(qkv && o && d_o && lse && delta && dqkv && B > 0 && N > 0 && H > 0 && B <= 65535 && H <= 65535, "apla_attn_bwd_dropout: bad arguments");
+  APLA_REQUIRE(apla_aligned16(qkv) && apla_aligned16(o) && apla_aligned16(d_o) && apla_aligned16(dqkv), "apla_attn_bwd_dropout: pointers must be 16-byte aligned");
+  DropArgs da;
+  if (int rc = drop_args(p, seed, offset, da, "apla_attn_bwd_dropout")) return rc;
+  const dim3 grid((N + 127) / 128, H, B);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, grid, dim3(256), 0, stream, (const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse, delta, (bf16*)dqkv, N, H, scale,
+                     (const int32_t*)nullptr, B * N, da);
+  APLA_CHECK_LAUNCH("apla_attn_bwd_dropout");
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, grid, dim3(256), 0, stream, (const bf16*)qkv, (const bf16*)d_o, lse, delta, (bf16*)dqkv, N, H, scale,
+                     (const int32_t*)nullptr, B * N, da);
+  APLA_CHECK_LAUNCH("apla_attn_bwd_dropout");
+  return APLA_OK;
 }
 
 extern "C" int apla_attn_fwd_cls(const void* qkv, void* o, float* lse, int B, int N, int H, float scale,

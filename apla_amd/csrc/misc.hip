@@ -948,15 +948,7 @@ extern "C" int apla_weight_norm_bwd(const float* dw, const float* v, const float
 // shipped configurations use 0; main.py:101-111 can set them.  The keep decision of element i is word (i & 3) of
 // Philox4x32-10(counter = {i >> 2 (64 bit), offset (64 bit)}, key = seed (64 bit)) compared with p * 2^32: counter-based, so the mask
 // does not depend on the launch geometry and the oracle (oracle/apla_oracle.py:philox_keep_mask) reproduces it bit for bit.
-__device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, unsigned k1) {
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0], p1 = (unsigned long long)0xCD9E8D57u * c[2];
-    const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1;
-    c[1] = (unsigned)p1; c[3] = (unsigned)p0; c[0] = n0; c[2] = n2;
-    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-  }
-}
+// (philox4x32_10: common.h)
 
 // y = keep ? x / (1 - p) : 0, keep bytes written for the backward.  One thread = 8 consecutive elements (two Philox blocks).
 template <typename T>

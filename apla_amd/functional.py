@@ -24,11 +24,18 @@ def _h():
 
 
 def require_no_dropout(drop_module, training: bool):
-    """Dropout INSIDE the fused softmax (attn_drop, appla_attn.py:58) is not implemented: 0 in every shipped APLA config."""
+    """The PACKED (block-diagonal) attention path has no attention-probability dropout (the dense path has: attention_core(attn_drop=);
+    0 in every shipped APLA config, and the reference's own dinov2 blocks never pass one: dinov2/layers/attention.py)."""
     p = getattr(drop_module, "p", 0.0)
     if training and p and p > 0.0:
-        raise NotImplementedError(f"attention-probability dropout p={p} is not supported on the HIP path (it would sit inside the fused "
-                                  "softmax; all shipped APLA configs use 0); proj_drop / drop_rate / drop_path_rate are")
+        raise NotImplementedError(f"attention-probability dropout p={p} is not supported for packed (block-diagonal) batches on the HIP "
+                                  "path; dense batches, proj_drop / drop_rate / drop_path_rate are")
+
+
+def active_p(drop_module, training: bool) -> float:
+    """The probability an nn.Dropout would apply right now (0 in evaluation mode)."""
+    p = float(getattr(drop_module, "p", 0.0) or 0.0)
+    return p if (training and p > 0.0) else 0.0
 
 
 class _DropoutFn(torch.autograd.Function):
@@ -474,17 +481,46 @@ def attention_core_varlen(qkv, cu_seqlens, max_n, H, scale, runs=None):
     return _AttnVarlenFn.apply(qkv, cu_seqlens, max_n, H, scale)
 
 
-def attention_core(qkv, B, N, H, scale):
+class _AttnCoreDropFn(torch.autograd.Function):
+    """Attention with dropout on the probabilities (appla_attn.py:56-58).  The mask is a function of (seed, row, key): the backward
+    regenerates it, nothing but qkv, o and lse is saved."""
+
+    @staticmethod
+    def forward(ctx, qkv, B, N, H, scale, p, seed):
+        qkv2 = qkv.reshape(B * N, -1).contiguous()
+        o, lse = ops.attn_fwd_dropout(qkv2, B, N, H, scale, p, seed)
+        ctx.save_for_backward(qkv2, o, lse)
+        ctx.dims = (B, N, H, scale, p, seed)
+        ctx.mark_non_differentiable(lse)
+        return o.reshape(B, N, H * 64), lse
+
+    @staticmethod
+    def backward(ctx, do, _dlse):
+        qkv2, o, lse = ctx.saved_tensors
+        B, N, H, scale, p, seed = ctx.dims
+        dqkv = ops.attn_bwd_dropout(qkv2, o, _as2d_bf16(do), lse, B, N, H, scale, p, seed)
+        return dqkv.reshape(B, N, -1), None, None, None, None, None, None
+
+
+def attention_core(qkv, B, N, H, scale, attn_drop: float = 0.0):
+    """(o, lse).  ``attn_drop`` > 0: dropout on the attention probabilities with a fresh 64-bit seed drawn from torch's CPU generator
+    (``torch.manual_seed`` makes a run repeatable), as ``dropout`` does."""
     if qkv.shape[-1] != 3 * H * 64:
         raise NotImplementedError(f"the HIP attention kernel needs head_dim 64 (got {qkv.shape[-1] // (3 * H)})")
+    if attn_drop and attn_drop > 0.0:
+        if attn_drop >= 1.0:
+            raise ValueError("attn_drop must be < 1")
+        seed = int(torch.empty((), dtype=torch.int64).random_())
+        return _AttnCoreDropFn.apply(qkv, B, N, H, scale, float(attn_drop), seed)
     return _AttnCoreFn.apply(qkv, B, N, H, scale)
 
 
-def attention_module_forward(x, qkv_w, qkv_b, proj_w, proj_b, num_heads, scale, want_attn):
-    """Plain (non-APLA) Attention.forward, vit.py:184-196: returns (x, attn|None)."""
+def attention_module_forward(x, qkv_w, qkv_b, proj_w, proj_b, num_heads, scale, want_attn, attn_drop: float = 0.0):
+    """Plain (non-APLA) Attention.forward, vit.py:184-196: returns (x, attn|None).  The attention matrix returned on demand is the
+    softmax itself (before its dropout), as the kernels keep only its log-sum-exp."""
     B, N, _ = x.shape
     qkv = linear(x, qkv_w, qkv_b)
-    o, lse = attention_core(qkv, B, N, num_heads, scale)
+    o, lse = attention_core(qkv, B, N, num_heads, scale, attn_drop)
     y = linear(o, proj_w, proj_b).to(x.dtype)
     attn = ops.attn_probs(qkv.detach().reshape(B * N, -1), lse, B, N, num_heads, scale) if want_attn else None
     return y, attn

@@ -450,6 +450,33 @@ def attn_fwd(qkv: torch.Tensor, B: int, N: int, H: int, scale: float, *, o: Opti
     return o, lse
 
 
+def attn_fwd_dropout(qkv: torch.Tensor, B: int, N: int, H: int, scale: float, p: float, seed: int, offset: int = 0):
+    """attn_fwd with dropout on the attention probabilities (appla_attn.py:56-58): (o, lse); the mask is regenerated from
+    (seed, offset) by attn_bwd_dropout, nothing is stored (include/apla_hip.h: apla_attn_fwd_dropout)."""
+    _req(qkv, half(), "qkv", 2)
+    if tuple(qkv.shape) != (B * N, 3 * H * 64) or not qkv.is_contiguous():
+        raise ValueError(f"attn_fwd_dropout: qkv must be contiguous [{B * N}, {3 * H * 64}], got {tuple(qkv.shape)}")
+    o = torch.empty(B * N, H * 64, device=qkv.device, dtype=half())
+    lse = torch.empty(B, H, N, device=qkv.device, dtype=torch.float32)
+    check(lib().apla_attn_fwd_dropout(qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), B, N, H, float(scale), float(p),
+                                      int(seed) & 0xFFFFFFFFFFFFFFFF, int(offset) & 0xFFFFFFFF, _stream()), "apla_attn_fwd_dropout")
+    return o, lse
+
+
+def attn_bwd_dropout(qkv: torch.Tensor, o: torch.Tensor, do: torch.Tensor, lse: torch.Tensor, B: int, N: int, H: int, scale: float,
+                     p: float, seed: int, offset: int = 0):
+    _req(qkv, half(), "qkv", 2), _req(o, half(), "o", 2), _req(do, half(), "do", 2), _req(lse, torch.float32, "lse", 3)
+    if tuple(qkv.shape) != (B * N, 3 * H * 64) or tuple(o.shape) != (B * N, H * 64) or tuple(do.shape) != tuple(o.shape) or \
+            tuple(lse.shape) != (B, H, N) or not (qkv.is_contiguous() and o.is_contiguous() and do.is_contiguous() and lse.is_contiguous()):
+        raise ValueError("attn_bwd_dropout: bad operand shapes")
+    delta = torch.empty_like(lse)
+    dqkv = torch.empty_like(qkv)
+    check(lib().apla_attn_bwd_dropout(qkv.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(), delta.data_ptr(), dqkv.data_ptr(), B, N, H,
+                                      float(scale), float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, int(offset) & 0xFFFFFFFF, _stream()),
+          "apla_attn_bwd_dropout")
+    return dqkv
+
+
 def attn_bwd(qkv: torch.Tensor, o: torch.Tensor, do: torch.Tensor, lse: torch.Tensor, B: int, N: int, H: int,
              scale: float, *, dqkv: Optional[torch.Tensor] = None, delta: Optional[torch.Tensor] = None):
     _req(qkv, half(), "qkv", 2), _req(o, half(), "o", 2), _req(do, half(), "do", 2)

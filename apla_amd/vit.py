@@ -85,9 +85,9 @@ class Attention(nn.Module):
         self.return_attn_matrix = False
 
     def forward(self, x):
-        AF.require_no_dropout(self.attn_drop, self.training)
         y, attn = AF.attention_module_forward(x, self.qkv.weight, self.qkv.bias, self.proj.weight, self.proj.bias,
-                                              self.num_heads, self.scale, self.return_attn_matrix)
+                                              self.num_heads, self.scale, self.return_attn_matrix,
+                                              AF.active_p(self.attn_drop, self.training))   # vit.py:190-192
         return AF.dropout(y, self.proj_drop, self.training), attn
 
 

@@ -194,6 +194,15 @@ int apla_attn_varlen_bwd(const void* qkv, const void* o, const void* d_o, const 
  *       one-workgroup-per-head forward; the persistent forward takes ONE maximum per row instead of a running one per 64 keys and
  *       agrees with them to rounding (tests/test_kernels_gpu.py).  Bits 8.. of `variant`: schedule experiments (diagnostics). */
 int apla_attn_fwd_ex(const void* qkv, void* o, float* lse, int B, int N, int H, float scale, int variant, hipStream_t stream);
+/* Attention with dropout on the attention probabilities (appla_attn.py:56-58: attn = softmax(...); attn = self.attn_drop(attn); x = attn @ v;
+ * settable from main.py:109-111 --adr, 0 in every shipped configuration): o = (keep ? attn / (1 - p) : 0) v.  The keep decision of
+ * (b, h, q, key) is word (key & 3) of Philox4x32-10(counter {key >> 2, row (64 bit), offset}, key = seed) >= p * 2^32 with row =
+ * (b * H + h) * N + q: counter-based, so forward and backward regenerate the same mask (nothing is stored) and the oracle reproduces
+ * it bit for bit.  lse is the softmax's own (undropped).  Uniform batches, key- / query-blocked kernels.  0 < p < 1. */
+int apla_attn_fwd_dropout(const void* qkv, void* o, float* lse, int B, int N, int H, float scale, float p,
+                          unsigned long long seed, unsigned offset, hipStream_t stream);
+int apla_attn_bwd_dropout(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv, int B,
+                          int N, int H, float scale, float p, unsigned long long seed, unsigned offset, hipStream_t stream);
 /* Name of the kernel an attention launch is dispatched to (the same decision code as the launch itself): backward = 0 | 1,
  * packed = 1 for the block-diagonal entry points (N = max_n there).  Diagnostics / bench records; no reference counterpart. */
 int apla_attn_kernel_name(int backward, int packed, int B, int N, int H, int variant, char* buf, int buflen);

@@ -145,6 +145,35 @@ def attention_fwd(qkv: Tensor, num_heads: int, scale: float, return_attn: bool =
     return (o, lse, attn) if return_attn else (o, lse)
 
 
+def attention_dropout_fwd_bwd(qkv: Tensor, num_heads: int, scale: float, keep: Tensor, p_drop: float, do: Optional[Tensor] = None):
+    """appla_attn.py:56-60 WITH its dropout on the attention probabilities: attn = softmax(q k^T * scale); attn = attn_drop(attn), i.e.
+    nn.Dropout: attn_d = keep ? attn / (1 - p) : 0; x = attn_d @ v.  ``keep`` [B,H,N,N] bool is the mask (philox_attn_keep_mask for the
+    kernels' own).  Returns (o, lse) and, with ``do`` given, dqkv by autograd-free formulas: d attn = (dO V^T) o keep / (1 - p),
+    dS = attn o (d attn - rowsum(attn o d attn)), dV = attn_d^T dO."""
+    B, N, D3 = qkv.shape
+    D = D3 // 3
+    d = D // num_heads
+    t = qkv.reshape(B, N, 3, num_heads, d).permute(2, 0, 3, 1, 4)
+    q, k, v = t[0], t[1], t[2]
+    s = (q @ k.transpose(-2, -1)) * scale
+    m = s.max(-1, keepdim=True).values
+    e = torch.exp(s - m)
+    l = e.sum(-1, keepdim=True)
+    attn = e / l
+    attn_d = attn * keep.to(attn.dtype) / (1.0 - p_drop)
+    o = (attn_d @ v).transpose(1, 2).reshape(B, N, D)
+    lse = (m + torch.log(l)).squeeze(-1)
+    if do is None:
+        return o, lse
+    doh = do.reshape(B, N, num_heads, d).permute(0, 2, 1, 3)
+    dv = attn_d.transpose(-2, -1) @ doh
+    dattn = (doh @ v.transpose(-2, -1)) * keep.to(attn.dtype) / (1.0 - p_drop)
+    ds = attn * (dattn - (attn * dattn).sum(-1, keepdim=True)) * scale
+    dq = ds @ k
+    dk = ds.transpose(-2, -1) @ q
+    return o, lse, torch.stack([dq, dk, dv], 0).permute(1, 3, 0, 2, 4).reshape(B, N, D3)
+
+
 def attention_varlen_fwd(qkv: Tensor, seqlens, num_heads: int, scale: float):
     """Block-diagonal attention over a packed batch: qkv [total, 3*D]; sequence s owns tokens
     [sum(seqlens[:s]), sum(seqlens[:s+1])) and attends to itself only — what
@@ -525,6 +554,21 @@ def philox_keep_mask(n, p, seed, offset=0):
     t = float(np.float32(p)) * 4294967296.0
     threshold = 4294967295 if t >= 4294967295.0 else int(t)
     return words >= threshold
+
+
+def philox_attn_keep_mask(B, H, N, p, seed, offset=0):
+    """keep[b,h,q,k] of apla_attn_fwd_dropout / apla_attn_bwd_dropout (include/apla_hip.h): word (k & 3) of
+    Philox4x32-10(counter {k >> 2, row & 0xffffffff, row >> 32, offset}, key seed) >= p * 2^32 with row = (b * H + h) * N + q."""
+    import numpy as np
+    rows = np.arange(B * H * N, dtype=np.uint64)
+    kg = np.arange((N + 3) // 4, dtype=np.uint64)
+    R, K = np.meshgrid(rows, kg, indexing="ij")
+    ctr = np.stack([K & 0xFFFFFFFF, R & 0xFFFFFFFF, R >> 32, np.full_like(K, offset & 0xFFFFFFFF)], axis=-1)
+    key = np.stack([np.full_like(K, seed & 0xFFFFFFFF), np.full_like(K, (seed >> 32) & 0xFFFFFFFF)], axis=-1)
+    words = philox4x32_10(ctr, key).reshape(B * H * N, -1)[:, :N].astype(np.uint64)
+    t = float(np.float32(p)) * 4294967296.0
+    threshold = 4294967295 if t >= 4294967295.0 else int(t)
+    return torch.from_numpy(words >= threshold).reshape(B, H, N, N)
 
 
 def drop_path(x, u, drop_prob):

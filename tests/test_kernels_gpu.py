@@ -386,6 +386,36 @@ def test_attention_persistent_forward_walks_its_heads(ops, B, N, H):
         assert float((lse[b].cpu().double() - lref[0]).abs().max()) < 2e-4
 
 
+@pytest.mark.parametrize("B,N,H,p", [(2, 197, 2, 0.1), (1, 64, 1, 0.5), (3, 300, 2, 0.25), (2, 129, 3, 0.1), (1, 33, 1, 0.9), (2, 257, 2, 0.3)])
+def test_attention_probability_dropout_fwd_bwd(ops, B, N, H, p):
+    """dropout INSIDE the attention (appla_attn.py:56-58, main.py --adr) — forward and the three gradients against the
+    oracle's dense masked softmax, with the mask the oracle regenerates from (seed, offset) through its own Philox4x32-10
+    (oracle/apla_oracle.py:philox_attn_keep_mask; the generator itself is pinned by the Random123 known-answer vectors).  The mask
+    is never stored: the forward and the two backward kernels each rebuild it in their own tiling, so agreement of all three with ONE
+    oracle mask checks the counter mapping of every kernel.  lse stays the softmax's own."""
+    D, scale, seed, offset = 64 * H, 64 ** -0.5, 0x1234_5678_9ABC_DEF1 + N, 7
+    qkv, qkvd = bf(rnd(B, N, 3 * D, seed=51))
+    do, dod = bf(rnd(B, N, D, seed=52))
+    keep = O.philox_attn_keep_mask(B, H, N, p, seed, offset)
+    assert abs(float(keep.float().mean()) - (1 - p)) < 0.02
+    oref, lref, dref = O.attention_dropout_fwd_bwd(qkvd, H, scale, keep, float(torch.tensor(p, dtype=torch.float32)), dod)
+    o, lse = ops.attn_fwd_dropout(dev(qkv).reshape(B * N, 3 * D), B, N, H, scale, p, seed, offset)
+    assert rel_err(o.cpu().reshape(B, N, D), oref) < BF16_OUT
+    assert float((lse.cpu().double() - lref).abs().max()) < 2e-4
+    # a different offset is a different mask; the same arguments the same bits
+    o2, _ = ops.attn_fwd_dropout(dev(qkv).reshape(B * N, 3 * D), B, N, H, scale, p, seed, offset + 1)
+    o3, _ = ops.attn_fwd_dropout(dev(qkv).reshape(B * N, 3 * D), B, N, H, scale, p, seed, offset)
+    assert not torch.equal(o2, o) and torch.equal(o3, o)
+    # backward evaluated at the 16-bit o the kernel saved (delta = rowsum(dO o O))
+    _, _, dref = O.attention_dropout_fwd_bwd(qkvd, H, scale, keep, float(torch.tensor(p, dtype=torch.float32)), dod)
+    got = ops.attn_bwd_dropout(dev(qkv).reshape(B * N, 3 * D), o, dev(do).reshape(B * N, D), lse, B, N, H, scale, p, seed, offset).cpu().reshape(B, N, 3 * D)
+    for i, nm in enumerate(("dq", "dk", "dv")):
+        e = rel_err(got[..., i * D:(i + 1) * D], dref[..., i * D:(i + 1) * D])
+        assert e < 2e-2, (nm, e)
+    with pytest.raises(Exception):
+        ops.attn_fwd_dropout(dev(qkv).reshape(B * N, 3 * D), B, N, H, scale, 1.0, seed)
+
+
 @pytest.mark.parametrize("attn_variant", [0, 1], indirect=True)
 def test_attention_online_softmax_rescale_branch(ops, attn_variant):
     """Force the running max to jump at a later key block (guide rule 26): one key spikes against every query."""

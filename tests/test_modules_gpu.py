@@ -231,3 +231,31 @@ def test_sixteen_bit_gradient_stream_against_the_fp32_one(half):
     assert set(res["stream"][2]) == set(res["fp32"][2]) and len(res["stream"][2]) == 8        # proj_weight1 / proj_bias1 of four blocks
     for n, g_ in res["fp32"][2].items():
         assert rel_err(res["stream"][2][n].cpu(), g_.double().cpu()) < (2e-2 if half == torch.bfloat16 else 3e-3), n
+
+
+def test_apla_attention_with_attention_dropout_trains_and_is_the_identity_in_eval_mode():
+    """`main.py --adr` (src/main.py:109-111 -> attn_drop_rate -> APLA_Attention(attn_drop=)): in training mode the module's forward goes
+    through the dropout attention kernels (different outputs for different draws, gradients for every trainable tensor, the expected
+    value of the output close to the undropped one); in evaluation mode the dropout is the identity (bitwise the p = 0 module)."""
+    from apla_amd.apla.appla_attn import APLA_Attention
+    D, H, B, N = 128, 2, 4, 197
+    att, ref = make_module(APLA_Attention, D, H, 16, seed=3).cuda(), make_module(APLA_Attention, D, H, 16, seed=3).cuda()
+    att.attn_drop.p = 0.2                      # (what APLA_Attention(attn_drop=0.2) sets: nn.Dropout(attn_drop), appla_attn.py:46)
+    assert torch.equal(att.inds, ref.inds) and torch.equal(att.proj_weight1, ref.proj_weight1)
+    x = torch.randn(B, N, D, device="cuda")
+    att.eval(), ref.eval()
+    assert torch.equal(att(x)[0], ref(x)[0])
+    att.train(), ref.train()
+    torch.manual_seed(1)
+    y1 = att(x)[0]
+    y2 = att(x)[0]
+    torch.manual_seed(1)
+    y1b = att(x)[0]
+    assert torch.equal(y1, y1b) and not torch.equal(y1, y2)          # the seed comes from torch's CPU generator
+    y0 = ref(x)[0]
+    mean = torch.stack([att(x)[0].float() for _ in range(48)]).mean(0)
+    assert float((mean - y0.float()).abs().max()) < 0.35 * float((y1.float() - y0.float()).abs().max())   # E[dropout(attn)] = attn
+    xg = x.clone().requires_grad_(True)
+    att(xg)[0].float().square().mean().backward()
+    assert att.proj_weight1.grad is not None and att.proj_bias1.grad is not None and xg.grad is not None
+    assert float(att.proj_weight1.grad.abs().max()) > 0 and torch.isfinite(xg.grad).all()
