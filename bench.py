@@ -71,6 +71,22 @@ def dominant_kernel_held_clock():
         return None
 
 
+SUSTAINED_FILE = os.path.join(ROOT, "profiles", "bench_sustained.json")   # the same command with --steps 3000, committed per round
+
+
+def sustained_record():
+    """A STORED figure beside the short window this run times: the same bench command over 3 000 steps (37 s), where the socket's power
+    controller has no averaging window left to draw from and the step time is the steady-state one.  Provenance
+    (file, round, code version) travels with it; null when the file is missing."""
+    try:
+        with open(SUSTAINED_FILE) as f:
+            d = json.load(f)
+        return {"stored": True, "file": os.path.relpath(SUSTAINED_FILE, ROOT), "taken_at": d.get("taken_at"), "steps": d["steps"],
+                "ms_per_step": d["ms_per_step"], "images_per_sec": d["value"], "socket_w_mean": (d.get("power") or {}).get("mean_w")}
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def build_model(backbone, r, n_classes, img, patch, seed=0):
     from apla_amd.models import Classifier
     torch.manual_seed(seed)
@@ -599,6 +615,8 @@ def main():
                       "reserved_cus": eng.reserve_cus,
                       "env": {k: os.environ.get(k) for k in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS", "APLA_RESERVE_CUS", "APLA_FORCE_EXCHANGE")}},
             "final_loss": round(loss, 4),
+            # steady state of the same command (a stored record: the short window above can draw on the power controller's averaging)
+            "sustained": sustained_record() if is_cfg2 and world == 1 and args.dtype == "bf16" else None,
             # rank 0's socket during the timed steps: the GEMM launches of the step run AT the cap (tools/power_probe.py)
             "power": power,
             "roofline": {"bound": "mfma", "kernel": f"{dom_kernel} (apla_gemm_nt, fc1+activation launch) M={M} N={Fdim} K={bb.embed_dim}",

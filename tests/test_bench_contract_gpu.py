@@ -50,6 +50,8 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert pm["fp16"]["logits_rel_max"] < 2.0e-3 and pm["fp16"]["logits_rel_l2"] < 1.5e-3 and abs(pm["fp16"]["loss"] - pm["loss_reference"]) < 1e-3
     assert pm["fp16"]["logits_rel_max"] < pm["bf16"]["logits_rel_max"]
     assert f16["steps"] == 3 and f16["ms_per_step"] > 0 and abs(f16["images_per_sec"] - 128 / (f16["ms_per_step"] * 1e-3)) < 0.01 * f16["images_per_sec"]
+    su = d["sustained"]                          # the steady-state figure of the same command: a stored record with its provenance
+    assert su is None or (su["stored"] is True and su["file"].startswith("profiles/") and su["steps"] >= 1000 and su["ms_per_step"] > 0.9 * d["ms_per_step"] * 0.8)
     rk = d["ranks"]                              # a one-rank run has no exchange: nothing waited for
     assert rk["ms_per_step"] == [rk["ms_per_step_min"]] == [rk["ms_per_step_max"]] and rk["exchange_wait_ms"] == [None] and rk["exchange_chunks"] == 0
     pw = d["power"]                              # socket telemetry of the timed steps (null only where the driver's hwmon files are missing)
