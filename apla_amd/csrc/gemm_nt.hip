@@ -171,7 +171,8 @@ __global__ __launch_bounds__(256, 2) void gemm_persist_kernel(GemmParams p, int 
   constexpr int BMv = 32 * MI;
   constexpr int STG = (BMv + BN) * BK * 2;
   __shared__ __attribute__((aligned(16))) char smem[2 * STG + 2048];  // + 2 x 1 KB bias pieces
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int frow = lane & 15, fq = lane >> 4;
   const int nk = p.K / BK;
@@ -183,36 +184,50 @@ __global__ __launch_bounds__(256, 2) void gemm_persist_kernel(GemmParams p, int 
   const int slots = (G >> 3) + ((G & 7) > xcd ? 1 : 0);
   const bool has_bias = p.bias != nullptr;
 
-  const bf16* a_src[MI];
-  const bf16* w_src[4];
+  // LDS-DMA addressing (round 5): a piece's source is a wave-uniform 64-bit base (tile origin + K offset: scalar registers, two scalar
+  // adds per K-step) plus a 32-bit lane offset that does not depend on the K-step — `global_load_lds_dwordx4 voff, s[base]`, its LDS
+  // destination written to m0 from scalar arithmetic.  With per-lane 64-bit pointers (18 registers) hipcc issued per piece and K-step
+  // a 64-bit vector add, a vector add + v_readfirstlane for m0 (the wave index was not known to be uniform) and a 64-bit register
+  // copy: 36 vector instructions per wave and K-step beside 40 MFMAs — and vector and matrix work of the two waves of a SIMD do not
+  // overlap in these kernels.  The W offsets are the same for every tile; the A offsets differ only in the
+  // last row tile (rows >= M re-read row M - 1).
+  const char* a_base = nullptr;
+  const char* w_base = nullptr;
+  unsigned a_off[MI], w_off[4];
   const float* b_src = nullptr;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int row = (wave * 4 + it) * 8 + (lane >> 3);   // LDS row; holds W row w_row_of_lds_row(row)
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    w_off[it] = (unsigned)((w_row_of_lds_row(row) * p.ldw + chunk * 8) * 2);
+  }
   auto setup = [&](int tile) {
     int tm, tn;
     tile_coords(tile, tiles_m, p.tiles_n, p.ngrp, tm, tn);
+    const int last = p.M - 1 - tm * BMv;    // last valid row of this tile (>= BMv - 1 except in the last row tile)
 #pragma unroll
     for (int it = 0; it < MI; ++it) {
       const int row = (wave * MI + it) * 8 + (lane >> 3);
       const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-      int gr = tm * BMv + row;
-      gr = gr < p.M ? gr : p.M - 1;
-      a_src[it] = p.A + (size_t)gr * p.lda + chunk * 8;
+      const int rel = row < last ? row : last;
+      a_off[it] = (unsigned)((rel * p.lda + chunk * 8) * 2);
     }
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int row = (wave * 4 + it) * 8 + (lane >> 3);   // LDS row; holds W row w_row_of_lds_row(row)
-      const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-      w_src[it] = p.W + (size_t)(tn * BN + w_row_of_lds_row(row)) * p.ldw + chunk * 8;
-    }
+    a_base = (const char*)(p.A + (size_t)tm * BMv * p.lda);
+    w_base = (const char*)(p.W + (size_t)tn * BN * p.ldw);
     if (has_bias) b_src = p.bias + tn * BN + (lane & 31) * 4;  // lanes 32..63 duplicate (keeps EXEC full, stays in bounds)
   };
+  auto dma = [&](unsigned lds_dst, unsigned voff, const char* sbase) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_dst), "v"(voff), "s"(sbase) : "memory");
+  };
   auto stage = [&](int sbuf, int k0) {
-    char* base = smem + sbuf * STG;
+    const unsigned base = lds0 + sbuf * STG;
+    const char* ak = a_base + (size_t)k0 * 2;
+    const char* wk = w_base + (size_t)k0 * 2;
 #pragma unroll
-    for (int it = 0; it < MI; ++it)
-      __builtin_amdgcn_global_load_lds(GLBP(a_src[it] + k0), LDSP(base + (wave * MI + it) * 1024), 16, 0, 0);
+    for (int it = 0; it < MI; ++it) dma(base + (wave * MI + it) * 1024, a_off[it], ak);
 #pragma unroll
-    for (int it = 0; it < 4; ++it)
-      __builtin_amdgcn_global_load_lds(GLBP(w_src[it] + k0), LDSP(base + BMv * BK * 2 + (wave * 4 + it) * 1024), 16, 0, 0);
+    for (int it = 0; it < 4; ++it) dma(base + BMv * BK * 2 + (wave * 4 + it) * 1024, w_off[it], wk);
   };
   auto stage_bias = [&](int bbuf) {
     if (has_bias && wave == 0) __builtin_amdgcn_global_load_lds(GLBP(b_src), LDSP(smem + 2 * STG + bbuf * 1024), 16, 0, 0);
