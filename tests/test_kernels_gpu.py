@@ -1052,7 +1052,7 @@ def test_cross_entropy_soft_targets(ops):
     assert abs(float(l1) - float(l2)) < 1e-6 * float(l2) and rel_err(d1.cpu(), d2.cpu().double()) < 1e-6
 
 
-@pytest.mark.parametrize("B,N", [(128, 197), (96, 50), (40, 256), (64, 257), (48, 288), (30, 225), (23, 32)])
+@pytest.mark.parametrize("B,N", [(128, 197), (96, 50), (40, 256), (64, 257), (48, 288), (30, 225), (23, 32), (60, 129), (90, 96)])
 def test_attn_bwd_fused_short_sequence_kernel_equals_split_kernels_at_full_occupancy(ops, B, N):
     """The one-workgroup-per-head backward (N <= 288) and the persistent backward (N <= 256: one workgroup per CU walking its
     heads, every load one phase ahead of its use) against the query-/key-blocked kernels on identical inputs, with enough

@@ -20,6 +20,14 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_sq -- python3 tools/gemm_one.py 3072 768 1 4 6 > /dev/null 2>&1
 python3 tools/pmc_summary.py $O/pmc_sq "gemm_persist_kernel" > $O/pmc_sq.txt
+# the two persistent attention kernels of the step: traffic and issue counters (same conventions)
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_attn_$c -- python3 tools/attn_one.py > /dev/null 2>&1
+  python3 tools/pmc_summary.py $O/pmc_attn_$c "attn_" > $O/pmc_attn_$c.txt
+done
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_attn_sq -- python3 tools/attn_one.py > /dev/null 2>&1
+python3 tools/pmc_summary.py $O/pmc_attn_sq "attn_" > $O/pmc_attn_sq.txt
+rm -rf $O/pmc_attn_FETCH_SIZE $O/pmc_attn_WRITE_SIZE $O/pmc_attn_sq
 python3 - <<PY
 import re, json
 def val(path, name):
