@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""A/B timing of the persistent attention backward's schedule experiments (bits 8.. of `variant`) in ONE process: interleaved rounds,
-median and minimum per variant (cdna guide, methodology rule 24).  ATT_B / ATT_N / ATT_XP="0,1,2,3,4,6" in the environment.  GPU only."""
+"""A/B timing harness of the attention backward in ONE process: interleaved rounds on four rotating operand sets, median and minimum
+per entry of ATT_XP (cdna guide, methodology rule 24).  Round 5 ran its schedule experiments and ablations through it as run-time flags
+in bits 8.. of `variant` (results: profiles/r05_attn_experiments.md); the flags were removed from the kernels afterwards, the library
+masks those bits off, so all entries now time the same kernel (base variant ATT_BASE, default 3 = persistent).  ATT_B / ATT_N.  GPU only."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""A/B timing of forward-attention schedule experiments (bits 8.. of `variant`) in one process, interleaved rounds.  GPU only."""
+"""Timing harness of the attention forward in one process (interleaved rounds, four rotating operand sets; ATT_BASE = kernel variant:
+0 auto / persistent, 2 one workgroup per head).  Round 5's ablation flags travelled in bits 8.. of `variant` (ATT_XP) and were removed
+from the kernels afterwards: profiles/r05_attn_experiments.md.  GPU only."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
