@@ -568,7 +568,9 @@ __device__ __forceinline__ void q_pin(QRegs& r) {
 }
 
 constexpr int FWDP_PAD_ROWS = 24;
-constexpr int FWDP_MAX_NT = 7;
+constexpr int FWDP_MAX_NT = 9;      // up to 7 blocks: one wave per block; 8 / 9: four waves walking the blocks
+constexpr int FWDP_BLOCK_WAVES = 4;
+constexpr int FWDP_MAX_ROWS = 280;   // 4 x 280 x 128 B of K, V + 3 KB of zero rows + 16 KB of store buffers = 159.0 KB of the CU's 160 KB
 template <int NT>
 __global__ __launch_bounds__(64 * (NT + 1), 2) void attn_fwd_persist_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
                                                                           float* __restrict__ lse, int N, int H, float scale,
@@ -772,6 +774,208 @@ __global__ __launch_bounds__(64 * (NT + 1), 2) void attn_fwd_persist_kernel(cons
 #if defined(APLA_ATT_STAMPS)
   if (lane == 0 && blockIdx.x < 512) for (int k_ = 0; k_ < 16; ++k_) apla_att_dbg[(blockIdx.x * 8 + wave) * 16 + k_] = st_acc[k_];
 #endif
+}
+
+// The same kernel for 8 or 9 blocks (225..288 tokens: the 257 of ViT-*/14 at 224 px).  16 NT score registers need two waves per SIMD,
+// so NW = 4 compute waves (+ the loader) WALK the query blocks of a head — wave w takes blocks w, w + 4, (w + 8) — with the same
+// pipeline per block as the kernel above has per head: the q rows of the wave's next block (of this head or of the next) are requested
+// when the block's last score product has been issued, O of the previous block is stored at the start of the next one.  One barrier
+// per head.  (A two-group online form with one wave per block needs three waves per SIMD = 168 registers and spills 41-57 under hipcc.)
+template <int NT, int NW>
+__global__ __launch_bounds__(64 * (NW + 1), 2) void attn_fwd_persist_blocks_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
+                                                                          float* __restrict__ lse, int N, int H, float scale,
+                                                                          int BH, int NR) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, h2 = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int D = H * 64;
+  const long ld = 3L * D;
+  const float c = scale * LOG2E;
+  const int TB = NR * 128;                 // bytes per buffer; layout K0 | K1 | V0 | V1 | zero rows
+  const int npc = NR >> 3;                 // 1 KB pieces (8 rows x 128 B) per buffer
+  const FragOffs fo = frag_offs(lane);
+  const unsigned k0a = lds_addr(smem), v0a = k0a + 2 * TB;
+
+  // zero rows behind V1, and the first rows of V1 itself: the first head's last V tile overruns V0 into V1 before any DMA has
+  // written there (whatever the LDS held times P = 0 must not be NaN)
+  for (int i = tid; i < FWDP_PAD_ROWS * 8; i += 64 * (NW + 1)) {
+    *(f32x4*)(smem + 4 * TB + i * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+    *(f32x4*)(smem + 3 * TB + i * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  auto base_of = [&](int idx) { const int b = idx / H, h = idx - b * H; return qkv + (long)b * N * ld + h * 64; };
+  // loader wave: K and V of one head, 2 * npc pieces of 8 rows x 128 B; the XOR swizzle of tile_off goes on the source column (the
+  // LDS side of a DMA is lane-linear).  A piece's address is (wave-uniform piece base) + (a 32-bit lane offset that takes two values,
+  // for even and odd pieces): nothing but scalar adds between two DMA instructions (computed per piece, the swizzle and the 64-bit
+  // row products cost ~240 cycles per piece: 11.8k cycles per head, more than the compute waves need for the head itself).  Only
+  // the buffer's last piece can hold rows >= N (they re-read row N - 1) and takes the long way.
+  const int lr = lane >> 3;
+  const int f_even = (((lr >> 1) & 1) << 2) | (lr >> 2);
+  const unsigned loff_even = (unsigned)(lr * (int)ld * 2 + (((lane & 7) ^ f_even) << 4));
+  const unsigned loff_odd = (unsigned)(lr * (int)ld * 2 + (((lane & 7) ^ f_even ^ 2) << 4));
+  const int nfull = N >> 3;   // pieces without a row >= N
+  auto stage_buf = [&](const bf16* src, char* dst) {
+    const char* pb = (const char*)src;
+    const long step = 8L * ld * 2;
+    int pr = 0;
+#pragma unroll 1
+    for (; pr + 1 < nfull; pr += 2) {
+      __builtin_amdgcn_global_load_lds(ATT_GLBP(pb + loff_even), ATT_LDSP(dst + pr * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(ATT_GLBP(pb + step + loff_odd), ATT_LDSP(dst + pr * 1024 + 1024), 16, 0, 0);
+      pb += 2 * step;
+    }
+    for (; pr < npc; ++pr) {   // an odd full piece and / or the ragged last piece
+      const int row = pr * 8 + lr;
+      const int f = (((row >> 1) & 1) << 2) | ((row >> 2) & 3);
+      const int gr = row < N ? row : N - 1;
+      __builtin_amdgcn_global_load_lds(ATT_GLBP(src + (long)gr * ld + (((lane & 7) ^ f) << 3)), ATT_LDSP(dst + pr * 1024), 16, 0, 0);
+    }
+  };
+  auto stage_head = [&](const bf16* hb, int par) {
+    stage_buf(hb + D, smem + par * TB);
+    stage_buf(hb + 2 * D, smem + 2 * TB + par * TB);
+  };
+
+  int idx = blockIdx.x;
+  if (idx >= BH) return;
+  const int G = gridDim.x;
+  if (wave == NW) {   // ------------------------------------------------------------------------------ loader wave
+    stage_head(base_of(idx), 0);
+    int par = 0;
+    while (true) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      const int next = idx + G;
+      if (next >= BH) break;
+      par ^= 1;
+      stage_head(base_of(next), par);
+      idx = next;
+    }
+    return;
+  }
+  // ---------------------------------------------------------------------------------------------------- compute waves
+  // head coordinates (b, h) advance by G heads per step without a division
+  const int gq = G / H, gr_ = G - gq * H;
+  int hb_ = idx / H, hh_ = idx - hb_ * H;       // current head
+  const bf16* base = qkv + (long)hb_ * N * ld + hh_ * 64;
+  QRegs qr;
+  {
+    const int q0 = wave * 32 + (lane & 31);
+    q_prefetch(qr, base + (long)(q0 < N ? q0 : N - 1) * ld + 8 * h2);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  q_pin(qr);
+  int par = 0;
+  bool have_prev = false;
+  int pb_ = hb_, ph_ = hh_, pblk = wave;        // the block whose O is still in registers (deferred store)
+  f32x16 acc_o[2];
+  float m_fin = 0.f, l_fin = 1.f;
+  char* wbuf = smem + 4 * TB + FWDP_PAD_ROWS * 128 + wave * 4096;   // this wave's 4 KB store buffer (whole-line stores: store_acc_T_staged)
+  auto store_prev = [&]() {   // block pblk of head (pb_, ph_)
+    const float l_tot = l_fin + __shfl_xor(l_fin, 32, 64);
+    store_acc_T_staged(acc_o, wbuf, o + (long)pb_ * N * D + ph_ * 64, D, pblk * 32, N, lane, 1.0f / l_tot);
+    const int pq = pblk * 32 + (lane & 31);
+    if (pq < N && h2 == 0) lse[((long)pb_ * H + ph_) * N + pq] = m_fin * scale + __logf(l_tot);
+  };
+  while (true) {
+    __builtin_amdgcn_s_barrier();   // K, V of head idx are in LDS (the loader waited for them); every wave is done with the previous head
+    asm volatile("" ::: "memory");
+    const int next = idx + G;
+    const bool has_next = next < BH;
+    int nb_ = hb_ + gq, nh_ = hh_ + gr_;
+    if (nh_ >= H) { nh_ -= H; ++nb_; }
+    const bf16* nbase = has_next ? qkv + (long)nb_ * N * ld + nh_ * 64 : base;
+#pragma unroll 1
+    for (int blk = wave; blk < NT; blk += NW) {
+    if (have_prev) store_prev();
+    // the wave's next block: of this head, else its first block of the next head (the very last block re-reads its own rows, never used)
+    const bool more = blk + NW < NT;
+    const int nq = (more ? blk + NW : wave) * 32 + (lane & 31);
+    const bf16* nqp = (more ? base : nbase) + (long)(nq < N ? nq : N - 1) * ld + 8 * h2;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = __builtin_bit_cast(bf16x8, qr.q[ks]);
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // per-head copies of the fragment bases behind an opaque move: every tile is then an instruction immediate away from four
+    // registers; left visible, hipcc hoists one address per (tile, fragment) out of the head loop — 56 lane constants at seven tiles
+    unsigned kr[4], vt[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      kr[k] = k0a + par * TB + fo.rf[k];
+      vt[k] = v0a + par * TB + fo.tr[k];
+      asm volatile("" : "+v"(kr[k]), "+v"(vt[k]));
+    }
+    // ---------------------------------------------------------------- S^T = K Q^T, all tiles
+    f32x16 sc[NT];
+    static_for<0, NT>([&](auto T) {
+      constexpr int t = decltype(T)::value, OFF = t * 4096;
+      sc[t] = MFMA_F32_32x32x16_H16(row_frag_at<OFF>(kr[0]), qf[0], zero);
+#pragma unroll
+      for (int ks = 1; ks < 4; ++ks) sc[t] = MFMA_F32_32x32x16_H16(row_frag_at<OFF>(kr[ks]), qf[ks], sc[t]);
+    });
+    asm volatile("" :: "v"(sc[NT - 1][15]));
+    q_prefetch(qr, nqp);   // qf is dead
+    if (N < 32 * NT) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if ((NT - 1) * 32 + acc_row(i, h2) >= N) sc[NT - 1][i] = -INFINITY;
+    }
+    // ---------------------------------------------------------------- softmax: one maximum per row
+    float mx = sc[0][0];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sc[t][i]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mc = mx * c;
+    float l = 0.f;
+    bf16x8 pp[NT][2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        sc[t][i] = __builtin_amdgcn_exp2f(fmaf(sc[t][i], c, -mc));
+        l += sc[t][i];
+      }
+      pp[t][0] = acc_to_operand(sc[t], 0);
+      pp[t][1] = acc_to_operand(sc[t], 1);
+    }
+    asm volatile("" :: "v"(pp[NT - 1][1]));
+    // ---------------------------------------------------------------- O^T = V^T P^T, all tiles
+    static_for<0, NT>([&](auto T) {
+      constexpr int t = decltype(T)::value, OFF = t * 4096;
+      TrPair tf[4];   // [2 sk + dt]
+      tr_issue_at<OFF>(tf[0], vt[0], vt[1]);
+      tr_issue_at<OFF>(tf[1], vt[2], vt[3]);
+      tr_issue_at<OFF + 2048>(tf[2], vt[0], vt[1]);
+      tr_issue_at<OFF + 2048>(tf[3], vt[2], vt[3]);
+      lds_landed(tf);
+      if constexpr (t == 0) {
+        acc_o[0] = MFMA_F32_32x32x16_H16(tr_join(tf[0]), pp[t][0], zero);
+        acc_o[1] = MFMA_F32_32x32x16_H16(tr_join(tf[1]), pp[t][0], zero);
+      } else {
+        acc_o[0] = MFMA_F32_32x32x16_H16(tr_join(tf[0]), pp[t][0], acc_o[0]);
+        acc_o[1] = MFMA_F32_32x32x16_H16(tr_join(tf[1]), pp[t][0], acc_o[1]);
+      }
+      acc_o[0] = MFMA_F32_32x32x16_H16(tr_join(tf[2]), pp[t][1], acc_o[0]);
+      acc_o[1] = MFMA_F32_32x32x16_H16(tr_join(tf[3]), pp[t][1], acc_o[1]);
+    });
+    asm volatile("" :: "v"(acc_o[0][15]), "v"(acc_o[1][15]));
+    m_fin = mx;
+    l_fin = l;
+    // the q rows of the wave's next block: requested a softmax and a PV ago
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    q_pin(qr);
+    have_prev = true;
+    pb_ = hb_; ph_ = hh_; pblk = blk;
+    }
+    if (!has_next) break;
+    idx = next;
+    hb_ = nb_; hh_ = nh_;
+    base = nbase;
+    par ^= 1;
+  }
+  if (have_prev) store_prev();
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dQ (+delta)
@@ -1866,14 +2070,14 @@ static void apla_allow_lds(std::atomic<unsigned long long>& mask, const void* ke
 
 // B sequences of (at most) N tokens; cu == nullptr: uniform batch, else packed with cu[B+1] token offsets and `total` tokens
 // Which kernel a launch takes (ONE decision code for the launch and for apla_attn_kernel_name).  `packed`: block-diagonal batch.
-enum AttnKernel { ATTN_FWD_BLOCKED, ATTN_FWD_SMALL, ATTN_FWD_PERSIST, ATTN_BWD_SPLIT, ATTN_BWD_SMALL, ATTN_BWD_TINY, ATTN_BWD_PERSIST };
+enum AttnKernel { ATTN_FWD_BLOCKED, ATTN_FWD_SMALL, ATTN_FWD_PERSIST, ATTN_BWD_SPLIT, ATTN_BWD_SMALL, ATTN_BWD_TINY, ATTN_BWD_PERSIST, ATTN_FWD_PERSIST_BLOCKS };
 static const char* const ATTN_KERNEL_NAMES[] = {"attn_fwd_kernel", "attn_fwd_small_kernel", "attn_fwd_persist_kernel", "attn_bwd_dq_kernel + attn_bwd_dkv_kernel",
-                                                "attn_bwd_small_kernel<288,4>", "attn_bwd_small_kernel<64,2>", "attn_bwd_persist_kernel"};
+                                                "attn_bwd_small_kernel<288,4>", "attn_bwd_small_kernel<64,2>", "attn_bwd_persist_kernel", "attn_fwd_persist_blocks_kernel"};
 static AttnKernel attn_fwd_choice(bool packed, int B, int N, int H, int variant) {
   // uniform batch of short sequences with at least one head per CU: the persistent kernel (variant 2 pins the
   // one-workgroup-per-head kernel, variant 3 the persistent one wherever it applies)
-  if (!packed && N > TINY_MAX_ROWS && N <= 32 * FWDP_MAX_NT && variant != 1 && variant != 2 && (variant == 3 || (long)B * H >= apla_num_cus()))
-    return ATTN_FWD_PERSIST;
+  if (!packed && N > TINY_MAX_ROWS && N <= FWDP_MAX_ROWS && variant != 1 && variant != 2 && (variant == 3 || (long)B * H >= apla_num_cus()))
+    return N <= 224 ? ATTN_FWD_PERSIST : ATTN_FWD_PERSIST_BLOCKS;   // one wave per 32-row block up to 7 blocks, four waves walking 8 or 9
   return (N <= SMALL_MAX_ROWS && variant != 1) ? ATTN_FWD_SMALL : ATTN_FWD_BLOCKED;
 }
 static AttnKernel attn_bwd_choice(bool packed, int B, int N, int H, int variant) {
@@ -1891,10 +2095,17 @@ static int launch_attn_fwd(const void* qkv, void* o, float* lse, const int32_t* 
   g_attn_variant &= 0xff;
   APLA_REQUIRE(g_attn_variant >= 0 && g_attn_variant <= 3, "%s: unknown kernel variant %d", who, g_attn_variant);
   const AttnKernel kchoice = attn_fwd_choice(cu != nullptr, B, N, H, g_attn_variant);
-  if (kchoice == ATTN_FWD_PERSIST) {
+  if (kchoice == ATTN_FWD_PERSIST || kchoice == ATTN_FWD_PERSIST_BLOCKS) {
     const int nt = (N + 31) / 32, BH = B * H, NR = (N + 7) / 8 * 8;
-    const size_t lds = (size_t)(4 * NR + FWDP_PAD_ROWS) * 128 + (size_t)nt * 4096;   // K0 K1 V0 V1, zero rows, per-wave store buffers
+    const size_t lds = (size_t)(4 * NR + FWDP_PAD_ROWS) * 128 + (size_t)(nt <= 7 ? nt : FWDP_BLOCK_WAVES) * 4096;   // K0 K1 V0 V1, zero rows, per-wave store buffers
     const int G = BH < apla_num_cus() ? BH : apla_num_cus();
+#define APLA_FWDPB_CASE(NTV)                                                                                                         \
+    case NTV: {                                                                                                                      \
+      auto kern = attn_fwd_persist_blocks_kernel<NTV, FWDP_BLOCK_WAVES>;                                                             \
+      static std::atomic<unsigned long long> lds_ok{0};                                                                              \
+      apla_allow_lds(lds_ok, (const void*)kern, (int)lds);                                                                           \
+      hipLaunchKernelGGL(kern, dim3(G), dim3(64 * (FWDP_BLOCK_WAVES + 1)), lds, stream, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, BH, NR); \
+    } break;
 #define APLA_FWDP_CASE(NTV)                                                                                                          \
     case NTV: {                                                                                                                      \
       auto kern = attn_fwd_persist_kernel<NTV>;                                                                                      \
@@ -1903,10 +2114,11 @@ static int launch_attn_fwd(const void* qkv, void* o, float* lse, const int32_t* 
       hipLaunchKernelGGL(kern, dim3(G), dim3(64 * (NTV + 1)), lds, stream, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, BH, NR);     \
     } break;
     switch (nt) {
-      APLA_FWDP_CASE(3) APLA_FWDP_CASE(4) APLA_FWDP_CASE(5) APLA_FWDP_CASE(6) APLA_FWDP_CASE(7)
+      APLA_FWDP_CASE(3) APLA_FWDP_CASE(4) APLA_FWDP_CASE(5) APLA_FWDP_CASE(6) APLA_FWDP_CASE(7) APLA_FWDPB_CASE(8) APLA_FWDPB_CASE(9)
       default: apla_set_error("%s: bad block count %d", who, nt); return APLA_EINVAL;
     }
 #undef APLA_FWDP_CASE
+#undef APLA_FWDPB_CASE
     APLA_CHECK_LAUNCH(who);
     return APLA_OK;
   }
