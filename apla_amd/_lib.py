@@ -60,6 +60,7 @@ SIGNATURES = {
     "apla_attn_fwd_cls": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "apla_attn_bwd_cls": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "apla_attn_probs": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
+    "apla_attn_probs_dropout": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_ulonglong, c_uint, c_void_p]),
     "apla_dw_workspace_bytes": (c_long, [c_int, c_int, c_int]),
     "apla_proj_dw": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                              c_int, c_void_p]),

@@ -54,8 +54,10 @@ class APLA_Attention(nn.Module):
     def _attend(self, x):
         B, N, _ = x.shape
         qkv = AF.linear(x, self.qkv.weight, self.qkv.bias)
-        o, lse = AF.attention_core(qkv, B, N, self.num_heads, self.scale, AF.active_p(self.attn_drop, self.training))   # appla_attn.py:56-60
-        return qkv, o, lse
+        p = AF.active_p(self.attn_drop, self.training)
+        seed = AF.draw_seed() if p > 0.0 else 0
+        o, lse = AF.attention_core(qkv, B, N, self.num_heads, self.scale, p, seed)   # appla_attn.py:56-60
+        return qkv, o, lse, (p, seed)
 
     def _project(self, o, gamma=None):
         return AF.apla_projection(o, self.proj_weight1, self.proj_bias1, self.proj_weight2, self.proj_bias2,
@@ -65,10 +67,10 @@ class APLA_Attention(nn.Module):
         """``ls_gamma`` (extension, used by VisionTransformer.run_blocks): the block's frozen LayerScale vector; when given,
         x is ls1(attention(x)) with the scale folded into the projection GEMM."""
         B, N, _ = x.shape
-        qkv, o, lse = self._attend(x)
+        qkv, o, lse, (p, seed) = self._attend(x)
         # proj_drop (appla_attn.py:82) commutes with the LayerScale vector folded into the projection: both are element-wise
         y = AF.dropout(self._project(o, ls_gamma).to(x.dtype), self.proj_drop, self.training)
         attn = None
         if self.return_attn_matrix:
-            attn = ops.attn_probs(qkv.detach().reshape(B * N, -1), lse, B, N, self.num_heads, self.scale)
+            attn = ops.attn_probs(qkv.detach().reshape(B * N, -1), lse, B, N, self.num_heads, self.scale, p, seed)   # after attn_drop (:58, :83)
         return y, attn

@@ -1894,8 +1894,11 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_persist_kernel(const bf16* __
 
 // ------------------------------------------------------------------------------------------------ attention matrix on demand
 // attn[b,h,q,k] = exp(q·k*scale - lse[q]).  Visualisation path only (Block.forward(return_attention=True)); plain VALU.
+// DROP: the matrix the reference returns in training mode — after its dropout (appla_attn.py:56-58, 83): kept entries / (1 - p),
+// the others 0, with the keep decision of the forward / backward kernels (drop_keep4 of (row, key group)).
+template <bool DROP>
 __global__ __launch_bounds__(256) void attn_probs_kernel(const bf16* __restrict__ qkv, const float* __restrict__ lse,
-                                                         float* __restrict__ attn, int N, int H, float scale) {
+                                                         float* __restrict__ attn, int N, int H, float scale, DropArgs da) {
   const int b = blockIdx.z, h = blockIdx.y, q = blockIdx.x;
   const int D = H * 64;
   const long ld = 3L * D;
@@ -1903,7 +1906,8 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(const bf16* __restrict_
   __shared__ float qs[64];
   if (threadIdx.x < 64) qs[threadIdx.x] = (float)qrow[threadIdx.x];
   __syncthreads();
-  const float l = lse[((long)b * H + h) * N + q];
+  const long row = ((long)b * H + h) * N + q;
+  const float l = lse[row];
   for (int k = threadIdx.x; k < N; k += 256) {
     const bf16* krow = qkv + ((long)b * N + k) * ld + D + h * 64;
     float acc = 0.f;
@@ -1913,7 +1917,9 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(const bf16* __restrict_
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc += qs[d8 * 8 + j] * (float)kv[j];
     }
-    attn[(((long)b * H + h) * N + q) * N + k] = __expf(acc * scale - l);
+    float pr = __expf(acc * scale - l);
+    if constexpr (DROP) pr = ((drop_keep4(da, (unsigned long long)row, (unsigned)k >> 2) >> (k & 3)) & 1) ? pr * da.inv_keep : 0.f;
+    attn[row * N + k] = pr;
   }
 }
 
@@ -2282,6 +2288,16 @@ extern "C" int apla_attn_bwd_dropout(const void* qkv, const void* o, const void*
   return APLA_OK;
 }
 
+extern "C" int apla_attn_probs_dropout(const void* qkv, const float* lse, float* attn, int B, int N, int H, float scale, float p,
+                                       unsigned long long seed, unsigned offset, hipStream_t stream) {
+  APLA_REQUIRE(qkv && lse && attn && B > 0 && N > 0 && H > 0 && B <= 65535 && H <= 65535, "apla_attn_probs_dropout: bad arguments");
+  DropArgs da;
+  if (int rc = drop_args(p, seed, offset, da, "apla_attn_probs_dropout")) return rc;
+  hipLaunchKernelGGL(attn_probs_kernel<true>, dim3(N, H, B), dim3(256), 0, stream, (const bf16*)qkv, lse, attn, N, H, scale, da);
+  APLA_CHECK_LAUNCH("apla_attn_probs_dropout");
+  return APLA_OK;
+}
+
 extern "C" int apla_attn_fwd_cls(const void* qkv, void* o, float* lse, int B, int N, int H, float scale,
                                  hipStream_t stream) {
   APLA_REQUIRE(qkv && o && lse && B > 0 && N > 0 && H > 0 && B <= 65535, "apla_attn_fwd_cls: bad arguments");
@@ -2293,7 +2309,7 @@ extern "C" int apla_attn_fwd_cls(const void* qkv, void* o, float* lse, int B, in
 extern "C" int apla_attn_probs(const void* qkv, const float* lse, float* attn, int B, int N, int H, float scale,
                                hipStream_t stream) {
   APLA_REQUIRE(qkv && lse && attn && B > 0 && N > 0 && H > 0 && B <= 65535 && H <= 65535, "apla_attn_probs: bad arguments");
-  hipLaunchKernelGGL(attn_probs_kernel, dim3(N, H, B), dim3(256), 0, stream, (const bf16*)qkv, lse, attn, N, H, scale);
+  hipLaunchKernelGGL(attn_probs_kernel<false>, dim3(N, H, B), dim3(256), 0, stream, (const bf16*)qkv, lse, attn, N, H, scale, DropArgs{});
   APLA_CHECK_LAUNCH("apla_attn_probs");
   return APLA_OK;
 }

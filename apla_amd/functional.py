@@ -502,27 +502,31 @@ class _AttnCoreDropFn(torch.autograd.Function):
         return dqkv.reshape(B, N, -1), None, None, None, None, None, None
 
 
-def attention_core(qkv, B, N, H, scale, attn_drop: float = 0.0):
-    """(o, lse).  ``attn_drop`` > 0: dropout on the attention probabilities with a fresh 64-bit seed drawn from torch's CPU generator
-    (``torch.manual_seed`` makes a run repeatable), as ``dropout`` does."""
+def draw_seed() -> int:
+    """A fresh 64-bit seed from torch's CPU generator (``torch.manual_seed`` makes a run repeatable), as ``dropout`` draws its own."""
+    return int(torch.empty((), dtype=torch.int64).random_())
+
+
+def attention_core(qkv, B, N, H, scale, attn_drop: float = 0.0, seed: Optional[int] = None):
+    """(o, lse).  ``attn_drop`` > 0: dropout on the attention probabilities under ``seed`` (default: a fresh ``draw_seed()``)."""
     if qkv.shape[-1] != 3 * H * 64:
         raise NotImplementedError(f"the HIP attention kernel needs head_dim 64 (got {qkv.shape[-1] // (3 * H)})")
     if attn_drop and attn_drop > 0.0:
         if attn_drop >= 1.0:
             raise ValueError("attn_drop must be < 1")
-        seed = int(torch.empty((), dtype=torch.int64).random_())
-        return _AttnCoreDropFn.apply(qkv, B, N, H, scale, float(attn_drop), seed)
+        return _AttnCoreDropFn.apply(qkv, B, N, H, scale, float(attn_drop), draw_seed() if seed is None else int(seed))
     return _AttnCoreFn.apply(qkv, B, N, H, scale)
 
 
 def attention_module_forward(x, qkv_w, qkv_b, proj_w, proj_b, num_heads, scale, want_attn, attn_drop: float = 0.0):
-    """Plain (non-APLA) Attention.forward, vit.py:184-196: returns (x, attn|None).  The attention matrix returned on demand is the
-    softmax itself (before its dropout), as the kernels keep only its log-sum-exp."""
+    """Plain (non-APLA) Attention.forward, vit.py:184-196: returns (x, attn|None).  The attention matrix returned on demand is
+    rebuilt from qkv and the kernels' log-sum-exp — after its dropout when ``attn_drop`` is active, as the reference returns it."""
     B, N, _ = x.shape
     qkv = linear(x, qkv_w, qkv_b)
-    o, lse = attention_core(qkv, B, N, num_heads, scale, attn_drop)
+    seed = draw_seed() if attn_drop and attn_drop > 0.0 else 0
+    o, lse = attention_core(qkv, B, N, num_heads, scale, attn_drop, seed)
     y = linear(o, proj_w, proj_b).to(x.dtype)
-    attn = ops.attn_probs(qkv.detach().reshape(B * N, -1), lse, B, N, num_heads, scale) if want_attn else None
+    attn = ops.attn_probs(qkv.detach().reshape(B * N, -1), lse, B, N, num_heads, scale, attn_drop or 0.0, seed) if want_attn else None
     return y, attn
 
 

@@ -578,13 +578,20 @@ def attn_bwd_cls(qkv: torch.Tensor, o: torch.Tensor, do_cls: torch.Tensor, lse: 
     return dqkv
 
 
-def attn_probs(qkv: torch.Tensor, lse: torch.Tensor, B: int, N: int, H: int, scale: float) -> torch.Tensor:
+def attn_probs(qkv: torch.Tensor, lse: torch.Tensor, B: int, N: int, H: int, scale: float, p: float = 0.0, seed: int = 0,
+               offset: int = 0) -> torch.Tensor:
+    """softmax(q k^T scale) [B, H, N, N] fp32 from qkv and the forward's lse; ``p`` > 0: the matrix after the dropout that
+    attn_fwd_dropout applied with the same (p, seed, offset) — kept entries / (1 - p), the others 0 (appla_attn.py:56-58, 83)."""
     _req(qkv, half(), "qkv", 2), _req(lse, torch.float32, "lse", 3)
-    if tuple(qkv.shape) != (B * N, 3 * H * 64) or not qkv.is_contiguous() or tuple(lse.shape) != (B, H, N):
+    if tuple(qkv.shape) != (B * N, 3 * H * 64) or not qkv.is_contiguous() or tuple(lse.shape) != (B, H, N) or not lse.is_contiguous():
         raise ValueError("attn_probs: shape mismatch")
     attn = torch.empty(B, H, N, N, device=qkv.device, dtype=torch.float32)
-    check(lib().apla_attn_probs(qkv.data_ptr(), lse.data_ptr(), attn.data_ptr(), B, N, H, float(scale), _stream()),
-          "apla_attn_probs")
+    if p and p > 0.0:
+        check(lib().apla_attn_probs_dropout(qkv.data_ptr(), lse.data_ptr(), attn.data_ptr(), B, N, H, float(scale), float(p),
+                                            int(seed) & 0xFFFFFFFFFFFFFFFF, int(offset) & 0xFFFFFFFF, _stream()), "apla_attn_probs_dropout")
+    else:
+        check(lib().apla_attn_probs(qkv.data_ptr(), lse.data_ptr(), attn.data_ptr(), B, N, H, float(scale), _stream()),
+              "apla_attn_probs")
     return attn
 
 

@@ -234,6 +234,10 @@ int apla_attn_bwd_cls(const void* qkv, const void* o, const void* do_cls, const 
  * used only by Block.forward(return_attention=True) (vit.py:279-287). */
 int apla_attn_probs(const void* qkv, const float* lse, float* attn, int B, int N, int H, float scale,
                     hipStream_t stream);
+/* The same matrix AFTER the dropout of apla_attn_fwd_dropout with the same (p, seed, offset): kept entries / (1 - p), the others 0 —
+ * what APLA_Attention.forward returns in training mode (appla_attn.py:56-58, 83). */
+int apla_attn_probs_dropout(const void* qkv, const float* lse, float* attn, int B, int N, int H, float scale, float p,
+                            unsigned long long seed, unsigned offset, hipStream_t stream);
 
 /* The APLA output projection as one forward and one backward operator (appla_attn.py:62-79 and its autograd), composed of
  * the entry points of this header — no kernels of their own.

@@ -418,6 +418,15 @@ def test_attention_probability_dropout_fwd_bwd(ops, B, N, H, p):
         assert e < 2e-2, (nm, e)
     with pytest.raises(Exception):
         ops.attn_fwd_dropout(dev(qkv).reshape(B * N, 3 * D), B, N, H, scale, 1.0, seed)
+    # the matrix the module returns in training mode (appla_attn.py:58, :83): the softmax after the SAME dropout — zero exactly where the
+    # oracle's mask drops, softmax / (1 - p) elsewhere
+    t = qkvd.reshape(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    aref = torch.softmax((t[0] @ t[1].transpose(-2, -1)) * scale, -1) * keep.double() / (1.0 - float(torch.tensor(p, dtype=torch.float32)))
+    a = ops.attn_probs(dev(qkv).reshape(B * N, 3 * D), lse, B, N, H, scale, p, seed, offset).cpu()
+    assert torch.equal(a != 0, keep & (a != 0)) and float(((a == 0) != ~keep).float().mean()) < 1e-3    # (an underflowed kept entry may be 0)
+    assert float((a.double() - aref).abs().max()) < 2e-3 * float(aref.abs().max())
+    a0 = ops.attn_probs(dev(qkv).reshape(B * N, 3 * D), lse, B, N, H, scale).cpu()
+    assert float((a0.sum(-1) - 1).abs().max()) < 1e-3
 
 
 @pytest.mark.parametrize("attn_variant", [0, 1], indirect=True)

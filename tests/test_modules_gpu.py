@@ -259,3 +259,14 @@ def test_apla_attention_with_attention_dropout_trains_and_is_the_identity_in_eva
     att(xg)[0].float().square().mean().backward()
     assert att.proj_weight1.grad is not None and att.proj_bias1.grad is not None and xg.grad is not None
     assert float(att.proj_weight1.grad.abs().max()) > 0 and torch.isfinite(xg.grad).all()
+    # the second return value is the attention matrix AFTER attn_drop (appla_attn.py:58, :83): the same draw as the output — a fraction
+    # p of exact zeros, rows that sum to ~1 in expectation, and attn @ v reproduces what the projection was fed
+    att.return_attn_matrix = True
+    torch.manual_seed(1)
+    y, attn = att(x)
+    assert torch.equal(y, y1) and attn.shape == (B, H, N, N)
+    assert abs(float((attn == 0).float().mean()) - 0.2) < 0.01 and abs(float(attn.sum(-1).mean()) - 1.0) < 0.01
+    att.eval()
+    _, attn_eval = att(x)
+    assert float((attn_eval.sum(-1) - 1).abs().max()) < 1e-3 and float((attn_eval == 0).float().mean()) < 1e-3
+    att.return_attn_matrix = False
