@@ -18,6 +18,9 @@
 #include <type_traits>
 
 #include <atomic>
+#include <map>
+#include <mutex>
+#include <utility>
 
 #include "common.h"
 
@@ -2081,8 +2084,10 @@ static const char* const ATTN_KERNEL_NAMES[] = {"attn_fwd_kernel", "attn_fwd_sma
                                                 "attn_bwd_small_kernel<288,4>", "attn_bwd_small_kernel<64,2>", "attn_bwd_persist_kernel", "attn_fwd_persist_blocks_kernel"};
 static AttnKernel attn_fwd_choice(bool packed, int B, int N, int H, int variant) {
   // uniform batch of short sequences with at least one head per CU: the persistent kernel (variant 2 pins the
-  // one-workgroup-per-head kernel, variant 3 the persistent one wherever it applies)
-  if (!packed && N > TINY_MAX_ROWS && N <= FWDP_MAX_ROWS && variant != 1 && variant != 2 && (variant == 3 || (long)B * H >= apla_num_cus()))
+  // one-workgroup-per-head kernel, variant 3 the persistent one wherever it applies).  Measured against the one-workgroup-per-head
+  // kernel at 6 144 heads: 50 tokens 47.1 -> 32.5 us, 37 tokens 36.1 -> 24.5, 65 tokens 68.9 -> 44.6, 96 tokens 83.2 -> 59.8 (up to
+  // 96 tokens several workgroups share a CU: fwdp_grid; one per CU 45.0 / 42.1 / 55.6 / 64.5)
+  if (!packed && N <= FWDP_MAX_ROWS && variant != 1 && variant != 2 && (variant == 3 || (long)B * H >= apla_num_cus()))
     return N <= 224 ? ATTN_FWD_PERSIST : ATTN_FWD_PERSIST_BLOCKS;   // one wave per 32-row block up to 7 blocks, four waves walking 8 or 9
   return (N <= SMALL_MAX_ROWS && variant != 1) ? ATTN_FWD_SMALL : ATTN_FWD_BLOCKED;
 }
@@ -2096,6 +2101,28 @@ static AttnKernel attn_bwd_choice(bool packed, int B, int N, int H, int variant)
   return ATTN_BWD_SPLIT;
 }
 
+// Grid of a persistent forward launch: the workgroups that are resident at once (occupancy of the kernel at its LDS size x CUs),
+// never more than heads.  The occupancy query is a host-side table lookup of the runtime (no stream operation: safe under capture);
+// its answers are kept per (kernel, LDS size).
+static int fwdp_grid(const void* kern, int threads, size_t lds, int BH) {
+  static std::mutex mu;
+  static std::map<std::pair<const void*, size_t>, int> per_cu;
+  int k = 0;
+  {
+    std::lock_guard<std::mutex> g(mu);
+    auto it = per_cu.find({kern, lds});
+    if (it != per_cu.end()) k = it->second;
+  }
+  if (k == 0) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&k, kern, threads, lds) != hipSuccess || k < 1) { (void)hipGetLastError(); k = 1; }
+    if (k > 8) k = 8;
+    std::lock_guard<std::mutex> g(mu);
+    per_cu[{kern, lds}] = k;
+  }
+  const long g = (long)apla_num_cus() * k;
+  return (int)(BH < g ? BH : g);
+}
+
 static int launch_attn_fwd(const void* qkv, void* o, float* lse, const int32_t* cu, int total, int B, int N, int H,
                            float scale, int g_attn_variant, hipStream_t stream, const char* who) {
   g_attn_variant &= 0xff;
@@ -2104,12 +2131,13 @@ static int launch_attn_fwd(const void* qkv, void* o, float* lse, const int32_t* 
   if (kchoice == ATTN_FWD_PERSIST || kchoice == ATTN_FWD_PERSIST_BLOCKS) {
     const int nt = (N + 31) / 32, BH = B * H, NR = (N + 7) / 8 * 8;
     const size_t lds = (size_t)(4 * NR + FWDP_PAD_ROWS) * 128 + (size_t)(nt <= 7 ? nt : FWDP_BLOCK_WAVES) * 4096;   // K0 K1 V0 V1, zero rows, per-wave store buffers
-    const int G = BH < apla_num_cus() ? BH : apla_num_cus();
+    int G = 0;   // workgroups: as many per CU as fit (short sequences: up to eight small workgroups), each walking BH / G heads
 #define APLA_FWDPB_CASE(NTV)                                                                                                         \
     case NTV: {                                                                                                                      \
       auto kern = attn_fwd_persist_blocks_kernel<NTV, FWDP_BLOCK_WAVES>;                                                             \
       static std::atomic<unsigned long long> lds_ok{0};                                                                              \
       apla_allow_lds(lds_ok, (const void*)kern, (int)lds);                                                                           \
+      G = fwdp_grid((const void*)kern, 64 * (FWDP_BLOCK_WAVES + 1), lds, BH);                                                        \
       hipLaunchKernelGGL(kern, dim3(G), dim3(64 * (FWDP_BLOCK_WAVES + 1)), lds, stream, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, BH, NR); \
     } break;
 #define APLA_FWDP_CASE(NTV)                                                                                                          \
@@ -2117,10 +2145,11 @@ static int launch_attn_fwd(const void* qkv, void* o, float* lse, const int32_t* 
       auto kern = attn_fwd_persist_kernel<NTV>;                                                                                      \
       static std::atomic<unsigned long long> lds_ok{0};                                                                              \
       apla_allow_lds(lds_ok, (const void*)kern, (int)lds);                                                                           \
+      G = fwdp_grid((const void*)kern, 64 * (NTV + 1), lds, BH);                                                                     \
       hipLaunchKernelGGL(kern, dim3(G), dim3(64 * (NTV + 1)), lds, stream, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, BH, NR);     \
     } break;
     switch (nt) {
-      APLA_FWDP_CASE(3) APLA_FWDP_CASE(4) APLA_FWDP_CASE(5) APLA_FWDP_CASE(6) APLA_FWDP_CASE(7) APLA_FWDPB_CASE(8) APLA_FWDPB_CASE(9)
+      APLA_FWDP_CASE(1) APLA_FWDP_CASE(2) APLA_FWDP_CASE(3) APLA_FWDP_CASE(4) APLA_FWDP_CASE(5) APLA_FWDP_CASE(6) APLA_FWDP_CASE(7) APLA_FWDPB_CASE(8) APLA_FWDPB_CASE(9)
       default: apla_set_error("%s: bad block count %d", who, nt); return APLA_EINVAL;
     }
 #undef APLA_FWDP_CASE

@@ -185,14 +185,15 @@ int apla_attn_varlen_bwd(const void* qkv, const void* o, const void* d_o, const 
                          const int32_t* cu_seqlens, int S, int total, int max_n, int H, float scale, hipStream_t stream);
 
 /* The attention entry points with an explicit kernel choice (`variant`; the plain entry points pass 0):
- *   0 = auto: uniform batches of 65..224 tokens with at least one head per CU use the persistent forward (one workgroup per CU
- *       walking its heads, K / V double-buffered by a loader wave, one row maximum per head) and, up to 256 tokens, the persistent
- *       backward (every load one phase ahead of its use); other batches of up to 288 tokens the one-workgroup-per-head kernels
- *       (whole K / V of a head in LDS); longer sequences the key-/query-blocked kernels;
+ *   0 = auto: uniform batches of up to 280 tokens with at least one head per CU use the persistent forward (resident workgroups
+ *       walking their heads, K / V double-buffered by a loader wave, one row maximum per head: one wave per 32-row block up to 224
+ *       tokens — several small workgroups per CU up to 96 —, four waves walking 8 or 9 blocks above) and, for 65..256 tokens, the
+ *       persistent backward (every load one phase ahead of its use); other batches of up to 288 tokens the one-workgroup-per-head
+ *       kernels (whole K / V of a head in LDS); longer sequences the key-/query-blocked kernels;
  *   1 = always the blocked kernels; 2 = the one-workgroup-per-head kernels (never the persistent ones); 3 = the persistent
  *       kernels wherever they apply.  The backward kernels compute bitwise the same results, and so do the blocked and the
  *       one-workgroup-per-head forward; the persistent forward takes ONE maximum per row instead of a running one per 64 keys and
- *       agrees with them to rounding (tests/test_kernels_gpu.py).  Bits 8.. of `variant`: schedule experiments (diagnostics). */
+ *       agrees with them to rounding (tests/test_kernels_gpu.py).  Bits 8.. of `variant` are ignored. */
 int apla_attn_fwd_ex(const void* qkv, void* o, float* lse, int B, int N, int H, float scale, int variant, hipStream_t stream);
 /* Attention with dropout on the attention probabilities (appla_attn.py:56-58: attn = softmax(...); attn = self.attn_drop(attn); x = attn @ v;
  * settable from main.py:109-111 --adr, 0 in every shipped configuration): o = (keep ? attn / (1 - p) : 0) v.  The keep decision of

@@ -355,11 +355,13 @@ def test_attention_packed_as_runs_of_uniform_batches(ops, runs, H, half):
 
 
 @pytest.mark.parametrize("B,N,H", [(24, 197, 12), (128, 197, 12), (70, 129, 4), (40, 224, 8), (300, 65, 1),
-                                   (128, 257, 12), (30, 257, 12), (64, 256, 6), (50, 280, 8), (70, 225, 4), (1, 257, 2)])
+                                   (128, 257, 12), (30, 257, 12), (64, 256, 6), (50, 280, 8), (70, 225, 4), (1, 257, 2),
+                                   (100, 50, 6), (700, 33, 2), (2100, 17, 1), (64, 64, 4), (3000, 1, 1), (5, 50, 2)])
 def test_attention_persistent_forward_walks_its_heads(ops, B, N, H):
     """attn_fwd_persist_kernel with MORE heads than workgroups (one workgroup per CU walks its heads: double-buffered K / V fed by the
     loader wave, q rows requested a head ahead, O stored one head late) — the small cases of test_attention_fwd_bwd give every
-    workgroup exactly one head.  225..280 tokens: attn_fwd_persist_blocks_kernel (four waves walking the 8 or 9 query blocks).  Against the one-workgroup-per-head kernel (itself checked against the oracle there): one maximum per
+    workgroup exactly one head.  225..280 tokens: attn_fwd_persist_blocks_kernel (four waves walking the 8 or 9 query blocks); up to
+    128 tokens several small workgroups share a CU (the grid is the kernel's occupancy x CUs).  Against the one-workgroup-per-head kernel (itself checked against the oracle there): one maximum per
     row instead of four running ones, so equal to rounding — O within 4 ulp of the largest 16-bit output, lse within 2e-6 — and, on a sample
     of heads spread over the walk, against the fp64 oracle."""
     from apla_amd import ops as OPS
