@@ -1579,8 +1579,9 @@ constexpr int PERSIST_MAX_ROWS = 256;
 // NT = 32-row blocks per sequence (compile time: the four tiles then sit at instruction-immediate distances of NT * 4 KB).
 // STAGED: the dQ / dK / dV tiles leave through a per-wave 4 KB LDS buffer as whole lines (store_acc_T_staged); the eight buffers
 // fit beside the four tiles up to seven blocks (N <= 224), the eight-block case stores directly.
+constexpr int bwdp_waves(int nt) { return nt <= 7 ? nt + 1 : 8; }   // up to seven blocks: one wave per block + the loader wave
 template <int NT, bool STAGED>
-__global__ __launch_bounds__(512, 2) void attn_bwd_persist_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
+__global__ __launch_bounds__(64 * bwdp_waves(NT), 2) void attn_bwd_persist_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
                                                                   const bf16* __restrict__ dout, const float* __restrict__ lse,
                                                                   float* __restrict__ delta, bf16* __restrict__ dqkv, int N,
                                                                   int H, float scale, int BH) {
@@ -1637,6 +1638,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_persist_kernel(const bf16* __
   // plus a 32-bit lane offset that takes two values (even / odd pieces): scalar adds only between two DMA instructions.  Pieces
   // that hold rows >= N (they re-read row N - 1) take the long way: at most four per tile.
   constexpr bool LOADER = NT <= 7;
+  constexpr int LW = bwdp_waves(NT) - 1;   // the loader wave (LOADER): the workgroup has NT + 1 waves, so that short sequences run
+                                           // several workgroups per CU (8 waves of 238 registers fill a CU: 4 x 2, 2 x 3 or 2 x 4 waves)
   auto stage_tile_fast = [&](const bf16* src, long lds_, char* dst) {
     const int lr = lane >> 3;
     const int f_even = (((lr >> 1) & 1) << 2) | (lr >> 2);
@@ -1681,7 +1684,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_persist_kernel(const bf16* __
   if (idx >= BH) return;
   Head hd = head_of(idx);
   if constexpr (LOADER) {
-    if (wave == 7) {   // ---------------------------------------------------------------------------- loader wave
+    if (wave == LW) {   // --------------------------------------------------------------------------- loader wave
       stage_tile_fast(hd.base + D, ld, KA);
       stage_tile_fast(hd.base + 2 * D, ld, VA);
       while (true) {
@@ -2094,14 +2097,14 @@ static AttnKernel attn_fwd_choice(bool packed, int B, int N, int H, int variant)
 static AttnKernel attn_bwd_choice(bool packed, int B, int N, int H, int variant) {
   // uniform batch of short sequences with at least one head per CU: the persistent kernel (every load one phase ahead of its use);
   // variant 2 pins the one-workgroup-per-head kernels, variant 3 the persistent one wherever it applies (tests, A/B timing)
-  if (!packed && N <= PERSIST_MAX_ROWS && variant != 1 && variant != 2 && (variant == 3 || ((long)B * H >= apla_num_cus() && N > TINY_MAX_ROWS)))
+  if (!packed && N <= PERSIST_MAX_ROWS && variant != 1 && variant != 2 && (variant == 3 || (long)B * H >= apla_num_cus()))
     return ATTN_BWD_PERSIST;
   if (N <= TINY_MAX_ROWS && variant != 1) return ATTN_BWD_TINY;
   if (N <= SMALL_MAX_ROWS_BWD && variant != 1) return ATTN_BWD_SMALL;
   return ATTN_BWD_SPLIT;
 }
 
-// Grid of a persistent forward launch: the workgroups that are resident at once (occupancy of the kernel at its LDS size x CUs),
+// Grid of a persistent launch (forward and backward): the workgroups that are resident at once (occupancy of the kernel at its LDS size x CUs),
 // never more than heads.  The occupancy query is a host-side table lookup of the runtime (no stream operation: safe under capture);
 // its answers are kept per (kernel, LDS size).
 static int fwdp_grid(const void* kern, int threads, size_t lds, int BH) {
@@ -2180,14 +2183,15 @@ static int launch_attn_bwd(const void* qkv, const void* o, const void* d_o, cons
     const int NP = (N + 31) / 32 * 32, BH = B * H;
     const int nt = NP / 32;
     const bool staged = nt <= 7;       // 4 tiles + 2 KB + 8 x 4 KB of store buffers: 162 KB at eight blocks, one CU has 160
-    const size_t lds = (size_t)nt * 4096 * 4 + 2 * PERSIST_MAX_ROWS * 4 + (staged ? 8 * 4096 : 0);
-    const int G = BH < apla_num_cus() ? BH : apla_num_cus();
+    const size_t lds = (size_t)nt * 4096 * 4 + 2 * PERSIST_MAX_ROWS * 4 + (staged ? (size_t)nt * 4096 : 0);   // (a store buffer per compute wave)
+    int G = 0;
 #define APLA_PERSIST_CASE(NTV)                                                                                                       \
     case NTV: {                                                                                                                      \
       auto kern = attn_bwd_persist_kernel<NTV, (NTV <= 7)>;                                                                          \
       static std::atomic<unsigned long long> lds_ok{0};                                                                              \
       apla_allow_lds(lds_ok, (const void*)kern, (int)lds);                                                                           \
-      hipLaunchKernelGGL(kern, dim3(G), dim3(512), lds, stream, (const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse, delta, (bf16*)dqkv, N, H, scale, BH); \
+      G = fwdp_grid((const void*)kern, 64 * bwdp_waves(NTV), lds, BH);                                                               \
+      hipLaunchKernelGGL(kern, dim3(G), dim3(64 * bwdp_waves(NTV)), lds, stream, (const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse, delta, (bf16*)dqkv, N, H, scale, BH); \
     } break;
     switch (nt) {
       APLA_PERSIST_CASE(1) APLA_PERSIST_CASE(2) APLA_PERSIST_CASE(3) APLA_PERSIST_CASE(4)

@@ -1067,10 +1067,12 @@ def test_cross_entropy_soft_targets(ops):
     assert abs(float(l1) - float(l2)) < 1e-6 * float(l2) and rel_err(d1.cpu(), d2.cpu().double()) < 1e-6
 
 
-@pytest.mark.parametrize("B,N", [(128, 197), (96, 50), (40, 256), (64, 257), (48, 288), (30, 225), (23, 32), (60, 129), (90, 96)])
+@pytest.mark.parametrize("B,N", [(128, 197), (96, 50), (40, 256), (64, 257), (48, 288), (30, 225), (23, 32), (60, 129), (90, 96),
+                                 (512, 50), (300, 17), (120, 64), (70, 65), (400, 1)])
 def test_attn_bwd_fused_short_sequence_kernel_equals_split_kernels_at_full_occupancy(ops, B, N):
-    """The one-workgroup-per-head backward (N <= 288) and the persistent backward (N <= 256: one workgroup per CU walking its
-    heads, every load one phase ahead of its use) against the query-/key-blocked kernels on identical inputs, with enough
+    """The one-workgroup-per-head backward (N <= 288) and the persistent backward (N <= 256: resident workgroups of one wave per
+    32-row block + a loader wave walking their heads, every load one phase ahead of its use; up to 96 tokens two to four of them per
+    CU) against the query-/key-blocked kernels on identical inputs, with enough
     heads to fill the chip several times over: bitwise equal (same products in the same order), delta included, and
     reproducible.  (A first version of the fused kernel let the 64-float lse DMA pieces spill into the delta rows next to them:
     invisible at the small batches of the parity tests above, a race at full occupancy.)"""
