@@ -106,6 +106,38 @@ def test_fp16_attention_and_layernorm():
         assert y.dtype == torch.float16 and rel_err(y.cpu(), yref) < F16_OUT
 
 
+@pytest.mark.parametrize("B,N,H", [(64, 197, 4), (40, 257, 8), (300, 50, 2), (30, 256, 12)])
+def test_fp16_persistent_attention_kernels(B, N, H):
+    """The persistent attention kernels of the fp16 build at sizes that select them (at least one head per CU): the forward (one wave
+    per block / four waves walking nine blocks / several workgroups per CU) against the one-workgroup-per-head kernel and, on sampled
+    sequences, the fp64 oracle; the backward bitwise against the blocked kernels."""
+    from apla_amd import ops
+    D, scale = 64 * H, 64 ** -0.5
+    qkv, qkvd = hf(rnd(B * N, 3 * D, seed=41))
+    do, _ = hf(rnd(B * N, D, seed=42) * 1e-2)
+    with ops.use_half(torch.float16):
+        q, g = qkv.cuda(), do.cuda()
+        old = ops.set_attn_variant(2)
+        try:
+            o_ref, lse_ref = ops.attn_fwd(q, B, N, H, scale)
+            ops.set_attn_variant(0)
+            assert "persist" in ops.attn_kernel_name("fwd", B, N, H) and (N > 256 or "persist" in ops.attn_kernel_name("bwd", B, N, H))
+            o, lse = ops.attn_fwd(q, B, N, H, scale)
+            d0 = ops.attn_bwd(q, o, g, lse, B, N, H, scale).clone()
+            ops.set_attn_variant(1)
+            d1 = ops.attn_bwd(q, o, g, lse, B, N, H, scale).clone()
+        finally:
+            ops.set_attn_variant(old)
+    assert o.dtype == torch.float16 and torch.equal(d0, d1)
+    top = float(o_ref.float().abs().max())
+    assert float((o.float() - o_ref.float()).abs().max()) < 4 * 2 ** -12 * top      # a few units in the last place of the largest outputs
+    assert float((lse - lse_ref).abs().max()) < 2e-6 * max(1.0, float(lse_ref.abs().max()))
+    for b in (0, B - 1):
+        oref, lref = O.attention_fwd(qkvd[b * N:(b + 1) * N].reshape(1, N, 3 * D), H, scale)
+        assert rel_err(o[b * N:(b + 1) * N].cpu().reshape(1, N, D), oref) < F16_OUT
+        assert float((lse[b].cpu().double() - lref[0]).abs().max()) < 2e-4
+
+
 def test_fp16_engine_cfg1_logits_within_1e3_of_reference():
     """BASELINE config 1 with fp16 operands and a static loss scale: logits against the REFERENCE's CPU output within the
     north-star 1e-3; loss, gradients and the first AdamW step within (tighter than) the bf16 tolerances."""
