@@ -9,13 +9,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libapla_hip.so")          # bf16 operands (default, benchmarked)
 OUT_F16 = os.path.join(HERE, "libapla_hip_f16.so")  # same sources with -DAPLA_FP16: IEEE fp16 operands
-SOURCES = ["errors.cpp", "gemm_nt.hip", "gemm_pp2.hip", "gemm_w4.hip", "gemm_tp.hip", "gemm_small.hip", "layernorm.hip", "attention.hip", "apla_dw.hip", "optim.hip", "misc.hip"]
+SOURCES = ["errors.cpp", "gemm_nt.hip", "gemm_pp2.hip", "gemm_w4.hip", "gemm_tp.hip", "gemm_lw.hip", "gemm_small.hip", "layernorm.hip", "attention.hip", "apla_dw.hip", "optim.hip", "misc.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"]
 # Sources whose kernels count their own s_waitcnt (LDS-DMA rings, ds_read_tr pipelines, asm operand loads): a register spill puts scratch
 # loads and stores into the same in-order vmcnt queue and silently breaks those counts (round 4: the fused attention backward at
 # three waves per SIMD spilled 74 registers and returned wrong gradients).  Their objects are only accepted spill-free.
-NO_SPILL = ("gemm_nt.hip", "gemm_pp2.hip", "gemm_w4.hip", "gemm_tp.hip", "attention.hip", "apla_dw.hip", "layernorm.hip")
+NO_SPILL = ("gemm_nt.hip", "gemm_pp2.hip", "gemm_w4.hip", "gemm_tp.hip", "gemm_lw.hip", "attention.hip", "apla_dw.hip", "layernorm.hip")
 
 
 def _stale(obj, src):

@@ -543,6 +543,10 @@ __global__ __launch_bounds__(576, 4) void attn_fwd_small_kernel(const bf16* __re
 //   LDS    K and V double-buffered, [NR rows][64] each with NR = N rounded up to 8, then 24 zero rows (the last 32-row tile of V
 //          reads past NR: zeros times P = 0; the overrun of K lands in the next buffer and its scores are masked by select), then a
 //          4 KB store buffer per compute wave (O leaves as whole lines).
+//          LIMITATION (documented, not guarded): the last V tile of buffer V0 overruns into V1 — the NEXT head's V, possibly still
+//          under DMA — and relies on P = 0 for those keys: finite values there contribute exactly 0, but an Inf / NaN in the
+//          neighbouring head's V (an fp16 overflow upstream) gives 0 * Inf = NaN in an otherwise finite head.  The one-workgroup-per-
+//          head kernels (variant 2) have no such coupling; 24 private zero rows per V buffer do not fit the 160 KB at 280 tokens.
 //   head i barrier (K, V of head i landed; every wave is done with head i - 1) | loader: K, V of head i + 1 into the other buffers |
 //          store O of head i - 1 (deferred, so that no wave ever waits for its own stores) | QK^T of ALL tiles: S stays in 16 * NT
 //          registers, q rows of head i + 1 requested into the registers q just left | ONE row maximum, exp2, row sum, P rounded
@@ -2126,6 +2130,12 @@ static int fwdp_grid(const void* kern, int threads, size_t lds, int BH) {
   return (int)(BH < g ? BH : g);
 }
 
+// Dynamic LDS of a persistent-forward instantiation at the LONGEST sequence it serves (NR = N rounded up to 8 rows varies inside one
+// block count: 197 and 224 tokens are both NT = 7).  The limit is raised once per (instantiation, device), so it must be the maximum.
+static constexpr int fwdp_max_lds(int nt, int store_waves) {
+  return (4 * (32 * nt < FWDP_MAX_ROWS ? 32 * nt : FWDP_MAX_ROWS) + FWDP_PAD_ROWS) * 128 + store_waves * 4096;
+}
+
 static int launch_attn_fwd(const void* qkv, void* o, float* lse, const int32_t* cu, int total, int B, int N, int H,
                            float scale, int g_attn_variant, hipStream_t stream, const char* who) {
   g_attn_variant &= 0xff;
@@ -2139,7 +2149,7 @@ static int launch_attn_fwd(const void* qkv, void* o, float* lse, const int32_t* 
     case NTV: {                                                                                                                      \
       auto kern = attn_fwd_persist_blocks_kernel<NTV, FWDP_BLOCK_WAVES>;                                                             \
       static std::atomic<unsigned long long> lds_ok{0};                                                                              \
-      apla_allow_lds(lds_ok, (const void*)kern, (int)lds);                                                                           \
+      apla_allow_lds(lds_ok, (const void*)kern, fwdp_max_lds(NTV, FWDP_BLOCK_WAVES));   /* the instantiation's maximum, not this call's */ \
       G = fwdp_grid((const void*)kern, 64 * (FWDP_BLOCK_WAVES + 1), lds, BH);                                                        \
       hipLaunchKernelGGL(kern, dim3(G), dim3(64 * (FWDP_BLOCK_WAVES + 1)), lds, stream, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, BH, NR); \
     } break;
@@ -2147,7 +2157,7 @@ static int launch_attn_fwd(const void* qkv, void* o, float* lse, const int32_t* 
     case NTV: {                                                                                                                      \
       auto kern = attn_fwd_persist_kernel<NTV>;                                                                                      \
       static std::atomic<unsigned long long> lds_ok{0};                                                                              \
-      apla_allow_lds(lds_ok, (const void*)kern, (int)lds);                                                                           \
+      apla_allow_lds(lds_ok, (const void*)kern, fwdp_max_lds(NTV, NTV));                                                             \
       G = fwdp_grid((const void*)kern, 64 * (NTV + 1), lds, BH);                                                                     \
       hipLaunchKernelGGL(kern, dim3(G), dim3(64 * (NTV + 1)), lds, stream, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, BH, NR);     \
     } break;

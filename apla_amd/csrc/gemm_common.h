@@ -40,6 +40,8 @@ bool apla_gemm_w4_covers(int M, int N, int K, long lda, long ldw, int epilogue, 
 int apla_gemm_w4_tile_rows(int M, int N, int epilogue, int out_dtype, int exp, int reserve);    // 160, or 128
 int apla_gemm_tp_launch(const GemmParams& p, int epilogue, int out_dtype, hipStream_t stream);   // gemm_tp.hip
 bool apla_gemm_tp_covers(int M, int N, int K, long lda, long ldw, int epilogue, int out_dtype, int w_panel);
+int apla_gemm_lw_launch(const GemmParams& p, int epilogue, int out_dtype, hipStream_t stream);   // gemm_lw.hip (loader-wave form of the 4-wave kernel)
+bool apla_gemm_lw_covers(int M, int N, int K, long lda, long ldw, int epilogue, int out_dtype, int w_panel);
 
 // Tile walk.  Linear tile ids are dealt to XCDs in contiguous runs (each XCD has its own 4 MB L2).  With n fastest, a run
 // touches ALL column tiles, i.e. the whole weight matrix: fine while W fits next to the streaming A panels (N = 768:
@@ -272,8 +274,12 @@ __device__ __forceinline__ void persist_epilogue(const GemmParams& p, f32x4 (&ac
         Vec8IO<bf16>::store(c_at(m, n), lo, hi);
       } else if constexpr (EPI == APLA_EPI_GELU) {
         f32x4 hl, hh, gl, gh;
+#if defined(APLA_ABL_NOGELU)   // diagnostic build: both outputs are the accumulators (the two stores without the GELU arithmetic)
+        hl = lo; hh = hi; gl = lo; gh = hi;
+#else
         gelu_and_grad4(lo, hl, gl);
         gelu_and_grad4(hi, hh, gh);
+#endif
         Vec8IO<bf16>::store(c_at(m, n), hl, hh);
         Vec8IO<bf16>::store((bf16*)p.aux_out + ((p.w_panel & 8) ? ((size_t)(n >> 5) * p.M + m) * 32 + (n & 31) : (size_t)m * p.ld_aux_out + n), gl, gh);
       } else if constexpr (EPI == APLA_EPI_GELU_FWD) {

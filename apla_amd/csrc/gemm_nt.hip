@@ -194,7 +194,8 @@ __global__ __launch_bounds__(256, 2) void gemm_persist_kernel(GemmParams p, int 
   const char* a_base = nullptr;
   const char* w_base = nullptr;
   unsigned a_off[MI], w_off[4];
-  const float* b_src = nullptr;
+  const char* b_src = nullptr;                   // the tile's 128 bias values (wave-uniform); lane l reads 16 bytes at b_off
+  const unsigned b_off = (lane & 31) * 16;       // lanes 32..63 duplicate (keeps EXEC full, stays in bounds)
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
@@ -215,12 +216,19 @@ __global__ __launch_bounds__(256, 2) void gemm_persist_kernel(GemmParams p, int 
     }
     a_base = (const char*)(p.A + (size_t)tm * BMv * p.lda);
     w_base = (const char*)(p.W + (size_t)tn * BN * p.ldw);
-    if (has_bias) b_src = p.bias + tn * BN + (lane & 31) * 4;  // lanes 32..63 duplicate (keeps EXEC full, stays in bounds)
+    if (has_bias) b_src = (const char*)(p.bias + tn * BN);
   };
   auto dma = [&](unsigned lds_dst, unsigned voff, const char* sbase) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_dst), "v"(voff), "s"(sbase) : "memory");
   };
+#if defined(APLA_ABL_NODMA)   // diagnostic build: only the first two stages of a workgroup are loaded (both ring buffers then hold real
+  int abl_dma_left = 2;       // operands); what the K loop costs once NO wave issues LDS-DMA = the ceiling of any loader-wave variant
+#endif
   auto stage = [&](int sbuf, int k0) {
+#if defined(APLA_ABL_NODMA)
+    if (abl_dma_left <= 0) return;
+    --abl_dma_left;
+#endif
     const unsigned base = lds0 + sbuf * STG;
     const char* ak = a_base + (size_t)k0 * 2;
     const char* wk = w_base + (size_t)k0 * 2;
@@ -229,8 +237,10 @@ __global__ __launch_bounds__(256, 2) void gemm_persist_kernel(GemmParams p, int 
 #pragma unroll
     for (int it = 0; it < 4; ++it) dma(base + BMv * BK * 2 + (wave * 4 + it) * 1024, w_off[it], wk);
   };
+  // the bias piece goes through the same helper as the operand pieces: every LDS-DMA of this kernel writes m0 itself, right in front
+  // of its instruction (hipcc does not know that the asm changes m0; a builtin DMA beside it would rely on hipcc re-materialising it)
   auto stage_bias = [&](int bbuf) {
-    if (has_bias && wave == 0) __builtin_amdgcn_global_load_lds(GLBP(b_src), LDSP(smem + 2 * STG + bbuf * 1024), 16, 0, 0);
+    if (has_bias && wave == 0) dma(lds0 + 2 * STG + bbuf * 1024, b_off, b_src);
   };
 
   int idx = slot;
@@ -238,11 +248,16 @@ __global__ __launch_bounds__(256, 2) void gemm_persist_kernel(GemmParams p, int 
 #if defined(APLA_ABL_CLOCK)  // diagnostic build: the core clock this workgroup ran at (tools/gemm_clock.py)
   const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
+
   int tile = xbeg + idx;
   setup(tile);
   stage(0, 0);
   stage_bias(0);
   int cur = 0, bb = 0;
+#if defined(APLA_ABL_NOREAD)
+  bf16x8 abl_af[MI], abl_wf[4];
+  bool abl_have = false;
+#endif
   bool counted = false;  // may the first wait of this tile leave the previous tile's stores outstanding?
   while (true) {
     int tm, tn;
@@ -275,11 +290,19 @@ __global__ __launch_bounds__(256, 2) void gemm_persist_kernel(GemmParams p, int 
       }
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
+#if defined(APLA_ABL_NOREAD)   // diagnostic build: the fragments of the very first K-half stay in registers for the whole run
+        bf16x8 (&af)[MI] = abl_af; bf16x8 (&wf)[4] = abl_wf;
+        if (!abl_have) {
+          abl_have = true;
+#else
         bf16x8 af[MI], wf[4];
+        {
+#endif
 #pragma unroll
         for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(As + lds_off(wm * (MI * 16) + i * 16 + frow, ks * 4 + fq));
 #pragma unroll
         for (int j = 0; j < 4; ++j) wf[j] = *(const bf16x8*)(Ws + lds_off(wn * 64 + j * 16 + frow, ks * 4 + fq));
+        }
         if constexpr ((EXP & 1) != 0) {
           // experiment 1: the first K-half's fragment reads are issued BEFORE the next stage's LDS-DMA, whose ~9 issue slots then
           // cover the reads' latency (as the ping-pong kernel's prepare phase does)
@@ -381,6 +404,8 @@ inline Sched pick_schedule(int epi, int out_dtype, int M, int N, int K, int lda,
   // 17 forces the tile-alternating kernel (gemm_tp.hip: 160 x 256 tiles, one 8-wave workgroup per CU whose two wave groups swap the
   // compute and the service role per tile) wherever it is instantiated
   if (g_variant == 17 && apla_gemm_tp_covers(M, N, K, lda, ldw, epi, out_dtype, w_panel)) return {4, 0};
+  // 18 forces the loader-wave form of the 4-wave kernel (gemm_lw.hip: the same 160 x 128 x 64 tiles, 4 compute + 1 or 2 loader waves)
+  if (g_variant == 18 && apla_gemm_lw_covers(M, N, K, lda, ldw, epi, out_dtype, w_panel)) return {5, 5};
   // automatic: the forward-only GELU from 8192 rows (measured back to back, M = 25216, image outputs, one process: 141.4 us against
   // 149.2 us on the wide 4-wave kernel; the two-output GELU and the plain stores tie or lose there: profiles/r04_tp_*)
   if (g_variant == 4 && epi == APLA_EPI_GELU_FWD && M >= 8192 && apla_gemm_tp_covers(M, N, K, lda, ldw, epi, out_dtype, w_panel)) return {4, 0};
@@ -418,6 +443,7 @@ int launch(const GemmParams& p, int g_variant, hipStream_t stream) {
   if (sc.kind == 2) return apla_gemm_pp2_launch(p, EPI, odt, stream);
   if (sc.kind == 3) return apla_gemm_w4_launch(p, EPI, odt, stream);
   if (sc.kind == 4) return apla_gemm_tp_launch(p, EPI, odt, stream);
+  if (sc.kind == 5) return apla_gemm_lw_launch(p, EPI, odt, stream);
   if (sc.kind == 1) {
     if (sc.mi == 5) return launch_persist<EPI, OutT, 5>(p, stream);
     return launch_persist<EPI, OutT, 4>(p, stream);
@@ -521,7 +547,7 @@ extern "C" int apla_gemm_nt_ex(const void* A, int lda, const void* W, int ldw, c
                                int N, int K, int epilogue, int out_dtype, const void* aux_in, int ld_aux_in,
                                void* aux_out, int ld_aux_out, int flags, hipStream_t stream) {
   const int tag = flags & 0xff, v = (flags >> 8) & 0xff;
-  APLA_REQUIRE(v == 0 || v == 1 || v == 4 || v == 9 || v == 14 || v == 15 || v == 16 || v == 17, "apla_gemm_nt_ex: unknown schedule %d", v);
+  APLA_REQUIRE(v == 0 || v == 1 || v == 4 || v == 9 || v == 14 || v == 15 || v == 16 || v == 17 || v == 18, "apla_gemm_nt_ex: unknown schedule %d", v);
   return gemm_nt_impl(A, lda, W, ldw, bias, C, ldc, M, N, K, epilogue, out_dtype, aux_in, ld_aux_in, aux_out, ld_aux_out, tag,
                       v == 0 ? 4 : (v == 1 ? 0 : v), stream, (flags >> 16) & 15, (flags >> 20) & 0xff, (flags >> 28) & 7);
 }
@@ -540,6 +566,7 @@ extern "C" int apla_gemm_nt_kernel_name(int M, int N, int K, int epilogue, int o
   const char* ot = out_dtype == APLA_F32 ? "float" : "bf16";
 #endif
   if (sc.kind == 4) snprintf(buf, buflen, "gemm_tp_kernel<%s,%s>", epi_names[epilogue], ot);
+  else if (sc.kind == 5) snprintf(buf, buflen, "gemm_lw_kernel<%s,%s,%d>", epi_names[epilogue], ot, sc.mi);
   else if (sc.kind == 3 && apla_gemm_w4_tile_rows(M, N, epilogue, out_dtype, exp, reserve) == 128) snprintf(buf, buflen, "gemm_w4_kernel<%s,%s,128 rows>", epi_names[epilogue], ot);
   else if (sc.kind == 3) snprintf(buf, buflen, "gemm_w4_kernel<%s,%s>", epi_names[epilogue], ot);
   else if (sc.kind == 2 && apla_gemm_pp2_tile_rows(M, N, epilogue, out_dtype, exp, reserve) == 256) snprintf(buf, buflen, "gemm_pp2_kernel<%s,%s,256 rows>", epi_names[epilogue], ot);

@@ -74,6 +74,9 @@ class Dinov2Trainer:
             owner.append(len(chunks))
         chunks.append((lo, opt.offsets[-1]))
         self.exchanger = GradExchanger(opt.grads, chunks, self.pg, always=force)
+        # chunks started by a gradient hook (their all-reduce runs under the rest of backward) vs after backward (no overlap left): a
+        # tensor that gets no gradient keeps its chunk — and, by the descending launch order, every lower one — open until the end
+        self.exchange_counts = {"from_hooks": 0, "after_backward": 0}
         self._chunk_size = [owner.count(k) for k in range(len(chunks))]
         self._reset_exchange()
         if not self.exchanger.active:
@@ -99,6 +102,7 @@ class Dinov2Trainer:
         while self._chunk_next >= 0 and self._chunk_seen[self._chunk_next] >= self._chunk_size[self._chunk_next]:
             self.exchanger.launch_chunk(self._chunk_next)
             self._chunk_next -= 1
+            self.exchange_counts["from_hooks"] += 1      # overlapped with the rest of backward
 
     def _finish_exchange(self):
         """After backward: the chunks not launched yet (tensors that received no gradient this iteration keep theirs open), in the
@@ -109,6 +113,7 @@ class Dinov2Trainer:
         while self._chunk_next >= 0:
             ex.launch_chunk(self._chunk_next)
             self._chunk_next -= 1
+            self.exchange_counts["after_backward"] += 1  # nothing left to overlap with: a tensor of this (or a later) chunk got no gradient
         ex.wait()
         self._reset_exchange()
 

@@ -187,8 +187,9 @@ int apla_attn_varlen_bwd(const void* qkv, const void* o, const void* d_o, const 
 /* The attention entry points with an explicit kernel choice (`variant`; the plain entry points pass 0):
  *   0 = auto: uniform batches of up to 280 tokens with at least one head per CU use the persistent forward (resident workgroups
  *       walking their heads, K / V double-buffered by a loader wave, one row maximum per head: one wave per 32-row block up to 224
- *       tokens — several small workgroups per CU up to 96 —, four waves walking 8 or 9 blocks above) and, for 65..256 tokens, the
- *       persistent backward (every load one phase ahead of its use); other batches of up to 288 tokens the one-workgroup-per-head
+ *       tokens — several small workgroups per CU up to 96 —, four waves walking 8 or 9 blocks above) and, up to 256 tokens, the
+ *       persistent backward (every load one phase ahead of its use; several small workgroups per CU for short sequences, down to
+ *       one token); other batches of up to 288 tokens the one-workgroup-per-head
  *       kernels (whole K / V of a head in LDS); longer sequences the key-/query-blocked kernels;
  *   1 = always the blocked kernels; 2 = the one-workgroup-per-head kernels (never the persistent ones); 3 = the persistent
  *       kernels wherever they apply.  The backward kernels compute bitwise the same results, and so do the blocked and the

@@ -814,6 +814,48 @@ def test_gemm_tile_alternating_kernel(ops, M, N, K):
         ops.set_gemm_variant(old)
 
 
+@pytest.mark.parametrize("M,N,K", [(25216, 3072, 768), (1000, 256, 2304), (130, 512, 256), (1, 128, 128), (90000, 128, 192)])
+def test_gemm_loader_wave_kernel(ops, M, N, K):
+    """gemm_lw.hip (schedule 18, round 6: the 4-wave persistent kernel with its LDS-DMA issue moved to one or two LOADER waves; measured
+    1.7-1.9 x slower than the product kernel — profiles/r06_a_lw_gemm.md — and kept as a selectable schedule for that record): STORE,
+    GELU_FWD, GELU and MUL with row-major and image outputs, with and without bias, one and two loader waves, CUs reserved — the bits
+    of schedule 15 (same tiles, same K order, same epilogue code); row tails, one row, many tiles per workgroup."""
+    a, ad = bf(rnd(M, K, seed=161))
+    w, wd = bf(rnd(N, K, scale=K ** -0.5, seed=162))
+    bias = dev(rnd(N, seed=163))
+    A, W = dev(a), dev(w)
+    g_in = dev(bf(rnd(M, N, seed=164))[0])
+    old = ops.set_gemm_variant(15)
+    try:
+        ref = ops.gemm_nt(A, W, bias).clone()
+        ref_nb = ops.gemm_nt(A, W, None).clone()
+        g_ref = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        h_ref = ops.gemm_nt(A, W, bias, epilogue=ops.EPI_GELU, aux_out=g_ref).clone()
+        m_ref = ops.gemm_nt(A, W, bias, epilogue=ops.EPI_MUL, aux_in=g_in).clone()
+        if M <= 30000:
+            assert rel_err(ref.cpu(), ad @ wd.t() + bias.cpu().double()) < BF16_OUT
+        ops.set_gemm_variant(18)
+        assert ops.gemm_kernel_name(M, N, K, ops.EPI_GELU).startswith("gemm_lw_kernel<GELU")
+        hi_ = torch.zeros(N // 32, M, 32, device="cuda", dtype=torch.bfloat16)
+        gi = torch.zeros(N // 32, M, 32, device="cuda", dtype=torch.bfloat16)
+        for loaders in (0, 1):          # GemmParams::exp bit 0: two loader waves per workgroup
+            ops._GEMM_EXP = loaders
+            for rep in range(2):        # (twice: a race would not repeat itself)
+                assert torch.equal(ops.gemm_nt(A, W, bias), ref), (loaders, rep)
+                assert torch.equal(ops.gemm_nt(A, W, bias, epilogue=ops.EPI_GELU_FWD), h_ref), (loaders, rep)
+                g2 = torch.zeros_like(g_ref)
+                assert torch.equal(ops.gemm_nt(A, W, bias, epilogue=ops.EPI_GELU, aux_out=g2), h_ref) and torch.equal(g2, g_ref), (loaders, rep)
+                assert torch.equal(ops.gemm_nt(A, W, bias, epilogue=ops.EPI_MUL, aux_in=g_in), m_ref), (loaders, rep)
+                ops.gemm_nt(A, W, bias, epilogue=ops.EPI_GELU, aux_out=gi.zero_(), out=hi_.zero_())
+                assert torch.equal(hi_, ops.k_panels(h_ref)) and torch.equal(gi, ops.k_panels(g_ref)), (loaders, rep)
+            assert torch.equal(ops.gemm_nt(A, W, None), ref_nb)   # no bias piece in the stream
+            with ops.reserved_cus(150):      # few workgroups, many tiles each
+                assert torch.equal(ops.gemm_nt(A, W, bias), ref)
+    finally:
+        ops._GEMM_EXP = 0
+        ops.set_gemm_variant(old)
+
+
 @pytest.mark.parametrize("M,N,K", [(27400, 768, 1536), (27400, 768, 768), (1000, 256, 2304), (130, 512, 256), (257, 256, 3072)])
 def test_gemm_small_row_tiles(ops, M, N, K):
     """The 256-row tile of the ping-pong kernel and the 128-row tile of the wide 4-wave kernel (bf16 STORE; chosen where the tile count

@@ -8,7 +8,7 @@ cd "$(dirname "$0")/../apla_amd/build"
 mkdir -p exp
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result"
-OBJS="errors gemm_nt gemm_pp2 gemm_w4 gemm_tp gemm_small layernorm attention apla_dw optim misc"
+OBJS="errors gemm_nt gemm_pp2 gemm_w4 gemm_tp gemm_lw gemm_small layernorm attention apla_dw optim misc"
 build() {  # name source "defines"
   $HIPCC $FLAGS $3 -c ../csrc/$2.hip -o exp/$2_$1.o
   local objs=""

@@ -21,6 +21,7 @@ from apla_amd import ops
 from apla_amd._lib import lib
 
 M = 25216
+LAST_CYCLES = 0
 PER_CU_CYCLE = 4096.0   # bf16 FLOP per CU and core cycle: 4 SIMDs x one 16x16x32 MFMA (16 384 FLOP) per 16 cycles
 
 
@@ -29,20 +30,26 @@ def clock_of(reader, n_wg):
     rc = getattr(lib(), reader)(buf)
     assert rc == 0, rc
     g = sorted(buf[2 * i] / buf[2 * i + 1] * 0.1 for i in range(n_wg) if buf[2 * i + 1])
+    global LAST_CYCLES
+    cyc = sorted(buf[2 * i] for i in range(n_wg) if buf[2 * i + 1])
+    LAST_CYCLES = cyc[len(cyc) // 2]          # median workgroup's whole run in core cycles
     return g[len(g) // 2], g[0], g[-1]
 
 
 def main():
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
-    for fn in ("apla_abl_clock_nt", "apla_abl_clock_w4", "apla_abl_clock_pp2"):
-        getattr(lib(), fn).argtypes = [ctypes.c_void_p]
+    for fn in ("apla_abl_clock_nt", "apla_abl_clock_w4", "apla_abl_clock_pp2", "apla_abl_clock_lw"):
+        if hasattr(lib(), fn):
+            getattr(lib(), fn).argtypes = [ctypes.c_void_p]
     cases = [("qkv", 2304, 768, ops.EPI_STORE, 16, "wide 4-wave", "apla_abl_clock_w4", 512),
              ("qkv", 2304, 768, ops.EPI_STORE, 9, "ping-pong", "apla_abl_clock_pp2", 256),
              ("proj", 768, 768, ops.EPI_STORE, 16, "wide 4-wave", "apla_abl_clock_w4", 474),
              ("fc2", 768, 3072, ops.EPI_STORE, 9, "ping-pong", "apla_abl_clock_pp2", 237),
              ("dqkv", 768, 2304, ops.EPI_STORE, 9, "ping-pong", "apla_abl_clock_pp2", 237),
              ("fc1+GELU", 3072, 768, ops.EPI_GELU, 15, "4-wave 128-wide", "apla_abl_clock_nt", 512),
-             ("dfc2*gelu'", 3072, 768, ops.EPI_MUL, 15, "4-wave 128-wide", "apla_abl_clock_nt", 512)]
+             ("dfc2*gelu'", 3072, 768, ops.EPI_MUL, 15, "4-wave 128-wide", "apla_abl_clock_nt", 512),
+             ("fc1+GELU", 3072, 768, ops.EPI_GELU, 18, "loader-wave", "apla_abl_clock_lw", 512),
+             ("dfc2*gelu'", 3072, 768, ops.EPI_MUL, 18, "loader-wave", "apla_abl_clock_lw", 512)]
     print(f"# Core clock inside the GEMM launches of the step (config 2, M = {M}; {seconds:g} s of back-to-back launches before each reading)\n")
     print("| launch | kernel | operands | launch us | TFLOP/s | core clock GHz (median workgroup; min / max) | FLOP per CU and core cycle | of 4096 |")
     print("|---|---|---|---:|---:|---:|---:|---:|")
@@ -82,7 +89,8 @@ def main():
             ghz, lo, hi = clock_of(reader, n_wg)
             flop = 2.0 * M * N * K
             per_cycle = flop / 256 / (us * 1e-6 * ghz * 1e9)
-            print(f"| {name} N={N} K={K} | {kname} | {data} | {us:.1f} | {flop / us / 1e6:.0f} | {ghz:.3f} ({lo:.3f} / {hi:.3f}) | {per_cycle:.0f} | {per_cycle / PER_CU_CYCLE:.3f} |", flush=True)
+            ksteps = (-(-M // (160 if variant in (15, 18) else 320))) * (N // (128 if variant in (15, 18) else 256)) * (K // 64) / n_wg   # mean 64-wide K-steps per workgroup
+            print(f"| {name} N={N} K={K} | {kname} | {data} | {us:.1f} | {flop / us / 1e6:.0f} | {ghz:.3f} ({lo:.3f} / {hi:.3f}) | {per_cycle:.0f} | {per_cycle / PER_CU_CYCLE:.3f} | {LAST_CYCLES} cycles per workgroup = {LAST_CYCLES / ksteps:.0f} per 64-wide K-step (epilogue share included) |", flush=True)
     ops.set_gemm_variant(0)
 
 

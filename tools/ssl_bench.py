@@ -155,7 +155,7 @@ def main():
                       "unit": "images/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 2),
                       "dtype": args.dtype, "data": "synthetic", "roofline": roofline, "power": power,
                       **({"loss_scale": tr.loss_scale, "skipped_steps": tr.skipped_steps} if args.dtype == "fp16" else {}),
-                      **({"exchange": {"chunks_mb": [round((b - a) * 4 / 2 ** 20, 1) for a, b in tr.exchanger.chunks], "backend": "nccl, one rank"}}
+                      **({"exchange": {"chunks_mb": [round((b - a) * 4 / 2 ** 20, 1) for a, b in tr.exchanger.chunks], "backend": "nccl, one rank", "chunk_launches": dict(tr.exchange_counts)}}
                          if args.force_exchange else {}),
                       "config": {"workload": f"{args.backbone}/14 student+teacher, 2x224 + 8x98 crops, bs={args.batch}, partial_size={args.partial_size}, "
                                              f"{args.prototypes} prototypes, masked patches {int(batch['images']['n_masked_patches'])} "
