@@ -63,10 +63,26 @@ def dominant_kernel_held_clock():
             h = json.load(f)["held_clock"]
         ghz = float(h["core_clock_ghz_random_operands"])
         peak = float(h["mfma_issue_peak_flop_per_cu_and_cycle"]) * 256 * ghz / 1e3
-        return {"stored": True, "source": h["source"], "core_clock_ghz": ghz, "core_clock_ghz_on_zero_operands": h["core_clock_ghz_zero_operands"],
+        return {"stored": True, "source": h["source"], "taken_at": h.get("taken_at"), "core_clock_ghz": ghz, "core_clock_ghz_on_zero_operands": h["core_clock_ghz_zero_operands"],
                 "launch_us": h["launch_us_random_operands"], "launch_us_on_zero_operands": h["launch_us_zero_operands"],
                 "peak_at_held_clock": round(peak, 1), "unit": "TFLOP/s",
                 "frac_at_held_clock": round(float(h["flop_per_cu_and_core_cycle"]) / float(h["mfma_issue_peak_flop_per_cu_and_cycle"]), 4)}
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+KERNELS_FILE = os.path.join(ROOT, "profiles", "roofline_kernels.json")   # tools/roofline_table.py over the round's rocprofv3 trace of this command
+
+
+def roofline_kernels():
+    """The step's top kernels, each against its own roofline: algorithmic FLOP and bytes per launch, the average duration rocprofv3
+    measured, fraction of the MFMA or HBM peak, counter traffic where PMC passes exist.  A STORED record (a kernel trace cannot run
+    inside the timed bench): file, round and trace travel with it; null when the file is missing."""
+    try:
+        with open(KERNELS_FILE) as f:
+            d = json.load(f)
+        return {"stored": True, "file": os.path.relpath(KERNELS_FILE, ROOT), "taken_at": d.get("taken_at"), "source": d.get("source"),
+                "kernel_time_ms_per_step": d.get("kernel_time_ms_per_step"), "kernels": d["kernels"]}
     except (OSError, KeyError, ValueError):
         return None
 
@@ -557,13 +573,23 @@ def main():
         for _ in range(args.warmup):
             eng16.train_step()
         torch.cuda.synchronize()
+        marks16 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]     # per-step durations, as the main leg takes them
         t16 = time.perf_counter()
-        for _ in range(args.steps):
+        marks16[0].record()
+        for k in range(args.steps):
             eng16.train_step()
+            marks16[k + 1].record()
         torch.cuda.synchronize()
         e16 = time.perf_counter() - t16
-        fp16_rec = {"ms_per_step": round(e16 / args.steps * 1e3, 3), "images_per_sec": round(args.batch * args.steps / e16, 1),
+        per16 = torch.tensor([marks16[k].elapsed_time(marks16[k + 1]) for k in range(args.steps)], dtype=torch.float64)
+        k16_ms = eng16.time_fc1_launches(3)      # its dominant launch in place, HIP events on the launch stream (as `roofline.kernel_ms`)
+        torch.cuda.synchronize()
+        fp16_rec = {"ms_per_step": round(e16 / args.steps * 1e3, 3), "ms_per_step_median": round(float(per16.median()), 3) if args.steps else None,
+                    "ms_per_step_min": round(float(per16.min()), 3) if args.steps else None, "ms_per_step_max": round(float(per16.max()), 3) if args.steps else None,
+                    "images_per_sec": round(args.batch * args.steps / e16, 1),
                     "steps": args.steps, "warmup": args.warmup, "loss_scale": 1024.0, "final_loss": round(float(eng16.loss), 4),
+                    "fc1_gelu_kernel_ms": round(k16_ms, 4),
+                    "fc1_gelu_frac_of_peak": round(2.0 * args.batch * eng16.N * model16.backbone.embed_dim * eng16.blocks[0].F * (2 if eng16.swiglu else 1) / (k16_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
                     "library": "libapla_hip_f16.so (same sources, -DAPLA_FP16)"}
         del eng16, model16
         torch.cuda.empty_cache()
@@ -629,6 +655,8 @@ def main():
                          "peak_probe": peak_rec,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "held_clock": dominant_kernel_held_clock() if is_cfg2 else None,
+                         # every large kernel of the step against its own roofline (stored, from the round's rocprofv3 trace of this command)
+                         "kernels": roofline_kernels() if is_cfg2 and args.dtype == "bf16" else None,
                          "algorithmic_bytes": 2.0 * (M * bb.embed_dim + eng.blocks[0].F * bb.embed_dim + 2 * M * eng.blocks[0].F),
                          "kernel_ms": round(k_ms, 4), "kernel_ms_back_to_back": round(iso_ms, 4),
                          # whole step: algorithmic FLOPs and the FLOPs the kernels actually execute — the CLS-only

@@ -57,6 +57,34 @@ def test_host_side_queries_answer_without_a_gpu():
     assert h.apla_dw_workspace_bytes(5519, 65536, 256) == (65536 * 256 + 65536) * 4   # more tiles than CUs: one slab
 
 
+def test_stored_roofline_records_name_the_kernel_the_dispatch_runs():
+    """The stored records bench.py quotes beside its live numbers (profiles/pmc_dominant_kernel.json: counter traffic and held clock of
+    the dominant launch; profiles/roofline_kernels.json: every large kernel against its own roofline) must be records of the kernel
+    the library's dispatch runs TODAY for BASELINE config 2's fc1 + GELU launch: a dispatch change without re-measured counters fails
+    here.  Also the table's own arithmetic: algorithmic FLOP of the dominant launch, fractions = achieved / peak."""
+    import json
+    from apla_amd import ops
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    name = ops.gemm_kernel_name(25216, 3072, 768, ops.EPI_GELU, out_image=True, aux_image=True)     # the step keeps h and GELU' as images
+    pmc = json.load(open(os.path.join(root, "profiles", "pmc_dominant_kernel.json")))
+    assert pmc["kernel"].startswith(name + " "), (pmc["kernel"], name)
+    assert pmc["kernel"].endswith("M=25216 N=3072 K=768 (fc1+GELU launch)") and pmc["FETCH_SIZE_KiB"] > 0 and pmc["WRITE_SIZE_KiB"] > 0
+    assert pmc["held_clock"]["taken_at"] and pmc["held_clock"]["source"].startswith("profiles/")
+    assert os.path.exists(os.path.join(root, pmc["held_clock"]["source"].split(" ")[0]))
+    tab = json.load(open(os.path.join(root, "profiles", "roofline_kernels.json")))
+    ks = tab["kernels"]
+    assert len(ks) >= 8 and tab["taken_at"]
+    dom = ks[0]
+    kind, targs = name.split("<")[0], name.split("<")[1].rstrip(">").split(",")       # e.g. gemm_persist_kernel, [GELU, bf16, 5]
+    assert dom["kernel"].startswith(kind + "<" + targs[0] + ",") and dom["call_site"].startswith("fc1")
+    assert dom["flop"] == 2.0 * 25216 * 3072 * 768 and dom["bound"] == "mfma" and dom["peak"] == 2500.0
+    for k in ks:
+        work = k["flop"] if k["bound"] == "mfma" else k["bytes"]
+        assert abs(k["achieved"] - work / k["us"] / 1e6) <= 0.01 * k["achieved"] + 1e-3, k["kernel"]
+        assert abs(k["frac"] - k["achieved"] / k["peak"]) < 1e-3 and 0.0 < k["frac"] < 1.0, k["kernel"]
+        assert k["traffic_bytes"] is None or k["traffic_bytes"] > 0
+
+
 def test_no_cpu_fallback():
     """The product path must fail loudly on CPU tensors instead of computing something else."""
     import torch

@@ -65,14 +65,15 @@ def short(name):
     m = re.match(r"(?:void )?(gemm_\w+_kernel|gemm_nt_kernel)<(\d), (\w+)(.*)>", name)
     if m:
         rest = m.group(4)
-        if m.group(1) == "gemm_pp2_kernel":
-            t = re.match(r",\s*(\d+)$", rest)
+        if m.group(1) == "gemm_pp2_kernel":      # <EPI, T, TAG, MI>; the profiler's demangler garbles TAG = 5 into "5, sched MI" (above)
+            t = re.match(r",\s*(\d+)(?:,\s*(?:sched )?(\d+))?$", rest)
             if t:
-                rest = f" [{TAGS[t.group(1)]}]" if t.group(1) in TAGS else ""
-        elif m.group(1) == "gemm_w4_kernel":   # <EPI, T, PRIO, VNS, TAG>
-            t = re.match(r",\s*(\w+),\s*(\d+),\s*(\d+)$", rest)
+                rest = (f" [{TAGS[t.group(1)]}]" if t.group(1) in TAGS else "") + (", 256 rows" if t.group(2) == "4" else "")
+        elif m.group(1) == "gemm_w4_kernel":   # <EPI, T, PRIO, VNS, TAG[, KSPLIT, MI]>
+            t = re.match(r",\s*(\w+),\s*(\d+),\s*(\d+)(?:,\s*(\w+),\s*(\d+))?$", rest)
             if t:
-                rest = (f" [{TAGS[t.group(3)]}]" if t.group(3) in TAGS else "") + ("" if (t.group(1), t.group(2)) in (("true", "2"), ("1", "2")) else f" prio={t.group(1)} ring={t.group(2)}")
+                rest = (f" [{TAGS[t.group(3)]}]" if t.group(3) in TAGS else "") + ("" if (t.group(1), t.group(2)) in (("true", "2"), ("1", "2")) else f" prio={t.group(1)} ring={t.group(2)}") \
+                       + (", split-K" if t.group(4) in ("true", "1") else "") + (", 128 rows" if t.group(5) == "4" else "")
         return f"{m.group(1)}<{EPI.get(m.group(2), m.group(2))},{m.group(3)}{rest}>"
     name = re.sub(r"^void ", "", name)
     name = re.sub(r"\(.*$", "", name)
@@ -84,7 +85,8 @@ def short(name):
 def shape_tf(label, avg_us):
     """TFLOP/s of a GEMM row at config 2, from its call-site tag or epilogue; None for other kernels."""
     m = re.search(r"\[(\w+)\]", label)
-    key = m.group(1) if m else ("GELU" if label.startswith("gemm_pp2_kernel<GELU,") else "MUL" if "<MUL," in label else None)
+    big = label.startswith(("gemm_pp2_kernel", "gemm_persist_kernel", "gemm_lw_kernel", "gemm_w4_kernel", "gemm_tp_kernel"))
+    key = m.group(1) if m else ("GELU" if big and "<GELU," in label else "MUL" if big and "<MUL," in label else None)
     if key not in CFG2:
         return None
     n, k = CFG2[key]
