@@ -88,18 +88,25 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
   }
 }
 
-template <int EPI, typename OutT>
+// BNv = 128: the 2 x 2 wave grid this work started from (wave tile 64 x 64).  BNv = 64 (round 6): a 128 x 64 tile, the four waves
+// stacked along M (wave tile 32 x 64) — the instance behind widths that are multiples of 64 but not of 128 (the reference's vit_tiny:
+// D = 192, utils/transformers/vit.py:511-525); every epilogue, row-major operands, no speed claim.
+template <int EPI, typename OutT, int BNv = BN>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams p) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+  constexpr int MI = BNv == 128 ? 4 : 2;            // 16-row fragments per wave
+  constexpr int WP = BNv * BK * 2 / 1024 / 4;       // W pieces per wave and K-step
+  constexpr int STG = (BM + BNv) * BK * 2;
+  __shared__ __attribute__((aligned(16))) char smem[2 * STG];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = BNv == 128 ? wave >> 1 : wave, wn = BNv == 128 ? wave & 1 : 0;
+  const int tiles_n = p.N / BNv;
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int tm = wg / p.tiles_n, tn = wg - tm * p.tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BNv;
 
-  // per-lane source rows / chunks for the 4 A pieces and 4 W pieces this wave stages per K-step
+  // per-lane source rows / chunks for the 4 A pieces and WP W pieces this wave stages per K-step
   const bf16* a_src[4];
-  const bf16* w_src[4];
+  const bf16* w_src[WP];
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const int piece = wave * 4 + it;
@@ -108,22 +115,25 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams p) {
     int gr = m0 + row;
     gr = gr < p.M ? gr : p.M - 1;  // tail rows: re-read the last valid row, never stored
     a_src[it] = p.A + (size_t)gr * p.lda + chunk * 8;
+  }
+#pragma unroll
+  for (int it = 0; it < WP; ++it) {
+    const int row = (wave * WP + it) * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
     w_src[it] = p.W + (size_t)(n0 + row) * p.ldw + chunk * 8;
   }
 
   auto stage = [&](int s, int k0) {
-    char* base = smem + s * STAGE_BYTES;
+    char* base = smem + s * STG;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int piece = wave * 4 + it;
-      __builtin_amdgcn_global_load_lds(GLBP(a_src[it] + k0), LDSP(base + piece * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(GLBP(w_src[it] + k0), LDSP(base + BM * BK * 2 + piece * 1024), 16, 0, 0);
-    }
+    for (int it = 0; it < 4; ++it) __builtin_amdgcn_global_load_lds(GLBP(a_src[it] + k0), LDSP(base + (wave * 4 + it) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int it = 0; it < WP; ++it) __builtin_amdgcn_global_load_lds(GLBP(w_src[it] + k0), LDSP(base + BM * BK * 2 + (wave * WP + it) * 1024), 16, 0, 0);
   };
 
-  f32x4 acc[4][4];
+  f32x4 acc[MI][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -134,24 +144,24 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams p) {
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) stage(cur ^ 1, (kt + 1) * BK);
-    const char* As = smem + cur * STAGE_BYTES;
+    const char* As = smem + cur * STG;
     const char* Ws = As + BM * BK * 2;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 af[4], wf[4];
+      bf16x8 af[MI], wf[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(As + lds_off(wm * 64 + i * 16 + frow, ks * 4 + fq));
+      for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(As + lds_off(wm * (MI * 16) + i * 16 + frow, ks * 4 + fq));
 #pragma unroll
       for (int j = 0; j < 4; ++j) wf[j] = *(const bf16x8*)(Ws + lds_off(wn * 64 + j * 16 + frow, ks * 4 + fq));
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = MFMA_F32_16x16x32_H16(wf[j], af[i], acc[i][j]);
     }
     __syncthreads();
   }
 
-  gemm_epilogue<EPI, OutT>(p, acc, m0, n0, wm, wn, lane);
+  gemm_epilogue<EPI, OutT, MI>(p, acc, m0, n0, wm, wn, lane);
 }
 
 
@@ -439,6 +449,12 @@ inline Sched pick_schedule(int epi, int out_dtype, int M, int N, int K, int lda,
 template <int EPI, typename OutT>
 int launch(const GemmParams& p, int g_variant, hipStream_t stream) {
   const int odt = std::is_same<OutT, float>::value ? APLA_F32 : APLA_H16;
+  if (p.N % BN != 0) {       // a multiple of 64 only (gemm_nt_impl checked): the 128 x 64 instance of the simple kernel, whatever the schedule asked for
+    dim3 grid(((p.M + BM - 1) / BM) * (p.N / 64)), block(256);
+    hipLaunchKernelGGL((gemm_nt_kernel<EPI, OutT, 64>), grid, block, 0, stream, p);
+    APLA_CHECK_LAUNCH("apla_gemm_nt");
+    return APLA_OK;
+  }
   const Sched sc = pick_schedule(EPI, odt, p.M, p.N, p.K, (p.w_panel & 2) ? 32 : p.lda, (p.w_panel & 1) ? 32 : p.ldw, p.w_panel, g_variant);
   if (sc.kind == 2) return apla_gemm_pp2_launch(p, EPI, odt, stream);
   if (sc.kind == 3) return apla_gemm_w4_launch(p, EPI, odt, stream);
@@ -462,7 +478,8 @@ static int gemm_nt_impl(const void* A, int lda, const void* W, int ldw, const fl
                         void* aux_out, int ld_aux_out, int tag, int variant, hipStream_t stream, int w_panel = 0, int reserve = 0,
                         int exp = 0) {
   APLA_REQUIRE(M > 0 && N > 0 && K > 0, "apla_gemm_nt: empty problem M=%d N=%d K=%d", M, N, K);
-  APLA_REQUIRE(N % BN == 0 && K % BK == 0, "apla_gemm_nt: need N%%128==0 and K%%64==0 (N=%d K=%d)", N, K);
+  APLA_REQUIRE(N % 64 == 0 && K % BK == 0, "apla_gemm_nt: need N%%64==0 and K%%64==0 (N=%d K=%d)", N, K);
+  APLA_REQUIRE(N % BN == 0 || w_panel == 0, "apla_gemm_nt_ex: operand / output images need N%%128==0 (N=%d)", N);
   APLA_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && ((w_panel & 2) || lda >= K) && ((w_panel & 1) || ldw >= K), "apla_gemm_nt: bad lda/ldw (%d,%d) K=%d", lda, ldw, K);
   if (w_panel & 12) {
     const bool sw = epilogue == APLA_EPI_SWIGLU || epilogue == APLA_EPI_SWIGLU_BWD;
@@ -559,7 +576,8 @@ extern "C" int apla_gemm_nt_kernel_name(int M, int N, int K, int epilogue, int o
   static const char* const epi_names[] = {"STORE", "GELU", "RESIDUAL", "MUL", "SWIGLU", "SWIGLU_BWD", "GELU_FWD"};
   APLA_REQUIRE(epilogue >= 0 && epilogue <= 6, "apla_gemm_nt_kernel_name: unknown epilogue %d", epilogue);
   const int v = (flags >> 8) & 0xff, w_panel = (flags >> 16) & 15, reserve = (flags >> 20) & 0xff, exp = (flags >> 28) & 7;
-  const Sched sc = pick_schedule(epilogue, out_dtype, M, N, K, (w_panel & 2) ? 32 : K, (w_panel & 1) ? 32 : K, w_panel, v == 0 ? 4 : (v == 1 ? 0 : v));
+  Sched sc = pick_schedule(epilogue, out_dtype, M, N, K, (w_panel & 2) ? 32 : K, (w_panel & 1) ? 32 : K, w_panel, v == 0 ? 4 : (v == 1 ? 0 : v));
+  if (N % BN != 0) sc = {0, 2};     // the 128 x 64 instance of the simple kernel (launch())
 #if defined(APLA_FP16)
   const char* ot = out_dtype == APLA_F32 ? "float" : "f16";
 #else
@@ -572,6 +590,7 @@ extern "C" int apla_gemm_nt_kernel_name(int M, int N, int K, int epilogue, int o
   else if (sc.kind == 2 && apla_gemm_pp2_tile_rows(M, N, epilogue, out_dtype, exp, reserve) == 256) snprintf(buf, buflen, "gemm_pp2_kernel<%s,%s,256 rows>", epi_names[epilogue], ot);
   else if (sc.kind == 2) snprintf(buf, buflen, "gemm_pp2_kernel<%s,%s>", epi_names[epilogue], ot);
   else if (sc.kind == 1) snprintf(buf, buflen, "gemm_persist_kernel<%s,%s,%d>", epi_names[epilogue], ot, sc.mi);
+  else if (sc.mi == 2) snprintf(buf, buflen, "gemm_nt_kernel<%s,%s,64>", epi_names[epilogue], ot);
   else snprintf(buf, buflen, "gemm_nt_kernel<%s,%s>", epi_names[epilogue], ot);
   return APLA_OK;
 }

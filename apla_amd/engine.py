@@ -145,8 +145,8 @@ class AplaTrainEngine:
                 W1, b1, r = a.proj.weight, a.proj.bias, self.D
                 inds = torch.arange(self.D)
                 names = (f"backbone.blocks.{i}.attn.proj.weight", f"backbone.blocks.{i}.attn.proj.bias")
-            if self.D % 128 != 0:
-                raise NotImplementedError(f"engine needs dim % 128 == 0 (D={self.D})")
+            if self.D % 64 != 0:       # (= 64 * heads anyway; widths that are not multiples of 128 — vit_tiny's 192 — run the 64-wide GEMM tile)
+                raise NotImplementedError(f"engine needs dim % 64 == 0 (D={self.D})")
             expect += list(names)
             self.blocks_train.append((W1, b1, inds, r))
         expect += ["fc.weight", "fc.bias"]
@@ -381,7 +381,7 @@ class AplaTrainEngine:
         # together, at most DW_BATCH at a time.  Needs one r for all blocks and no row padding; else block by block.
         self.dw_batch = 0
         if os.environ.get("APLA_DW_BATCH", "1") != "0" and len({st.r for st in self.blocks}) == 1 and \
-                all(st.r_pad == st.r for st in self.blocks) and self.L > 2:
+                all(st.r_pad == st.r for st in self.blocks) and self.L > 2 and self.D % 128 == 0:
             self.dw_batch = min(int(os.environ.get("APLA_DW_BATCH_MAX", "6")), ops.DW_MAX_BATCH)
         self._dw_pending = []
         if self.dw_batch > 1:
@@ -390,7 +390,7 @@ class AplaTrainEngine:
         self.dyg = e(M * rmax)
         self.dw_ws = ops.dw_workspace(M, rmax, D, dev)
         for st in self.blocks:
-            if ops.lib().apla_dw_workspace_bytes(M, st.r_pad, D) > self.dw_ws.numel() * 4:
+            if ops.lib().apla_dw_workspace_bytes(M, st.r_pad, (D + 127) // 128 * 128) > self.dw_ws.numel() * 4:
                 self.dw_ws = ops.dw_workspace(M, st.r_pad, D, dev)
 
     @_half_mode

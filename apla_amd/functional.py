@@ -596,8 +596,8 @@ class _AplaProjFn(torch.autograd.Function):
 
 def apla_projection(o, W1, b1, W2, b2, inds, state: AplaProjState, gamma=None):
     """``gamma`` (optional, frozen): the block's LayerScale vector, folded into the projection (ls1(proj(o)) in one GEMM)."""
-    if W1.shape[1] % 128 != 0:
-        raise NotImplementedError(f"APLA HIP projection needs dim % 128 == 0 (got dim={W1.shape[1]})")
+    if W1.shape[1] % 64 != 0:
+        raise NotImplementedError(f"APLA HIP projection needs dim % 64 == 0 (got dim={W1.shape[1]})")
     if gamma is not None and gamma.requires_grad:
         raise NotImplementedError("a trainable LayerScale cannot be folded into the projection")
     with torch.no_grad():

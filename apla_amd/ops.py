@@ -76,6 +76,7 @@ def _rows2d(t: torch.Tensor, name: str):
 # Kernel-schedule choice of the GEMM / attention wrappers: test and benchmark hooks kept HERE, in Python (the C-ABI itself is
 # stateless: the choice travels as a per-call argument of the *_ex entry points).  0 = auto.
 _GEMM_VARIANT = 0
+_DW_PAD = {}         # proj_dw: padded operands of widths that are multiples of 64 only
 _ATTN_VARIANT = int(os.environ.get("APLA_ATTN_VARIANT", "0"))
 _GEMM_EXP = 0       # experiment selector of apla_gemm_nt_ex (flags bits 28-30): tools/gemm_bench.py only
 _RESERVED_CUS = 0   # CUs the persistent GEMM launches leave free (apla_gemm_nt_ex flags bits 20-27): see reserved_cus()
@@ -596,6 +597,8 @@ def attn_probs(qkv: torch.Tensor, lse: torch.Tensor, B: int, N: int, H: int, sca
 
 
 def dw_workspace(M: int, r: int, D: int, device) -> torch.Tensor:
+    if D % 64 == 0:
+        D = (D + 127) // 128 * 128        # widths that are multiples of 64 only run padded (proj_dw)
     nbytes = lib().apla_dw_workspace_bytes(M, r, D)
     if nbytes < 0:
         raise ValueError(f"apla_proj_dw needs r%64==0 and D%128==0 (r={r}, D={D})")
@@ -652,6 +655,23 @@ def proj_dw(dyg: torch.Tensor, x: torch.Tensor, dW1: torch.Tensor, db1: torch.Te
     Mx, D, ldx = _rows2d(x, "x")
     if Mx != M or tuple(dW1.shape) != (r, D) or db1.numel() != r or not dyg.is_contiguous() or not dW1.is_contiguous():
         raise ValueError("proj_dw: shape mismatch")
+    if D % 128 != 0 and D % 64 == 0:
+        # The kernel tiles the feature axis of x in 128s.  A width that is a multiple of 64 only (the reference's vit_tiny, D = 192:
+        # utils/transformers/vit.py:511-525) runs on a zero-padded copy of x and a padded fp32 result whose first D columns are the answer
+        # (buffers cached per shape: stable addresses under hipGraph capture).  A toy-model path: two extra copies per call.
+        Dp = (D + 127) // 128 * 128
+        key = (M, r, D, x.device, half())
+        if key not in _DW_PAD:
+            _DW_PAD[key] = (torch.zeros(M, Dp, device=x.device, dtype=half()), torch.empty(r, Dp, device=x.device, dtype=torch.float32),
+                            torch.empty(r, device=x.device, dtype=torch.float32))
+        xp, dWp, dbp = _DW_PAD[key]
+        xp[:, :D].copy_(x)
+        proj_dw(dyg, xp, dWp, dbp, row_scale=row_scale, workspace=workspace)
+        if accumulate:
+            dW1.add_(dWp[:, :D]), db1.add_(dbp)
+        else:
+            dW1.copy_(dWp[:, :D]), db1.copy_(dbp)
+        return
     if row_scale is not None:
         _req(row_scale, torch.float32, "row_scale", 1)
         if row_scale.numel() != r:

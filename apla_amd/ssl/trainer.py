@@ -74,9 +74,9 @@ class Dinov2Trainer:
             owner.append(len(chunks))
         chunks.append((lo, opt.offsets[-1]))
         self.exchanger = GradExchanger(opt.grads, chunks, self.pg, always=force)
-        # chunks started by a gradient hook (their all-reduce runs under the rest of backward) vs after backward (no overlap left): a
-        # tensor that gets no gradient keeps its chunk — and, by the descending launch order, every lower one — open until the end
-        self.exchange_counts = {"from_hooks": 0, "after_backward": 0}
+        # exchange_counts (set up by _reset_exchange): chunks started by a gradient hook (their all-reduce runs under the rest of backward)
+        # vs after backward (no overlap left): a tensor that gets no gradient keeps its chunk — and, by the descending launch order,
+        # every lower one — open until the end
         self._chunk_size = [owner.count(k) for k in range(len(chunks))]
         self._reset_exchange()
         if not self.exchanger.active:
@@ -97,6 +97,8 @@ class Dinov2Trainer:
     def _reset_exchange(self):
         n = len(self.exchanger.chunks)
         self._chunk_seen, self._chunk_next = [0] * n, n - 1     # _chunk_next: the one chunk that may be launched now
+        if not hasattr(self, "exchange_counts"):                # cumulative over the run (not reset per iteration)
+            self.exchange_counts = {"from_hooks": 0, "after_backward": 0}
 
     def _launch_ready(self):
         while self._chunk_next >= 0 and self._chunk_seen[self._chunk_next] >= self._chunk_size[self._chunk_next]:

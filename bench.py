@@ -376,6 +376,30 @@ def launch_ranks(n, argv):
     return rc
 
 
+def gather_rank_records(mine, world, device):
+    """Every rank's [ms_per_step, exchange_wait_ms or -1, socket_w or -1] on every rank, in rank order (an all_gather of three doubles
+    over the job's process group: RCCL on the GPU, gloo in --launcher-check)."""
+    if world <= 1:
+        return [list(mine)]
+    me = torch.tensor(list(mine), device=device, dtype=torch.float64)
+    allr = [torch.empty_like(me) for _ in range(world)]
+    torch.distributed.all_gather(allr, me)
+    return [a.tolist() for a in allr]
+
+
+def ranks_record(per_rank, exchange_chunks, reserved_cus):
+    """The `ranks` object of the bench line: one entry per rank in every list, so that a scaling curve explains itself."""
+    return {"ms_per_step": [round(r[0], 3) for r in per_rank],
+            "ms_per_step_min": round(min(r[0] for r in per_rank), 3), "ms_per_step_max": round(max(r[0] for r in per_rank), 3),
+            # mean time per step the compute stream stood at GradExchanger.wait(): null = no exchange in this run
+            "exchange_wait_ms": [None if r[1] < 0 else round(r[1], 4) for r in per_rank],
+            "exchange_chunks": exchange_chunks,
+            # what each rank's socket drew during the timed steps (driver hwmon, 10 ms samples); null where not readable
+            "socket_w": [None if (len(r) < 3 or r[2] < 0) else round(r[2], 1) for r in per_rank],
+            "reserved_cus": reserved_cus,
+            "env": {k: os.environ.get(k) for k in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS", "APLA_RESERVE_CUS", "APLA_FORCE_EXCHANGE")}}
+
+
 def launcher_check(world, rank, args):
     """--launcher-check: the rendezvous / MAX-over-ranks / one-JSON-line plumbing of a multi-rank run WITHOUT the GPU step
     (gloo, CPU tensors) — what tests/test_dist_cpu.py runs in the build container, where there is no GPU."""
@@ -387,12 +411,16 @@ def launcher_check(world, rank, args):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         time.sleep(0.001 * (1 + rank))
+    mine_ms = (time.perf_counter() - t0) / max(args.steps, 1) * 1e3
     dist.barrier()
     tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    # the per-rank arrays of the real line, through the same two helpers (rank r slept (1 + r) ms per step: the lists must come back in rank order)
+    per_rank = gather_rank_records([mine_ms, -1.0, -1.0], world, "cpu")
     if rank == 0:
         print(json.dumps({"metric": "launcher-check (no GPU step)", "value": None, "n_gpus": world, "ranks_seen": int(seen.item()),
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(float(tt) / max(args.steps, 1) * 1e3, 3),
+                          "ranks": ranks_record(per_rank, 0, int(os.environ.get("APLA_RESERVE_CUS", "0") or 0)),
                           "backend": "gloo"}), flush=True)
     dist.destroy_process_group()
 
@@ -536,12 +564,7 @@ def main():
     wait_ms = eng.exchanger.mean_wait_ms()
     eng.exchanger.time_waits(False)
     rank_ms = float(per_step.mean()) if args.steps else 0.0
-    per_rank = [[rank_ms, -1.0 if wait_ms is None else wait_ms, -1.0 if power is None else power["mean_w"]]]
-    if world > 1:
-        mine = torch.tensor(per_rank[0], device="cuda", dtype=torch.float64)
-        allr = [torch.empty_like(mine) for _ in range(world)]
-        torch.distributed.all_gather(allr, mine)
-        per_rank = [a.tolist() for a in allr]
+    per_rank = gather_rank_records([rank_ms, -1.0 if wait_ms is None else wait_ms, -1.0 if power is None else power["mean_w"]], world, "cuda")
     if world > 1:
         tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -631,15 +654,7 @@ def main():
                        "global_batch": world * args.batch, "parallelism": f"dp{world}",
                        "hip_graphs": not args.no_graphs},
             "images_per_sec_per_gpu": round(img_s / world, 1), "peak_mem_gib": round(peak_mem, 2),
-            "ranks": {"ms_per_step": [round(r[0], 3) for r in per_rank],
-                      "ms_per_step_min": round(min(r[0] for r in per_rank), 3), "ms_per_step_max": round(max(r[0] for r in per_rank), 3),
-                      # mean time per step the compute stream stood at GradExchanger.wait(): null = no exchange in this run
-                      "exchange_wait_ms": [None if r[1] < 0 else round(r[1], 4) for r in per_rank],
-                      "exchange_chunks": len(eng.chunks) if eng.exchanger.active else 0,
-                      # what each rank's socket drew during the timed steps (driver hwmon, 10 ms samples); null where not readable
-                      "socket_w": [None if (len(r) < 3 or r[2] < 0) else round(r[2], 1) for r in per_rank],
-                      "reserved_cus": eng.reserve_cus,
-                      "env": {k: os.environ.get(k) for k in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS", "APLA_RESERVE_CUS", "APLA_FORCE_EXCHANGE")}},
+            "ranks": ranks_record(per_rank, len(eng.chunks) if eng.exchanger.active else 0, eng.reserve_cus),
             "final_loss": round(loss, 4),
             # steady state of the same command (a stored record: the short window above can draw on the power controller's averaging)
             "sustained": sustained_record() if is_cfg2 and world == 1 and args.dtype == "bf16" else None,

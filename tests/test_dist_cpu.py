@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def _dp_worker(outdir):
+def _dp_worker(outdir, n_chunks=2):
     import torch.distributed as dist
     from conftest import load_golden, t
     from oracle import apla_oracle as O
@@ -24,9 +24,10 @@ def _dp_worker(outdir):
     p = {k[2:]: t(g[k], torch.float64) for k in g.files if k.startswith("p.")}
     cfg = dict(patch=patch, depth=L, heads=H, r=r)
     gen = torch.Generator().manual_seed(0)
-    images = torch.randn(4, 3, 48, 48, generator=gen, dtype=torch.float64)
-    labels = torch.randint(0, C, (4,), generator=gen)
-    sl = slice(rank * 2, rank * 2 + 2)  # this rank's shard of the global batch
+    per = 2 if world <= 3 else 1        # images per rank
+    images = torch.randn(per * world, 3, 48, 48, generator=gen, dtype=torch.float64)
+    labels = torch.randint(0, C, (per * world,), generator=gen)
+    sl = slice(rank * per, rank * per + per)  # this rank's shard of the global batch
     logits, ctx = O.vit_forward(images[sl], p, cfg)
     loss, dl = O.cross_entropy_fwd_bwd(logits, labels[sl])
     grads = O.vit_backward(dl, ctx, p, cfg)
@@ -34,7 +35,7 @@ def _dp_worker(outdir):
     flat = torch.cat([grads[n].reshape(-1) for n in names])
     offs = np.cumsum([0] + [grads[n].numel() for n in names])
     block_offs = [int(offs[2 * i]) for i in range(L)]
-    chunks = backward_order_chunks(block_offs, flat.numel(), 2)
+    chunks = backward_order_chunks(block_offs, flat.numel(), n_chunks)
     assert chunks[0][1] == flat.numel() and chunks[-1][0] == 0   # backward order: tail first
     ex = GradExchanger(flat, chunks)
     for k in range(len(chunks)):
@@ -52,11 +53,14 @@ def _dp_worker(outdir):
         np.save(os.path.join(outdir, "result.npy"), np.array([err, float(mean_loss - loss_f), world]))
 
 
-def test_chunked_allreduce_matches_full_batch(tmp_path):
+@pytest.mark.parametrize("world,n_chunks", [(2, 2), (3, 4), (8, 4)])
+def test_chunked_allreduce_matches_full_batch(tmp_path, world, n_chunks):
+    """World sizes beyond two (8 = the driver's scaling run): the chunked SUM all-reduce and the 1 / world of the
+    optimizer reproduce the full-batch gradient of the oracle, the averaged loss the full-batch loss."""
     from apla_amd.dist import launch
-    launch(_dp_worker, (str(tmp_path),), n_procs=2, backend="gloo")
-    err, dloss, world = np.load(tmp_path / "result.npy")
-    assert world == 2 and err < 1e-12 and abs(dloss) < 1e-12
+    launch(_dp_worker, (str(tmp_path), n_chunks), n_procs=world, backend="gloo")
+    err, dloss, w = np.load(tmp_path / "result.npy")
+    assert w == world and err < 1e-12 and abs(dloss) < 1e-12
 
 
 def test_backward_order_chunks_properties():
@@ -79,20 +83,27 @@ def test_single_process_exchanger_is_identity():
     assert ex.grad_scale == 1.0 and torch.equal(flat, torch.arange(10, dtype=torch.float32))
 
 
-def test_bench_self_launches_its_ranks():
-    """`python bench.py --gpus 2` with no launcher environment must start the two ranks itself and print ONE JSON line with
-    n_gpus = 2.  Here (no GPU) the children run --launcher-check: the same spawn / rendezvous / MAX-over-ranks
-    plumbing over gloo without the GPU step."""
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_self_launches_its_ranks(world):
+    """`python bench.py --gpus N` with no launcher environment must start the N ranks itself and print ONE JSON line with
+    n_gpus = N.  Here (no GPU) the children run --launcher-check: the same spawn / rendezvous / MAX-over-ranks
+    plumbing over gloo without the GPU step — at N = 8 too, the driver's scaling run: the per-rank lists of the line
+    (`ranks`, built by the helpers the real line uses) have one entry per rank, in rank order."""
     import json
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--launcher-check"],
-                       capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1", "--launcher-check"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["steps"] == 3
+    assert d["n_gpus"] == world and d["ranks_seen"] == world and d["steps"] == 3
+    rk = d["ranks"]
+    assert len(rk["ms_per_step"]) == world and len(rk["exchange_wait_ms"]) == world and len(rk["socket_w"]) == world
+    assert rk["ms_per_step"][0] == rk["ms_per_step_min"] and rk["ms_per_step"][-1] == rk["ms_per_step_max"]      # rank r sleeps (1 + r) ms per step
+    assert all(a <= b + 0.5 for a, b in zip(rk["ms_per_step"][:-1], rk["ms_per_step"][1:])), rk["ms_per_step"]
+    assert rk["env"]["NCCL_MAX_NCHANNELS"] == "8" and rk["reserved_cus"] == 8          # the RCCL channel budget travels to every rank
 
 
 def test_bench_parent_fails_when_a_rank_fails():

@@ -27,12 +27,13 @@ def _worker(outdir, use_graphs):
     rank, world = dist.get_rank(), dist.get_world_size()
     torch.cuda.set_device(0)
     gen = torch.Generator().manual_seed(0)
-    images = torch.randn(8, 3, 32, 32, generator=gen)
-    labels = torch.randint(0, 10, (8,), generator=gen)
+    images = torch.randn(4 * world, 3, 32, 32, generator=gen)
+    labels = torch.randint(0, 10, (4 * world,), generator=gen)
     sl = slice(rank * 4, rank * 4 + 4)
     eng = AplaTrainEngine(small_vit(depth=4, r=64), 4, 32, optim=OptimConfig(lr=1e-3, weight_decay=1e-2, grad_clipping=1.0),
                           process_group=dist.group.WORLD, use_graphs=use_graphs)
-    assert eng.world == 2 and len(eng.chunks) == 4 and len(eng.seg_cuts) == 4
+    assert eng.world == world and len(eng.chunks) == 4 and len(eng.seg_cuts) == 4 and eng.exchanger.grad_scale == 1.0 / world
+    assert sorted(eng.chunks)[0][0] == 0 and sorted(eng.chunks)[-1][1] == eng.flat_grads.numel()      # the chunks tile the buffer
     # step 1 in two halves, so that the exchanged gradient (SUM over ranks; the optimizer applies 1/world) can be stored
     eng.set_batch(images[sl].cuda(), labels[sl].cuda())
     eng.forward_backward()
@@ -47,18 +48,22 @@ def _worker(outdir, use_graphs):
     dist.barrier()
 
 
-@pytest.mark.parametrize("use_graphs", [False, True])
-def test_two_rank_step_equals_full_batch_step(tmp_path, use_graphs):
+@pytest.mark.parametrize("world,use_graphs", [(2, False), (2, True), (3, True), (5, True)])
+def test_two_rank_step_equals_full_batch_step(tmp_path, world, use_graphs):
+    """World sizes 3 and 5 as well (sizes the code had never executed; 5 ranks + this process = the six processes a
+    box lets one user put on its GPU — the 8-rank plumbing runs on the CPU, tests/test_dist_cpu.py): 1 / world in the optimizer,
+    chunk tiling, replicas bit-identical, the update equal to the one-process full-batch step and to the oracle's."""
     from apla_amd.dist import launch
     from apla_amd.engine import AplaTrainEngine, OptimConfig
     from test_engine_gpu import small_vit
-    launch(_worker, (str(tmp_path), use_graphs), n_procs=2, backend="gloo")
-    p0, p1 = np.load(tmp_path / "params_0.npy"), np.load(tmp_path / "params_1.npy")
-    assert np.array_equal(p0, p1)                                   # replicas stay bit-identical
+    launch(_worker, (str(tmp_path), use_graphs), n_procs=world, backend="gloo")
+    p0 = np.load(tmp_path / "params_0.npy")
+    for r in range(1, world):
+        assert np.array_equal(p0, np.load(tmp_path / f"params_{r}.npy")), r       # replicas stay bit-identical
     gen = torch.Generator().manual_seed(0)
-    images = torch.randn(8, 3, 32, 32, generator=gen)
-    labels = torch.randint(0, 10, (8,), generator=gen)
-    eng = AplaTrainEngine(small_vit(depth=4, r=64), 8, 32, optim=OptimConfig(lr=1e-3, weight_decay=1e-2, grad_clipping=1.0),
+    images = torch.randn(4 * world, 3, 32, 32, generator=gen)
+    labels = torch.randint(0, 10, (4 * world,), generator=gen)
+    eng = AplaTrainEngine(small_vit(depth=4, r=64), 4 * world, 32, optim=OptimConfig(lr=1e-3, weight_decay=1e-2, grad_clipping=1.0),
                           use_graphs=use_graphs)
     for _ in range(3):
         eng.train_step(images.cuda(), labels.cuda())
@@ -81,7 +86,8 @@ def test_two_rank_step_equals_full_batch_step(tmp_path, use_graphs):
     for _ in range(3):
         _, _, _, gnorm = O.train_step(images.double(), labels, p, cfg, state, lr=1e-3, wd=1e-2, clip=1.0)
     g0 = np.load(tmp_path / "grads_0.npy")
-    assert np.array_equal(g0, np.load(tmp_path / "grads_1.npy"))     # both ranks hold the same exchanged buffer
+    for r in range(1, world):
+        assert np.array_equal(g0, np.load(tmp_path / f"grads_{r}.npy")), r     # every rank holds the same exchanged buffer
     lf, cf = O.vit_forward(images.double(), oracle_params(model), cfg)
     _, dlf = O.cross_entropy_fwd_bwd(lf, labels)
     gref = O.vit_backward(dlf, cf, oracle_params(model), cfg)        # first-step gradients before the clip (train_step clips in place)

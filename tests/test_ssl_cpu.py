@@ -119,6 +119,9 @@ def test_chunked_exchange_launch_order_is_rank_invariant():
             tr._chunk_seen[k] += 1
             tr._launch_ready()
             assert tr.exchanger.order == list(range(len(sizes) - 1, len(sizes) - 1 - len(tr.exchanger.order), -1))
+        n_hook = len(tr.exchanger.order)
         tr._finish_exchange()
         assert tr.exchanger.order == [4, 3, 2, 1, 0] and tr.exchanger.waited == 1
         assert tr._chunk_seen == [0] * 5 and tr._chunk_next == 4
+        # how many chunks left from a hook (overlapped with backward) and how many only after it is on record
+        assert sum(tr.exchange_counts.values()) == 5 and tr.exchange_counts["from_hooks"] == n_hook
