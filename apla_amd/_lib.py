@@ -44,6 +44,11 @@ SIGNATURES = {
     "apla_layernorm_bwd_ex": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_long, c_void_p, c_void_p, c_void_p,
                                       c_void_p, c_int, c_void_p, c_int, c_long, c_void_p, c_long, c_void_p, c_int, c_void_p,
                                       c_int, c_int, c_void_p]),
+    "apla_layernorm_fwd_dp": (c_int, [c_void_p, c_int, c_long, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
+                                      c_void_p, c_int, c_int, c_float, c_void_p, c_long, c_void_p, c_long, c_void_p, c_int, c_void_p]),
+    "apla_layernorm_bwd_dp": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_long, c_void_p, c_void_p, c_void_p,
+                                      c_void_p, c_int, c_void_p, c_int, c_long, c_void_p, c_long, c_void_p, c_int, c_void_p,
+                                      c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "apla_gemm_nt_kernel_name": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_char_p, c_int]),
     "apla_attn_kernel_name": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_char_p, c_int]),
     "apla_attn_fwd_dropout": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_ulonglong, c_uint, c_void_p]),

@@ -25,11 +25,13 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const ResT* x, long 
                                                      const float* __restrict__ beta, YT* __restrict__ y, int ldy,
                                                      float* __restrict__ mean_o, float* __restrict__ rstd_o, int M,
                                                      int D, float eps, const bf16* __restrict__ add, long adds,
-                                                     ResT* xout, long xouts) {
+                                                     ResT* xout, long xouts, const float* __restrict__ add_scale, int scale_period) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nchunk = D >> 2;
   for (int m = blockIdx.x * ROWS_PER_BLOCK + wave; m < M; m += gridDim.x * ROWS_PER_BLOCK) {
     const ResT* xr = x + (size_t)m * xs;
+    // stochastic depth (vit.py:74-93, :284-285): the branch of sample m / scale_period enters with its per-sample factor 0 or 1 / keep_prob
+    const float bscale = add_scale != nullptr ? add_scale[m / scale_period] : 1.0f;
     f32x4 v[NC];
     float s = 0.f;
 #pragma unroll
@@ -38,7 +40,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const ResT* x, long 
       if (ch < nchunk) {
         v[c] = Vec4IO<ResT>::load(xr + ch * 4);
         if (add != nullptr) {
-          v[c] += Vec4IO<bf16>::load(add + (size_t)m * adds + ch * 4);
+          v[c] += Vec4IO<bf16>::load(add + (size_t)m * adds + ch * 4) * bscale;
           Vec4IO<ResT>::store(xout + (size_t)m * xouts + ch * 4, v[c]);
           if constexpr (sizeof(ResT) == 2) {  // statistics of the value as stored (bf16-rounded), like a separate LN pass would see
 #pragma unroll
@@ -87,7 +89,8 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const DYT* __restric
                                                      const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                      const GT* dres, GT* dx, long dxs, bf16* __restrict__ dxb, long dbs,
                                                      const int32_t* __restrict__ inds, int r, bf16* __restrict__ gout,
-                                                     int M, int D, int dres_period) {
+                                                     int M, int D, int dres_period, const float* __restrict__ dy_scale,
+                                                     const float* __restrict__ g_scale, int scale_period) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* rowbuf = (float*)smem_raw;  // [ROWS_PER_BLOCK][D] when GATHER
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -99,8 +102,11 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const DYT* __restric
       const DYT* dyr = dy + (size_t)m * lddy;
       // mean_i == NULL: x holds the NORMALISED row (what the forward wrote with gamma == NULL), saved in 16 bits: the backward
       // then reads 2 bytes per element instead of the 4 of the fp32 residual row
-      const float mean = mean_i != nullptr ? mean_i[m] : 0.f, rstd = rstd_i[m];
-      const float xsc = mean_i != nullptr ? rstd : 1.0f;
+      // stochastic depth: dy_scale = the per-sample factor of the branch this LayerNorm fed (its gradient is linear in the factor, so
+      // it is applied here, at the end of the branch's backward chain); g_scale = the factor of the branch whose dW reads `gout`
+      const float mean = mean_i != nullptr ? mean_i[m] : 0.f, rstd = rstd_i[m] * (dy_scale != nullptr ? dy_scale[m / scale_period] : 1.0f);
+      const float xsc = mean_i != nullptr ? rstd_i[m] : 1.0f;
+      const float gsc = g_scale != nullptr ? g_scale[m / scale_period] : 1.0f;
       // dres_period > 1: only every dres_period-th row of the incoming residual gradient is non-zero (the CLS rows below the
       // final norm, vit.py:416-419) and the rest is NOT read — no zero-fill of the stream, no read of zeros
       const bool has_res = dres != nullptr && (dres_period <= 1 || m % dres_period == 0);
@@ -135,7 +141,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const DYT* __restric
           if (has_res) o += Vec4IO<GT>::load(dres + (size_t)m * dxs + ch * 4);
           Vec4IO<GT>::store(dxr + ch * 4, o);
           if (dxb != nullptr) Vec4IO<bf16>::store(dxb + (size_t)m * dbs + ch * 4, o);
-          if constexpr (GATHER) *(f32x4*)(rowbuf + wave * D + ch * 4) = o;
+          if constexpr (GATHER) *(f32x4*)(rowbuf + wave * D + ch * 4) = o * gsc;
         }
       }
     }
@@ -157,7 +163,8 @@ template <bool GATHER, int NC8>
 __global__ __launch_bounds__(LN_THREADS) void ln_bwd2_kernel(const bf16* __restrict__ dy, int lddy, const bf16* __restrict__ xh,
                                                       long xs, const float* __restrict__ rstd_i, const bf16* dres, bf16* dx,
                                                       long dxs, const int32_t* __restrict__ inds, int r,
-                                                      bf16* __restrict__ gout, int M, int D, int dres_period) {
+                                                      bf16* __restrict__ gout, int M, int D, int dres_period,
+                                                      const float* __restrict__ dy_scale, const float* __restrict__ g_scale, int scale_period) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* rowbuf = (float*)smem_raw;  // [2 * ROWS_PER_BLOCK][D] when GATHER
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -170,7 +177,8 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd2_kernel(const bf16* __restr
     const int mr = live ? m : M - 1;        // a dead half-wave re-reads the last row (keeps the cross-lane sums uniform), stores nothing
     const bf16* xr = xh + (size_t)mr * xs;
     const bf16* dyr = dy + (size_t)mr * lddy;
-    const float rstd = rstd_i[mr];
+    const float rstd = rstd_i[mr] * (dy_scale != nullptr ? dy_scale[mr / scale_period] : 1.0f);     // (stochastic depth: see ln_bwd_kernel)
+    const float gsc = g_scale != nullptr ? g_scale[mr / scale_period] : 1.0f;
     const bool has_res = dres != nullptr && (dres_period <= 1 || mr % dres_period == 0);
     bf16x8 xv[NC8], dv[NC8], rv[NC8];
 #pragma unroll
@@ -207,7 +215,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd2_kernel(const bf16* __restr
           float o = ((float)dv[c][e] - c1 - (float)xv[c][e] * c2) * rstd;
           if (has_res) o += (float)rv[c][e];
           ov[e] = (bf16)o;
-          if constexpr (GATHER) rowbuf[(2 * wave + half) * D + ch * 8 + e] = o;
+          if constexpr (GATHER) rowbuf[(2 * wave + half) * D + ch * 8 + e] = o * gsc;
         }
         if (live) *(bf16x8*)(dx + (size_t)m * dxs + ch * 8) = ov;
       }
@@ -243,17 +251,19 @@ inline int ln_grid(int M) {
 
 }  // namespace
 
-extern "C" int apla_layernorm_fwd(const void* x, int res_dtype, long x_row_stride, const float* gamma,
-                                  const float* beta, void* y, int y_dtype, int ldy, float* mean, float* rstd, int M,
-                                  int D, float eps, const void* add_in, long add_row_stride, void* x_out,
-                                  long x_out_row_stride, hipStream_t stream) {
+extern "C" int apla_layernorm_fwd_dp(const void* x, int res_dtype, long x_row_stride, const float* gamma,
+                                     const float* beta, void* y, int y_dtype, int ldy, float* mean, float* rstd, int M,
+                                     int D, float eps, const void* add_in, long add_row_stride, void* x_out,
+                                     long x_out_row_stride, const float* add_scale, int scale_period, hipStream_t stream) {
+  APLA_REQUIRE(add_scale == nullptr || (add_in != nullptr && scale_period >= 1), "apla_layernorm_fwd_dp: a per-sample scale needs add_in and scale_period >= 1");
+  if (add_scale == nullptr) scale_period = 1;
   APLA_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 256 * MAXC, "apla_layernorm_fwd: need D%%4==0 and D<=1536 (D=%d)", D);
   APLA_REQUIRE(x && y && mean && rstd && ((gamma == nullptr) == (beta == nullptr)), "apla_layernorm_fwd: null pointer (gamma and beta are given together or not at all)");
   APLA_REQUIRE(x_row_stride % 4 == 0 && ldy % 4 == 0 && x_row_stride >= D && ldy >= D, "apla_layernorm_fwd: strides must be >= D and multiples of 4");
   APLA_REQUIRE(apla_aligned16(x) && (gamma == nullptr || (apla_aligned16(gamma) && apla_aligned16(beta))) && (((uintptr_t)y) & 7) == 0, "apla_layernorm_fwd: alignment");
   APLA_REQUIRE(add_in == nullptr || (x_out != nullptr && add_row_stride % 4 == 0 && add_row_stride >= D && x_out_row_stride % 4 == 0 && x_out_row_stride >= D),
                "apla_layernorm_fwd: fused residual add needs x_out and valid strides");
-#define LN_FWD_NC(T, Y, NCV) hipLaunchKernelGGL((ln_fwd_kernel<T, Y, NCV>), dim3(ln_grid(M)), dim3(LN_THREADS), 0, stream, (const T*)x, x_row_stride, gamma, beta, (Y*)y, ldy, mean, rstd, M, D, eps, (const bf16*)add_in, add_row_stride, (T*)x_out, x_out_row_stride)
+#define LN_FWD_NC(T, Y, NCV) hipLaunchKernelGGL((ln_fwd_kernel<T, Y, NCV>), dim3(ln_grid(M)), dim3(LN_THREADS), 0, stream, (const T*)x, x_row_stride, gamma, beta, (Y*)y, ldy, mean, rstd, M, D, eps, (const bf16*)add_in, add_row_stride, (T*)x_out, x_out_row_stride, add_scale, scale_period)
 #define LN_FWD(T, Y)                                    \
   do {                                                  \
     const int nc_ = (D + 255) / 256;                    \
@@ -277,11 +287,21 @@ extern "C" int apla_layernorm_fwd(const void* x, int res_dtype, long x_row_strid
   return APLA_OK;
 }
 
-extern "C" int apla_layernorm_bwd_ex(const void* dy, int dy_dtype, int lddy, const void* x, int x_dtype, long x_row_stride,
+extern "C" int apla_layernorm_fwd(const void* x, int res_dtype, long x_row_stride, const float* gamma,
+                                  const float* beta, void* y, int y_dtype, int ldy, float* mean, float* rstd, int M,
+                                  int D, float eps, const void* add_in, long add_row_stride, void* x_out,
+                                  long x_out_row_stride, hipStream_t stream) {
+  return apla_layernorm_fwd_dp(x, res_dtype, x_row_stride, gamma, beta, y, y_dtype, ldy, mean, rstd, M, D, eps, add_in, add_row_stride,
+                               x_out, x_out_row_stride, nullptr, 1, stream);
+}
+
+extern "C" int apla_layernorm_bwd_dp(const void* dy, int dy_dtype, int lddy, const void* x, int x_dtype, long x_row_stride,
                                      const float* gamma, const float* mean, const float* rstd, const void* dres_in,
                                      int dres_row_period, void* dx_out, int grad_dtype, long dx_row_stride, void* dx_bf16_copy,
                                      long copy_row_stride, const int32_t* inds, int r, void* gather_out, int M, int D,
-                                     hipStream_t stream) {
+                                     const float* dy_scale, const float* gather_scale, int scale_period, hipStream_t stream) {
+  APLA_REQUIRE((dy_scale == nullptr && gather_scale == nullptr) || scale_period >= 1, "apla_layernorm_bwd_dp: scale_period >= 1");
+  if (dy_scale == nullptr && gather_scale == nullptr) scale_period = 1;
   APLA_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 256 * MAXC, "apla_layernorm_bwd: need D%%4==0 and D<=1536 (D=%d)", D);
   APLA_REQUIRE(dy && x && rstd && dx_out && dres_row_period >= 0, "apla_layernorm_bwd: null pointer");
   APLA_REQUIRE(lddy % 4 == 0 && x_row_stride % 4 == 0 && dx_row_stride % 4 == 0 && lddy >= D && x_row_stride >= D && dx_row_stride >= D, "apla_layernorm_bwd: bad strides");
@@ -300,7 +320,7 @@ extern "C" int apla_layernorm_bwd_ex(const void* dy, int dy_dtype, int lddy, con
 #define LN_BWD2(GA, NCV)                                                                                                           \
     hipLaunchKernelGGL((ln_bwd2_kernel<GA, NCV>), grid2, dim3(LN_THREADS), lds2, stream, (const bf16*)dy, lddy, (const bf16*)x,      \
                        x_row_stride, rstd, (const bf16*)dres_in, (bf16*)dx_out, dx_row_stride, inds, r, (bf16*)gather_out, M, D,    \
-                       dres_row_period)
+                       dres_row_period, dy_scale, gather_scale, scale_period)
 #define LN_BWD2_G(NCV) do { if (gather) LN_BWD2(true, NCV); else LN_BWD2(false, NCV); } while (0)
     if (nc8 <= 1) LN_BWD2_G(1);
     else if (nc8 == 2) LN_BWD2_G(2);
@@ -317,7 +337,7 @@ extern "C" int apla_layernorm_bwd_ex(const void* dy, int dy_dtype, int lddy, con
 #define LN_BWD_NC(X, Y, G, GA, NCV)                                                                                    \
   hipLaunchKernelGGL((ln_bwd_kernel<X, Y, G, GA, NCV>), dim3(ln_grid(M)), dim3(LN_THREADS), lds, stream, (const Y*)dy, lddy,  \
                      (const X*)x, x_row_stride, gamma, mean, rstd, (const G*)dres_in, (G*)dx_out, dx_row_stride,       \
-                     (bf16*)dx_bf16_copy, copy_row_stride, inds, r, (bf16*)gather_out, M, D, dres_row_period)
+                     (bf16*)dx_bf16_copy, copy_row_stride, inds, r, (bf16*)gather_out, M, D, dres_row_period, dy_scale, gather_scale, scale_period)
 #define LN_BWD(X, Y, G, GA)                             \
   do {                                                  \
     const int nc_ = (D + 255) / 256;                    \
@@ -349,6 +369,15 @@ extern "C" int apla_layernorm_bwd_ex(const void* dy, int dy_dtype, int lddy, con
 #undef LN_BWD_NC
   APLA_CHECK_LAUNCH("apla_layernorm_bwd");
   return APLA_OK;
+}
+
+extern "C" int apla_layernorm_bwd_ex(const void* dy, int dy_dtype, int lddy, const void* x, int x_dtype, long x_row_stride,
+                                     const float* gamma, const float* mean, const float* rstd, const void* dres_in,
+                                     int dres_row_period, void* dx_out, int grad_dtype, long dx_row_stride, void* dx_bf16_copy,
+                                     long copy_row_stride, const int32_t* inds, int r, void* gather_out, int M, int D,
+                                     hipStream_t stream) {
+  return apla_layernorm_bwd_dp(dy, dy_dtype, lddy, x, x_dtype, x_row_stride, gamma, mean, rstd, dres_in, dres_row_period, dx_out, grad_dtype,
+                               dx_row_stride, dx_bf16_copy, copy_row_stride, inds, r, gather_out, M, D, nullptr, nullptr, 1, stream);
 }
 
 extern "C" int apla_layernorm_bwd(const void* dy, int dy_dtype, int lddy, const void* x, int x_dtype, long x_row_stride,

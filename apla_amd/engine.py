@@ -89,10 +89,17 @@ class AplaTrainEngine:
         self.D, self.L, self.H = bb.embed_dim, bb.depth, bb.num_heads
         if self.D != 64 * self.H:
             raise NotImplementedError("HIP attention kernel needs head_dim == 64")
-        for name, mod in model.named_modules():   # the captured launch sequence has no dropout / stochastic depth: never ignore one silently
-            if (isinstance(mod, nn.Dropout) and mod.p > 0.0) or (getattr(mod, "drop_prob", None) or 0.0) > 0.0:
-                raise NotImplementedError(f"{name}: dropout / stochastic depth > 0 is implemented on the module path only "
-                                          "(apla_amd.vit / apla_amd.functional), not in the fused step; every shipped APLA config uses 0")
+        for name, mod in model.named_modules():   # the captured launch sequence has no element-wise dropout: never ignore one silently
+            if isinstance(mod, nn.Dropout) and mod.p > 0.0:
+                raise NotImplementedError(f"{name}: nn.Dropout with p > 0 is implemented on the module path only (apla_amd.vit / "
+                                          "apla_amd.functional), not in the fused step (stochastic depth is: main.py --dpr); every shipped APLA config uses 0")
+        # stochastic depth (vit.py:74-93, :257, :284-285; main.py --dpr): fused into the LayerNorm kernels as one factor per sample and
+        # branch (apla_layernorm_fwd_dp / _bwd_dp), drawn per step into `dp_scale` BEFORE the captured launches run
+        self.dp_rates = [float(getattr(getattr(blk, "drop_path", None), "drop_prob", 0.0) or 0.0) for blk in bb.blocks]
+        if any(not (0.0 <= q < 1.0) for q in self.dp_rates):
+            raise ValueError(f"drop_path rates must be in [0, 1): {self.dp_rates}")
+        self.dp_on = any(q > 0.0 for q in self.dp_rates)
+        self._dp_given = None
         self.Np = (img_size // self.patch) ** 2
         self.N = self.Np + 1
         self.M = self.B * self.N
@@ -317,6 +324,12 @@ class AplaTrainEngine:
     def _alloc_buffers(self):
         dev, M, D, B, N, H, L = self.device, self.M, self.D, self.B, self.N, self.H, self.L
         e = lambda *s, dt=ops.half(): torch.empty(*s, device=dev, dtype=dt)  # noqa: E731
+        # stochastic depth: rows 2 i / 2 i + 1 = the per-sample factors floor(keep + u) / keep of block i's attention / MLP branch
+        self.dp_scale = torch.ones(2 * L, B, device=dev, dtype=torch.float32) if self.dp_on else None
+        if self.dp_on:
+            self._dp_keep = torch.tensor([1.0 - q for q in self.dp_rates for _ in (0, 1)], device=dev, dtype=torch.float32)[:, None]
+            self._dp_gen = torch.Generator(device=dev)
+            self._dp_gen.manual_seed(int(torch.empty((), dtype=torch.int64).random_()))     # one draw from torch's default CPU generator: torch.manual_seed repeats a run
         self.images = e(B, 3, self.S, self.S, dt=torch.float32)
         self.labels = torch.zeros(B, device=dev, dtype=torch.int32)
         self.targets = torch.zeros(B, self.C, device=dev, dtype=torch.float32) if self.soft_targets else None
@@ -435,6 +448,7 @@ class AplaTrainEngine:
         """``inference``: the no-grad forward of forward_only — fc1 runs the forward-only GELU epilogue (GELU' is neither
         computed nor stored); everything else is the training forward."""
         B, N, H, D = self.B, self.N, self.H, self.D
+        dps = (lambda k: None) if (inference or not self.dp_on) else (lambda k: self.dp_scale[k])     # stochastic depth: training only
         ops.patchify(self.images, self.patch, self.Kp, out=self.cols)
         ops.gemm_nt(self.cols, self.Wpe_i, self.bpe, out=self.patches, tag=ops.TAG_PATCH)
         ops.assemble_tokens(self.patches, self.cls, self.pos, B, self.Np, out=self.res)
@@ -448,19 +462,19 @@ class AplaTrainEngine:
                 ops.layernorm_fwd(self.res, None, None, self.eps, out=xh1, mean=self.mean_scratch, rstd=self.rstd1[0])
             else:
                 ops.layernorm_fwd(self.res, None, None, self.eps, out=xh1, mean=self.mean_scratch, rstd=self.rstd1[i],
-                                  add=self.branch, x_out=self.res)
+                                  add=self.branch, x_out=self.res, add_scale=dps(2 * i - 1), scale_period=N)
             if i == self.L - 1 and self.cls_only_tail:
                 # last block: K and V for every token, Q for the CLS rows only (the only query that is ever used)
                 ops.gemm_nt(xh1, st.Wkv_i, st.bqkv[D:], out=self.qkv[i][:, D:], tag=ops.TAG_QKV)
                 self._gemm_rows(xh1.view(B, N * D)[:, :D], st.Wqkv[:D], st.bqkv[:D], out=self.qkv[i].view(B, N * 3 * D)[:, :D])
-                self._forward_last_block_tail(st, i)
+                self._forward_last_block_tail(st, i, dps)
                 break
             ops.gemm_nt(xh1, st.Wqkv_i, st.bqkv, out=self.qkv[i], tag=ops.TAG_QKV)
             ops.attn_fwd(self.qkv[i], B, N, H, self.scale, o=self.o[i], lse=self.lse[i])
             ops.gemm_nt(self.o[i], st.Wnat_i, st.bnat, out=self.branch, tag=ops.TAG_PROJ)
             xh2 = self.xh2[i]
             ops.layernorm_fwd(self.res, None, None, self.eps, out=xh2, mean=self.mean_scratch, rstd=self.rstd2[i],
-                              add=self.branch, x_out=self.res)
+                              add=self.branch, x_out=self.res, add_scale=dps(2 * i), scale_period=N)
             ev = self._fc1_events
             if ev is not None:   # bench.py: HIP events around the dominant launch, in its place inside the step (eager replay only)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -478,7 +492,7 @@ class AplaTrainEngine:
         # final norm on the CLS rows only (vit.py:416-419) with the last residual add fused, fp32 head + mean CE
         ops.layernorm_fwd(self.res, self.gf, self.bf_, self.eps, out=self.xn, mean=self.meanf, rstd=self.rstdf,
                           rows=B, row_stride=N * D, add=self.branch_cls if self.cls_only_tail else self.branch,
-                          add_row_stride=D if self.cls_only_tail else None, x_out=self.res)
+                          add_row_stride=D if self.cls_only_tail else None, x_out=self.res, add_scale=dps(2 * self.L - 1), scale_period=1)
         ops.sgemm_small(self.xn, self._param_view("fc.weight"), trans_b=True, bias=self._param_view("fc.bias"),
                         out=self.logits)
         ops.cross_entropy(self.logits, self.targets if self.soft_targets else self.labels, dlogits=self.dlogits,
@@ -502,7 +516,7 @@ class AplaTrainEngine:
                 return ops.gemm_nt_small(a, w, bias, workspace=ws, **kw)
         return ops.gemm_nt(a, w, bias, **kw)
 
-    def _forward_last_block_tail(self, st, i):
+    def _forward_last_block_tail(self, st, i, dps=lambda k: None):
         """Block L-1 after its qkv GEMM.  The head reads only x[:, 0] of this block's output (vit.py:416-419) and rows do not
         mix after the attention, so everything from the attention on runs for the B CLS rows only: one query per head
         against all keys (apla_attn_fwd_cls), then projection, LN2, MLP on [B, D] instead of [B*N, D] (about 0.28 TFLOP
@@ -513,7 +527,8 @@ class AplaTrainEngine:
         ops.attn_fwd_cls(self.qkv[i], B, N, H, self.scale, o=self.o[i], lse=self.lse[i])
         self._gemm_rows(cls(self.o[i]), st.Wnat, st.bnat, out=self.branch_cls)
         ops.layernorm_fwd(self.res, None, None, self.eps, out=self.ln_cls, mean=self.mean2_cls, rstd=self.rstd2_cls,
-                          rows=B, row_stride=N * D, add=self.branch_cls, add_row_stride=D, x_out=self.res, D=D)
+                          rows=B, row_stride=N * D, add=self.branch_cls, add_row_stride=D, x_out=self.res, D=D,
+                          add_scale=dps(2 * i), scale_period=1)
         if self.swiglu:
             ops.gemm_nt(self.ln_cls, st.W12, st.b12, epilogue=ops.EPI_SWIGLU, aux_out=cls(self.act_saved[i]), out=self.h_cls)
         else:
@@ -566,8 +581,9 @@ class AplaTrainEngine:
             ops.gemm_nt(self.Gb, st.WoutT, None, epilogue=ops.EPI_MUL, aux_in=self.act_io[i], out=self.dact_out)
             ops.gemm_nt(self.dact_out, st.Wdfc1_i, None, out=self.dln, tag=ops.TAG_DFC1)
         dyg = (self.dyg_all[i] if self.dw_batch > 1 else self.dyg)[:M * st.r_pad].view(M, st.r_pad)
+        dps = (lambda k: self.dp_scale[k]) if self.dp_on else (lambda k: None)      # stochastic depth: the branches' per-sample factors
         ops.layernorm_bwd(self.dln, self.xh2[i], None, None, self.rstd2[i], dres=self.G, out=self.G,
-                          out_bf16=copy, inds=st.inds, r=st.r_pad, gathered=dyg)
+                          out_bf16=copy, inds=st.inds, r=st.r_pad, gathered=dyg, dy_scale=dps(2 * i + 1), gather_scale=dps(2 * i), scale_period=N)
         if self.dw_batch > 1:
             self._dw_pending.append((st, dyg, self.o[i]))
             if len(self._dw_pending) == self.dw_batch:
@@ -579,7 +595,8 @@ class AplaTrainEngine:
         ops.gemm_nt(self.Gb, st.WnatT_i, None, out=self.dO, tag=ops.TAG_DPROJ)
         ops.attn_bwd(self.qkv[i], self.o[i], self.dO, self.lse[i], B, N, H, self.scale, dqkv=self.dqkv, delta=self.delta)
         ops.gemm_nt(self.dqkv, st.WqkvT_i, None, out=self.dln, tag=ops.TAG_DQKV)
-        ops.layernorm_bwd(self.dln, self.xh1[i], None, None, self.rstd1[i], dres=self.G, out=self.G, out_bf16=copy)
+        ops.layernorm_bwd(self.dln, self.xh1[i], None, None, self.rstd1[i], dres=self.G, out=self.G, out_bf16=copy,
+                          dy_scale=dps(2 * i), scale_period=N)
 
     def _backward_last_block(self):
         """Backward of block L-1 exploiting that only the CLS rows (token 0 of every sequence) of the incoming residual
@@ -602,8 +619,10 @@ class AplaTrainEngine:
             xh, xh_stride, rstd = self.ln_cls, D, self.rstd2_cls
         else:                     # (diagnostic full forward) rows b*N of the dense buffers
             xh, xh_stride, rstd = self.xh2[i], N * D, self.rstd2[i][::N].contiguous()
+        dps = (lambda k: self.dp_scale[k]) if self.dp_on else (lambda k: None)
         ops.layernorm_bwd(self.dln_cls, xh, None, None, rstd, dres=self.G, out=self.G, out_bf16=copy, inds=st.inds, r=st.r_pad,
-                          gathered=dyg, rows=B, row_stride=N * D, x_row_stride=xh_stride)
+                          gathered=dyg, rows=B, row_stride=N * D, x_row_stride=xh_stride,
+                          dy_scale=dps(2 * i + 1), gather_scale=dps(2 * i), scale_period=1)
         self._proj_dw(st, dyg, cls(self.o[i]))
         if i == 0:
             return
@@ -611,7 +630,8 @@ class AplaTrainEngine:
         ops.attn_bwd_cls(self.qkv[i], self.o[i], self.dO_cls, self.lse[i], B, N, H, self.scale, dqkv=self.dqkv)
         ops.gemm_nt(self.dqkv, st.WqkvT_i, None, out=self.dln, tag=ops.TAG_DQKV)
         # first dense backward of the step: the incoming stream holds the CLS rows only (see _backward_head)
-        ops.layernorm_bwd(self.dln, self.xh1[i], None, None, self.rstd1[i], dres=self.G, out=self.G, out_bf16=copy, dres_period=N)
+        ops.layernorm_bwd(self.dln, self.xh1[i], None, None, self.rstd1[i], dres=self.G, out=self.G, out_bf16=copy, dres_period=N,
+                          dy_scale=dps(2 * i), scale_period=N)
 
     def _segment(self, k):
         """Segment k of the step: segment 0 = weight re-scatter + forward + head + the backward down to block seg_cuts[0];
@@ -659,11 +679,24 @@ class AplaTrainEngine:
                 raise ValueError("class-id labels [B] expected (build the engine with soft_targets=True for probability targets)")
             self.labels.copy_(labels.to(torch.int32), non_blocking=True)
 
+    def set_drop_path_uniforms(self, u: Optional[torch.Tensor]):
+        """Tests / reproducibility: the uniform numbers u [2 L, B] of the NEXT steps' DropPath draws (row 2 i / 2 i + 1 = block i's
+        attention / MLP branch; vit.py:74-82: factor = floor(keep_prob + u) / keep_prob) instead of the engine's own generator;
+        None returns to the generator."""
+        self._dp_given = None if u is None else u.to(self.device, torch.float32).reshape(2 * self.L, self.B)
+
+    def _draw_drop_path(self):
+        """One factor per (block, branch, sample) for this step, written into the static buffer the (captured) LayerNorm launches read."""
+        u = self._dp_given if self._dp_given is not None else torch.rand(2 * self.L, self.B, device=self.device, generator=self._dp_gen)
+        torch.div(torch.floor(self._dp_keep + u), self._dp_keep, out=self.dp_scale)
+
     @_half_mode
     def forward_backward(self):
         """Forward + loss + backward of the batch in self.images/self.labels; grads land in the flat buffer.
         With world > 1 the gradient all-reduce of each chunk is launched on a side stream as soon as its segment of the
         backward has been enqueued."""
+        if self.dp_on:
+            self._draw_drop_path()
         if self.use_graphs and self._graphs is None:
             self._capture()
         for k in range(len(self.seg_cuts)):

@@ -80,8 +80,6 @@ class ModulePathTrainer:
 
 
 def wants_dropout(model) -> bool:
-    """Does any module of `model` ask for dropout or stochastic depth?  (What AplaTrainEngine refuses.)"""
-    for mod in model.modules():
-        if (isinstance(mod, torch.nn.Dropout) and mod.p > 0.0) or (getattr(mod, "drop_prob", None) or 0.0) > 0.0:
-            return True
-    return False
+    """Does any module of `model` ask for element-wise dropout (nn.Dropout with p > 0: --dr / --adr)?  That is what AplaTrainEngine
+    refuses; stochastic depth alone (DropPath, --dpr) stays on the fused step since round 6 (fused into its LayerNorm kernels)."""
+    return any(isinstance(mod, torch.nn.Dropout) and mod.p > 0.0 for mod in model.modules())

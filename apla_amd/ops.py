@@ -304,10 +304,12 @@ def layernorm_fwd(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional
                   out_dtype=None, rows: Optional[int] = None, row_stride: Optional[int] = None,
                   out: Optional[torch.Tensor] = None, mean: Optional[torch.Tensor] = None,
                   rstd: Optional[torch.Tensor] = None, add: Optional[torch.Tensor] = None,
-                  x_out: Optional[torch.Tensor] = None, add_row_stride: Optional[int] = None, D: Optional[int] = None):
+                  x_out: Optional[torch.Tensor] = None, add_row_stride: Optional[int] = None, D: Optional[int] = None,
+                  add_scale: Optional[torch.Tensor] = None, scale_period: int = 1):
     """x: [M,D] residual stream (fp32|bf16).  With rows/row_stride given, x (and add / x_out) are flat buffers and row m
     starts at m*row_stride (CLS-row selection).  With ``add`` (bf16 branch output) the residual update x_out = x + add is
     fused (x_out may alias x).  gamma = beta = None: y is the normalised row itself (pass ``D``).
+    ``add_scale`` (fp32, one per sample; ``scale_period`` rows per sample): stochastic depth, x_out = x + add_scale[m // scale_period] * add.
     Returns (y [M,D], mean [M], rstd [M])."""
     _req(x, None, "x")
     if (gamma is None) != (beta is None) or (gamma is None and D is None and rows is not None):
@@ -346,9 +348,13 @@ def layernorm_fwd(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional
             adds = row_stride if add_row_stride is None else add_row_stride  # e.g. a compact [M, D] branch added into strided rows
             if (M - 1) * adds + D > add.numel() or (M - 1) * row_stride + D > x_out.numel():
                 raise ValueError("layernorm_fwd: strided add / x_out exceed their buffers")
-    rc = lib().apla_layernorm_fwd(x.data_ptr(), _DT[x.dtype], xs, _ptr(gamma), _ptr(beta), out.data_ptr(),
-                                  _DT[out.dtype], out.stride(0), mean.data_ptr(), rstd.data_ptr(), M, D, float(eps),
-                                  _ptr(add), adds, _ptr(x_out), xouts, _stream())
+    if add_scale is not None:
+        _req(add_scale, torch.float32, "add_scale", 1)
+        if add is None or scale_period < 1 or add_scale.numel() * scale_period < M:
+            raise ValueError("layernorm_fwd: add_scale needs `add` and one entry per sample (M <= len * scale_period)")
+    rc = lib().apla_layernorm_fwd_dp(x.data_ptr(), _DT[x.dtype], xs, _ptr(gamma), _ptr(beta), out.data_ptr(),
+                                     _DT[out.dtype], out.stride(0), mean.data_ptr(), rstd.data_ptr(), M, D, float(eps),
+                                     _ptr(add), adds, _ptr(x_out), xouts, _ptr(add_scale), int(scale_period), _stream())
     check(rc, "apla_layernorm_fwd")
     return out, mean, rstd
 
@@ -358,12 +364,15 @@ def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: Optional[torch.Tenso
                   dres: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
                   out_bf16: Optional[torch.Tensor] = None, inds: Optional[torch.Tensor] = None, r: int = 0,
                   gathered: Optional[torch.Tensor] = None, rows: Optional[int] = None,
-                  row_stride: Optional[int] = None, x_row_stride: Optional[int] = None, dres_period: int = 0):
+                  row_stride: Optional[int] = None, x_row_stride: Optional[int] = None, dres_period: int = 0,
+                  dy_scale: Optional[torch.Tensor] = None, gather_scale: Optional[torch.Tensor] = None, scale_period: int = 1):
     """dx = dres + LN_bwd_dx(dy).  Returns (dx, gathered | None).  ``out`` (the gradient stream, fp32|bf16) may alias
     ``dres``; ``out_bf16`` optionally receives a bf16 copy.  With rows/row_stride: x, out (and out_bf16) are flat
     buffers whose row m starts at m*row_stride (only those rows are read/written); ``x_row_stride`` gives x its own pitch.
     mean = None: ``x`` is the normalised row saved by layernorm_fwd(gamma=None); gamma = None: no affine part;
-    dres_period p > 1: dres is read in rows m % p == 0 only and taken as zero elsewhere (apla_layernorm_bwd_ex)."""
+    dres_period p > 1: dres is read in rows m % p == 0 only and taken as zero elsewhere (apla_layernorm_bwd_ex).
+    Stochastic depth (apla_layernorm_bwd_dp): dx = dres + dy_scale[m // scale_period] * LN_bwd_dx(dy), gathered columns times
+    gather_scale[m // scale_period]; fp32 vectors with one entry per sample."""
     _req(dy, None, "dy", 2), _req(x, None, "x")
     M, D, lddy = _rows2d(dy, "dy")
     if rows is None:
@@ -409,9 +418,15 @@ def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: Optional[torch.Tenso
     _req(rstd, torch.float32, "rstd", 1)
     if rstd.numel() < M or (mean is not None and mean.numel() < M) or (gamma is not None and gamma.numel() != D) or dres_period < 0:
         raise ValueError("layernorm_bwd: statistics / gamma sizes")
-    rc = lib().apla_layernorm_bwd_ex(dy.data_ptr(), _DT[dy.dtype], lddy, x.data_ptr(), _DT[x.dtype], xs, _ptr(gamma),
+    for sc, nm in ((dy_scale, "dy_scale"), (gather_scale, "gather_scale")):
+        if sc is not None:
+            _req(sc, torch.float32, nm, 1)
+            if scale_period < 1 or sc.numel() * scale_period < M:
+                raise ValueError(f"layernorm_bwd: {nm} needs one entry per sample (M <= len * scale_period)")
+    rc = lib().apla_layernorm_bwd_dp(dy.data_ptr(), _DT[dy.dtype], lddy, x.data_ptr(), _DT[x.dtype], xs, _ptr(gamma),
                                      _ptr(mean), rstd.data_ptr(), _ptr(dres), int(dres_period), out.data_ptr(), _DT[out.dtype], dxs,
-                                     _ptr(out_bf16), cbs, _ptr(inds), r, _ptr(gathered), M, D, _stream())
+                                     _ptr(out_bf16), cbs, _ptr(inds), r, _ptr(gathered), M, D, _ptr(dy_scale), _ptr(gather_scale),
+                                     int(scale_period), _stream())
     check(rc, "apla_layernorm_bwd")
     return out, gathered
 

@@ -165,6 +165,25 @@ int apla_layernorm_bwd_ex(const void* dy, int dy_dtype, int lddy, const void* x,
                           void* dx_out, int grad_dtype, long dx_row_stride, void* dx_bf16_copy, long copy_row_stride,
                           const int32_t* inds, int r, void* gather_out, int M, int D, hipStream_t stream);
 
+/* Stochastic depth fused into the two LayerNorm kernels (round 6).  Replaces DropPath around both branches of a block
+ * (utils/transformers/vit.py:74-93 drop_path / DropPath, :284-285 `x = x + self.drop_path(...)`; main.py --dpr): sample b keeps a branch with
+ * factor scale[b] = floor(keep_prob + u_b) / keep_prob (0 or 1 / keep_prob, one float per sample, drawn by the caller).
+ *   apla_layernorm_fwd_dp : apla_layernorm_fwd with x_new = x + add_scale[m / scale_period] * add_in (add_scale NULL: factor 1).
+ *   apla_layernorm_bwd_dp : apla_layernorm_bwd_ex with dx_out = dres_in + dy_scale[m / scale_period] * LN_backward_dx(dy; ...) — the
+ *                           branch's whole backward chain is linear in its factor, so the factor is applied once, where the chain
+ *                           ends — and gather_out[m, j] = gather_scale[m / scale_period] * dx_out[m, inds[j]] (the factor of the branch
+ *                           whose projection dW reads the gathered columns).  Either scale may be NULL (1).
+ * scale_period = rows per sample (N tokens; 1 when the rows are one per sample, e.g. the CLS rows). */
+int apla_layernorm_fwd_dp(const void* x, int res_dtype, long x_row_stride, const float* gamma, const float* beta,
+                          void* y, int y_dtype, int ldy, float* mean, float* rstd, int M, int D, float eps,
+                          const void* add_in, long add_row_stride, void* x_out, long x_out_row_stride,
+                          const float* add_scale, int scale_period, hipStream_t stream);
+int apla_layernorm_bwd_dp(const void* dy, int dy_dtype, int lddy, const void* x, int x_dtype, long x_row_stride,
+                          const float* gamma, const float* mean, const float* rstd, const void* dres_in, int dres_row_period,
+                          void* dx_out, int grad_dtype, long dx_row_stride, void* dx_bf16_copy, long copy_row_stride,
+                          const int32_t* inds, int r, void* gather_out, int M, int D, const float* dy_scale,
+                          const float* gather_scale, int scale_period, hipStream_t stream);
+
 /* Gather only (used when the projection output gradient is already materialised): out[m,j] = src[m,inds[j]] bf16. */
 int apla_gather_cols(const void* src, int res_dtype, long src_row_stride, const int32_t* inds, int r, void* out,
                      int M, int D, hipStream_t stream);

@@ -398,9 +398,10 @@ def main(params, args):
     from apla_amd.module_trainer import ModulePathTrainer, wants_dropout
     module_path = wants_dropout(model)
     if module_path:
-        # --dr / --dpr (main.py:101-111): the fused step has no dropout / stochastic depth; train on the drop-in module path
+        # --dr / --adr (main.py:101-111): the fused step has no element-wise dropout; train on the drop-in module path (--dpr alone keeps
+        # the fused step: stochastic depth is one factor per sample and branch inside its LayerNorm kernels)
         if is_rank0():
-            print("[main] drop_rate / drop_path_rate > 0: training on the module path (apla_amd.module_trainer), not the fused step", flush=True)
+            print("[main] drop_rate / attn_drop_rate > 0: training on the module path (apla_amd.module_trainer), not the fused step", flush=True)
         eng = ModulePathTrainer(model.to(dev), lr=run["lr"], weight_decay=run["wd"], grad_clipping=run["grad_clipping"],
                                 process_group=dist.group.WORLD if world > 1 else None, compute_dtype=hdt,
                                 loss_scale="dynamic" if hdt == torch.float16 else 1.0, soft_targets=run["soft_targets"])

@@ -304,19 +304,24 @@ def mlp_bwd_dx(dy: Tensor, ctx, p: Dict[str, Tensor], prefix: str, swiglu: bool)
 
 
 def block_fwd(x: Tensor, p: Dict[str, Tensor], i: int, num_heads: int, r: int, swiglu: bool = False,
-              eps: float = 1e-6):
-    """Block.forward, vit.py:279-288: x += ls1(attn(norm1 x)); x += ls2(mlp(norm2 x)).
-    drop_path / dropout are identity (p=0 in every shipped config, SURVEY §5 hazard 14)."""
+              eps: float = 1e-6, dp=None):
+    """Block.forward, vit.py:279-288: x += drop_path(ls1(attn(norm1 x))); x += drop_path(ls2(mlp(norm2 x))).
+    ``dp`` = (s1, s2): the per-sample factors floor(keep_prob + u) / keep_prob of the two DropPath calls (vit.py:74-82; `drop_path`
+    below builds them from the uniform numbers), None = identity (p = 0 in every shipped config, SURVEY §5 hazard 14).  nn.Dropout
+    sites stay identity here (Mlp.drop / proj_drop: `philox_keep_mask` pins their mask on the module path)."""
     pre = f"blocks.{i}."
+    bc = (lambda s_: s_.reshape((-1,) + (1,) * (x.ndim - 1)).to(x.dtype))
     n1, mean1, rstd1 = layernorm_fwd(x, p[pre + "norm1.weight"], p[pre + "norm1.bias"], eps)
     y, _, actx = apla_attention_fwd(n1, p, pre + "attn.", num_heads, r)
     g1 = p.get(pre + "ls1.gamma")
-    x1 = x + (y * g1 if g1 is not None else y)
+    y = y * g1 if g1 is not None else y
+    x1 = x + (y * bc(dp[0]) if dp is not None else y)
     n2, mean2, rstd2 = layernorm_fwd(x1, p[pre + "norm2.weight"], p[pre + "norm2.bias"], eps)
     z, mctx = mlp_fwd(n2, p, pre + "mlp.", swiglu)
     g2 = p.get(pre + "ls2.gamma")
-    x2 = x1 + (z * g2 if g2 is not None else z)
-    ctx = dict(x=x, mean1=mean1, rstd1=rstd1, actx=actx, x1=x1, mean2=mean2, rstd2=rstd2, mctx=mctx)
+    z = z * g2 if g2 is not None else z
+    x2 = x1 + (z * bc(dp[1]) if dp is not None else z)
+    ctx = dict(x=x, mean1=mean1, rstd1=rstd1, actx=actx, x1=x1, mean2=mean2, rstd2=rstd2, mctx=mctx, dp=dp)
     return x2, ctx
 
 
@@ -324,12 +329,16 @@ def block_bwd(dx2: Tensor, ctx, p: Dict[str, Tensor], i: int, num_heads: int, sw
               need_dx: bool = True):
     """Backward of the block for the APLA trainable set: returns (dx_in | None, dW1, db1)."""
     pre = f"blocks.{i}."
+    dp = ctx.get("dp")
+    bc = (lambda s_: s_.reshape((-1,) + (1,) * (dx2.ndim - 1)).to(dx2.dtype))
     g2 = p.get(pre + "ls2.gamma")
-    dz = dx2 * g2 if g2 is not None else dx2
+    dz = dx2 * bc(dp[1]) if dp is not None else dx2          # d(drop_path(z)) / dz = the sample's factor
+    dz = dz * g2 if g2 is not None else dz
     dn2 = mlp_bwd_dx(dz, ctx["mctx"], p, pre + "mlp.", swiglu)
     dx1 = dx2 + layernorm_bwd_dx(dn2, ctx["x1"], p[pre + "norm2.weight"], ctx["mean2"], ctx["rstd2"])
     g1 = p.get(pre + "ls1.gamma")
-    dy = dx1 * g1 if g1 is not None else dx1
+    dy = dx1 * bc(dp[0]) if dp is not None else dx1
+    dy = dy * g1 if g1 is not None else dy
     dn1, dW1, db1 = apla_attention_bwd(dy, ctx["actx"], p, pre + "attn.", num_heads, need_dx)
     if not need_dx:
         return None, dW1, db1
@@ -450,8 +459,10 @@ def vit_forward(images: Tensor, p: Dict[str, Tensor], cfg: Dict, keep_ctx: bool 
     state_dict plus ``fc.weight``/``fc.bias`` for the classifier head."""
     x = embed_tokens(images, p, cfg["patch"])
     ctxs = []
+    dps = cfg.get("dp_scale")       # [2 * depth, B]: rows 2 i / 2 i + 1 = the factors of block i's attention / MLP branch (stochastic depth)
     for i in range(cfg["depth"]):
-        x, c = block_fwd(x, p, i, cfg["heads"], cfg["r"], cfg.get("swiglu", False), cfg.get("eps", 1e-6))
+        x, c = block_fwd(x, p, i, cfg["heads"], cfg["r"], cfg.get("swiglu", False), cfg.get("eps", 1e-6),
+                         dp=None if dps is None else (dps[2 * i], dps[2 * i + 1]))
         ctxs.append(c if keep_ctx else None)
     cls_in = x[:, 0]
     xn, meanf, rstdf = layernorm_fwd(cls_in, p["norm.weight"], p["norm.bias"], cfg.get("eps", 1e-6))

@@ -402,11 +402,17 @@ def test_main_entry_point_with_dropout_trains_on_the_module_path(tmp_path):
     batch, the session file keeps the reference layout, and a run without the flags still takes the fused step."""
     import main
     from apla_amd.module_trainer import ModulePathTrainer, wants_dropout
+    os.makedirs(tmp_path / "dp", exist_ok=True)
     path = os.path.join(os.path.dirname(__file__), "params", "tiny", "apla.yml")
     args = main.parse_arguments(["--params_path", path, "--steps_per_epoch", "6", "--save_dir", str(tmp_path), "--lr", "0.002",
                                  "--dr", "0.1", "--dpr", "0.1"])
     params = main.update_params_from_args(main.load_parameters(path), args)
     assert params["model_params"]["transformers_params"]["drop_rate"] == 0.1
+    # --dpr alone keeps the fused step (round 6: stochastic depth inside its LayerNorm kernels)
+    args_dp = main.parse_arguments(["--params_path", path, "--steps_per_epoch", "4", "--save_dir", str(tmp_path / "dp"), "--lr", "0.002", "--dpr", "0.2"])
+    params_dp = main.update_params_from_args(main.load_parameters(path), args_dp)
+    assert params_dp["model_params"]["transformers_params"]["drop_path_rate"] == 0.2 and np.isfinite(main.main(params_dp, args_dp))
+    assert not wants_dropout(small_vit(depth=2))
     loss = main.main(params, args)
     assert np.isfinite(loss)
     sess = torch.load(tmp_path / "tiny.pth", weights_only=False)
@@ -756,7 +762,8 @@ def test_cross_entropy_rejects_out_of_range_labels():
 
 
 def test_fused_step_refuses_dropout():
-    """The captured launch sequence has no dropout / stochastic depth: a model that asks for one must not be trained as if it did not."""
+    """The captured launch sequence has no element-wise dropout: a model that asks for one must not be trained as if it did not.
+    Stochastic depth is accepted since round 6 (next test)."""
     from apla_amd.engine import AplaTrainEngine
     from apla_amd.vit import DropPath
     model = small_vit(depth=2)
@@ -765,7 +772,70 @@ def test_fused_step_refuses_dropout():
         AplaTrainEngine(model, 4, 32)
     model.backbone.blocks[1].mlp.drop.p = 0.0
     model.backbone.blocks[1].drop_path = DropPath(0.2)
-    with pytest.raises(NotImplementedError, match="module path only"):
-        AplaTrainEngine(model, 4, 32)
+    assert AplaTrainEngine(model, 4, 32).dp_on
     model.backbone.blocks[1].drop_path = torch.nn.Identity()
-    AplaTrainEngine(model, 4, 32)
+    assert not AplaTrainEngine(model, 4, 32).dp_on
+
+
+@pytest.mark.parametrize("use_graphs", [False, True])
+@pytest.mark.parametrize("res_dtype,grad_dtype", [(torch.float32, torch.bfloat16), (torch.float32, torch.float32)])
+def test_engine_stochastic_depth_vs_oracle(use_graphs, res_dtype, grad_dtype):
+    """main.py --dpr on the FUSED step (VERDICT r05 #7a): DropPath around both branches of every block (utils/transformers/vit.py:74-93,
+    :257, :284-285) as one factor per sample and branch inside the LayerNorm kernels (apla_layernorm_fwd_dp / _bwd_dp) — forward AND the
+    whole backward (both dX chains, the gathered columns of dW1, the CLS-only last block) against the fp64 oracle given the SAME uniform
+    numbers, with samples that drop the attention branch, the MLP branch, both or neither in every block; a second step with new
+    numbers through the captured graphs; inference (forward_only) ignores the factors; the engine's own draws have the right rate."""
+    from apla_amd.engine import AplaTrainEngine, OptimConfig
+    from apla_amd.vit import DropPath
+    depth, B = 4, 8
+    model = small_vit(depth=depth)
+    rates = [0.0, 0.1, 0.3, 0.5]                       # vit.py:178: a linear ramp over the blocks (block 0 keeps everything)
+    for blk, q in zip(model.backbone.blocks, rates):
+        if q > 0:
+            blk.drop_path = DropPath(q)
+    p = oracle_params(model)
+    g = torch.Generator().manual_seed(11)
+    images, labels = torch.randn(B, 3, 32, 32, generator=g), torch.randint(0, 10, (B,), generator=g)
+    eng = AplaTrainEngine(model, B, 32, res_dtype=res_dtype, grad_dtype=grad_dtype, use_graphs=use_graphs,
+                          optim=OptimConfig(lr=1e-3, weight_decay=1e-2, grad_clipping=1.0))
+    assert eng.dp_on and eng.dp_rates == rates
+    keep = torch.tensor([1.0 - q for q in rates for _ in (0, 1)], dtype=torch.float64)[:, None]
+    cfg = dict(patch=16, depth=depth, heads=2, r=64)
+    for step in range(2):
+        u = torch.rand(2 * depth, B, generator=g)
+        if step == 0:      # make sure the last block (CLS-only kernels) sees every combination
+            u[2 * depth - 2, :4] = torch.tensor([0.05, 0.95, 0.05, 0.95])
+            u[2 * depth - 1, :4] = torch.tensor([0.05, 0.05, 0.95, 0.95])
+        scale = torch.floor(keep + u.double()) / keep
+        assert step == 1 or (scale[2 * depth - 2:, :4] == 0).sum() == 4
+        logits_ref, ctx = O.vit_forward(images.double(), p, dict(cfg, dp_scale=scale))
+        loss_ref, dl = O.cross_entropy_fwd_bwd(logits_ref, labels)
+        grads_ref = O.vit_backward(dl, ctx, p, cfg)
+        eng.set_drop_path_uniforms(u)
+        eng.set_batch(images.cuda(), labels.cuda())
+        eng.forward_backward()
+        torch.cuda.synchronize()
+        assert torch.allclose(eng.dp_scale.cpu().double(), scale, atol=1e-6)
+        assert rel_err(eng.logits.cpu(), logits_ref) < LOGIT_TOL, step
+        assert abs(float(eng.loss) - float(loss_ref)) < 5e-3
+        for n, gr in eng.grads().items():
+            n2 = n[len("backbone."):] if n.startswith("backbone.") else n
+            assert rel_l2(gr.cpu(), grads_ref[n2]) < GRAD_TOL, (step, n)
+    # the plain forward (no factors) differs, and inference ignores them
+    logits_plain, _ = O.vit_forward(images.double(), p, cfg, keep_ctx=False)
+    assert rel_err(logits_ref, logits_plain) > 10 * LOGIT_TOL
+    lg, _, _ = eng.forward_only(images.cuda(), labels.cuda())
+    torch.cuda.synchronize()
+    assert rel_err(lg.cpu(), logits_plain) < LOGIT_TOL
+    # the engine's own generator: factors are 0 or 1 / keep at the configured rate
+    eng.set_drop_path_uniforms(None)
+    zeros = torch.zeros(2 * depth)
+    for _ in range(40):
+        eng.train_step()
+        torch.cuda.synchronize()
+        sc = eng.dp_scale.cpu()
+        assert all(bool(((sc[k] == 0) | ((sc[k] - 1.0 / float(keep[k])).abs() < 1e-6)).all()) for k in range(2 * depth))
+        zeros += (sc == 0).float().mean(1)
+    got = zeros / 40
+    assert float(got[:2].max()) == 0.0 and abs(float(got[6:].mean()) - 0.5) < 0.12 and abs(float(got[4:6].mean()) - 0.3) < 0.12, got
+    assert np.isfinite(float(eng.loss))
