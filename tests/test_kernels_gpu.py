@@ -1139,6 +1139,21 @@ def test_attn_bwd_fused_short_sequence_kernel_equals_split_kernels_at_full_occup
         ops.set_attn_variant(old)
     for v in (2, 3, 0):
         assert torch.equal(res[v][0], res[1][0]) and torch.equal(res[v][1], res[1][1]), v
+    # ... and against the fp64 oracle (appla_attn.py:56-60 differentiated by hand, oracle/apla_oracle.py:attention_bwd), as the forward's
+    # test does: all twelve heads of the first, a middle and the last sequence of the walk — at (128, 197) and (64, 257) the launch is
+    # the persistent / one-workgroup-per-head kernel with every CU busy (the bitwise chain above was anchored to
+    # kernels the oracle had only seen at <= 9 heads).  dq, dk, dv and delta = rowsum(dO * O).
+    dqkv, delta = res[0]
+    D = 64 * H
+    for b in sorted({0, B // 3, B - 1}):
+        rows = slice(b * N, (b + 1) * N)
+        q64, o64, do64 = (t[rows].cpu().double().reshape(1, N, -1) for t in (qkv, o, do))
+        ref = O.attention_bwd(do64, q64, o64, lse[b].cpu().double().reshape(1, H, N), H, scale)
+        got = dqkv[rows].cpu().double().reshape(1, N, 3 * D)
+        for part, name in ((slice(0, D), "dq"), (slice(D, 2 * D), "dk"), (slice(2 * D, 3 * D), "dv")):
+            assert rel_err(got[..., part], ref[..., part]) < BF16_OUT, (b, name)
+        dref = (do64.reshape(N, H, 64) * o64.reshape(N, H, 64)).sum(-1).t()
+        assert float((delta[b].cpu().double() - dref).abs().max()) < 1e-4 * max(1.0, float(dref.abs().max())), b
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 768, 768), (128, 768, 3072), (128, 3072, 768), (37, 128, 256), (300, 192, 1536)])
