@@ -89,10 +89,28 @@ class AplaTrainEngine:
         self.D, self.L, self.H = bb.embed_dim, bb.depth, bb.num_heads
         if self.D != 64 * self.H:
             raise NotImplementedError("HIP attention kernel needs head_dim == 64")
-        for name, mod in model.named_modules():   # the captured launch sequence has no element-wise dropout: never ignore one silently
-            if isinstance(mod, nn.Dropout) and mod.p > 0.0:
-                raise NotImplementedError(f"{name}: nn.Dropout with p > 0 is implemented on the module path only (apla_amd.vit / "
-                                          "apla_amd.functional), not in the fused step (stochastic depth is: main.py --dpr); every shipped APLA config uses 0")
+        # Element-wise dropout (main.py --dr / --adr; 0 in every shipped configuration): the nn.Dropout sites of the reference — pos_drop
+        # (vit.py:395), attn_drop on the attention probabilities and proj_drop (appla_attn.py:58, :82), Mlp.drop after the activation and
+        # after fc2 (vit.py:152-168) — run as counter-based mask passes around the step's launches (apla_dropout_fwd / _bwd,
+        # apla_attn_fwd_dropout / _bwd_dropout; masks reproducible from one seed + the step count).  Such a step is launched eagerly (the
+        # counters change per step) and runs the last block on every token; a nn.Dropout anywhere else is refused, never ignored.
+        pd = lambda m: float(m.p) if isinstance(m, nn.Dropout) else 0.0     # noqa: E731
+        self.p_pos = pd(getattr(bb, "pos_drop", None))
+        self.p_attn = [pd(getattr(blk.attn, "attn_drop", None)) for blk in bb.blocks]
+        self.p_proj = [pd(getattr(blk.attn, "proj_drop", None)) for blk in bb.blocks]
+        self.p_mlp = [pd(getattr(blk.mlp, "drop", None)) for blk in bb.blocks]
+        known = {id(m) for m in [getattr(bb, "pos_drop", None)] + [getattr(blk.attn, a, None) for blk in bb.blocks for a in ("attn_drop", "proj_drop")]
+                 + [getattr(blk.mlp, "drop", None) for blk in bb.blocks]}
+        for name, mod in model.named_modules():
+            if isinstance(mod, nn.Dropout) and mod.p > 0.0 and id(mod) not in known:
+                raise NotImplementedError(f"{name}: this nn.Dropout is not one of the reference's sites (pos_drop, attn_drop, proj_drop, Mlp.drop); "
+                                          "train on the module path (apla_amd.module_trainer)")
+        allp = [self.p_pos] + self.p_attn + self.p_proj + self.p_mlp
+        if any(not (0.0 <= q < 1.0) for q in allp):
+            raise ValueError("dropout probabilities must be in [0, 1)")
+        self.drop_on = any(q > 0.0 for q in allp)
+        self._drop_seed = int(torch.empty((), dtype=torch.int64).random_()) if self.drop_on else 0   # torch.manual_seed repeats a run
+        self._drop_step = 0
         # stochastic depth (vit.py:74-93, :257, :284-285; main.py --dpr): fused into the LayerNorm kernels as one factor per sample and
         # branch (apla_layernorm_fwd_dp / _bwd_dp), drawn per step into `dp_scale` BEFORE the captured launches run
         self.dp_rates = [float(getattr(getattr(blk, "drop_path", None), "drop_prob", 0.0) or 0.0) for blk in bb.blocks]
@@ -120,9 +138,9 @@ class AplaTrainEngine:
         self.optim = optim or OptimConfig()
         self.pg = process_group
         self.world = 1   # set from the GradExchanger below: ONE source for "how many ranks sum into the gradient buffer"
-        self.use_graphs = use_graphs
+        self.use_graphs = use_graphs and not self.drop_on
         # diagnostic switch: APLA_FULL_LAST_BLOCK=1 runs the last block's forward on all rows (A/B of the CLS-only tail)
-        self.cls_only_tail = os.environ.get("APLA_FULL_LAST_BLOCK") != "1"
+        self.cls_only_tail = os.environ.get("APLA_FULL_LAST_BLOCK") != "1" and not self.drop_on
         self.scale = bb.blocks[0].attn.scale
         self.step_count = 0
         self._graphs = None
@@ -352,7 +370,8 @@ class AplaTrainEngine:
         self.h = e(M, self.blocks[0].F)
         # fc1's output h and dfc2's product go straight to a plain-store GEMM (fc2, dfc1): where both sides allow it they are
         # written as K-panel images by the producing epilogue (ops.gemm_nt with a 3-D `out`) and read as such
-        F, use = self.blocks[0].F, os.environ.get("APLA_W_PANELS", "1") != "0"
+        # (element-wise dropout works on row-major h / GELU': its mask is indexed by the row-major element number, as the oracle's)
+        F, use = self.blocks[0].F, os.environ.get("APLA_W_PANELS", "1") != "0" and not (self.drop_on and any(q > 0 for q in self.p_mlp))
         epi_f, n_f = (ops.EPI_SWIGLU, 2 * F) if self.swiglu else (ops.EPI_GELU, F)       # fc1 / w12: epilogue and GEMM width
         self.h_img = use and ops.gemm_out_image_ok(M, n_f, D, epi_f) and ops.gemm_panel_ok(M, D, F)
         self.h_out = self.h.view(F // 32, M, 32) if self.h_img else self.h
@@ -372,6 +391,13 @@ class AplaTrainEngine:
         self.row_loss = e(B, dt=torch.float32)
         self.loss = e(1, dt=torch.float32)
         self.dxn = e(B, D, dt=torch.float32)
+        if self.drop_on:    # keep bytes of the two branch sites per block (the backward masks the same elements), scratch for the others
+            u8 = lambda n: torch.empty(n, device=dev, dtype=torch.uint8)       # noqa: E731
+            self.keep_a = [u8(M * D) if self.p_proj[i] > 0 else None for i in range(L)]
+            self.keep_b = [u8(M * D) if self.p_mlp[i] > 0 else None for i in range(L)]
+            self.keep_h = u8(M * self.blocks[0].F) if any(q > 0 for q in self.p_mlp) else None
+            self.keep_pos = u8(M * D) if self.p_pos > 0 else None
+            self.Gm = e(M, D)
         # backward
         self.G = torch.zeros(M, D, device=dev, dtype=self.grad_dtype)               # residual-gradient stream (never re-zeroed)
         self.Gb = self.G if self.grad_dtype == ops.half() else torch.zeros(M, D, device=dev, dtype=ops.half())
@@ -394,7 +420,7 @@ class AplaTrainEngine:
         # together, at most DW_BATCH at a time.  Needs one r for all blocks and no row padding; else block by block.
         self.dw_batch = 0
         if os.environ.get("APLA_DW_BATCH", "1") != "0" and len({st.r for st in self.blocks}) == 1 and \
-                all(st.r_pad == st.r for st in self.blocks) and self.L > 2 and self.D % 128 == 0:
+                all(st.r_pad == st.r for st in self.blocks) and self.L > 2 and self.D % 128 == 0 and not self.drop_on:
             self.dw_batch = min(int(os.environ.get("APLA_DW_BATCH_MAX", "6")), ops.DW_MAX_BATCH)
         self._dw_pending = []
         if self.dw_batch > 1:
@@ -452,6 +478,9 @@ class AplaTrainEngine:
         ops.patchify(self.images, self.patch, self.Kp, out=self.cols)
         ops.gemm_nt(self.cols, self.Wpe_i, self.bpe, out=self.patches, tag=ops.TAG_PATCH)
         ops.assemble_tokens(self.patches, self.cls, self.pos, B, self.Np, out=self.res)
+        drop = self.drop_on and not inference
+        if drop and self.p_pos > 0:       # pos_drop (vit.py:395)
+            ops.dropout_fwd(self.res, self.p_pos, self._drop_seed, self._drop_offset(0), out=self.res, keep=self.keep_pos)
         # The residual updates x += branch (vit.py:284-285) are fused into the NEXT LayerNorm: the projection / fc2 GEMMs store
         # their (LayerScale-folded) branch output in bf16 — as the reference's fp16-autocast Linear does before the fp32
         # residual add — and the LN kernel forms x_new = x + branch in registers, writes it and normalises it in one pass.
@@ -470,8 +499,14 @@ class AplaTrainEngine:
                 self._forward_last_block_tail(st, i, dps)
                 break
             ops.gemm_nt(xh1, st.Wqkv_i, st.bqkv, out=self.qkv[i], tag=ops.TAG_QKV)
-            ops.attn_fwd(self.qkv[i], B, N, H, self.scale, o=self.o[i], lse=self.lse[i])
+            if drop and self.p_attn[i] > 0:   # attn_drop (appla_attn.py:58): the mask is rebuilt by the backward from the same counters
+                ops.attn_fwd_dropout(self.qkv[i], B, N, H, self.scale, self.p_attn[i], self._drop_seed, self._drop_offset(4 + 4 * i),
+                                     o=self.o[i], lse=self.lse[i])
+            else:
+                ops.attn_fwd(self.qkv[i], B, N, H, self.scale, o=self.o[i], lse=self.lse[i])
             ops.gemm_nt(self.o[i], st.Wnat_i, st.bnat, out=self.branch, tag=ops.TAG_PROJ)
+            if drop and self.p_proj[i] > 0:   # proj_drop (appla_attn.py:82; commutes with the LayerScale vector folded into the weight)
+                ops.dropout_fwd(self.branch, self.p_proj[i], self._drop_seed, self._drop_offset(1 + 4 * i), out=self.branch, keep=self.keep_a[i])
             xh2 = self.xh2[i]
             ops.layernorm_fwd(self.res, None, None, self.eps, out=xh2, mean=self.mean_scratch, rstd=self.rstd2[i],
                               add=self.branch, x_out=self.res, add_scale=dps(2 * i), scale_period=N)
@@ -488,7 +523,13 @@ class AplaTrainEngine:
             if ev is not None:
                 e1.record()
                 ev.append((e0, e1))
+            mlp_drop = drop and self.p_mlp[i] > 0 and not self.swiglu        # Mlp.drop, both sites (vit.py:164-167); SwiGLUFFNFused has none
+            if mlp_drop:    # after the activation: h is masked, and GELU' with the same mask — dfc2's epilogue then needs no change
+                ops.dropout_fwd(self.h, self.p_mlp[i], self._drop_seed, self._drop_offset(2 + 4 * i), out=self.h, keep=self.keep_h)
+                ops.dropout_bwd(self.act_saved[i], self.keep_h, self.p_mlp[i], out=self.act_saved[i])
             ops.gemm_nt(self.h_out, st.Wout_i, st.bout, out=self.branch, tag=ops.TAG_FC2)
+            if mlp_drop:    # after fc2
+                ops.dropout_fwd(self.branch, self.p_mlp[i], self._drop_seed, self._drop_offset(3 + 4 * i), out=self.branch, keep=self.keep_b[i])
         # final norm on the CLS rows only (vit.py:416-419) with the last residual add fused, fp32 head + mean CE
         ops.layernorm_fwd(self.res, self.gf, self.bf_, self.eps, out=self.xn, mean=self.meanf, rstd=self.rstdf,
                           rows=B, row_stride=N * D, add=self.branch_cls if self.cls_only_tail else self.branch,
@@ -574,16 +615,30 @@ class AplaTrainEngine:
         st = self.blocks[i]
         B, N, H, M, D = self.B, self.N, self.H, self.M, self.D
         copy = None if self.Gb is self.G else self.Gb
+        mlp_drop = self.drop_on and self.p_mlp[i] > 0 and not self.swiglu
+        proj_drop = self.drop_on and self.p_proj[i] > 0
+        # gradient entering the MLP branch: through the mask of the dropout after fc2 (the one after the activation lives in the saved GELU')
+        g_in = ops.dropout_bwd(self.Gb, self.keep_b[i], self.p_mlp[i], out=self.Gm) if mlp_drop else self.Gb
         if self.swiglu:
-            ops.gemm_nt(self.Gb, st.WoutT, None, epilogue=ops.EPI_SWIGLU_BWD, aux_in=self.act_saved[i], out=self.dact_out)
+            ops.gemm_nt(g_in, st.WoutT, None, epilogue=ops.EPI_SWIGLU_BWD, aux_in=self.act_saved[i], out=self.dact_out)
             ops.gemm_nt(self.dact_out, st.Wdfc1_i, None, out=self.dln, tag=ops.TAG_DFC1)
         else:
-            ops.gemm_nt(self.Gb, st.WoutT, None, epilogue=ops.EPI_MUL, aux_in=self.act_io[i], out=self.dact_out)
+            ops.gemm_nt(g_in, st.WoutT, None, epilogue=ops.EPI_MUL, aux_in=self.act_io[i], out=self.dact_out)
             ops.gemm_nt(self.dact_out, st.Wdfc1_i, None, out=self.dln, tag=ops.TAG_DFC1)
         dyg = (self.dyg_all[i] if self.dw_batch > 1 else self.dyg)[:M * st.r_pad].view(M, st.r_pad)
         dps = (lambda k: self.dp_scale[k]) if self.dp_on else (lambda k: None)      # stochastic depth: the branches' per-sample factors
-        ops.layernorm_bwd(self.dln, self.xh2[i], None, None, self.rstd2[i], dres=self.G, out=self.G,
-                          out_bf16=copy, inds=st.inds, r=st.r_pad, gathered=dyg, dy_scale=dps(2 * i + 1), gather_scale=dps(2 * i), scale_period=N)
+        if proj_drop:
+            # the projection's output gradient passes proj_drop's mask (and the attention branch's DropPath factor) BEFORE both of its
+            # consumers — the gathered columns of dW1 and the dX product —, so the LayerNorm backward gathers nothing here
+            ops.layernorm_bwd(self.dln, self.xh2[i], None, None, self.rstd2[i], dres=self.G, out=self.G, out_bf16=copy,
+                              dy_scale=dps(2 * i + 1), scale_period=N)
+            ops.dropout_bwd(self.Gb, self.keep_a[i], self.p_proj[i], out=self.Gm)
+            if self.dp_on:
+                ops.scale_samples(self.Gm.view(B, N * D), self.dp_scale[2 * i], out=self.Gm.view(B, N * D))
+            ops.gather_cols(self.Gm, st.inds, st.r_pad, out=dyg)
+        else:
+            ops.layernorm_bwd(self.dln, self.xh2[i], None, None, self.rstd2[i], dres=self.G, out=self.G,
+                              out_bf16=copy, inds=st.inds, r=st.r_pad, gathered=dyg, dy_scale=dps(2 * i + 1), gather_scale=dps(2 * i), scale_period=N)
         if self.dw_batch > 1:
             self._dw_pending.append((st, dyg, self.o[i]))
             if len(self._dw_pending) == self.dw_batch:
@@ -592,11 +647,15 @@ class AplaTrainEngine:
             self._proj_dw(st, dyg, self.o[i])
         if i == 0:
             return  # nothing upstream of block 0's projection is trainable
-        ops.gemm_nt(self.Gb, st.WnatT_i, None, out=self.dO, tag=ops.TAG_DPROJ)
-        ops.attn_bwd(self.qkv[i], self.o[i], self.dO, self.lse[i], B, N, H, self.scale, dqkv=self.dqkv, delta=self.delta)
+        ops.gemm_nt(self.Gm if proj_drop else self.Gb, st.WnatT_i, None, out=self.dO, tag=ops.TAG_DPROJ)
+        if self.drop_on and self.p_attn[i] > 0:
+            ops.attn_bwd_dropout(self.qkv[i], self.o[i], self.dO, self.lse[i], B, N, H, self.scale, self.p_attn[i], self._drop_seed,
+                                 self._drop_offset(4 + 4 * i), dqkv=self.dqkv, delta=self.delta)
+        else:
+            ops.attn_bwd(self.qkv[i], self.o[i], self.dO, self.lse[i], B, N, H, self.scale, dqkv=self.dqkv, delta=self.delta)
         ops.gemm_nt(self.dqkv, st.WqkvT_i, None, out=self.dln, tag=ops.TAG_DQKV)
         ops.layernorm_bwd(self.dln, self.xh1[i], None, None, self.rstd1[i], dres=self.G, out=self.G, out_bf16=copy,
-                          dy_scale=dps(2 * i), scale_period=N)
+                          dy_scale=None if proj_drop else dps(2 * i), scale_period=N)    # (with proj_drop the factor is already in Gm)
 
     def _backward_last_block(self):
         """Backward of block L-1 exploiting that only the CLS rows (token 0 of every sequence) of the incoming residual
@@ -640,8 +699,15 @@ class AplaTrainEngine:
             if k == 0:
                 self.refresh_weights()
                 self._forward()
-                self._backward_head()
-                self._backward_last_block()
+                if self.drop_on:    # every block runs its dense backward: the stream below the final norm is zero outside the CLS rows
+                    self.G.zero_()
+                    if self.Gb is not self.G:
+                        self.Gb.zero_()
+                    self._backward_head()
+                    self._backward_block(self.L - 1)
+                else:
+                    self._backward_head()
+                    self._backward_last_block()
                 hi = self.L - 1
             else:
                 hi = self.seg_cuts[k - 1]
@@ -679,6 +745,15 @@ class AplaTrainEngine:
                 raise ValueError("class-id labels [B] expected (build the engine with soft_targets=True for probability targets)")
             self.labels.copy_(labels.to(torch.int32), non_blocking=True)
 
+    def _drop_offset(self, site: int) -> int:
+        """Philox offset of a dropout site in the current step: sites 0 = pos_drop, 1 + 4 i / 2 + 4 i / 3 + 4 i / 4 + 4 i = block i's
+        proj_drop / Mlp.drop after the activation / Mlp.drop after fc2 / attn_drop; a fresh set per step (`_drop_step` counts from 1)."""
+        return self._drop_step * (4 * self.L + 8) + site
+
+    def set_dropout_seed(self, seed: int, step: int = 0):
+        """Tests / reproducibility: the key of every dropout mask (and the step counter the offsets derive from)."""
+        self._drop_seed, self._drop_step = int(seed), int(step)
+
     def set_drop_path_uniforms(self, u: Optional[torch.Tensor]):
         """Tests / reproducibility: the uniform numbers u [2 L, B] of the NEXT steps' DropPath draws (row 2 i / 2 i + 1 = block i's
         attention / MLP branch; vit.py:74-82: factor = floor(keep_prob + u) / keep_prob) instead of the engine's own generator;
@@ -697,6 +772,8 @@ class AplaTrainEngine:
         backward has been enqueued."""
         if self.dp_on:
             self._draw_drop_path()
+        if self.drop_on:
+            self._drop_step += 1
         if self.use_graphs and self._graphs is None:
             self._capture()
         for k in range(len(self.seg_cuts)):

@@ -431,10 +431,13 @@ def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: Optional[torch.Tenso
     return out, gathered
 
 
-def gather_cols(src: torch.Tensor, inds: torch.Tensor, r: int) -> torch.Tensor:
+def gather_cols(src: torch.Tensor, inds: torch.Tensor, r: int, *, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _req(src, None, "src", 2), _req(inds, torch.int32, "inds", 1)
     M, D, ss = _rows2d(src, "src")
-    out = torch.empty(M, r, device=src.device, dtype=half())
+    if out is None:
+        out = torch.empty(M, r, device=src.device, dtype=half())
+    if tuple(out.shape) != (M, r) or out.dtype != half() or not out.is_contiguous():
+        raise ValueError("gather_cols: bad output buffer")
     check(lib().apla_gather_cols(src.data_ptr(), _DT[src.dtype], ss, inds.data_ptr(), r, out.data_ptr(), M, D,
                                  _stream()), "apla_gather_cols")
     return out
@@ -466,27 +469,38 @@ def attn_fwd(qkv: torch.Tensor, B: int, N: int, H: int, scale: float, *, o: Opti
     return o, lse
 
 
-def attn_fwd_dropout(qkv: torch.Tensor, B: int, N: int, H: int, scale: float, p: float, seed: int, offset: int = 0):
+def attn_fwd_dropout(qkv: torch.Tensor, B: int, N: int, H: int, scale: float, p: float, seed: int, offset: int = 0, *,
+                     o: Optional[torch.Tensor] = None, lse: Optional[torch.Tensor] = None):
     """attn_fwd with dropout on the attention probabilities (appla_attn.py:56-58): (o, lse); the mask is regenerated from
     (seed, offset) by attn_bwd_dropout, nothing is stored (include/apla_hip.h: apla_attn_fwd_dropout)."""
     _req(qkv, half(), "qkv", 2)
     if tuple(qkv.shape) != (B * N, 3 * H * 64) or not qkv.is_contiguous():
         raise ValueError(f"attn_fwd_dropout: qkv must be contiguous [{B * N}, {3 * H * 64}], got {tuple(qkv.shape)}")
-    o = torch.empty(B * N, H * 64, device=qkv.device, dtype=half())
-    lse = torch.empty(B, H, N, device=qkv.device, dtype=torch.float32)
+    if o is None:
+        o = torch.empty(B * N, H * 64, device=qkv.device, dtype=half())
+    if lse is None:
+        lse = torch.empty(B, H, N, device=qkv.device, dtype=torch.float32)
+    _req(o, half(), "o", 2), _req(lse, torch.float32, "lse", 3)
+    if tuple(o.shape) != (B * N, H * 64) or tuple(lse.shape) != (B, H, N) or not (o.is_contiguous() and lse.is_contiguous()):
+        raise ValueError("attn_fwd_dropout: bad output buffers")
     check(lib().apla_attn_fwd_dropout(qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), B, N, H, float(scale), float(p),
                                       int(seed) & 0xFFFFFFFFFFFFFFFF, int(offset) & 0xFFFFFFFF, _stream()), "apla_attn_fwd_dropout")
     return o, lse
 
 
 def attn_bwd_dropout(qkv: torch.Tensor, o: torch.Tensor, do: torch.Tensor, lse: torch.Tensor, B: int, N: int, H: int, scale: float,
-                     p: float, seed: int, offset: int = 0):
+                     p: float, seed: int, offset: int = 0, *, dqkv: Optional[torch.Tensor] = None, delta: Optional[torch.Tensor] = None):
     _req(qkv, half(), "qkv", 2), _req(o, half(), "o", 2), _req(do, half(), "do", 2), _req(lse, torch.float32, "lse", 3)
     if tuple(qkv.shape) != (B * N, 3 * H * 64) or tuple(o.shape) != (B * N, H * 64) or tuple(do.shape) != tuple(o.shape) or \
             tuple(lse.shape) != (B, H, N) or not (qkv.is_contiguous() and o.is_contiguous() and do.is_contiguous() and lse.is_contiguous()):
         raise ValueError("attn_bwd_dropout: bad operand shapes")
-    delta = torch.empty_like(lse)
-    dqkv = torch.empty_like(qkv)
+    if delta is None:
+        delta = torch.empty_like(lse)
+    if dqkv is None:
+        dqkv = torch.empty_like(qkv)
+    _req(dqkv, half(), "dqkv", 2), _req(delta, torch.float32, "delta", 3)
+    if dqkv.shape != qkv.shape or delta.shape != lse.shape or not (dqkv.is_contiguous() and delta.is_contiguous()):
+        raise ValueError("attn_bwd_dropout: bad output buffers")
     check(lib().apla_attn_bwd_dropout(qkv.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(), delta.data_ptr(), dqkv.data_ptr(), B, N, H,
                                       float(scale), float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, int(offset) & 0xFFFFFFFF, _stream()),
           "apla_attn_bwd_dropout")
@@ -850,35 +864,41 @@ def weight_norm_bwd(dw: torch.Tensor, v: torch.Tensor, g: torch.Tensor, norm: to
     return dv, dg
 
 
-def dropout_fwd(x: torch.Tensor, p: float, seed: int, offset: int = 0):
-    """(y, keep) of include/apla_hip.h:apla_dropout_fwd for a contiguous fp32 / 16-bit tensor whose size is a multiple of 8."""
+def dropout_fwd(x: torch.Tensor, p: float, seed: int, offset: int = 0, *, out: Optional[torch.Tensor] = None, keep: Optional[torch.Tensor] = None):
+    """(y, keep) of include/apla_hip.h:apla_dropout_fwd for a contiguous fp32 / 16-bit tensor whose size is a multiple of 8
+    (``out`` may be ``x`` itself: element-wise, in place)."""
     _req(x, None, "x")
     if x.dtype not in (torch.float32, half()) or not x.is_contiguous() or x.numel() % 8 or not 0.0 <= p < 1.0:
         raise ValueError("dropout_fwd: contiguous fp32 / 16-bit tensor with numel % 8 == 0 and 0 <= p < 1 expected")
-    y = torch.empty_like(x)
-    keep = torch.empty(x.numel(), device=x.device, dtype=torch.uint8)
+    y = torch.empty_like(x) if out is None else out
+    if keep is None:
+        keep = torch.empty(x.numel(), device=x.device, dtype=torch.uint8)
+    if y.dtype != x.dtype or y.numel() != x.numel() or not y.is_contiguous() or keep.dtype != torch.uint8 or keep.numel() < x.numel() or not keep.is_contiguous():
+        raise ValueError("dropout_fwd: bad output buffers")
     check(lib().apla_dropout_fwd(x.data_ptr(), _DT[x.dtype], y.data_ptr(), keep.data_ptr(), x.numel(), float(p), int(seed) & (2 ** 64 - 1),
                                  int(offset) & (2 ** 64 - 1), _stream()), "apla_dropout_fwd")
     return y, keep
 
 
-def dropout_bwd(dy: torch.Tensor, keep: torch.Tensor, p: float) -> torch.Tensor:
+def dropout_bwd(dy: torch.Tensor, keep: torch.Tensor, p: float, *, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _req(dy, None, "dy"), _req(keep, torch.uint8, "keep", 1)
-    if dy.dtype not in (torch.float32, half()) or not dy.is_contiguous() or keep.numel() != dy.numel() or dy.numel() % 8:
+    if dy.dtype not in (torch.float32, half()) or not dy.is_contiguous() or keep.numel() < dy.numel() or dy.numel() % 8:
         raise ValueError("dropout_bwd: dy must match the forward's tensor")
-    dx = torch.empty_like(dy)
+    dx = torch.empty_like(dy) if out is None else out
+    if dx.dtype != dy.dtype or dx.numel() != dy.numel() or not dx.is_contiguous():
+        raise ValueError("dropout_bwd: bad output buffer")
     check(lib().apla_dropout_bwd(dy.data_ptr(), _DT[dy.dtype], keep.data_ptr(), dx.data_ptr(), dy.numel(), float(p), _stream()), "apla_dropout_bwd")
     return dx
 
 
-def scale_samples(x: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
-    """y[s] = x[s] * scale[s] over the leading dimension (include/apla_hip.h:apla_scale_samples)."""
+def scale_samples(x: torch.Tensor, scale: torch.Tensor, *, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y[s] = x[s] * scale[s] over the leading dimension (include/apla_hip.h:apla_scale_samples); ``out`` may be ``x``."""
     _req(x, None, "x"), _req(scale, torch.float32, "scale", 1)
     S = x.shape[0]
     per = x.numel() // max(S, 1)
     if x.dtype not in (torch.float32, half()) or not x.is_contiguous() or scale.numel() != S or per % 8 or not scale.is_contiguous():
         raise ValueError("scale_samples: contiguous [S, ...] tensor with a multiple of 8 elements per sample and S scales expected")
-    y = torch.empty_like(x)
+    y = torch.empty_like(x) if out is None else out
     check(lib().apla_scale_samples(x.data_ptr(), _DT[x.dtype], y.data_ptr(), scale.data_ptr(), S, per, _stream()), "apla_scale_samples")
     return y
 

@@ -248,28 +248,34 @@ def apla_proj_bwd(dy: Tensor, x: Tensor, W1: Tensor, W2: Tensor, indices: Tensor
 
 
 def apla_attention_fwd(x: Tensor, p: Dict[str, Tensor], prefix: str, num_heads: int, r: int,
-                       return_attn: bool = False):
+                       return_attn: bool = False, attn_drop=None):
     """APLA_Attention.forward (appla_attn.py:50-83) on a parameter dict keyed like the reference
-    state_dict (``<prefix>qkv.weight`` … ``<prefix>inds``)."""
+    state_dict (``<prefix>qkv.weight`` … ``<prefix>inds``).  ``attn_drop`` = (keep [B,H,N,N] bool, p): attn_drop of appla_attn.py:58."""
     D = x.shape[-1]
     scale = (D // num_heads) ** -0.5  # appla_attn.py:15
     qkv = linear_fwd(x, p[prefix + "qkv.weight"], p.get(prefix + "qkv.bias"))
-    res = attention_fwd(qkv, num_heads, scale, return_attn)
+    if attn_drop is not None:
+        res = attention_dropout_fwd_bwd(qkv, num_heads, scale, attn_drop[0], attn_drop[1])
+    else:
+        res = attention_fwd(qkv, num_heads, scale, return_attn)
     o = res[0]
     y = apla_proj_fwd(o, p[prefix + "proj_weight1"], p[prefix + "proj_bias1"],
                       p[prefix + "proj_weight2"], p[prefix + "proj_bias2"], p[prefix + "inds"])
-    ctx = (x, qkv, o, res[1])
-    return (y, res[2], ctx) if return_attn else (y, None, ctx)
+    ctx = (x, qkv, o, res[1], attn_drop)
+    return (y, res[2], ctx) if (return_attn and attn_drop is None) else (y, None, ctx)
 
 
 def apla_attention_bwd(dy: Tensor, ctx, p: Dict[str, Tensor], prefix: str, num_heads: int, need_dx: bool = True):
-    x, qkv, o, lse = ctx
+    x, qkv, o, lse, attn_drop = ctx
     D = x.shape[-1]
     scale = (D // num_heads) ** -0.5
     do, dW1, db1 = apla_proj_bwd(dy, o, p[prefix + "proj_weight1"], p[prefix + "proj_weight2"], p[prefix + "inds"])
     if not need_dx:
         return None, dW1, db1
-    dqkv = attention_bwd(do, qkv, o, lse, num_heads, scale)
+    if attn_drop is not None:
+        dqkv = attention_dropout_fwd_bwd(qkv, num_heads, scale, attn_drop[0], attn_drop[1], do)[2]
+    else:
+        dqkv = attention_bwd(do, qkv, o, lse, num_heads, scale)
     dx = dqkv @ p[prefix + "qkv.weight"]
     return dx, dW1, db1
 
@@ -279,7 +285,8 @@ def apla_attention_bwd(dy: Tensor, ctx, p: Dict[str, Tensor], prefix: str, num_h
 # ----------------------------------------------------------------------------------------------
 
 
-def mlp_fwd(x: Tensor, p: Dict[str, Tensor], prefix: str, swiglu: bool):
+def mlp_fwd(x: Tensor, p: Dict[str, Tensor], prefix: str, swiglu: bool, m_h=None):
+    """``m_h`` [.., F]: the multiplicative mask keep / (1 - p) of Mlp.drop after the activation (vit.py:164-165); SwiGLUFFNFused has no dropout."""
     if swiglu:
         x12 = linear_fwd(x, p[prefix + "w12.weight"], p[prefix + "w12.bias"])
         x1, x2 = x12.chunk(2, dim=-1)
@@ -287,7 +294,9 @@ def mlp_fwd(x: Tensor, p: Dict[str, Tensor], prefix: str, swiglu: bool):
         return linear_fwd(h, p[prefix + "w3.weight"], p[prefix + "w3.bias"]), (x12,)
     a = linear_fwd(x, p[prefix + "fc1.weight"], p[prefix + "fc1.bias"])
     h = gelu_fwd(a)
-    return linear_fwd(h, p[prefix + "fc2.weight"], p[prefix + "fc2.bias"]), (a,)
+    if m_h is not None:
+        h = h * m_h
+    return linear_fwd(h, p[prefix + "fc2.weight"], p[prefix + "fc2.bias"]), (a, m_h)
 
 
 def mlp_bwd_dx(dy: Tensor, ctx, p: Dict[str, Tensor], prefix: str, swiglu: bool) -> Tensor:
@@ -297,31 +306,40 @@ def mlp_bwd_dx(dy: Tensor, ctx, p: Dict[str, Tensor], prefix: str, swiglu: bool)
         dh = dy @ p[prefix + "w3.weight"]
         dx12 = torch.cat([dh * x2 * silu_grad(x1), dh * silu(x1)], dim=-1)
         return dx12 @ p[prefix + "w12.weight"]
-    (a,) = ctx
+    a, m_h = ctx if len(ctx) == 2 else (ctx[0], None)
     dh = dy @ p[prefix + "fc2.weight"]
+    if m_h is not None:
+        dh = dh * m_h
     da = dh * gelu_grad(a)
     return da @ p[prefix + "fc1.weight"]
 
 
 def block_fwd(x: Tensor, p: Dict[str, Tensor], i: int, num_heads: int, r: int, swiglu: bool = False,
-              eps: float = 1e-6, dp=None):
+              eps: float = 1e-6, dp=None, dm=None):
     """Block.forward, vit.py:279-288: x += drop_path(ls1(attn(norm1 x))); x += drop_path(ls2(mlp(norm2 x))).
     ``dp`` = (s1, s2): the per-sample factors floor(keep_prob + u) / keep_prob of the two DropPath calls (vit.py:74-82; `drop_path`
     below builds them from the uniform numbers), None = identity (p = 0 in every shipped config, SURVEY §5 hazard 14).  nn.Dropout
-    sites stay identity here (Mlp.drop / proj_drop: `philox_keep_mask` pins their mask on the module path)."""
+    ``dm``: the block's nn.Dropout sites as given masks — dict with optional "proj" [B,N,D] (proj_drop, appla_attn.py:82), "h" [B,N,F] and
+    "fc2" [B,N,D] (Mlp.drop after the activation and after fc2, vit.py:164-167), all MULTIPLICATIVE (keep / (1 - p); `philox_keep_mask`
+    gives the kernels' keep), and "attn" = (keep [B,H,N,N] bool, p) for attn_drop (appla_attn.py:58)."""
     pre = f"blocks.{i}."
+    dm = dm or {}
     bc = (lambda s_: s_.reshape((-1,) + (1,) * (x.ndim - 1)).to(x.dtype))
     n1, mean1, rstd1 = layernorm_fwd(x, p[pre + "norm1.weight"], p[pre + "norm1.bias"], eps)
-    y, _, actx = apla_attention_fwd(n1, p, pre + "attn.", num_heads, r)
+    y, _, actx = apla_attention_fwd(n1, p, pre + "attn.", num_heads, r, attn_drop=dm.get("attn"))
+    if dm.get("proj") is not None:
+        y = y * dm["proj"]
     g1 = p.get(pre + "ls1.gamma")
     y = y * g1 if g1 is not None else y
     x1 = x + (y * bc(dp[0]) if dp is not None else y)
     n2, mean2, rstd2 = layernorm_fwd(x1, p[pre + "norm2.weight"], p[pre + "norm2.bias"], eps)
-    z, mctx = mlp_fwd(n2, p, pre + "mlp.", swiglu)
+    z, mctx = mlp_fwd(n2, p, pre + "mlp.", swiglu, m_h=dm.get("h"))
+    if dm.get("fc2") is not None:
+        z = z * dm["fc2"]
     g2 = p.get(pre + "ls2.gamma")
     z = z * g2 if g2 is not None else z
     x2 = x1 + (z * bc(dp[1]) if dp is not None else z)
-    ctx = dict(x=x, mean1=mean1, rstd1=rstd1, actx=actx, x1=x1, mean2=mean2, rstd2=rstd2, mctx=mctx, dp=dp)
+    ctx = dict(x=x, mean1=mean1, rstd1=rstd1, actx=actx, x1=x1, mean2=mean2, rstd2=rstd2, mctx=mctx, dp=dp, dm=dm)
     return x2, ctx
 
 
@@ -334,11 +352,16 @@ def block_bwd(dx2: Tensor, ctx, p: Dict[str, Tensor], i: int, num_heads: int, sw
     g2 = p.get(pre + "ls2.gamma")
     dz = dx2 * bc(dp[1]) if dp is not None else dx2          # d(drop_path(z)) / dz = the sample's factor
     dz = dz * g2 if g2 is not None else dz
+    dm = ctx.get("dm") or {}
+    if dm.get("fc2") is not None:
+        dz = dz * dm["fc2"]
     dn2 = mlp_bwd_dx(dz, ctx["mctx"], p, pre + "mlp.", swiglu)
     dx1 = dx2 + layernorm_bwd_dx(dn2, ctx["x1"], p[pre + "norm2.weight"], ctx["mean2"], ctx["rstd2"])
     g1 = p.get(pre + "ls1.gamma")
     dy = dx1 * bc(dp[0]) if dp is not None else dx1
     dy = dy * g1 if g1 is not None else dy
+    if dm.get("proj") is not None:
+        dy = dy * dm["proj"]
     dn1, dW1, db1 = apla_attention_bwd(dy, ctx["actx"], p, pre + "attn.", num_heads, need_dx)
     if not need_dx:
         return None, dW1, db1
@@ -458,11 +481,14 @@ def vit_forward(images: Tensor, p: Dict[str, Tensor], cfg: Dict, keep_ctx: bool 
     cfg: dict(patch, depth, heads, r, swiglu, eps).  ``p`` holds backbone keys as in the reference
     state_dict plus ``fc.weight``/``fc.bias`` for the classifier head."""
     x = embed_tokens(images, p, cfg["patch"])
+    dms = cfg.get("drop_masks") or {}     # {"pos": multiplicative mask [B,N,D] of pos_drop (vit.py:395), "blocks": [block_fwd's dm per block]}
+    if dms.get("pos") is not None:
+        x = x * dms["pos"]
     ctxs = []
     dps = cfg.get("dp_scale")       # [2 * depth, B]: rows 2 i / 2 i + 1 = the factors of block i's attention / MLP branch (stochastic depth)
     for i in range(cfg["depth"]):
         x, c = block_fwd(x, p, i, cfg["heads"], cfg["r"], cfg.get("swiglu", False), cfg.get("eps", 1e-6),
-                         dp=None if dps is None else (dps[2 * i], dps[2 * i + 1]))
+                         dp=None if dps is None else (dps[2 * i], dps[2 * i + 1]), dm=(dms.get("blocks") or [None] * cfg["depth"])[i])
         ctxs.append(c if keep_ctx else None)
     cls_in = x[:, 0]
     xn, meanf, rstdf = layernorm_fwd(cls_in, p["norm.weight"], p["norm.bias"], cfg.get("eps", 1e-6))

@@ -762,19 +762,108 @@ def test_cross_entropy_rejects_out_of_range_labels():
 
 
 def test_fused_step_refuses_dropout():
-    """The captured launch sequence has no element-wise dropout: a model that asks for one must not be trained as if it did not.
-    Stochastic depth is accepted since round 6 (next test)."""
+    """A nn.Dropout the engine does not know must not be trained as if it were not there; the reference's own dropout sites and
+    stochastic depth are accepted since round 6 (next tests)."""
     from apla_amd.engine import AplaTrainEngine
     from apla_amd.vit import DropPath
     model = small_vit(depth=2)
     model.backbone.blocks[1].mlp.drop.p = 0.1
-    with pytest.raises(NotImplementedError, match="module path only"):
-        AplaTrainEngine(model, 4, 32)
+    e = AplaTrainEngine(model, 4, 32)
+    assert e.drop_on and not e.use_graphs         # a site of the reference: element-wise mask passes, launched eagerly (round 6)
     model.backbone.blocks[1].mlp.drop.p = 0.0
+    model.backbone.extra_drop = torch.nn.Dropout(0.3)       # not one of the reference's sites: refused, never ignored
+    with pytest.raises(NotImplementedError, match="not one of the reference's sites"):
+        AplaTrainEngine(model, 4, 32)
+    del model.backbone.extra_drop
     model.backbone.blocks[1].drop_path = DropPath(0.2)
     assert AplaTrainEngine(model, 4, 32).dp_on
     model.backbone.blocks[1].drop_path = torch.nn.Identity()
     assert not AplaTrainEngine(model, 4, 32).dp_on
+
+
+def _oracle_drop_masks(eng, B, N, D, F, H, step):
+    """The masks the engine's kernels draw in step `step`, rebuilt by the oracle's own Philox4x32-10 from (seed, offset):
+    multiplicative masks for the three element-wise sites of every block and pos_drop, the keep matrix for attn_drop."""
+    L, seed = eng.L, eng._drop_seed
+    off = lambda site: step * (4 * L + 8) + site       # noqa: E731  (engine._drop_offset)
+    mul = lambda n, p, site, shape: (torch.from_numpy(O.philox_keep_mask(n, p, seed, off(site))).double() / (1.0 - float(torch.tensor(p, dtype=torch.float32)))).reshape(shape)  # noqa: E731
+    blocks = []
+    for i in range(L):
+        dm = {}
+        if eng.p_proj[i] > 0:
+            dm["proj"] = mul(B * N * D, eng.p_proj[i], 1 + 4 * i, (B, N, D))
+        if eng.p_mlp[i] > 0:
+            dm["h"] = mul(B * N * F, eng.p_mlp[i], 2 + 4 * i, (B, N, F))
+            dm["fc2"] = mul(B * N * D, eng.p_mlp[i], 3 + 4 * i, (B, N, D))
+        if eng.p_attn[i] > 0:
+            pa = float(torch.tensor(eng.p_attn[i], dtype=torch.float32))
+            dm["attn"] = (O.philox_attn_keep_mask(B, H, N, eng.p_attn[i], seed, off(4 + 4 * i)), pa)
+        blocks.append(dm)
+    return {"pos": mul(B * N * D, eng.p_pos, 0, (B, N, D)) if eng.p_pos > 0 else None, "blocks": blocks}
+
+
+@pytest.mark.parametrize("sites", ["all", "mlp", "proj+attn+droppath"])
+def test_engine_elementwise_dropout_vs_oracle(sites):
+    """main.py --dr / --adr on the fused step (VERDICT r05 #7a): the reference's nn.Dropout sites — pos_drop (vit.py:395), attn_drop and
+    proj_drop (appla_attn.py:58, :82), Mlp.drop after the activation and after fc2 (vit.py:164-167) — as counter-based mask passes of the
+    C-ABI around the step's launches, alone and together with stochastic depth.  Logits, loss and every trainable gradient against the
+    fp64 oracle under the SAME masks, which the oracle rebuilds from (seed, offset) with its own Philox4x32-10 (pinned by the Random123
+    known-answer vectors); two steps (the masks change with the step counter); inference ignores every site."""
+    from apla_amd.engine import AplaTrainEngine, OptimConfig
+    from apla_amd.vit import DropPath
+    depth, B = 3, 4
+    model = small_vit(depth=depth)
+    bb = model.backbone
+    if sites in ("all", "mlp"):
+        for blk in bb.blocks:
+            blk.mlp.drop.p = 0.2
+    if sites in ("all", "proj+attn+droppath"):
+        for blk in bb.blocks:
+            blk.attn.proj_drop.p = 0.15
+            blk.attn.attn_drop.p = 0.1
+    if sites == "all":
+        bb.pos_drop.p = 0.1
+    if sites == "proj+attn+droppath":
+        for blk, q in zip(bb.blocks, (0.0, 0.2, 0.4)):
+            if q > 0:
+                blk.drop_path = DropPath(q)
+    p = oracle_params(model)
+    g = torch.Generator().manual_seed(13)
+    images, labels = torch.randn(B, 3, 32, 32, generator=g), torch.randint(0, 10, (B,), generator=g)
+    eng = AplaTrainEngine(model, B, 32, optim=OptimConfig(lr=1e-3, weight_decay=1e-2, grad_clipping=1.0))
+    assert eng.drop_on and not eng.use_graphs and not eng.cls_only_tail and eng.dp_on == (sites == "proj+attn+droppath")
+    eng.set_dropout_seed(0x0123_4567_89AB_CDEF, step=0)
+    N, D, F, H = eng.N, eng.D, eng.blocks[0].F, eng.H
+    cfg = dict(patch=16, depth=depth, heads=H, r=64)
+    for step in (1, 2):
+        extra = {}
+        if eng.dp_on:
+            u = torch.rand(2 * depth, B, generator=g)
+            keep = torch.tensor([1.0 - q for q in eng.dp_rates for _ in (0, 1)], dtype=torch.float64)[:, None]
+            extra["dp_scale"] = torch.floor(keep + u.double()) / keep
+            eng.set_drop_path_uniforms(u)
+        masks = _oracle_drop_masks(eng, B, N, D, F, H, step)
+        logits_ref, ctx = O.vit_forward(images.double(), p, dict(cfg, drop_masks=masks, **extra))
+        loss_ref, dl = O.cross_entropy_fwd_bwd(logits_ref, labels)
+        grads_ref = O.vit_backward(dl, ctx, p, cfg)
+        eng.set_batch(images.cuda(), labels.cuda())
+        eng.forward_backward()
+        torch.cuda.synchronize()
+        assert eng._drop_step == step
+        assert rel_err(eng.logits.cpu(), logits_ref) < LOGIT_TOL, step
+        assert abs(float(eng.loss) - float(loss_ref)) < 5e-3
+        for n, gr in eng.grads().items():
+            n2 = n[len("backbone."):] if n.startswith("backbone.") else n
+            assert rel_l2(gr.cpu(), grads_ref[n2]) < GRAD_TOL, (step, n)
+    logits_plain, _ = O.vit_forward(images.double(), p, cfg, keep_ctx=False)
+    assert rel_err(logits_ref, logits_plain) > 10 * LOGIT_TOL          # the masks did something
+    lg, _, _ = eng.forward_only(images.cuda(), labels.cuda())
+    torch.cuda.synchronize()
+    assert rel_err(lg.cpu(), logits_plain) < LOGIT_TOL                 # evaluation: every dropout is the identity
+    eng.optimizer_step()
+    eng.train_step()
+    torch.cuda.synchronize()
+    assert np.isfinite(float(eng.loss))
 
 
 @pytest.mark.parametrize("use_graphs", [False, True])

@@ -1151,7 +1151,9 @@ def test_attn_bwd_fused_short_sequence_kernel_equals_split_kernels_at_full_occup
         ref = O.attention_bwd(do64, q64, o64, lse[b].cpu().double().reshape(1, H, N), H, scale)
         got = dqkv[rows].cpu().double().reshape(1, N, 3 * D)
         for part, name in ((slice(0, D), "dq"), (slice(D, 2 * D), "dk"), (slice(2 * D, 3 * D), "dv")):
-            assert rel_err(got[..., part], ref[..., part]) < BF16_OUT, (b, name)
+            # (one token: the softmax is 1, dq = dk = 0 exactly in the oracle — the scale is then the gradient's as a whole)
+            den = max(float(ref[..., part].abs().max()), 1e-3 * float(ref.abs().max()))
+            assert float((got[..., part] - ref[..., part]).abs().max()) / den < BF16_OUT, (b, name)
         dref = (do64.reshape(N, H, 64) * o64.reshape(N, H, 64)).sum(-1).t()
         assert float((delta[b].cpu().double() - dref).abs().max()) < 1e-4 * max(1.0, float(dref.abs().max())), b
 

@@ -23,6 +23,12 @@ for step in "$@"; do
         APLA_LIB=$EXP/libapla_NT_$n.so CLOCK_ONLY="fc1,dfc2" CLOCK_KERNEL="" timeout -k 10 200 python3 tools/gemm_clock.py 0.5 2>&1 | grep "^|" | grep -v "launch |\|---" >> $OUT/nt_ablations.md || exit 1
       done
       cat $OUT/nt_ablations.md ;;
+    ngrp_pp2)   # tile walk of the ping-pong kernel on the N = 768 launches (fc2, dfc1, dqkv): n-tiles per column group from APLA_NGRP (NGRP build)
+      for G in -1 0 1 2 3 -1; do
+        echo "--- APLA_NGRP=$G" >> $OUT/ngrp_pp2.txt
+        APLA_NGRP=$G APLA_LIB=$EXP/libapla_NGRP.so GEMM_ONLY="fc2,dfc1,dqkv,qkv" GEMM_ROTATE=4 GEMM_VARIANTS=109 timeout -k 10 120 python3 tools/gemm_bench.py 2>&1 | grep "us" >> $OUT/ngrp_pp2.txt || exit 1
+      done
+      cat $OUT/ngrp_pp2.txt ;;
     *) echo "unknown step $step"; exit 2 ;;
   esac
 done
