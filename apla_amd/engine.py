@@ -815,14 +815,20 @@ class AplaTrainEngine:
         defaults/trainer.py:207-210, models.py:81-92): the step's own forward launch sequence with the current trainable rows,
         no backward.  Returns (logits [B, C] fp32, features [B, D] fp32 = the final-norm CLS token, mean CE loss or None);
         the tensors are the engine's buffers — clone what must outlive the next call."""
-        if images.shape[0] != self.B:
-            raise ValueError(f"this engine was built for batches of {self.B} images (got {images.shape[0]}); pad the last batch")
-        self.images.copy_(images, non_blocking=True)
+        b = images.shape[0]
+        if b > self.B or b < 1:
+            raise ValueError(f"this engine was built for batches of at most {self.B} images (got {b})")
+        self.images[:b].copy_(images, non_blocking=True)      # a short (last) batch: the other rows keep the previous batch — samples do not mix
         if labels is not None and not self.soft_targets:
-            self.labels.copy_(labels.to(torch.int32), non_blocking=True)
+            self.labels[:b].copy_(labels.to(torch.int32), non_blocking=True)
         self.refresh_weights()
         self._forward(inference=True)
-        return self.logits, self.xn, (self.loss if labels is not None and not self.soft_targets else None)
+        if b == self.B:
+            return self.logits, self.xn, (self.loss if labels is not None and not self.soft_targets else None)
+        loss = None
+        if labels is not None and not self.soft_targets:     # the kernel's loss is the mean over all B rows: redo it over the b real ones
+            loss = torch.nn.functional.cross_entropy(self.logits[:b], labels.to(self.device).long()).reshape(1)
+        return self.logits[:b], self.xn[:b], loss
 
     @_half_mode
     def time_fc1_launches(self, steps: int = 3) -> float:

@@ -68,6 +68,8 @@ def parse_arguments(argv=None):
         p.add_argument("--" + flag, action="store_true", default=False)
     # additions of this implementation
     p.add_argument("--steps_per_epoch", type=int, help="synthetic data only: iterations that make one epoch (default 100)")
+    p.add_argument("--module_path", action="store_true", default=False,
+                   help="train on the drop-in module path (autograd over the kernels) instead of the fused step")
     p.add_argument("--n_classes", type=int, help="classes when the dataset name is not a known one")
     p.add_argument("--dtype", choices=["bf16", "fp16"], default=None, help="16-bit operand type (default bf16; --mixed_precision alone keeps bf16)")
     return p.parse_args(argv)
@@ -395,21 +397,26 @@ def main(params, args):
         if pretrained and is_rank0():
             print("\033[93m[main] model_params.pretrained is true but there is no network and no --pretrained_path: random initialisation\033[0m")
     hdt = torch.float16 if args.dtype == "fp16" else torch.bfloat16
-    from apla_amd.module_trainer import ModulePathTrainer, wants_dropout
-    module_path = wants_dropout(model)
+    from apla_amd.module_trainer import ModulePathTrainer
+    # --dr / --dpr / --adr (main.py:101-111) keep the fused step since round 6: stochastic depth inside its LayerNorm kernels (free), the
+    # nn.Dropout sites as mask passes around its launches (profiles/r06_c_dropout_bench.md: 15.7 ms against 18.2 ms on the module path at
+    # config 2 with --dr 0.1).  The drop-in module path (autograd over the same kernels) takes what the engine refuses, or --module_path.
+    module_path = bool(getattr(args, "module_path", False))
+    eng = None
+    if not module_path:
+        try:
+            eng = AplaTrainEngine(model, run["batch"], run["img"], device=dev, process_group=dist.group.WORLD if world > 1 else None,
+                                  optim=OptimConfig(lr=run["lr"], weight_decay=run["wd"], grad_clipping=run["grad_clipping"]),
+                                  compute_dtype=hdt, loss_scale="dynamic" if hdt == torch.float16 else 1.0,
+                                  soft_targets=run["soft_targets"])
+        except NotImplementedError as e:
+            module_path = True
+            if is_rank0():
+                print(f"[main] the fused step does not take this model ({e}); training on the module path (apla_amd.module_trainer)", flush=True)
     if module_path:
-        # --dr / --adr (main.py:101-111): the fused step has no element-wise dropout; train on the drop-in module path (--dpr alone keeps
-        # the fused step: stochastic depth is one factor per sample and branch inside its LayerNorm kernels)
-        if is_rank0():
-            print("[main] drop_rate / attn_drop_rate > 0: training on the module path (apla_amd.module_trainer), not the fused step", flush=True)
         eng = ModulePathTrainer(model.to(dev), lr=run["lr"], weight_decay=run["wd"], grad_clipping=run["grad_clipping"],
                                 process_group=dist.group.WORLD if world > 1 else None, compute_dtype=hdt,
                                 loss_scale="dynamic" if hdt == torch.float16 else 1.0, soft_targets=run["soft_targets"])
-    else:
-        eng = AplaTrainEngine(model, run["batch"], run["img"], device=dev, process_group=dist.group.WORLD if world > 1 else None,
-                              optim=OptimConfig(lr=run["lr"], weight_decay=run["wd"], grad_clipping=run["grad_clipping"]),
-                              compute_dtype=hdt, loss_scale="dynamic" if hdt == torch.float16 else 1.0,
-                              soft_targets=run["soft_targets"])
     data = TensorBatches(run, rank, world, dev, args.steps_per_epoch)
     sched = make_schedule(run, data.steps)
     epochs = 0 if args.test else (1 if args.dry else run["epochs"])   # --test: evaluate the loaded weights only (main.py:219-222)

@@ -397,22 +397,36 @@ def test_main_entry_point_trains_on_synthetic_data(tmp_path):
 
 
 def test_main_entry_point_with_dropout_trains_on_the_module_path(tmp_path):
-    """main.py --dr / --dpr (the reference's main.py:101-111 overrides): the fused step refuses dropout, so the entry point trains on
-    the module path (apla_amd.module_trainer: autograd over the HIP kernels + FlatAdamW) — the loss must fall on a repeated synthetic
-    batch, the session file keeps the reference layout, and a run without the flags still takes the fused step."""
+    """main.py --dr / --dpr (the reference's main.py:101-111 overrides).  Since round 6 the fused step takes both (stochastic depth in
+    its LayerNorm kernels, the nn.Dropout sites as mask passes); `--module_path` selects the drop-in module path
+    (apla_amd.module_trainer: autograd over the HIP kernels + FlatAdamW), which round 5 used for every dropout run — on either the loss
+    must be finite / fall on a repeated synthetic batch and the session file keeps the reference layout."""
     import main
     from apla_amd.module_trainer import ModulePathTrainer, wants_dropout
     os.makedirs(tmp_path / "dp", exist_ok=True)
     path = os.path.join(os.path.dirname(__file__), "params", "tiny", "apla.yml")
     args = main.parse_arguments(["--params_path", path, "--steps_per_epoch", "6", "--save_dir", str(tmp_path), "--lr", "0.002",
-                                 "--dr", "0.1", "--dpr", "0.1"])
+                                 "--dr", "0.1", "--dpr", "0.1", "--module_path"])
     params = main.update_params_from_args(main.load_parameters(path), args)
     assert params["model_params"]["transformers_params"]["drop_rate"] == 0.1
+    # the same flags on the fused step (the default since round 6)
+    os.makedirs(tmp_path / "fused", exist_ok=True)
+    args_f = main.parse_arguments(["--params_path", path, "--steps_per_epoch", "4", "--save_dir", str(tmp_path / "fused"), "--lr", "0.002",
+                                   "--dr", "0.1", "--dpr", "0.1", "--adr", "0.05"])
+    params_f = main.update_params_from_args(main.load_parameters(path), args_f)
+    assert np.isfinite(main.main(params_f, args_f))
+    sess_f = torch.load(tmp_path / "fused" / "tiny.pth", weights_only=False)
+    assert tuple(sess_f["state_dict"]["backbone.blocks.0.attn.proj_weight1"].shape) == (8, 384)
     # --dpr alone keeps the fused step (round 6: stochastic depth inside its LayerNorm kernels)
     args_dp = main.parse_arguments(["--params_path", path, "--steps_per_epoch", "4", "--save_dir", str(tmp_path / "dp"), "--lr", "0.002", "--dpr", "0.2"])
     params_dp = main.update_params_from_args(main.load_parameters(path), args_dp)
     assert params_dp["model_params"]["transformers_params"]["drop_path_rate"] == 0.2 and np.isfinite(main.main(params_dp, args_dp))
     assert not wants_dropout(small_vit(depth=2))
+    # ... and the engine built from the --dr model runs its mask passes
+    from apla_amd.engine import AplaTrainEngine
+    m2 = small_vit(depth=2)
+    m2.backbone.blocks[0].mlp.drop.p = 0.1
+    assert AplaTrainEngine(m2, 4, 32).drop_on
     loss = main.main(params, args)
     assert np.isfinite(loss)
     sess = torch.load(tmp_path / "tiny.pth", weights_only=False)
@@ -486,8 +500,13 @@ def test_forward_only_and_evaluator():
         correct += int((lg.argmax(1) == lb).sum())
     assert abs(out["val_loss"] - sum(ls) / 3) < 1e-5 and abs(out["val_accuracy"] - correct / (3 * B)) < 1e-9
     assert out["knn_val_accuracy"] == 1.0        # k = 1 on its own bank: every image votes for its own label
+    # a short (last) batch: its rows' logits / features are those of the full batch, the loss is the mean over ITS rows
+    lg2, ft2, ls2 = eng.forward_only(batches[1][0][:2], batches[1][1][:2])
+    lgf, ftf, _ = eng.forward_only(*batches[1])
+    assert lg2.shape == (2, 10) and torch.equal(lg2, lgf[:2]) and torch.equal(ft2, ftf[:2])
+    assert abs(float(ls2) - float(torch.nn.functional.cross_entropy(lgf[:2], batches[1][1][:2].long()))) < 1e-6
     with pytest.raises(ValueError):
-        eng.forward_only(batches[0][0][:2])
+        eng.forward_only(torch.cat([batches[0][0], batches[1][0]]))          # more images than the engine's buffers hold
 
 
 def _full_size_properties(backbone, patch, img, B, r, n_classes=1000, compute_dtype=torch.bfloat16, loss_scale=1.0, need_gib=0.0,
