@@ -501,7 +501,8 @@ def test_forward_only_and_evaluator():
     assert abs(out["val_loss"] - sum(ls) / 3) < 1e-5 and abs(out["val_accuracy"] - correct / (3 * B)) < 1e-9
     assert out["knn_val_accuracy"] == 1.0        # k = 1 on its own bank: every image votes for its own label
     # a short (last) batch: its rows' logits / features are those of the full batch, the loss is the mean over ITS rows
-    lg2, ft2, ls2 = eng.forward_only(batches[1][0][:2], batches[1][1][:2])
+    lg2, ft2, ls2 = eng.forward_only(batches[1][0][:2], batches[1][1][:2])     # (rows 2, 3 of the buffers still hold batch 2's images)
+    lg2, ft2, ls2 = lg2.clone(), ft2.clone(), ls2.clone()                       # the returned tensors are the engine's buffers
     lgf, ftf, _ = eng.forward_only(*batches[1])
     assert lg2.shape == (2, 10) and torch.equal(lg2, lgf[:2]) and torch.equal(ft2, ftf[:2])
     assert abs(float(ls2) - float(torch.nn.functional.cross_entropy(lgf[:2], batches[1][1][:2].long()))) < 1e-6
