@@ -290,12 +290,13 @@ int apla_gemm_pp2_launch(const GemmParams& p_in, int epilogue, int out_dtype, hi
     return APLA_ENOSYS;
   GemmParams p = p_in;
   p.ngrp = pick_ngrp(p.N / QBN, QBN, p.K);
-  // Round 6: with at most three column tiles (the N = 768 launches of ViT-B: fc2, dfc1, dqkv — 4.7 / 3.5 MB of W) the plain walk wins:
-  // the three workgroups that share an A row tile run side by side on one XCD and the A panel is streamed ONCE, where one-tile column
-  // groups streamed it three times (counters: 2.5-2.6 x the algorithmic bytes, profiles/r06_a_bench_roofline.json).  Measured back to
-  // back with APLA_NGRP on the NGRP build (profiles/r06_b_ngrp_pp2.md): fc2 114 -> 108 us, dfc1 106 -> 104, dqkv 81.5 -> 77.5.
+  // Round 6: with at most four column tiles (the N = 768 launches of ViT-B — fc2, dfc1, dqkv: 4.7 / 3.5 MB of W — and the N = 1024 ones
+  // of ViT-L) the plain walk wins: the workgroups that share an A row tile run side by side on one XCD and the A panel is streamed ONCE,
+  // where one-tile column groups streamed it three / four times (counters: 2.5-2.6 x the algorithmic bytes,
+  // profiles/r06_a_bench_roofline.json).  Measured back to back with APLA_NGRP on the NGRP build (profiles/r06_b_ngrp_pp2.md): ViT-B
+  // fc2 114 -> 108 us, dfc1 106 -> 104, dqkv 81.5 -> 77.5; ViT-L fc2 561 -> 533, dqkv 403 -> 387; wider outputs (qkv) do not move.
 #if !defined(APLA_ABL_NGRP)
-  if (p.N / QBN <= 3) p.ngrp = 0;
+  if (p.N / QBN <= 4) p.ngrp = 0;
 #endif
   const int cus = 256 - (p.reserve > 0 && p.reserve < 192 ? p.reserve : 0);
   const int QBM = apla_gemm_pp2_tile_rows(p.M, p.N, epilogue, out_dtype, p.exp, p.reserve);

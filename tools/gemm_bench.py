@@ -16,6 +16,9 @@ SHAPES = [("qkv", 2304, 768, ops.EPI_STORE), ("proj", 768, 768, ops.EPI_STORE), 
           ("fc1+gelu_fwd", 3072, 768, ops.EPI_GELU_FWD), ("proj+res", 768, 768, ops.EPI_RESIDUAL), ("fc1+gelu", 3072, 768, ops.EPI_GELU),
           ("fc2+res", 768, 3072, ops.EPI_RESIDUAL), ("dfc2*g", 3072, 768, ops.EPI_MUL), ("dfc1", 768, 3072, ops.EPI_STORE),
           ("dproj", 768, 768, ops.EPI_STORE), ("dqkv", 768, 2304, ops.EPI_STORE)]
+if os.environ.get("GEMM_SHAPES"):  # custom shapes "name:N:K[:epilogue]", e.g. GEMM_M=65792 GEMM_SHAPES=fc2:1024:4096,qkv:3072:1024,fc1:4096:1024:gelu
+    EPIS = {"store": ops.EPI_STORE, "gelu": ops.EPI_GELU, "gelu_fwd": ops.EPI_GELU_FWD, "mul": ops.EPI_MUL}
+    SHAPES = [(f[0], int(f[1]), int(f[2]), EPIS[f[3]] if len(f) > 3 else ops.EPI_STORE) for f in (t.split(":") for t in os.environ["GEMM_SHAPES"].split(","))]
 if os.environ.get("GEMM_SQ"):  # square problems (e.g. GEMM_SQ=4096,8192) to compare with published figures for other kernels
     SHAPES = [(f"sq{v}", int(v), int(v), ops.EPI_STORE, int(v)) for v in os.environ["GEMM_SQ"].split(",")]
 VARIANTS = [int(v) for v in os.environ.get("GEMM_VARIANTS", "0,2,3").split(",")]

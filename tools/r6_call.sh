@@ -29,6 +29,14 @@ for step in "$@"; do
         APLA_NGRP=$G APLA_LIB=$EXP/libapla_NGRP.so GEMM_ONLY="fc2,dfc1,dqkv,qkv" GEMM_ROTATE=4 GEMM_VARIANTS=109 timeout -k 10 120 python3 tools/gemm_bench.py 2>&1 | grep "us" >> $OUT/ngrp_pp2.txt || exit 1
       done
       cat $OUT/ngrp_pp2.txt ;;
+    ngrp_cfg3)   # the same sweep at config 3's shapes (ViT-L/14, bs 256: M = 65 792, D = 1024, F = 4096): four column tiles at N = 1024
+      for G in -1 0 2 4 -1; do
+        echo "--- APLA_NGRP=$G" >> $OUT/ngrp_cfg3.txt
+        APLA_NGRP=$G APLA_LIB=$EXP/libapla_NGRP.so GEMM_M=65792 GEMM_SHAPES="fc2:1024:4096,dqkv:1024:3072,qkv:3072:1024,proj:1024:1024" GEMM_ROTATE=2 GEMM_VARIANTS=109 timeout -k 10 200 python3 tools/gemm_bench.py 2>&1 | grep "us" >> $OUT/ngrp_cfg3.txt || exit 1
+      done
+      cat $OUT/ngrp_cfg3.txt
+      echo "--- two-output GELU at config 3: ping-pong (9) vs 4-wave persistent (15)" >> $OUT/ngrp_cfg3.txt
+      GEMM_M=65792 GEMM_SHAPES="fc1:4096:1024:gelu,dfc2:4096:1024:mul" GEMM_IMAGES=1 GEMM_ROTATE=2 GEMM_VARIANTS=0,15 timeout -k 10 200 python3 tools/gemm_bench.py 2>&1 | grep "us" | tee -a $OUT/ngrp_cfg3.txt ;;
     *) echo "unknown step $step"; exit 2 ;;
   esac
 done
