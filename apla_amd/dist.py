@@ -65,13 +65,17 @@ def backward_order_chunks(offsets: Sequence[int], total: int, n_chunks: int = 2)
 
 
 class GradExchanger:
-    def __init__(self, flat_grads: torch.Tensor, chunks: Sequence[Tuple[int, int]], process_group=None, always: bool = False):
+    def __init__(self, flat_grads: torch.Tensor, chunks: Sequence[Tuple[int, int]], process_group=None, always: bool = False,
+                 local: bool = False):
         """``always``: issue the collectives even in a group of one process (diagnostic: lets a single-GPU box run the real
-        RCCL calls on the side stream; an all-reduce over one rank leaves the buffer unchanged)."""
+        RCCL calls on the side stream; an all-reduce over one rank leaves the buffer unchanged).  ``local``: never exchange, whatever
+        torch.distributed's state is (an engine that ONE rank of a job builds for itself, e.g. bench.py's parity check on rank 0:
+        without it `process_group=None` means the default group, and that rank would wait for collectives nobody else issues)."""
         self.flat = flat_grads
         self.chunks = list(chunks)
-        self.pg = process_group
-        self.world = self.world_of(process_group)
+        self.pg = None if local else process_group
+        self.world = 1 if local else self.world_of(process_group)
+        always = always and not local
         self.active = self.world > 1 or (always and dist.is_initialized() and process_group is not None)
         self._comm = torch.cuda.Stream() if (flat_grads.is_cuda and self.active) else None
         self._wait_events = None    # timing of wait(): see time_waits()

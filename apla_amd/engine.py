@@ -136,7 +136,10 @@ class AplaTrainEngine:
         self._scaler_step0 = 0.0   # the scaler's "steps taken" slot when _scaler_calls was last reset (checkpoint.load_session)
         self.res_dtype, self.grad_dtype = res_dtype, (grad_dtype or compute_dtype)
         self.optim = optim or OptimConfig()
-        self.pg = process_group
+        # process_group: a group, None = the default group when torch.distributed is initialised with more than one rank, or False =
+        # this engine never exchanges (a rank-local engine inside a multi-rank job: bench.py's parity checks on rank 0)
+        self.local_only = process_group is False
+        self.pg = None if self.local_only else process_group
         self.world = 1   # set from the GradExchanger below: ONE source for "how many ranks sum into the gradient buffer"
         self.use_graphs = use_graphs and not self.drop_on
         # diagnostic switch: APLA_FULL_LAST_BLOCK=1 runs the last block's forward on all rows (A/B of the CLS-only tail)
@@ -206,7 +209,7 @@ class AplaTrainEngine:
         # APLA_FORCE_EXCHANGE=1 (diagnostic): take the world > 1 path — four segments, collectives on the side stream — in a
         # process group of ONE rank, so that a single-GPU box exercises the real RCCL calls between the graph replays
         force = os.environ.get("APLA_FORCE_EXCHANGE") == "1" and self.pg is not None
-        self.world = GradExchanger.world_of(self.pg)
+        self.world = 1 if self.local_only else GradExchanger.world_of(self.pg)
         n_seg = min(4 if (self.world > 1 or force) else 2, max(self.L, 1))
         # segment s ends after the backward of block cut[s]; cut[-1] = 0.  e.g. L = 12, two segments: [6, 0]
         self.seg_cuts = [(self.L * (n_seg - 1 - s)) // n_seg for s in range(n_seg)]
@@ -222,7 +225,7 @@ class AplaTrainEngine:
         his = [n_total] + bounds[:-1]
         self.chunks = [(lo, hi) for lo, hi in zip(bounds, his)]
         assert self.chunks[-1][0] == 0 and all(hi > lo for lo, hi in self.chunks)
-        self.exchanger = GradExchanger(self.flat_grads, self.chunks, self.pg, always=force)
+        self.exchanger = GradExchanger(self.flat_grads, self.chunks, self.pg, always=force, local=self.local_only)
         # the optimizer divides by exactly the number of ranks the exchanger sums over (process_group=None with an initialised
         # default group of N ranks exchanges over those N ranks: the 1/world of the DDP mean must follow)
         assert self.world == self.exchanger.world, (self.world, self.exchanger.world)

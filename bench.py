@@ -250,7 +250,7 @@ def parity_cfg1(hdt, loss_scale):
     images = torch.randn(8, 3, 224, 224, generator=gen)
     labels = torch.randint(0, 10, (8,), generator=gen)
     eng = AplaTrainEngine(model, 8, 224, optim=OptimConfig(lr=1e-4, weight_decay=1e-5, grad_clipping=1.0), use_graphs=False,
-                          compute_dtype=hdt, loss_scale=loss_scale)
+                          compute_dtype=hdt, loss_scale=loss_scale, process_group=False)    # rank-local: rank 0 alone runs this check
     eng.set_batch(images.cuda(), labels.cuda())
     eng.forward_backward()
     torch.cuda.synchronize()
@@ -307,7 +307,7 @@ def parity_on_baseline_sample(dump, backbone, r, n_classes, img, patch):
     for name, hdt, ls in (("bf16", torch.bfloat16, 1.0), ("fp16", torch.float16, 1024.0)):
         model = build_model(backbone, r, n_classes, img, patch, seed=0)
         eng = AplaTrainEngine(model, bs, img, optim=OptimConfig(lr=1e-4, weight_decay=1e-5, grad_clipping=1.0), use_graphs=False,
-                              compute_dtype=hdt, loss_scale=ls)
+                              compute_dtype=hdt, loss_scale=ls, process_group=False)
         lg, _, loss = eng.forward_only(images.cuda(), labels.cuda())
         torch.cuda.synchronize()
         d = lg.cpu().double() - ref
@@ -457,6 +457,9 @@ def main():
     ap.add_argument("--reserve-cus", type=int, default=None, help="CUs the persistent GEMM launches leave to the collective when "
                     "world > 1 (APLA_RESERVE_CUS; default = the channel count); recorded in ranks.env")
     ap.add_argument("--launcher-check", action="store_true", help="multi-rank plumbing only (gloo, no GPU); used by the CPU tests")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="rehearsal of the N > 1 path on a one-GPU box: every rank on cuda:0, gloo instead of RCCL (which refuses two ranks on one "
+                         "device).  The whole default line is produced by the multi-rank code path; its timings mean nothing")
     args = ap.parse_args()
 
     if args.cpu_baseline_child:
@@ -489,6 +492,8 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     pg = None
     ranks_seen = 1
@@ -500,6 +505,8 @@ def main():
         if force_pg:
             os.environ.setdefault("MASTER_PORT", "29533")
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        elif args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         pg = dist.group.WORLD

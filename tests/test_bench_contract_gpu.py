@@ -77,6 +77,30 @@ def test_bench_reports_the_exchange_wait_on_the_forced_exchange_path():
     assert abs(rk["ms_per_step"][0] - d["ms_per_step"]) < 0.2 * d["ms_per_step"]
 
 
+def test_bench_default_line_through_the_multi_rank_path_on_one_gpu():
+    """The driver's scaling run is `bench.py --gpus N` with DEFAULT flags — parity checks on rank 0 included — and no run of it had ever
+    executed with more than one rank (the other multi-rank tests pass --no-parity).  `--rehearse-on-one-gpu` puts every rank on cuda:0
+    over gloo (RCCL refuses two ranks on one device) and leaves everything else as the real N > 1 path: rendezvous, per-rank batches,
+    four graph segments with the gradient exchange between them, MAX over ranks, the per-rank arrays — and rank 0's parity engines, which
+    must be rank-LOCAL (round 6: they were built with process_group=None = the default group, i.e. rank 0 alone would have issued
+    collectives and the job would have hung).  Three ranks: a world size that is neither 1 nor 2."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--rehearse-on-one-gpu", "--steps", "3", "--warmup", "2", "--no-peak-probe"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 3 and d["ranks_seen"] == 3 and d["config"]["global_batch"] == 3 * 128 and d["config"]["parallelism"] == "dp3"
+    rk = d["ranks"]
+    assert len(rk["ms_per_step"]) == 3 and len(rk["exchange_wait_ms"]) == 3 and rk["exchange_chunks"] == 4 and rk["reserved_cus"] == 8
+    assert all(w is not None and w >= 0.0 for w in rk["exchange_wait_ms"])
+    assert d["parity"]["logits_rel_max_over_batches"] < d["parity"]["tol_asserted"]            # rank 0's check ran, alone, and is right
+    assert d["parity_fp16"]["logits_rel_max_over_batches"] < d["parity_fp16"]["tol_asserted"]
+    assert "cpu_baseline" not in d and "fp16" not in d                                          # single-GPU legs only
+    assert d["value"] > 0 and abs(d["value"] - 3 * 128 / (d["ms_per_step"] * 1e-3)) < 0.02 * d["value"]
+
+
 def test_bench_selflaunch_two_ranks():
     """`python bench.py --gpus 2` starts its two ranks itself (reference: src/utils/launch.py:49-58).  With two
     GPUs it must print one line with n_gpus = 2 and ranks_seen = 2 (counted by an RCCL all-reduce).  On a one-GPU box rank 1
