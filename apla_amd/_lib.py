@@ -49,6 +49,16 @@ SIGNATURES = {
     "apla_layernorm_bwd_dp": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_long, c_void_p, c_void_p, c_void_p,
                                       c_void_p, c_int, c_void_p, c_int, c_long, c_void_p, c_long, c_void_p, c_int, c_void_p,
                                       c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "apla_layernorm_fwd_drop": (c_int, [c_void_p, c_int, c_long, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
+                                        c_void_p, c_int, c_int, c_float, c_void_p, c_long, c_void_p, c_long, c_void_p, c_int,
+                                        c_void_p, c_ulonglong, c_uint, c_float, c_long, c_void_p]),
+    "apla_layernorm_bwd_drop": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_long, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_int, c_void_p, c_int, c_long, c_void_p, c_long, c_void_p, c_int, c_void_p,
+                                        c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_long, c_void_p, c_void_p, c_ulonglong,
+                                        c_uint, c_float, c_void_p]),
+    "apla_dropout_fwd_dev": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_long, c_float, c_void_p, c_ulonglong, c_uint, c_void_p]),
+    "apla_gemm_nt_gelu_drop": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int,
+                                       c_void_p, c_ulonglong, c_uint, c_float, c_void_p]),
     "apla_gemm_nt_kernel_name": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_char_p, c_int]),
     "apla_attn_kernel_name": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_char_p, c_int]),
     "apla_attn_fwd_dropout": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_ulonglong, c_uint, c_void_p]),

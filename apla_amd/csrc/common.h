@@ -110,3 +110,24 @@ __device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, uns
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
   }
 }
+
+// Dropout inside other kernels (round 6): the keep decision of element i of a tensor is word (i & 3) of Philox4x32-10(counter {i >> 2,
+// offset}, key seed) >= threshold — the convention of apla_dropout_fwd (misc.hip), so a mask drawn inside a LayerNorm or GEMM epilogue
+// is the one the stand-alone pass and the oracle (oracle/apla_oracle.py:philox_keep_mask) draw.  `rng` points at {seed, step} in
+// device memory (the step counter advances outside the captured launches); offset = step * stride + site.
+struct DropArgsEw {
+  const unsigned long long* rng;   // NULL: no dropout
+  unsigned long long stride;       // offsets per step (the engine's 4 L + 8)
+  unsigned site;                   // which dropout of the step
+  unsigned threshold;              // keep iff word >= threshold  (= p * 2^32)
+  float inv_keep;                  // 1 / (1 - p)
+};
+__device__ __forceinline__ void drop_words4(const DropArgsEw& d, unsigned long long blk, unsigned (&c)[4]) {
+  const unsigned long long seed = d.rng[0], off = d.rng[1] * d.stride + d.site;
+  c[0] = (unsigned)blk; c[1] = (unsigned)(blk >> 32); c[2] = (unsigned)off; c[3] = (unsigned)(off >> 32);
+  philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
+}
+static inline unsigned apla_drop_threshold(float p) {
+  const double t = (double)p * 4294967296.0;
+  return t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+}

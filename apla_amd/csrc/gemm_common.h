@@ -26,6 +26,7 @@ struct GemmParams {
                 // or 2 * (256 - reserve) (4-wave) workgroups, so that the kernels of a concurrent collective find CUs of their own
   int exp;   // experiment selector (apla_gemm_nt_ex flags bits 28-30; tools/gemm_bench.py): schedule variants of the 4-wave kernel's
              // K loop compiled beside the product one for A/B timing inside one process; 0 = product
+  DropArgsEw drop;   // element-wise dropout of the GELU epilogue's two outputs (apla_gemm_nt_gelu_drop; rng == NULL: none)
   int tag;   // profiling tag (apla_gemm_nt_tagged): selects one of several identical kernel instantiations so that a rocprofv3
              // kernel trace tells the call sites of the step apart (qkv / proj / fc2 / dfc1 / dproj / dqkv …); 0 = untagged
 };
@@ -209,7 +210,7 @@ __device__ __forceinline__ void asm_load_row2(AuxRegs<bf16>& a0, AuxRegs<bf16>& 
   asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:64"
                : "=&v"(a0.lo), "=&v"(a1.lo) : "v"(p) : "memory");
 }
-template <int EPI, typename OutT, int MI>
+template <int EPI, typename OutT, int MI, bool DROP = false>
 __device__ __forceinline__ void persist_epilogue(const GemmParams& p, f32x4 (&acc)[MI][4], const float* bias_lds,
                                                  int m0, int n0, int wm, int wn, int lane) {
   const int frow = lane & 15, fq = lane >> 4;
@@ -280,6 +281,19 @@ __device__ __forceinline__ void persist_epilogue(const GemmParams& p, f32x4 (&ac
         gelu_and_grad4(lo, hl, gl);
         gelu_and_grad4(hi, hh, gh);
 #endif
+        if constexpr (DROP) {
+          // Mlp.drop after the activation (vit.py:164-165): h through the mask, and GELU' through the SAME mask — dfc2's epilogue
+          // (dh * GELU') then needs no change.  Element index = row-major position of (m, n) in [M, N], whatever layout the outputs have.
+          unsigned wa[4], wb[4];
+          const unsigned long long blk = ((unsigned long long)m * (unsigned long long)p.N + (unsigned long long)n) >> 2;
+          drop_words4(p.drop, blk, wa);
+          drop_words4(p.drop, blk + 1, wb);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float ka = wa[e] >= p.drop.threshold ? p.drop.inv_keep : 0.f, kb = wb[e] >= p.drop.threshold ? p.drop.inv_keep : 0.f;
+            hl[e] *= ka; gl[e] *= ka; hh[e] *= kb; gh[e] *= kb;
+          }
+        }
         Vec8IO<bf16>::store(c_at(m, n), hl, hh);
         Vec8IO<bf16>::store((bf16*)p.aux_out + ((p.w_panel & 8) ? ((size_t)(n >> 5) * p.M + m) * 32 + (n & 31) : (size_t)m * p.ld_aux_out + n), gl, gh);
       } else if constexpr (EPI == APLA_EPI_GELU_FWD) {

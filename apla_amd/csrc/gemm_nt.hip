@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams p) {
 // would make hipcc drain vmcnt(0) before every store (measured: 16 serialised load->wait->store round trips per tile).
 // Epilogue operands (residual / multiplier) are loaded up front, all at once.  BM = 32*MI (128/160) is picked on the
 // host to minimise tile-count quantisation over the 512 resident workgroups.
-template <int EPI, typename OutT, int MI, int EXP = 0>
+template <int EPI, typename OutT, int MI, int EXP = 0, bool DROP = false>
 __global__ __launch_bounds__(256, 2) void gemm_persist_kernel(GemmParams p, int tiles_m) {
   constexpr int BMv = 32 * MI;
   constexpr int STG = (BMv + BN) * BK * 2;
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256, 2) void gemm_persist_kernel(GemmParams p, int 
       }
       cur ^= 1;
     }
-    persist_epilogue<EPI, OutT, MI>(p, acc, (const float*)(smem + 2 * STG + bb * 1024), m0, n0, wm, wn, lane);
+    persist_epilogue<EPI, OutT, MI, DROP>(p, acc, (const float*)(smem + 2 * STG + bb * 1024), m0, n0, wm, wn, lane);
     asm volatile("" ::: "memory");
     if (!has_next) break;
     // a full (non-tail) tile issues exactly EpiStores::N store instructions per wave after the prefetch (epilogue operand
@@ -367,6 +367,13 @@ int launch_persist(const GemmParams& p_in, hipStream_t stream) {
   // clusters win the issue arbitration against this workgroup's epilogue VALU work instead of being spaced out by it); the other
   // epilogues do not move.  GemmParams::exp = 7 forces the plain loop (A/B), 1..3 force that schedule.
   constexpr int DEF = (EPI == APLA_EPI_GELU && MI == 5 && std::is_same<OutT, bf16>::value) ? 2 : 0;
+  if constexpr (EPI == APLA_EPI_GELU && std::is_same<OutT, bf16>::value) {
+    if (p.drop.rng != nullptr) {    // the two-output GELU with Mlp.drop inside (apla_gemm_nt_gelu_drop): the product schedule of this tile height
+      hipLaunchKernelGGL((gemm_persist_kernel<EPI, OutT, MI, DEF, true>), dim3(G), dim3(256), 0, stream, p, tiles_m);
+      APLA_CHECK_LAUNCH("apla_gemm_nt_gelu_drop");
+      return APLA_OK;
+    }
+  }
   const int e = p.exp == 0 ? DEF : (p.exp == 7 ? 0 : p.exp);
   if constexpr (MI == 5 && std::is_same<OutT, bf16>::value && (EPI == APLA_EPI_GELU || EPI == APLA_EPI_MUL)) {
     if (e == 1) { hipLaunchKernelGGL((gemm_persist_kernel<EPI, OutT, MI, 1>), dim3(G), dim3(256), 0, stream, p, tiles_m); APLA_CHECK_LAUNCH("apla_gemm_nt"); return APLA_OK; }
@@ -455,7 +462,8 @@ int launch(const GemmParams& p, int g_variant, hipStream_t stream) {
     APLA_CHECK_LAUNCH("apla_gemm_nt");
     return APLA_OK;
   }
-  const Sched sc = pick_schedule(EPI, odt, p.M, p.N, p.K, (p.w_panel & 2) ? 32 : p.lda, (p.w_panel & 1) ? 32 : p.ldw, p.w_panel, g_variant);
+  Sched sc = pick_schedule(EPI, odt, p.M, p.N, p.K, (p.w_panel & 2) ? 32 : p.lda, (p.w_panel & 1) ? 32 : p.ldw, p.w_panel, g_variant);
+  if (p.drop.rng != nullptr) sc = {1, (p.M >= 8192) ? 5 : pick_mi(p.M, p.N / BN)};   // dropout lives in the 4-wave persistent kernel's epilogue only
   if (sc.kind == 2) return apla_gemm_pp2_launch(p, EPI, odt, stream);
   if (sc.kind == 3) return apla_gemm_w4_launch(p, EPI, odt, stream);
   if (sc.kind == 4) return apla_gemm_tp_launch(p, EPI, odt, stream);
@@ -476,7 +484,7 @@ int launch(const GemmParams& p, int g_variant, hipStream_t stream) {
 static int gemm_nt_impl(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int M,
                         int N, int K, int epilogue, int out_dtype, const void* aux_in, int ld_aux_in,
                         void* aux_out, int ld_aux_out, int tag, int variant, hipStream_t stream, int w_panel = 0, int reserve = 0,
-                        int exp = 0) {
+                        int exp = 0, DropArgsEw drop = DropArgsEw{nullptr, 0, 0, 0, 1.0f}) {
   APLA_REQUIRE(M > 0 && N > 0 && K > 0, "apla_gemm_nt: empty problem M=%d N=%d K=%d", M, N, K);
   APLA_REQUIRE(N % 64 == 0 && K % BK == 0, "apla_gemm_nt: need N%%64==0 and K%%64==0 (N=%d K=%d)", N, K);
   APLA_REQUIRE(N % BN == 0 || w_panel == 0, "apla_gemm_nt_ex: operand / output images need N%%128==0 (N=%d)", N);
@@ -500,7 +508,7 @@ static int gemm_nt_impl(const void* A, int lda, const void* W, int ldw, const fl
   APLA_REQUIRE((w_panel & 4) || ldc % 4 == 0, "apla_gemm_nt: ldc %% 4 != 0");
   if (w_panel & 8) { ld_aux_in = ld_aux_in ? N : 0; ld_aux_out = ld_aux_out ? N : 0; }   // not read for an image; keeps the row-major checks quiet
   GemmParams p{(const bf16*)A, lda, (const bf16*)W, ldw, bias, C, ldc, aux_in, ld_aux_in, aux_out, ld_aux_out, M, N, K, N / BN, 0, w_panel, reserve, exp,
-               (tag >= 0 && tag < APLA_GEMM_TAGS) ? tag : 0};
+               drop, (tag >= 0 && tag < APLA_GEMM_TAGS) ? tag : 0};
   switch (epilogue) {
     case APLA_EPI_STORE:
       APLA_REQUIRE(ldc >= N, "apla_gemm_nt: ldc < N");
@@ -567,6 +575,17 @@ extern "C" int apla_gemm_nt_ex(const void* A, int lda, const void* W, int ldw, c
   APLA_REQUIRE(v == 0 || v == 1 || v == 4 || v == 9 || v == 14 || v == 15 || v == 16 || v == 17 || v == 18, "apla_gemm_nt_ex: unknown schedule %d", v);
   return gemm_nt_impl(A, lda, W, ldw, bias, C, ldc, M, N, K, epilogue, out_dtype, aux_in, ld_aux_in, aux_out, ld_aux_out, tag,
                       v == 0 ? 4 : (v == 1 ? 0 : v), stream, (flags >> 16) & 15, (flags >> 20) & 0xff, (flags >> 28) & 7);
+}
+
+// fc1 + GELU + GELU' with Mlp.drop (after the activation) inside the epilogue: include/apla_hip.h
+extern "C" int apla_gemm_nt_gelu_drop(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int M,
+                                      int N, int K, void* aux_out, int ld_aux_out, int flags, const unsigned long long* rng,
+                                      unsigned long long rng_stride, unsigned site, float p_drop, hipStream_t stream) {
+  APLA_REQUIRE(rng != nullptr && p_drop >= 0.f && p_drop < 1.f, "apla_gemm_nt_gelu_drop: rng (device {seed, step}) and 0 <= p < 1 required");
+  APLA_REQUIRE(N % BN == 0 && ((flags >> 16) & 3) == 0, "apla_gemm_nt_gelu_drop: N %% 128 == 0 and row-major operands (the 4-wave persistent kernel)");
+  const DropArgsEw dr{rng, rng_stride, site, apla_drop_threshold(p_drop), 1.0f / (1.0f - p_drop)};
+  return gemm_nt_impl(A, lda, W, ldw, bias, C, ldc, M, N, K, APLA_EPI_GELU, APLA_H16, nullptr, 0, aux_out, ld_aux_out, flags & 0xff, 4, stream,
+                      (flags >> 16) & 12, (flags >> 20) & 0xff, 0, dr);
 }
 
 // Which kernel does apla_gemm_nt_ex run this problem on?  Writes e.g. "gemm_persist_kernel<GELU,bf16,5>" (the name a rocprofv3

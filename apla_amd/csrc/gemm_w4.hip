@@ -319,7 +319,7 @@ extern "C" int apla_gemm_nt_splitk(const void* A, int lda, const void* W, int ld
   APLA_REQUIRE(out_dtype == APLA_F32 || out_dtype == APLA_H16, "apla_gemm_nt_splitk: unsupported out_dtype %d", out_dtype);
   const int S = w4_pick_split(M, N, K);
   APLA_REQUIRE(workspace_bytes >= (long)S * M * N * (long)sizeof(float), "apla_gemm_nt_splitk: workspace too small (ask apla_gemm_nt_splitk_workspace_bytes)");
-  GemmParams p{(const bf16*)A, lda, (const bf16*)W, ldw, nullptr, workspace, N, nullptr, 0, nullptr, 0, M, N, K, N / 128, 0, 0, 0, 0, 0};
+  GemmParams p{(const bf16*)A, lda, (const bf16*)W, ldw, nullptr, workspace, N, nullptr, 0, nullptr, 0, M, N, K, N / 128, 0, 0, 0, 0, DropArgsEw{nullptr, 0, 0, 0, 1.0f}, 0};
   p.ngrp = pick_ngrp(p.N / VBN, VBN, p.K);
   const int tiles_m = (M + 160 - 1) / 160;
   const long items = (long)tiles_m * (N / VBN) * S;

@@ -25,7 +25,8 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const ResT* x, long 
                                                      const float* __restrict__ beta, YT* __restrict__ y, int ldy,
                                                      float* __restrict__ mean_o, float* __restrict__ rstd_o, int M,
                                                      int D, float eps, const bf16* __restrict__ add, long adds,
-                                                     ResT* xout, long xouts, const float* __restrict__ add_scale, int scale_period) {
+                                                     ResT* xout, long xouts, const float* __restrict__ add_scale, int scale_period,
+                                                     DropArgsEw dr, long drop_row_stride) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nchunk = D >> 2;
   for (int m = blockIdx.x * ROWS_PER_BLOCK + wave; m < M; m += gridDim.x * ROWS_PER_BLOCK) {
@@ -40,7 +41,14 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const ResT* x, long 
       if (ch < nchunk) {
         v[c] = Vec4IO<ResT>::load(xr + ch * 4);
         if (add != nullptr) {
-          v[c] += Vec4IO<bf16>::load(add + (size_t)m * adds + ch * 4) * bscale;
+          f32x4 bv = Vec4IO<bf16>::load(add + (size_t)m * adds + ch * 4) * bscale;
+          if (dr.rng != nullptr) {   // nn.Dropout on the branch (proj_drop appla_attn.py:82, Mlp.drop after fc2 vit.py:166-167): element m * stride + col
+            unsigned w[4];
+            drop_words4(dr, (((unsigned long long)m * (unsigned long long)drop_row_stride) >> 2) + ch, w);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[e] = w[e] >= dr.threshold ? bv[e] * dr.inv_keep : 0.f;
+          }
+          v[c] += bv;
           Vec4IO<ResT>::store(xout + (size_t)m * xouts + ch * 4, v[c]);
           if constexpr (sizeof(ResT) == 2) {  // statistics of the value as stored (bf16-rounded), like a separate LN pass would see
 #pragma unroll
@@ -164,7 +172,8 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd2_kernel(const bf16* __restr
                                                       long xs, const float* __restrict__ rstd_i, const bf16* dres, bf16* dx,
                                                       long dxs, const int32_t* __restrict__ inds, int r,
                                                       bf16* __restrict__ gout, int M, int D, int dres_period,
-                                                      const float* __restrict__ dy_scale, const float* __restrict__ g_scale, int scale_period) {
+                                                      const float* __restrict__ dy_scale, const float* __restrict__ g_scale, int scale_period,
+                                                      bf16* __restrict__ masked, long mks, DropArgsEw dr, const float* __restrict__ mask_scale) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* rowbuf = (float*)smem_raw;  // [2 * ROWS_PER_BLOCK][D] when GATHER
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -179,6 +188,9 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd2_kernel(const bf16* __restr
     const bf16* dyr = dy + (size_t)mr * lddy;
     const float rstd = rstd_i[mr] * (dy_scale != nullptr ? dy_scale[mr / scale_period] : 1.0f);     // (stochastic depth: see ln_bwd_kernel)
     const float gsc = g_scale != nullptr ? g_scale[mr / scale_period] : 1.0f;
+    // `masked` (optional): a second copy of dx with the NEXT consumer's dropout mask (and its branch's per-sample factor) applied — the
+    // operand of that branch's dX GEMM; the gathered columns of dW1 are then taken from it
+    const float msc = (masked != nullptr && mask_scale != nullptr) ? mask_scale[mr / scale_period] : 1.0f;
     const bool has_res = dres != nullptr && (dres_period <= 1 || mr % dres_period == 0);
     bf16x8 xv[NC8], dv[NC8], rv[NC8];
 #pragma unroll
@@ -209,15 +221,31 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd2_kernel(const bf16* __restr
     for (int c = 0; c < NC8; ++c) {
       const int ch = hl + c * 32;
       if (ch < nchunk) {
-        bf16x8 ov;
+        bf16x8 ov, mv;
+        unsigned w[8];
+        if (masked != nullptr) {
+          unsigned a[4], b[4];
+          const unsigned long long blk = (((unsigned long long)mr * (unsigned long long)D) >> 2) + 2 * ch;
+          drop_words4(dr, blk, a);
+          drop_words4(dr, blk + 1, b);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { w[e] = a[e]; w[4 + e] = b[e]; }
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           float o = ((float)dv[c][e] - c1 - (float)xv[c][e] * c2) * rstd;
           if (has_res) o += (float)rv[c][e];
           ov[e] = (bf16)o;
-          if constexpr (GATHER) rowbuf[(2 * wave + half) * D + ch * 8 + e] = o * gsc;
+          float g = o * gsc;
+          if (masked != nullptr) {     // the mask acts on the value the stream holds (16-bit), as the stand-alone pass would
+            g = w[e] >= dr.threshold ? (float)ov[e] * dr.inv_keep * msc : 0.f;
+            mv[e] = (bf16)g;
+            g = (float)mv[e];
+          }
+          if constexpr (GATHER) rowbuf[(2 * wave + half) * D + ch * 8 + e] = g;
         }
         if (live) *(bf16x8*)(dx + (size_t)m * dxs + ch * 8) = ov;
+        if (live && masked != nullptr) *(bf16x8*)(masked + (size_t)m * mks + ch * 8) = mv;
       }
     }
     if constexpr (GATHER) {
@@ -251,11 +279,15 @@ inline int ln_grid(int M) {
 
 }  // namespace
 
-extern "C" int apla_layernorm_fwd_dp(const void* x, int res_dtype, long x_row_stride, const float* gamma,
-                                     const float* beta, void* y, int y_dtype, int ldy, float* mean, float* rstd, int M,
-                                     int D, float eps, const void* add_in, long add_row_stride, void* x_out,
-                                     long x_out_row_stride, const float* add_scale, int scale_period, hipStream_t stream) {
+extern "C" int apla_layernorm_fwd_drop(const void* x, int res_dtype, long x_row_stride, const float* gamma,
+                                       const float* beta, void* y, int y_dtype, int ldy, float* mean, float* rstd, int M,
+                                       int D, float eps, const void* add_in, long add_row_stride, void* x_out,
+                                       long x_out_row_stride, const float* add_scale, int scale_period, const unsigned long long* rng,
+                                       unsigned long long rng_stride, unsigned site, float p, long drop_row_stride, hipStream_t stream) {
   APLA_REQUIRE(add_scale == nullptr || (add_in != nullptr && scale_period >= 1), "apla_layernorm_fwd_dp: a per-sample scale needs add_in and scale_period >= 1");
+  APLA_REQUIRE(rng == nullptr || (add_in != nullptr && p >= 0.f && p < 1.f && drop_row_stride >= D && drop_row_stride % 4 == 0),
+               "apla_layernorm_fwd_drop: dropout needs add_in, 0 <= p < 1 and an index row stride >= D that is a multiple of 4");
+  const DropArgsEw dr{rng, rng_stride, site, rng ? apla_drop_threshold(p) : 0u, rng ? 1.0f / (1.0f - p) : 1.0f};
   if (add_scale == nullptr) scale_period = 1;
   APLA_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 256 * MAXC, "apla_layernorm_fwd: need D%%4==0 and D<=1536 (D=%d)", D);
   APLA_REQUIRE(x && y && mean && rstd && ((gamma == nullptr) == (beta == nullptr)), "apla_layernorm_fwd: null pointer (gamma and beta are given together or not at all)");
@@ -263,7 +295,7 @@ extern "C" int apla_layernorm_fwd_dp(const void* x, int res_dtype, long x_row_st
   APLA_REQUIRE(apla_aligned16(x) && (gamma == nullptr || (apla_aligned16(gamma) && apla_aligned16(beta))) && (((uintptr_t)y) & 7) == 0, "apla_layernorm_fwd: alignment");
   APLA_REQUIRE(add_in == nullptr || (x_out != nullptr && add_row_stride % 4 == 0 && add_row_stride >= D && x_out_row_stride % 4 == 0 && x_out_row_stride >= D),
                "apla_layernorm_fwd: fused residual add needs x_out and valid strides");
-#define LN_FWD_NC(T, Y, NCV) hipLaunchKernelGGL((ln_fwd_kernel<T, Y, NCV>), dim3(ln_grid(M)), dim3(LN_THREADS), 0, stream, (const T*)x, x_row_stride, gamma, beta, (Y*)y, ldy, mean, rstd, M, D, eps, (const bf16*)add_in, add_row_stride, (T*)x_out, x_out_row_stride, add_scale, scale_period)
+#define LN_FWD_NC(T, Y, NCV) hipLaunchKernelGGL((ln_fwd_kernel<T, Y, NCV>), dim3(ln_grid(M)), dim3(LN_THREADS), 0, stream, (const T*)x, x_row_stride, gamma, beta, (Y*)y, ldy, mean, rstd, M, D, eps, (const bf16*)add_in, add_row_stride, (T*)x_out, x_out_row_stride, add_scale, scale_period, dr, drop_row_stride)
 #define LN_FWD(T, Y)                                    \
   do {                                                  \
     const int nc_ = (D + 255) / 256;                    \
@@ -287,6 +319,14 @@ extern "C" int apla_layernorm_fwd_dp(const void* x, int res_dtype, long x_row_st
   return APLA_OK;
 }
 
+extern "C" int apla_layernorm_fwd_dp(const void* x, int res_dtype, long x_row_stride, const float* gamma,
+                                     const float* beta, void* y, int y_dtype, int ldy, float* mean, float* rstd, int M,
+                                     int D, float eps, const void* add_in, long add_row_stride, void* x_out,
+                                     long x_out_row_stride, const float* add_scale, int scale_period, hipStream_t stream) {
+  return apla_layernorm_fwd_drop(x, res_dtype, x_row_stride, gamma, beta, y, y_dtype, ldy, mean, rstd, M, D, eps, add_in, add_row_stride,
+                                 x_out, x_out_row_stride, add_scale, scale_period, nullptr, 0, 0, 0.f, D, stream);
+}
+
 extern "C" int apla_layernorm_fwd(const void* x, int res_dtype, long x_row_stride, const float* gamma,
                                   const float* beta, void* y, int y_dtype, int ldy, float* mean, float* rstd, int M,
                                   int D, float eps, const void* add_in, long add_row_stride, void* x_out,
@@ -295,13 +335,22 @@ extern "C" int apla_layernorm_fwd(const void* x, int res_dtype, long x_row_strid
                                x_out, x_out_row_stride, nullptr, 1, stream);
 }
 
-extern "C" int apla_layernorm_bwd_dp(const void* dy, int dy_dtype, int lddy, const void* x, int x_dtype, long x_row_stride,
-                                     const float* gamma, const float* mean, const float* rstd, const void* dres_in,
-                                     int dres_row_period, void* dx_out, int grad_dtype, long dx_row_stride, void* dx_bf16_copy,
-                                     long copy_row_stride, const int32_t* inds, int r, void* gather_out, int M, int D,
-                                     const float* dy_scale, const float* gather_scale, int scale_period, hipStream_t stream) {
-  APLA_REQUIRE((dy_scale == nullptr && gather_scale == nullptr) || scale_period >= 1, "apla_layernorm_bwd_dp: scale_period >= 1");
-  if (dy_scale == nullptr && gather_scale == nullptr) scale_period = 1;
+extern "C" int apla_layernorm_bwd_drop(const void* dy, int dy_dtype, int lddy, const void* x, int x_dtype, long x_row_stride,
+                                       const float* gamma, const float* mean, const float* rstd, const void* dres_in,
+                                       int dres_row_period, void* dx_out, int grad_dtype, long dx_row_stride, void* dx_bf16_copy,
+                                       long copy_row_stride, const int32_t* inds, int r, void* gather_out, int M, int D,
+                                       const float* dy_scale, const float* gather_scale, int scale_period, void* masked_out,
+                                       long masked_row_stride, const float* mask_scale, const unsigned long long* rng,
+                                       unsigned long long rng_stride, unsigned site, float p, hipStream_t stream) {
+  APLA_REQUIRE((dy_scale == nullptr && gather_scale == nullptr && mask_scale == nullptr) || scale_period >= 1, "apla_layernorm_bwd_dp: scale_period >= 1");
+  if (dy_scale == nullptr && gather_scale == nullptr && mask_scale == nullptr) scale_period = 1;
+  const bool fast = mean == nullptr && gamma == nullptr && x_dtype == APLA_H16 && dy_dtype == APLA_H16 && grad_dtype == APLA_H16 &&
+                    dx_bf16_copy == nullptr && D % 8 == 0;
+  APLA_REQUIRE(masked_out == nullptr || (fast && rng != nullptr && p >= 0.f && p < 1.f && masked_row_stride >= D && masked_row_stride % 8 == 0 &&
+                                         apla_aligned16(masked_out) && gather_scale == nullptr),
+               "apla_layernorm_bwd_drop: the masked copy needs the 16-bit normalised-row form (mean = gamma = NULL, 16-bit operands and stream), rng, "
+               "0 <= p < 1, an aligned buffer and no gather_scale (the branch's factor goes into mask_scale)");
+  const DropArgsEw dr{masked_out ? rng : nullptr, rng_stride, site, masked_out ? apla_drop_threshold(p) : 0u, masked_out ? 1.0f / (1.0f - p) : 1.0f};
   APLA_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 256 * MAXC, "apla_layernorm_bwd: need D%%4==0 and D<=1536 (D=%d)", D);
   APLA_REQUIRE(dy && x && rstd && dx_out && dres_row_period >= 0, "apla_layernorm_bwd: null pointer");
   APLA_REQUIRE(lddy % 4 == 0 && x_row_stride % 4 == 0 && dx_row_stride % 4 == 0 && lddy >= D && x_row_stride >= D && dx_row_stride >= D, "apla_layernorm_bwd: bad strides");
@@ -320,7 +369,7 @@ extern "C" int apla_layernorm_bwd_dp(const void* dy, int dy_dtype, int lddy, con
 #define LN_BWD2(GA, NCV)                                                                                                           \
     hipLaunchKernelGGL((ln_bwd2_kernel<GA, NCV>), grid2, dim3(LN_THREADS), lds2, stream, (const bf16*)dy, lddy, (const bf16*)x,      \
                        x_row_stride, rstd, (const bf16*)dres_in, (bf16*)dx_out, dx_row_stride, inds, r, (bf16*)gather_out, M, D,    \
-                       dres_row_period, dy_scale, gather_scale, scale_period)
+                       dres_row_period, dy_scale, gather_scale, scale_period, (bf16*)masked_out, masked_row_stride, dr, mask_scale)
 #define LN_BWD2_G(NCV) do { if (gather) LN_BWD2(true, NCV); else LN_BWD2(false, NCV); } while (0)
     if (nc8 <= 1) LN_BWD2_G(1);
     else if (nc8 == 2) LN_BWD2_G(2);
@@ -333,6 +382,7 @@ extern "C" int apla_layernorm_bwd_dp(const void* dy, int dy_dtype, int lddy, con
     APLA_CHECK_LAUNCH("apla_layernorm_bwd");
     return APLA_OK;
   }
+  APLA_REQUIRE(masked_out == nullptr, "apla_layernorm_bwd_drop: the masked copy exists on the 16-bit two-rows-per-wave form only (strides % 8, 16-byte aligned operands)");
   const size_t lds = gather ? (size_t)ROWS_PER_BLOCK * D * sizeof(float) : 0;
 #define LN_BWD_NC(X, Y, G, GA, NCV)                                                                                    \
   hipLaunchKernelGGL((ln_bwd_kernel<X, Y, G, GA, NCV>), dim3(ln_grid(M)), dim3(LN_THREADS), lds, stream, (const Y*)dy, lddy,  \
@@ -369,6 +419,16 @@ extern "C" int apla_layernorm_bwd_dp(const void* dy, int dy_dtype, int lddy, con
 #undef LN_BWD_NC
   APLA_CHECK_LAUNCH("apla_layernorm_bwd");
   return APLA_OK;
+}
+
+extern "C" int apla_layernorm_bwd_dp(const void* dy, int dy_dtype, int lddy, const void* x, int x_dtype, long x_row_stride,
+                                     const float* gamma, const float* mean, const float* rstd, const void* dres_in,
+                                     int dres_row_period, void* dx_out, int grad_dtype, long dx_row_stride, void* dx_bf16_copy,
+                                     long copy_row_stride, const int32_t* inds, int r, void* gather_out, int M, int D,
+                                     const float* dy_scale, const float* gather_scale, int scale_period, hipStream_t stream) {
+  return apla_layernorm_bwd_drop(dy, dy_dtype, lddy, x, x_dtype, x_row_stride, gamma, mean, rstd, dres_in, dres_row_period, dx_out, grad_dtype,
+                                 dx_row_stride, dx_bf16_copy, copy_row_stride, inds, r, gather_out, M, D, dy_scale, gather_scale, scale_period,
+                                 nullptr, 0, nullptr, nullptr, 0, 0, 0.f, stream);
 }
 
 extern "C" int apla_layernorm_bwd_ex(const void* dy, int dy_dtype, int lddy, const void* x, int x_dtype, long x_row_stride,

@@ -954,9 +954,14 @@ extern "C" int apla_weight_norm_bwd(const float* dw, const float* v, const float
 template <typename T>
 __global__ __launch_bounds__(256) void dropout_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, uint8_t* __restrict__ keep, long n,
                                                           unsigned threshold, float inv_keep, unsigned long long seed,
-                                                          unsigned long long offset) {
+                                                          unsigned long long offset, const unsigned long long* __restrict__ rng) {
   const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 8;
   if (i >= n) return;
+  if (rng != nullptr) {   // apla_dropout_fwd_dev: {seed, step} live in device memory; `seed` / `offset` carry stride and site
+    const unsigned long long stride = seed, site = offset;
+    seed = rng[0];
+    offset = rng[1] * stride + site;
+  }
   float v[8];
   ld8f<T>(x + i, v);
   unsigned char kb[8];
@@ -974,7 +979,7 @@ __global__ __launch_bounds__(256) void dropout_fwd_kernel(const T* __restrict__ 
   }
   f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
   st8f<T>(y + i, a, b, false);
-  *(unsigned long long*)(keep + i) = *(const unsigned long long*)kb;
+  if (keep != nullptr) *(unsigned long long*)(keep + i) = *(const unsigned long long*)kb;
 }
 
 // dx = keep ? dy / (1 - p) : 0
@@ -1014,10 +1019,25 @@ extern "C" int apla_dropout_fwd(const void* x, int dtype, void* y, uint8_t* keep
   const double t = (double)p * 4294967296.0;
   const unsigned threshold = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
   const unsigned blocks = (unsigned)((n / 8 + 255) / 256);
-  if (dtype == APLA_F32) hipLaunchKernelGGL(dropout_fwd_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)x, (float*)y, keep, n, threshold, 1.0f / (1.0f - p), seed, offset);
-  else if (dtype == APLA_H16) hipLaunchKernelGGL(dropout_fwd_kernel<bf16>, dim3(blocks), dim3(256), 0, stream, (const bf16*)x, (bf16*)y, keep, n, threshold, 1.0f / (1.0f - p), seed, offset);
+  if (dtype == APLA_F32) hipLaunchKernelGGL(dropout_fwd_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)x, (float*)y, keep, n, threshold, 1.0f / (1.0f - p), seed, offset, (const unsigned long long*)nullptr);
+  else if (dtype == APLA_H16) hipLaunchKernelGGL(dropout_fwd_kernel<bf16>, dim3(blocks), dim3(256), 0, stream, (const bf16*)x, (bf16*)y, keep, n, threshold, 1.0f / (1.0f - p), seed, offset, (const unsigned long long*)nullptr);
   else { apla_set_error("apla_dropout_fwd: unsupported dtype %d", dtype); return APLA_ENOSYS; }
   APLA_CHECK_LAUNCH("apla_dropout_fwd");
+  return APLA_OK;
+}
+
+// the same pass with {seed, step} read from device memory (offset = step * rng_stride + site) and the keep bytes optional: what a
+// captured launch sequence can replay with a new mask every step (include/apla_hip.h)
+extern "C" int apla_dropout_fwd_dev(const void* x, int dtype, void* y, uint8_t* keep, long n, float p, const unsigned long long* rng,
+                                    unsigned long long rng_stride, unsigned site, hipStream_t stream) {
+  APLA_REQUIRE(x && y && rng && n > 0 && n % 8 == 0 && p >= 0.f && p < 1.f, "apla_dropout_fwd_dev: need rng, n %% 8 == 0 and 0 <= p < 1 (n=%ld p=%f)", n, (double)p);
+  APLA_REQUIRE(apla_aligned16(x) && apla_aligned16(y) && (((uintptr_t)keep) & 7) == 0, "apla_dropout_fwd_dev: pointers must be 16-byte (keep: 8-byte) aligned");
+  const unsigned threshold = apla_drop_threshold(p);
+  const unsigned blocks = (unsigned)((n / 8 + 255) / 256);
+  if (dtype == APLA_F32) hipLaunchKernelGGL(dropout_fwd_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)x, (float*)y, keep, n, threshold, 1.0f / (1.0f - p), rng_stride, (unsigned long long)site, rng);
+  else if (dtype == APLA_H16) hipLaunchKernelGGL(dropout_fwd_kernel<bf16>, dim3(blocks), dim3(256), 0, stream, (const bf16*)x, (bf16*)y, keep, n, threshold, 1.0f / (1.0f - p), rng_stride, (unsigned long long)site, rng);
+  else { apla_set_error("apla_dropout_fwd_dev: unsupported dtype %d", dtype); return APLA_ENOSYS; }
+  APLA_CHECK_LAUNCH("apla_dropout_fwd_dev");
   return APLA_OK;
 }
 

@@ -135,13 +135,19 @@ class AplaTrainEngine:
         self._scaler_calls = 0
         self._scaler_step0 = 0.0   # the scaler's "steps taken" slot when _scaler_calls was last reset (checkpoint.load_session)
         self.res_dtype, self.grad_dtype = res_dtype, (grad_dtype or compute_dtype)
+        # Element-wise dropout runs INSIDE the step's kernels where it can (round 6, second form): proj_drop and the dropout after fc2 in
+        # the LayerNorm that adds the branch (forward) and in the LayerNorm backward that produces the branch's incoming gradient
+        # (a masked second copy), Mlp.drop after the activation in fc1's GELU epilogue, pos_drop as one pass — every mask from
+        # {seed, step} in DEVICE memory, so the step stays a captured launch sequence.  Needs the 16-bit gradient stream (the masked
+        # copy exists on that LayerNorm backward only); attention-probability dropout keeps its own kernels and an eager launch sequence.
+        self.drop_fused = self.drop_on and self.grad_dtype == compute_dtype and os.environ.get("APLA_DROPOUT_PASSES") != "1"
         self.optim = optim or OptimConfig()
         # process_group: a group, None = the default group when torch.distributed is initialised with more than one rank, or False =
         # this engine never exchanges (a rank-local engine inside a multi-rank job: bench.py's parity checks on rank 0)
         self.local_only = process_group is False
         self.pg = None if self.local_only else process_group
         self.world = 1   # set from the GradExchanger below: ONE source for "how many ranks sum into the gradient buffer"
-        self.use_graphs = use_graphs and not self.drop_on
+        self.use_graphs = use_graphs and (not self.drop_on or (self.drop_fused and not any(q > 0 for q in self.p_attn)))
         # diagnostic switch: APLA_FULL_LAST_BLOCK=1 runs the last block's forward on all rows (A/B of the CLS-only tail)
         self.cls_only_tail = os.environ.get("APLA_FULL_LAST_BLOCK") != "1" and not self.drop_on
         self.scale = bb.blocks[0].attn.scale
@@ -374,7 +380,7 @@ class AplaTrainEngine:
         # fc1's output h and dfc2's product go straight to a plain-store GEMM (fc2, dfc1): where both sides allow it they are
         # written as K-panel images by the producing epilogue (ops.gemm_nt with a 3-D `out`) and read as such
         # (element-wise dropout works on row-major h / GELU': its mask is indexed by the row-major element number, as the oracle's)
-        F, use = self.blocks[0].F, os.environ.get("APLA_W_PANELS", "1") != "0" and not (self.drop_on and any(q > 0 for q in self.p_mlp))
+        F, use = self.blocks[0].F, os.environ.get("APLA_W_PANELS", "1") != "0" and not (self.drop_on and not self.drop_fused and any(q > 0 for q in self.p_mlp))
         epi_f, n_f = (ops.EPI_SWIGLU, 2 * F) if self.swiglu else (ops.EPI_GELU, F)       # fc1 / w12: epilogue and GEMM width
         self.h_img = use and ops.gemm_out_image_ok(M, n_f, D, epi_f) and ops.gemm_panel_ok(M, D, F)
         self.h_out = self.h.view(F // 32, M, 32) if self.h_img else self.h
@@ -394,13 +400,16 @@ class AplaTrainEngine:
         self.row_loss = e(B, dt=torch.float32)
         self.loss = e(1, dt=torch.float32)
         self.dxn = e(B, D, dt=torch.float32)
-        if self.drop_on:    # keep bytes of the two branch sites per block (the backward masks the same elements), scratch for the others
+        if self.drop_on:
+            self.Gm = e(M, D)     # the incoming gradient of a branch through its dropout mask
+            self.drop_rng = torch.zeros(2, device=dev, dtype=torch.int64)        # {seed, step}: what the in-kernel masks are drawn from
+            self._sync_drop_rng()
+        if self.drop_on and not self.drop_fused:    # pass form: keep bytes of the two branch sites per block, scratch for the others
             u8 = lambda n: torch.empty(n, device=dev, dtype=torch.uint8)       # noqa: E731
             self.keep_a = [u8(M * D) if self.p_proj[i] > 0 else None for i in range(L)]
             self.keep_b = [u8(M * D) if self.p_mlp[i] > 0 else None for i in range(L)]
             self.keep_h = u8(M * self.blocks[0].F) if any(q > 0 for q in self.p_mlp) else None
             self.keep_pos = u8(M * D) if self.p_pos > 0 else None
-            self.Gm = e(M, D)
         # backward
         self.G = torch.zeros(M, D, device=dev, dtype=self.grad_dtype)               # residual-gradient stream (never re-zeroed)
         self.Gb = self.G if self.grad_dtype == ops.half() else torch.zeros(M, D, device=dev, dtype=ops.half())
@@ -482,8 +491,13 @@ class AplaTrainEngine:
         ops.gemm_nt(self.cols, self.Wpe_i, self.bpe, out=self.patches, tag=ops.TAG_PATCH)
         ops.assemble_tokens(self.patches, self.cls, self.pos, B, self.Np, out=self.res)
         drop = self.drop_on and not inference
+        fused = drop and self.drop_fused
+        dsite = lambda site, p_: (self.drop_rng, self._drop_stride, site, p_)       # noqa: E731  (in-kernel mask of a site)
         if drop and self.p_pos > 0:       # pos_drop (vit.py:395)
-            ops.dropout_fwd(self.res, self.p_pos, self._drop_seed, self._drop_offset(0), out=self.res, keep=self.keep_pos)
+            if fused:
+                ops.dropout_dev(self.res, self.p_pos, self.drop_rng, self._drop_stride, 0, out=self.res)
+            else:
+                ops.dropout_fwd(self.res, self.p_pos, self._drop_seed, self._drop_offset(0), out=self.res, keep=self.keep_pos)
         # The residual updates x += branch (vit.py:284-285) are fused into the NEXT LayerNorm: the projection / fc2 GEMMs store
         # their (LayerScale-folded) branch output in bf16 — as the reference's fp16-autocast Linear does before the fp32
         # residual add — and the LN kernel forms x_new = x + branch in registers, writes it and normalises it in one pass.
@@ -494,7 +508,8 @@ class AplaTrainEngine:
                 ops.layernorm_fwd(self.res, None, None, self.eps, out=xh1, mean=self.mean_scratch, rstd=self.rstd1[0])
             else:
                 ops.layernorm_fwd(self.res, None, None, self.eps, out=xh1, mean=self.mean_scratch, rstd=self.rstd1[i],
-                                  add=self.branch, x_out=self.res, add_scale=dps(2 * i - 1), scale_period=N)
+                                  add=self.branch, x_out=self.res, add_scale=dps(2 * i - 1), scale_period=N,
+                                  drop=dsite(3 + 4 * (i - 1), self.p_mlp[i - 1]) + (D,) if fused and self.p_mlp[i - 1] > 0 and not self.swiglu else None)
             if i == self.L - 1 and self.cls_only_tail:
                 # last block: K and V for every token, Q for the CLS rows only (the only query that is ever used)
                 ops.gemm_nt(xh1, st.Wkv_i, st.bqkv[D:], out=self.qkv[i][:, D:], tag=ops.TAG_QKV)
@@ -508,11 +523,12 @@ class AplaTrainEngine:
             else:
                 ops.attn_fwd(self.qkv[i], B, N, H, self.scale, o=self.o[i], lse=self.lse[i])
             ops.gemm_nt(self.o[i], st.Wnat_i, st.bnat, out=self.branch, tag=ops.TAG_PROJ)
-            if drop and self.p_proj[i] > 0:   # proj_drop (appla_attn.py:82; commutes with the LayerScale vector folded into the weight)
+            if drop and not fused and self.p_proj[i] > 0:   # proj_drop (appla_attn.py:82; commutes with the LayerScale vector folded into the weight)
                 ops.dropout_fwd(self.branch, self.p_proj[i], self._drop_seed, self._drop_offset(1 + 4 * i), out=self.branch, keep=self.keep_a[i])
             xh2 = self.xh2[i]
             ops.layernorm_fwd(self.res, None, None, self.eps, out=xh2, mean=self.mean_scratch, rstd=self.rstd2[i],
-                              add=self.branch, x_out=self.res, add_scale=dps(2 * i), scale_period=N)
+                              add=self.branch, x_out=self.res, add_scale=dps(2 * i), scale_period=N,
+                              drop=dsite(1 + 4 * i, self.p_proj[i]) + (D,) if fused and self.p_proj[i] > 0 else None)
             ev = self._fc1_events
             if ev is not None:   # bench.py: HIP events around the dominant launch, in its place inside the step (eager replay only)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -521,12 +537,14 @@ class AplaTrainEngine:
                 ops.gemm_nt(xh2, st.W12, st.b12, epilogue=ops.EPI_SWIGLU, aux_out=self.act_saved[i], out=self.h_out)
             elif inference:
                 ops.gemm_nt(xh2, st.Wfc1, st.bfc1, epilogue=ops.EPI_GELU_FWD, out=self.h_out)
+            elif fused and self.p_mlp[i] > 0:      # Mlp.drop after the activation inside the epilogue: h and GELU' through the same mask
+                ops.gemm_nt(xh2, st.Wfc1, st.bfc1, epilogue=ops.EPI_GELU, aux_out=self.act_io[i], out=self.h_out, drop=dsite(2 + 4 * i, self.p_mlp[i]))
             else:
                 ops.gemm_nt(xh2, st.Wfc1_i, st.bfc1, epilogue=ops.EPI_GELU, aux_out=self.act_io[i], out=self.h_out)
             if ev is not None:
                 e1.record()
                 ev.append((e0, e1))
-            mlp_drop = drop and self.p_mlp[i] > 0 and not self.swiglu        # Mlp.drop, both sites (vit.py:164-167); SwiGLUFFNFused has none
+            mlp_drop = drop and not fused and self.p_mlp[i] > 0 and not self.swiglu        # Mlp.drop, both sites (vit.py:164-167); SwiGLUFFNFused has none
             if mlp_drop:    # after the activation: h is masked, and GELU' with the same mask — dfc2's epilogue then needs no change
                 ops.dropout_fwd(self.h, self.p_mlp[i], self._drop_seed, self._drop_offset(2 + 4 * i), out=self.h, keep=self.keep_h)
                 ops.dropout_bwd(self.act_saved[i], self.keep_h, self.p_mlp[i], out=self.act_saved[i])
@@ -536,7 +554,8 @@ class AplaTrainEngine:
         # final norm on the CLS rows only (vit.py:416-419) with the last residual add fused, fp32 head + mean CE
         ops.layernorm_fwd(self.res, self.gf, self.bf_, self.eps, out=self.xn, mean=self.meanf, rstd=self.rstdf,
                           rows=B, row_stride=N * D, add=self.branch_cls if self.cls_only_tail else self.branch,
-                          add_row_stride=D if self.cls_only_tail else None, x_out=self.res, add_scale=dps(2 * self.L - 1), scale_period=1)
+                          add_row_stride=D if self.cls_only_tail else None, x_out=self.res, add_scale=dps(2 * self.L - 1), scale_period=1,
+                          drop=dsite(3 + 4 * (self.L - 1), self.p_mlp[-1]) + (N * D,) if fused and self.p_mlp[-1] > 0 and not self.swiglu else None)
         ops.sgemm_small(self.xn, self._param_view("fc.weight"), trans_b=True, bias=self._param_view("fc.bias"),
                         out=self.logits)
         ops.cross_entropy(self.logits, self.targets if self.soft_targets else self.labels, dlogits=self.dlogits,
@@ -620,8 +639,14 @@ class AplaTrainEngine:
         copy = None if self.Gb is self.G else self.Gb
         mlp_drop = self.drop_on and self.p_mlp[i] > 0 and not self.swiglu
         proj_drop = self.drop_on and self.p_proj[i] > 0
-        # gradient entering the MLP branch: through the mask of the dropout after fc2 (the one after the activation lives in the saved GELU')
-        g_in = ops.dropout_bwd(self.Gb, self.keep_b[i], self.p_mlp[i], out=self.Gm) if mlp_drop else self.Gb
+        fused = self.drop_fused
+        dsite = lambda site, p_: (self.drop_rng, self._drop_stride, site, p_)       # noqa: E731
+        # gradient entering the MLP branch: through the mask of the dropout after fc2 (the one after the activation lives in the saved GELU').
+        # Fused form: the LayerNorm backward (or, for the last block, the pass in _segment) that produced the stream wrote the masked copy.
+        if mlp_drop and not fused:
+            g_in = ops.dropout_bwd(self.Gb, self.keep_b[i], self.p_mlp[i], out=self.Gm)
+        else:
+            g_in = self.Gm if mlp_drop else self.Gb
         if self.swiglu:
             ops.gemm_nt(g_in, st.WoutT, None, epilogue=ops.EPI_SWIGLU_BWD, aux_in=self.act_saved[i], out=self.dact_out)
             ops.gemm_nt(self.dact_out, st.Wdfc1_i, None, out=self.dln, tag=ops.TAG_DFC1)
@@ -630,7 +655,12 @@ class AplaTrainEngine:
             ops.gemm_nt(self.dact_out, st.Wdfc1_i, None, out=self.dln, tag=ops.TAG_DFC1)
         dyg = (self.dyg_all[i] if self.dw_batch > 1 else self.dyg)[:M * st.r_pad].view(M, st.r_pad)
         dps = (lambda k: self.dp_scale[k]) if self.dp_on else (lambda k: None)      # stochastic depth: the branches' per-sample factors
-        if proj_drop:
+        if proj_drop and fused:
+            # one kernel: the stream, its copy through proj_drop's mask x the attention branch's DropPath factor (the dX operand), and the
+            # gathered columns of dW1 taken from that copy
+            ops.layernorm_bwd(self.dln, self.xh2[i], None, None, self.rstd2[i], dres=self.G, out=self.G, inds=st.inds, r=st.r_pad, gathered=dyg,
+                              dy_scale=dps(2 * i + 1), scale_period=N, masked=self.Gm, mask_scale=dps(2 * i), drop=dsite(1 + 4 * i, self.p_proj[i]))
+        elif proj_drop:
             # the projection's output gradient passes proj_drop's mask (and the attention branch's DropPath factor) BEFORE both of its
             # consumers — the gathered columns of dW1 and the dX product —, so the LayerNorm backward gathers nothing here
             ops.layernorm_bwd(self.dln, self.xh2[i], None, None, self.rstd2[i], dres=self.G, out=self.G, out_bf16=copy,
@@ -657,8 +687,10 @@ class AplaTrainEngine:
         else:
             ops.attn_bwd(self.qkv[i], self.o[i], self.dO, self.lse[i], B, N, H, self.scale, dqkv=self.dqkv, delta=self.delta)
         ops.gemm_nt(self.dqkv, st.WqkvT_i, None, out=self.dln, tag=ops.TAG_DQKV)
+        nxt = fused and i > 0 and self.p_mlp[i - 1] > 0 and not self.swiglu     # the stream's next consumer is block i - 1's MLP branch
         ops.layernorm_bwd(self.dln, self.xh1[i], None, None, self.rstd1[i], dres=self.G, out=self.G, out_bf16=copy,
-                          dy_scale=None if proj_drop else dps(2 * i), scale_period=N)    # (with proj_drop the factor is already in Gm)
+                          dy_scale=None if proj_drop else dps(2 * i), scale_period=N,    # (with proj_drop the factor is already in Gm)
+                          masked=self.Gm if nxt else None, drop=dsite(3 + 4 * (i - 1), self.p_mlp[i - 1]) if nxt else None)
 
     def _backward_last_block(self):
         """Backward of block L-1 exploiting that only the CLS rows (token 0 of every sequence) of the incoming residual
@@ -707,6 +739,8 @@ class AplaTrainEngine:
                     if self.Gb is not self.G:
                         self.Gb.zero_()
                     self._backward_head()
+                    if self.drop_fused and self.p_mlp[-1] > 0 and not self.swiglu:    # the last block's MLP branch: no LayerNorm backward above it writes the masked copy
+                        ops.dropout_dev(self.Gb, self.p_mlp[-1], self.drop_rng, self._drop_stride, 3 + 4 * (self.L - 1), out=self.Gm)
                     self._backward_block(self.L - 1)
                 else:
                     self._backward_head()
@@ -748,14 +782,23 @@ class AplaTrainEngine:
                 raise ValueError("class-id labels [B] expected (build the engine with soft_targets=True for probability targets)")
             self.labels.copy_(labels.to(torch.int32), non_blocking=True)
 
+    @property
+    def _drop_stride(self) -> int:
+        return 4 * self.L + 8
+
+    def _sync_drop_rng(self):
+        to_i64 = lambda v: v - (1 << 64) if v >= (1 << 63) else v      # noqa: E731  (the kernels read the words as unsigned)
+        self.drop_rng.copy_(torch.tensor([to_i64(self._drop_seed & ((1 << 64) - 1)), self._drop_step], dtype=torch.int64))
+
     def _drop_offset(self, site: int) -> int:
         """Philox offset of a dropout site in the current step: sites 0 = pos_drop, 1 + 4 i / 2 + 4 i / 3 + 4 i / 4 + 4 i = block i's
         proj_drop / Mlp.drop after the activation / Mlp.drop after fc2 / attn_drop; a fresh set per step (`_drop_step` counts from 1)."""
-        return self._drop_step * (4 * self.L + 8) + site
+        return self._drop_step * self._drop_stride + site
 
     def set_dropout_seed(self, seed: int, step: int = 0):
         """Tests / reproducibility: the key of every dropout mask (and the step counter the offsets derive from)."""
         self._drop_seed, self._drop_step = int(seed), int(step)
+        self._sync_drop_rng()
 
     def set_drop_path_uniforms(self, u: Optional[torch.Tensor]):
         """Tests / reproducibility: the uniform numbers u [2 L, B] of the NEXT steps' DropPath draws (row 2 i / 2 i + 1 = block i's
@@ -777,6 +820,7 @@ class AplaTrainEngine:
             self._draw_drop_path()
         if self.drop_on:
             self._drop_step += 1
+            self.drop_rng[1:].add_(1)       # outside the captured launches: they read {seed, step} from this buffer
         if self.use_graphs and self._graphs is None:
             self._capture()
         for k in range(len(self.seg_cuts)):

@@ -140,9 +140,10 @@ def set_attn_variant(v: int) -> int:
 
 def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, epilogue: int = EPI_STORE,
             out: Optional[torch.Tensor] = None, out_dtype=None, aux_in: Optional[torch.Tensor] = None,
-            aux_out: Optional[torch.Tensor] = None, tag: int = 0) -> torch.Tensor:
+            aux_out: Optional[torch.Tensor] = None, tag: int = 0, drop=None) -> torch.Tensor:
     """out[M,Nout] = epilogue(a[M,K] @ w[N,K]^T + bias).  See include/apla_hip.h:apla_gemm_nt / apla_gemm_nt_ex (`tag`: profiling
-    tag of the call site, TAG_*).  A 3-D contiguous operand [K/32, rows, 32] is taken as its K-panel image (k_panels()); a 3-D `out`
+    tag of the call site, TAG_*).  ``drop`` = (rng, stride, site, p) with EPI_GELU: Mlp.drop after the activation inside the epilogue
+    (apla_gemm_nt_gelu_drop; rng = device int64 [2] {seed, step}).  A 3-D contiguous operand [K/32, rows, 32] is taken as its K-panel image (k_panels()); a 3-D `out`
     [N/32, M, 32] is written as one (GELU / GELU_FWD / MUL epilogues)."""
     _req(a, half(), "a", None), _req(w, half(), "w", None)
     panel = 0
@@ -213,6 +214,14 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = Non
         raise TypeError("gemm_nt: this epilogue writes bf16")
     if epilogue == EPI_GELU_FWD and aux_out is not None:
         raise ValueError("gemm_nt: EPI_GELU_FWD saves nothing (use EPI_GELU to get gelu')")
+    if drop is not None:
+        rng, dstride, dsite, dp_ = drop
+        if epilogue != EPI_GELU or panel & 3 or rng.dtype != torch.int64 or rng.numel() != 2 or not rng.is_cuda:
+            raise ValueError("gemm_nt: drop needs the EPI_GELU epilogue, row-major operands and a device int64 [2] rng tensor")
+        check(lib().apla_gemm_nt_gelu_drop(a.data_ptr(), lda, w.data_ptr(), ldw, _ptr(bias), out.data_ptr(), ldc, M, N, K, _ptr(aux_out), ld_out,
+                                           (int(tag) & 0xff) | (panel << 16) | (_RESERVED_CUS << 20), rng.data_ptr(), int(dstride), int(dsite),
+                                           float(dp_), _stream()), "apla_gemm_nt_gelu_drop")
+        return out
     rc = lib().apla_gemm_nt_ex(a.data_ptr(), lda, w.data_ptr(), ldw, _ptr(bias), out.data_ptr(), ldc, M, N, K,
                                epilogue, _DT[out.dtype], _ptr(aux_in), ld_in, _ptr(aux_out), ld_out,
                                (int(tag) & 0xff) | (_GEMM_VARIANT << 8) | (panel << 16) | (_RESERVED_CUS << 20) | (_GEMM_EXP << 28), _stream())
@@ -305,11 +314,13 @@ def layernorm_fwd(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional
                   out: Optional[torch.Tensor] = None, mean: Optional[torch.Tensor] = None,
                   rstd: Optional[torch.Tensor] = None, add: Optional[torch.Tensor] = None,
                   x_out: Optional[torch.Tensor] = None, add_row_stride: Optional[int] = None, D: Optional[int] = None,
-                  add_scale: Optional[torch.Tensor] = None, scale_period: int = 1):
+                  add_scale: Optional[torch.Tensor] = None, scale_period: int = 1, drop=None):
     """x: [M,D] residual stream (fp32|bf16).  With rows/row_stride given, x (and add / x_out) are flat buffers and row m
     starts at m*row_stride (CLS-row selection).  With ``add`` (bf16 branch output) the residual update x_out = x + add is
     fused (x_out may alias x).  gamma = beta = None: y is the normalised row itself (pass ``D``).
     ``add_scale`` (fp32, one per sample; ``scale_period`` rows per sample): stochastic depth, x_out = x + add_scale[m // scale_period] * add.
+    ``drop`` = (rng, stride, site, p, index_row_stride): element-wise dropout of ``add`` inside the kernel (apla_layernorm_fwd_drop);
+    ``rng`` is a device int64 [2] tensor {seed, step}.
     Returns (y [M,D], mean [M], rstd [M])."""
     _req(x, None, "x")
     if (gamma is None) != (beta is None) or (gamma is None and D is None and rows is not None):
@@ -352,9 +363,13 @@ def layernorm_fwd(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional
         _req(add_scale, torch.float32, "add_scale", 1)
         if add is None or scale_period < 1 or add_scale.numel() * scale_period < M:
             raise ValueError("layernorm_fwd: add_scale needs `add` and one entry per sample (M <= len * scale_period)")
-    rc = lib().apla_layernorm_fwd_dp(x.data_ptr(), _DT[x.dtype], xs, _ptr(gamma), _ptr(beta), out.data_ptr(),
-                                     _DT[out.dtype], out.stride(0), mean.data_ptr(), rstd.data_ptr(), M, D, float(eps),
-                                     _ptr(add), adds, _ptr(x_out), xouts, _ptr(add_scale), int(scale_period), _stream())
+    rng, dstride, dsite, dp_, drow = (None, 0, 0, 0.0, D) if drop is None else drop
+    if rng is not None and (rng.dtype != torch.int64 or rng.numel() != 2 or not rng.is_cuda or add is None):
+        raise ValueError("layernorm_fwd: drop needs a device int64 [2] rng tensor {seed, step} and `add`")
+    rc = lib().apla_layernorm_fwd_drop(x.data_ptr(), _DT[x.dtype], xs, _ptr(gamma), _ptr(beta), out.data_ptr(),
+                                       _DT[out.dtype], out.stride(0), mean.data_ptr(), rstd.data_ptr(), M, D, float(eps),
+                                       _ptr(add), adds, _ptr(x_out), xouts, _ptr(add_scale), int(scale_period),
+                                       _ptr(rng), int(dstride), int(dsite), float(dp_), int(drow), _stream())
     check(rc, "apla_layernorm_fwd")
     return out, mean, rstd
 
@@ -365,14 +380,17 @@ def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: Optional[torch.Tenso
                   out_bf16: Optional[torch.Tensor] = None, inds: Optional[torch.Tensor] = None, r: int = 0,
                   gathered: Optional[torch.Tensor] = None, rows: Optional[int] = None,
                   row_stride: Optional[int] = None, x_row_stride: Optional[int] = None, dres_period: int = 0,
-                  dy_scale: Optional[torch.Tensor] = None, gather_scale: Optional[torch.Tensor] = None, scale_period: int = 1):
+                  dy_scale: Optional[torch.Tensor] = None, gather_scale: Optional[torch.Tensor] = None, scale_period: int = 1,
+                  masked: Optional[torch.Tensor] = None, mask_scale: Optional[torch.Tensor] = None, drop=None):
     """dx = dres + LN_bwd_dx(dy).  Returns (dx, gathered | None).  ``out`` (the gradient stream, fp32|bf16) may alias
     ``dres``; ``out_bf16`` optionally receives a bf16 copy.  With rows/row_stride: x, out (and out_bf16) are flat
     buffers whose row m starts at m*row_stride (only those rows are read/written); ``x_row_stride`` gives x its own pitch.
     mean = None: ``x`` is the normalised row saved by layernorm_fwd(gamma=None); gamma = None: no affine part;
     dres_period p > 1: dres is read in rows m % p == 0 only and taken as zero elsewhere (apla_layernorm_bwd_ex).
     Stochastic depth (apla_layernorm_bwd_dp): dx = dres + dy_scale[m // scale_period] * LN_bwd_dx(dy), gathered columns times
-    gather_scale[m // scale_period]; fp32 vectors with one entry per sample."""
+    gather_scale[m // scale_period]; fp32 vectors with one entry per sample.
+    ``masked`` [M,D] 16-bit + ``drop`` = (rng, stride, site, p) (+ ``mask_scale`` per sample): also writes dx through the dropout mask of
+    the branch that consumes it next, and gathers from that copy (apla_layernorm_bwd_drop; normalised-row 16-bit form only)."""
     _req(dy, None, "dy", 2), _req(x, None, "x")
     M, D, lddy = _rows2d(dy, "dy")
     if rows is None:
@@ -423,10 +441,18 @@ def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: Optional[torch.Tenso
             _req(sc, torch.float32, nm, 1)
             if scale_period < 1 or sc.numel() * scale_period < M:
                 raise ValueError(f"layernorm_bwd: {nm} needs one entry per sample (M <= len * scale_period)")
-    rc = lib().apla_layernorm_bwd_dp(dy.data_ptr(), _DT[dy.dtype], lddy, x.data_ptr(), _DT[x.dtype], xs, _ptr(gamma),
-                                     _ptr(mean), rstd.data_ptr(), _ptr(dres), int(dres_period), out.data_ptr(), _DT[out.dtype], dxs,
-                                     _ptr(out_bf16), cbs, _ptr(inds), r, _ptr(gathered), M, D, _ptr(dy_scale), _ptr(gather_scale),
-                                     int(scale_period), _stream())
+    rng, dstride, dsite, dp_ = (None, 0, 0, 0.0) if drop is None else drop
+    if masked is not None:
+        _req(masked, half(), "masked", 2)
+        if rng is None or rng.dtype != torch.int64 or rng.numel() != 2 or tuple(masked.shape) != (M, D) or rows is not None:
+            raise ValueError("layernorm_bwd: masked needs drop=(rng int64 [2], stride, site, p), an [M, D] buffer and dense rows")
+        if mask_scale is not None:
+            _req(mask_scale, torch.float32, "mask_scale", 1)
+    rc = lib().apla_layernorm_bwd_drop(dy.data_ptr(), _DT[dy.dtype], lddy, x.data_ptr(), _DT[x.dtype], xs, _ptr(gamma),
+                                       _ptr(mean), rstd.data_ptr(), _ptr(dres), int(dres_period), out.data_ptr(), _DT[out.dtype], dxs,
+                                       _ptr(out_bf16), cbs, _ptr(inds), r, _ptr(gathered), M, D, _ptr(dy_scale), _ptr(gather_scale),
+                                       int(scale_period), _ptr(masked), masked.stride(0) if masked is not None else 0, _ptr(mask_scale),
+                                       _ptr(rng if masked is not None else None), int(dstride), int(dsite), float(dp_), _stream())
     check(rc, "apla_layernorm_bwd")
     return out, gathered
 
@@ -878,6 +904,21 @@ def dropout_fwd(x: torch.Tensor, p: float, seed: int, offset: int = 0, *, out: O
     check(lib().apla_dropout_fwd(x.data_ptr(), _DT[x.dtype], y.data_ptr(), keep.data_ptr(), x.numel(), float(p), int(seed) & (2 ** 64 - 1),
                                  int(offset) & (2 ** 64 - 1), _stream()), "apla_dropout_fwd")
     return y, keep
+
+
+def dropout_dev(x: torch.Tensor, p: float, rng: torch.Tensor, stride: int, site: int, *, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = keep ? x / (1 - p) : 0 with the mask of (rng = device int64 [2] {seed, step}, offset = step * stride + site): apla_dropout_fwd_dev
+    (no keep bytes; ``out`` may be ``x``).  Forward of a site and — applied to the gradient — its backward."""
+    _req(x, None, "x")
+    if x.dtype not in (torch.float32, half()) or not x.is_contiguous() or x.numel() % 8 or not 0.0 <= p < 1.0 or \
+            rng.dtype != torch.int64 or rng.numel() != 2 or not rng.is_cuda:
+        raise ValueError("dropout_dev: contiguous fp32 / 16-bit tensor with numel % 8 == 0, 0 <= p < 1 and a device int64 [2] rng expected")
+    y = torch.empty_like(x) if out is None else out
+    if y.dtype != x.dtype or y.numel() != x.numel() or not y.is_contiguous():
+        raise ValueError("dropout_dev: bad output buffer")
+    check(lib().apla_dropout_fwd_dev(x.data_ptr(), _DT[x.dtype], y.data_ptr(), None, x.numel(), float(p), rng.data_ptr(), int(stride), int(site),
+                                     _stream()), "apla_dropout_fwd_dev")
+    return y
 
 
 def dropout_bwd(dy: torch.Tensor, keep: torch.Tensor, p: float, *, out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -104,6 +104,16 @@ int apla_gemm_nt_ex(const void* A, int lda, const void* W, int ldw, const float*
                     int K, int epilogue, int out_dtype, const void* aux_in, int ld_aux_in, void* aux_out,
                     int ld_aux_out, int flags, hipStream_t stream);
 
+/* apla_gemm_nt_ex(..., APLA_EPI_GELU, ...) with Mlp.drop after the activation (utils/transformers/vit.py:164-165) INSIDE the epilogue (round 6):
+ * C = drop(GELU(A W^T + b)) and aux_out = GELU'(.) through the SAME keep mask, so that the backward's dfc2 epilogue (dh * aux_out) needs no
+ * change.  The keep decision of output (m, n) is that of apla_dropout_fwd for element i = m * N + n (row-major position, whatever layout
+ * the outputs have: `flags` bits 18 / 19 = image outputs as in apla_gemm_nt_ex; bits 0-7 tag, 20-27 reserved CUs), with {seed, step} read
+ * from device memory and offset = step * rng_stride + site as in apla_layernorm_fwd_drop.  Runs on the 4-wave persistent kernel
+ * (N % 128 == 0, row-major operands). */
+int apla_gemm_nt_gelu_drop(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int M, int N, int K,
+                           void* aux_out, int ld_aux_out, int flags, const unsigned long long* rng, unsigned long long rng_stride,
+                           unsigned site, float p_drop, hipStream_t stream);
+
 /* C[M,N] = A[M,K] @ W[N,K]^T (+ bias) for problems with FEW output tiles and a LONG K (the input gradient of the DINO head's prototype
  * layer, dino_head.py:12-40: M = a few thousand rows, N = 256, K = 65 536 prototypes — 35 tiles of the tiled kernels, 2 048 K-steps
  * each): the K axis is cut into S parts (apla_gemm_nt_splitk_workspace_bytes / (M*N*4)), every (tile, part) pair is a work item of
@@ -183,6 +193,29 @@ int apla_layernorm_bwd_dp(const void* dy, int dy_dtype, int lddy, const void* x,
                           void* dx_out, int grad_dtype, long dx_row_stride, void* dx_bf16_copy, long copy_row_stride,
                           const int32_t* inds, int r, void* gather_out, int M, int D, const float* dy_scale,
                           const float* gather_scale, int scale_period, hipStream_t stream);
+
+/* The element-wise dropout of a branch inside the same two kernels (round 6; proj_drop appla_attn.py:82, Mlp.drop after fc2
+ * vit.py:166-167; main.py --dr).  The keep decision of element i is that of apla_dropout_fwd below — word (i & 3) of
+ * Philox4x32-10(counter {i >> 2, offset}, key seed) >= p * 2^32 — with {seed, step} read from DEVICE memory (`rng`, two 64-bit words) and
+ * offset = step * rng_stride + site: the step counter advances outside a captured launch sequence, the launches stay the same.
+ *   apla_layernorm_fwd_drop : apla_layernorm_fwd_dp with x_new = x + add_scale * (keep ? add_in / (1 - p) : 0); element index of
+ *                             add_in[m, c] = m * drop_row_stride + c (the row-major index in the branch's full [M, D] tensor, also when only
+ *                             every N-th row is visited).  rng NULL: no dropout.
+ *   apla_layernorm_bwd_drop : apla_layernorm_bwd_dp that also writes masked_out[m, c] = keep ? dx_out[m, c] / (1 - p) * mask_scale[sample] : 0
+ *                             (16-bit; element index m * D + c) — dx_out through the mask of the branch that consumes it NEXT, i.e. the
+ *                             operand of that branch's dX GEMM — and takes gather_out from masked_out.  16-bit normalised-row form only. */
+int apla_layernorm_fwd_drop(const void* x, int res_dtype, long x_row_stride, const float* gamma, const float* beta,
+                            void* y, int y_dtype, int ldy, float* mean, float* rstd, int M, int D, float eps,
+                            const void* add_in, long add_row_stride, void* x_out, long x_out_row_stride,
+                            const float* add_scale, int scale_period, const unsigned long long* rng, unsigned long long rng_stride,
+                            unsigned site, float p, long drop_row_stride, hipStream_t stream);
+int apla_layernorm_bwd_drop(const void* dy, int dy_dtype, int lddy, const void* x, int x_dtype, long x_row_stride,
+                            const float* gamma, const float* mean, const float* rstd, const void* dres_in, int dres_row_period,
+                            void* dx_out, int grad_dtype, long dx_row_stride, void* dx_bf16_copy, long copy_row_stride,
+                            const int32_t* inds, int r, void* gather_out, int M, int D, const float* dy_scale,
+                            const float* gather_scale, int scale_period, void* masked_out, long masked_row_stride,
+                            const float* mask_scale, const unsigned long long* rng, unsigned long long rng_stride, unsigned site,
+                            float p, hipStream_t stream);
 
 /* Gather only (used when the projection output gradient is already materialised): out[m,j] = src[m,inds[j]] bf16. */
 int apla_gather_cols(const void* src, int res_dtype, long src_row_stride, const int32_t* inds, int r, void* out,
@@ -389,6 +422,11 @@ int apla_weight_norm_bwd(const float* dw, const float* v, const float* g, const 
 int apla_dropout_fwd(const void* x, int dtype, void* y, uint8_t* keep, long n, float p, unsigned long long seed,
                      unsigned long long offset, hipStream_t stream);
 int apla_dropout_bwd(const void* dy, int dtype, const uint8_t* keep, void* dx, long n, float p, hipStream_t stream);
+/* apla_dropout_fwd with {seed, step} read from DEVICE memory (`rng`, two 64-bit words; offset = step * rng_stride + site) and `keep`
+ * optional (NULL: not written): the form a captured launch sequence replays with a new mask every step (round 6: pos_drop and the
+ * gradient entering the last block of the fused step).  The same call applied to a gradient is the site's backward. */
+int apla_dropout_fwd_dev(const void* x, int dtype, void* y, uint8_t* keep, long n, float p, const unsigned long long* rng,
+                         unsigned long long rng_stride, unsigned site, hipStream_t stream);
 int apla_scale_samples(const void* x, int dtype, void* y, const float* scale, long samples, long per_sample, hipStream_t stream);
 
 /* Self-distillation losses of the DINOv2-APLA step (dinov2/loss/dino_clstoken_loss.py,

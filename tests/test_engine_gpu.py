@@ -822,18 +822,27 @@ def _oracle_drop_masks(eng, B, N, D, F, H, step):
     return {"pos": mul(B * N * D, eng.p_pos, 0, (B, N, D)) if eng.p_pos > 0 else None, "blocks": blocks}
 
 
-@pytest.mark.parametrize("sites", ["all", "mlp", "proj+attn+droppath"])
-def test_engine_elementwise_dropout_vs_oracle(sites):
+@pytest.mark.parametrize("form", ["fused", "passes"])
+@pytest.mark.parametrize("sites", ["all", "mlp", "proj+attn+droppath", "dr"])
+def test_engine_elementwise_dropout_vs_oracle(sites, form, monkeypatch):
     """main.py --dr / --adr on the fused step (VERDICT r05 #7a): the reference's nn.Dropout sites — pos_drop (vit.py:395), attn_drop and
     proj_drop (appla_attn.py:58, :82), Mlp.drop after the activation and after fc2 (vit.py:164-167) — as counter-based mask passes of the
-    C-ABI around the step's launches, alone and together with stochastic depth.  Logits, loss and every trainable gradient against the
-    fp64 oracle under the SAME masks, which the oracle rebuilds from (seed, offset) with its own Philox4x32-10 (pinned by the Random123
+    C-ABI around the step's launches ("passes": eager, keep bytes) or, second form of round 6, INSIDE its kernels ("fused": the branch
+    sites in the LayerNorm forward / backward, the post-activation site in fc1's GELU epilogue, every mask from {seed, step} in device
+    memory — the step stays on hipGraphs unless attention dropout is on), alone and together with stochastic depth.  Both forms draw the
+    same masks.  Logits, loss and every trainable gradient against the fp64 oracle under the SAME masks, which the oracle rebuilds from (seed, offset) with its own Philox4x32-10 (pinned by the Random123
     known-answer vectors); two steps (the masks change with the step counter); inference ignores every site."""
     from apla_amd.engine import AplaTrainEngine, OptimConfig
     from apla_amd.vit import DropPath
     depth, B = 3, 4
+    if form == "passes":
+        monkeypatch.setenv("APLA_DROPOUT_PASSES", "1")
     model = small_vit(depth=depth)
     bb = model.backbone
+    if sites == "dr":          # main.py --dr: one rate at pos_drop, proj_drop and both Mlp.drop sites; no attention dropout -> graphs stay
+        bb.pos_drop.p = 0.1
+        for blk in bb.blocks:
+            blk.mlp.drop.p = blk.attn.proj_drop.p = 0.1
     if sites in ("all", "mlp"):
         for blk in bb.blocks:
             blk.mlp.drop.p = 0.2
@@ -851,7 +860,8 @@ def test_engine_elementwise_dropout_vs_oracle(sites):
     g = torch.Generator().manual_seed(13)
     images, labels = torch.randn(B, 3, 32, 32, generator=g), torch.randint(0, 10, (B,), generator=g)
     eng = AplaTrainEngine(model, B, 32, optim=OptimConfig(lr=1e-3, weight_decay=1e-2, grad_clipping=1.0))
-    assert eng.drop_on and not eng.use_graphs and not eng.cls_only_tail and eng.dp_on == (sites == "proj+attn+droppath")
+    assert eng.drop_on and not eng.cls_only_tail and eng.dp_on == (sites == "proj+attn+droppath") and eng.drop_fused == (form == "fused")
+    assert eng.use_graphs == (form == "fused" and sites in ("mlp", "dr"))      # captured unless the attention-dropout kernels (by-value counters) run
     eng.set_dropout_seed(0x0123_4567_89AB_CDEF, step=0)
     N, D, F, H = eng.N, eng.D, eng.blocks[0].F, eng.H
     cfg = dict(patch=16, depth=depth, heads=H, r=64)
