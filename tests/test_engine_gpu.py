@@ -789,7 +789,7 @@ def test_fused_step_refuses_dropout():
     model = small_vit(depth=2)
     model.backbone.blocks[1].mlp.drop.p = 0.1
     e = AplaTrainEngine(model, 4, 32)
-    assert e.drop_on and not e.use_graphs         # a site of the reference: element-wise mask passes, launched eagerly (round 6)
+    assert e.drop_on and e.drop_fused and e.use_graphs     # a site of the reference: its mask is drawn inside the step's kernels (round 6)
     model.backbone.blocks[1].mlp.drop.p = 0.0
     model.backbone.extra_drop = torch.nn.Dropout(0.3)       # not one of the reference's sites: refused, never ignored
     with pytest.raises(NotImplementedError, match="not one of the reference's sites"):
