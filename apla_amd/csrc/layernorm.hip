@@ -20,7 +20,7 @@ constexpr int LN_THREADS = 64 * ROWS_PER_BLOCK;
 // Optional fused residual add: x_new = x + add (add = bf16 branch output of the previous GEMM) is formed in registers,
 // written to xout and normalised in the same pass — the "x = x + branch" of vit.py:284-285 costs no kernel of its own and
 // no fp32 read-modify-write in a GEMM epilogue.
-template <typename ResT, typename YT, int NC>
+template <typename ResT, typename YT, int NC, bool DROP = false>
 __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const ResT* x, long xs, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, YT* __restrict__ y, int ldy,
                                                      float* __restrict__ mean_o, float* __restrict__ rstd_o, int M,
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const ResT* x, long 
         v[c] = Vec4IO<ResT>::load(xr + ch * 4);
         if (add != nullptr) {
           f32x4 bv = Vec4IO<bf16>::load(add + (size_t)m * adds + ch * 4) * bscale;
-          if (dr.rng != nullptr) {   // nn.Dropout on the branch (proj_drop appla_attn.py:82, Mlp.drop after fc2 vit.py:166-167): element m * stride + col
+          if constexpr (DROP) {   // nn.Dropout on the branch (proj_drop appla_attn.py:82, Mlp.drop after fc2 vit.py:166-167): element m * stride + col
             unsigned w[4];
             drop_words4(dr, (((unsigned long long)m * (unsigned long long)drop_row_stride) >> 2) + ch, w);
 #pragma unroll
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const DYT* __restric
 // wave, a half-wave each, 8 elements (16 bytes) per lane and access.  The one-row-per-wave form above moves 8 bytes per lane and
 // access for 16-bit operands and reached 4.3 TB/s on these shapes; rows of 768 / 1024 / 1536 elements are 3 / 4 / 6 whole chunks
 // per lane here.  dx = dres + (dy - mean(dy) - xhat * mean(dy * xhat)) * rstd.
-template <bool GATHER, int NC8>
+template <bool GATHER, int NC8, bool MASKED = false>
 __global__ __launch_bounds__(LN_THREADS) void ln_bwd2_kernel(const bf16* __restrict__ dy, int lddy, const bf16* __restrict__ xh,
                                                       long xs, const float* __restrict__ rstd_i, const bf16* dres, bf16* dx,
                                                       long dxs, const int32_t* __restrict__ inds, int r,
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd2_kernel(const bf16* __restr
     const float gsc = g_scale != nullptr ? g_scale[mr / scale_period] : 1.0f;
     // `masked` (optional): a second copy of dx with the NEXT consumer's dropout mask (and its branch's per-sample factor) applied — the
     // operand of that branch's dX GEMM; the gathered columns of dW1 are then taken from it
-    const float msc = (masked != nullptr && mask_scale != nullptr) ? mask_scale[mr / scale_period] : 1.0f;
+    const float msc = (MASKED && mask_scale != nullptr) ? mask_scale[mr / scale_period] : 1.0f;
     const bool has_res = dres != nullptr && (dres_period <= 1 || mr % dres_period == 0);
     bf16x8 xv[NC8], dv[NC8], rv[NC8];
 #pragma unroll
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd2_kernel(const bf16* __restr
       if (ch < nchunk) {
         bf16x8 ov, mv;
         unsigned w[8];
-        if (masked != nullptr) {
+        if constexpr (MASKED) {
           unsigned a[4], b[4];
           const unsigned long long blk = (((unsigned long long)mr * (unsigned long long)D) >> 2) + 2 * ch;
           drop_words4(dr, blk, a);
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd2_kernel(const bf16* __restr
           if (has_res) o += (float)rv[c][e];
           ov[e] = (bf16)o;
           float g = o * gsc;
-          if (masked != nullptr) {     // the mask acts on the value the stream holds (16-bit), as the stand-alone pass would
+          if constexpr (MASKED) {     // the mask acts on the value the stream holds (16-bit), as the stand-alone pass would
             g = w[e] >= dr.threshold ? (float)ov[e] * dr.inv_keep * msc : 0.f;
             mv[e] = (bf16)g;
             g = (float)mv[e];
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd2_kernel(const bf16* __restr
           if constexpr (GATHER) rowbuf[(2 * wave + half) * D + ch * 8 + e] = g;
         }
         if (live) *(bf16x8*)(dx + (size_t)m * dxs + ch * 8) = ov;
-        if (live && masked != nullptr) *(bf16x8*)(masked + (size_t)m * mks + ch * 8) = mv;
+        if constexpr (MASKED) { if (live) *(bf16x8*)(masked + (size_t)m * mks + ch * 8) = mv; }
       }
     }
     if constexpr (GATHER) {
@@ -295,15 +295,16 @@ extern "C" int apla_layernorm_fwd_drop(const void* x, int res_dtype, long x_row_
   APLA_REQUIRE(apla_aligned16(x) && (gamma == nullptr || (apla_aligned16(gamma) && apla_aligned16(beta))) && (((uintptr_t)y) & 7) == 0, "apla_layernorm_fwd: alignment");
   APLA_REQUIRE(add_in == nullptr || (x_out != nullptr && add_row_stride % 4 == 0 && add_row_stride >= D && x_out_row_stride % 4 == 0 && x_out_row_stride >= D),
                "apla_layernorm_fwd: fused residual add needs x_out and valid strides");
-#define LN_FWD_NC(T, Y, NCV) hipLaunchKernelGGL((ln_fwd_kernel<T, Y, NCV>), dim3(ln_grid(M)), dim3(LN_THREADS), 0, stream, (const T*)x, x_row_stride, gamma, beta, (Y*)y, ldy, mean, rstd, M, D, eps, (const bf16*)add_in, add_row_stride, (T*)x_out, x_out_row_stride, add_scale, scale_period, dr, drop_row_stride)
+#define LN_FWD_NC(T, Y, NCV) if (rng != nullptr) LN_FWD_NC2(T, Y, NCV, true); else LN_FWD_NC2(T, Y, NCV, false)
+#define LN_FWD_NC2(T, Y, NCV, DR) hipLaunchKernelGGL((ln_fwd_kernel<T, Y, NCV, DR>), dim3(ln_grid(M)), dim3(LN_THREADS), 0, stream, (const T*)x, x_row_stride, gamma, beta, (Y*)y, ldy, mean, rstd, M, D, eps, (const bf16*)add_in, add_row_stride, (T*)x_out, x_out_row_stride, add_scale, scale_period, dr, drop_row_stride)
 #define LN_FWD(T, Y)                                    \
   do {                                                  \
     const int nc_ = (D + 255) / 256;                    \
-    if (nc_ <= 1) LN_FWD_NC(T, Y, 1);                   \
-    else if (nc_ == 2) LN_FWD_NC(T, Y, 2);              \
-    else if (nc_ == 3) LN_FWD_NC(T, Y, 3);              \
-    else if (nc_ == 4) LN_FWD_NC(T, Y, 4);              \
-    else LN_FWD_NC(T, Y, 6);                            \
+    if (nc_ <= 1) { LN_FWD_NC(T, Y, 1); }               \
+    else if (nc_ == 2) { LN_FWD_NC(T, Y, 2); }          \
+    else if (nc_ == 3) { LN_FWD_NC(T, Y, 3); }          \
+    else if (nc_ == 4) { LN_FWD_NC(T, Y, 4); }          \
+    else { LN_FWD_NC(T, Y, 6); }                        \
   } while (0)
   if (res_dtype == APLA_F32 && y_dtype == APLA_H16) LN_FWD(float, bf16);
   else if (res_dtype == APLA_F32 && y_dtype == APLA_F32) LN_FWD(float, float);
@@ -315,6 +316,7 @@ extern "C" int apla_layernorm_fwd_drop(const void* x, int res_dtype, long x_row_
   }
 #undef LN_FWD
 #undef LN_FWD_NC
+#undef LN_FWD_NC2
   APLA_CHECK_LAUNCH("apla_layernorm_fwd");
   return APLA_OK;
 }
@@ -366,8 +368,9 @@ extern "C" int apla_layernorm_bwd_drop(const void* dy, int dy_dtype, int lddy, c
     const int g2 = (M + 2 * ROWS_PER_BLOCK - 1) / (2 * ROWS_PER_BLOCK);
     const dim3 grid2(g2 < 4096 ? g2 : 4096);
     const size_t lds2 = gather ? (size_t)2 * ROWS_PER_BLOCK * D * sizeof(float) : 0;
-#define LN_BWD2(GA, NCV)                                                                                                           \
-    hipLaunchKernelGGL((ln_bwd2_kernel<GA, NCV>), grid2, dim3(LN_THREADS), lds2, stream, (const bf16*)dy, lddy, (const bf16*)x,      \
+#define LN_BWD2(GA, NCV) do { if (masked_out != nullptr) LN_BWD2M(GA, NCV, true); else LN_BWD2M(GA, NCV, false); } while (0)
+#define LN_BWD2M(GA, NCV, MK)                                                                                                      \
+    hipLaunchKernelGGL((ln_bwd2_kernel<GA, NCV, MK>), grid2, dim3(LN_THREADS), lds2, stream, (const bf16*)dy, lddy, (const bf16*)x,      \
                        x_row_stride, rstd, (const bf16*)dres_in, (bf16*)dx_out, dx_row_stride, inds, r, (bf16*)gather_out, M, D,    \
                        dres_row_period, dy_scale, gather_scale, scale_period, (bf16*)masked_out, masked_row_stride, dr, mask_scale)
 #define LN_BWD2_G(NCV) do { if (gather) LN_BWD2(true, NCV); else LN_BWD2(false, NCV); } while (0)
@@ -379,6 +382,7 @@ extern "C" int apla_layernorm_bwd_drop(const void* dy, int dy_dtype, int lddy, c
     else LN_BWD2_G(8);
 #undef LN_BWD2_G
 #undef LN_BWD2
+#undef LN_BWD2M
     APLA_CHECK_LAUNCH("apla_layernorm_bwd");
     return APLA_OK;
   }
