@@ -248,6 +248,94 @@ def test_layernorm_normalised_row_mode(ops, M, D, N):
     assert rel_err(out2.cpu(), ref2) < 1.5 * BF16_OUT
 
 
+@pytest.mark.parametrize("M,D,N", [(6 * 7, 128, 7), (3 * 197, 768, 197), (4 * 50, 1024, 50), (2 * 33, 1536, 33)])
+def test_layernorm_regularisation_forms(ops, M, D, N):
+    """Round 6: the LayerNorm pair with a branch's regularisation inside.  Forward (apla_layernorm_fwd_dp / _drop): x_new = x +
+    scale[sample] * dropout(add) with the keep decision of element m * row_stride + c drawn in the kernel from {seed, step} in device
+    memory — against the oracle's philox_keep_mask (the definition of apla_dropout_fwd), dense rows and every N-th row of a larger tensor
+    (the index stride is the full tensor's).  Backward (apla_layernorm_bwd_dp / _drop): dx = dres + dy_scale[sample] * LN_bwd(dy), a second
+    copy of dx through the NEXT consumer's mask x its branch's factor, and the gathered columns taken from that copy.  Widths 128 .. 1536
+    (every chunk-count instantiation)."""
+    B = M // N
+    seed, step, stride, site, p = 0x5EED_1234_ABCD_0001, 3, 17, 5, 0.25
+    rng = torch.tensor([seed, step], dtype=torch.int64, device="cuda")
+    off = step * stride + site
+    inv = 1.0 / (1.0 - float(torch.tensor(p, dtype=torch.float32)))
+    x = rnd(M, D, seed=61) * 1.5 + 0.3
+    add, addd = bf(rnd(M, D, seed=62) * 0.5)
+    scale = torch.tensor([0.0, 1.25] * B)[:B].float()
+    keep = torch.from_numpy(O.philox_keep_mask(M * D, p, seed, off)).reshape(M, D)
+    xd = x.double() + scale.double().repeat_interleave(N)[:, None] * (addd * keep.double() * inv)
+    _, mref, rref = O.layernorm_fwd(xd, torch.ones(D, dtype=torch.float64), torch.zeros(D, dtype=torch.float64), 1e-6)
+    res = dev(x)
+    xh, _, rstd = ops.layernorm_fwd(res, None, None, 1e-6, add=dev(add), x_out=res, add_scale=dev(scale), scale_period=N,
+                                    drop=(rng, stride, site, p, D))
+    assert rel_err(res.cpu(), xd) < 1e-6 and rel_err(rstd.cpu(), rref) < 1e-5
+    xhat_ref = (xd - mref[:, None]) * rref[:, None]
+    assert rel_err(xh.cpu(), xhat_ref) < BF16_OUT
+    # every N-th row only (the CLS rows of the final norm): the mask index is the row's position in the FULL tensor
+    res2 = dev(x)
+    xn2 = torch.empty(B, D, device="cuda", dtype=torch.bfloat16)
+    m2, r2 = torch.empty(B, device="cuda"), torch.empty(B, device="cuda")
+    ops.layernorm_fwd(res2, None, None, 1e-6, out=xn2, mean=m2, rstd=r2, rows=B, row_stride=N * D, add=dev(add), x_out=res2, D=D,
+                      add_scale=dev(scale), scale_period=1, drop=(rng, stride, site, p, N * D))
+    assert rel_err(res2.cpu()[::N], xd[::N]) < 1e-6 and torch.equal(res2.cpu()[1::N], x[1::N])
+    # backward: stream, masked copy (other site), gathered columns
+    dy, dyd = bf(rnd(M, D, seed=63))
+    G0, G0d = bf(rnd(M, D, seed=64))
+    dys = torch.tensor([2.0, 0.0, 1.0] * B)[:B].float()
+    msc = torch.tensor([1.0, 0.0, 4.0 / 3.0] * B)[:B].float()
+    ref_dx = O.layernorm_bwd_dx(dyd, xd, torch.ones(D, dtype=torch.float64), mref, rref)
+    ref = G0d + dys.double().repeat_interleave(N)[:, None] * ref_dx
+    site2 = 9
+    keep2 = torch.from_numpy(O.philox_keep_mask(M * D, p, seed, step * stride + site2)).reshape(M, D)
+    inds = torch.randperm(D, generator=torch.Generator().manual_seed(3)).int()
+    r = 64
+    G, Gm = dev(G0), torch.zeros(M, D, device="cuda", dtype=torch.bfloat16)
+    out, gathered = ops.layernorm_bwd(dev(dy), xh, None, None, rstd, dres=G, out=G, inds=dev(inds), r=r, dy_scale=dev(dys), scale_period=N,
+                                      masked=Gm, mask_scale=dev(msc), drop=(rng, stride, site2, p))
+    assert rel_err(out.cpu(), ref) < 1.5 * BF16_OUT
+    want = out.cpu().double() * keep2.double() * inv * msc.double().repeat_interleave(N)[:, None]      # the mask acts on the stored stream
+    assert rel_err(Gm.cpu(), want) < BF16_OUT and bool(((Gm.cpu() == 0) | keep2).all())
+    assert torch.equal(gathered.cpu(), Gm.cpu()[:, inds[:r].long()])
+    # without a mask: the factor of the gathered columns is gather_scale
+    G = dev(G0)
+    out3, g3 = ops.layernorm_bwd(dev(dy), xh, None, None, rstd, dres=G, out=G, inds=dev(inds), r=r, dy_scale=dev(dys), gather_scale=dev(msc), scale_period=N)
+    assert torch.equal(out3, out)
+    assert rel_err(g3.cpu(), ref[:, inds[:r].long()] * msc.double().repeat_interleave(N)[:, None]) < 1.5 * BF16_OUT
+
+
+@pytest.mark.parametrize("M,N,K,img", [(300, 256, 128, False), (5000, 3072, 768, True), (9000, 768, 256, True), (1000, 384 * 4, 384, False)])
+def test_gemm_gelu_with_dropout_in_the_epilogue(ops, M, N, K, img):
+    """apla_gemm_nt_gelu_drop (round 6): fc1 + GELU + GELU' with Mlp.drop after the activation inside the epilogue — both outputs equal the
+    plain launch's outputs through ONE keep mask, the oracle's for element m * N + n, whatever layout the outputs have."""
+    a = dev(bf(rnd(M, K, seed=71))[0])
+    w = dev(bf(rnd(N, K, scale=K ** -0.5, seed=72))[0])
+    bias = dev(rnd(N, seed=73))
+    seed, step, stride, site, p = 0x0DDB_A11_5EED, 2, 56, 10, 0.3
+    rng = torch.tensor([seed, step], dtype=torch.int64, device="cuda")
+    g_ref = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    old = ops.set_gemm_variant(15)
+    try:
+        h_ref = ops.gemm_nt(a, w, bias, epilogue=ops.EPI_GELU, aux_out=g_ref)
+    finally:
+        ops.set_gemm_variant(old)
+    keep = torch.from_numpy(O.philox_keep_mask(M * N, p, seed, step * stride + site)).reshape(M, N).cuda()
+    inv = 1.0 / (1.0 - float(torch.tensor(p, dtype=torch.float32)))
+    if img:
+        h, g = torch.zeros(N // 32, M, 32, device="cuda", dtype=torch.bfloat16), torch.zeros(N // 32, M, 32, device="cuda", dtype=torch.bfloat16)
+    else:
+        h, g = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16), torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+    ops.gemm_nt(a, w, bias, epilogue=ops.EPI_GELU, aux_out=g, out=h, drop=(rng, stride, site, p))
+    if img:
+        h, g = h.permute(1, 0, 2).reshape(M, N), g.permute(1, 0, 2).reshape(M, N)
+    assert abs(float(keep.float().mean()) - (1 - p)) < 0.01
+    assert bool(((h == 0) | keep).all()) and bool(((g == 0) | keep).all())
+    # kept entries: the plain outputs times 1 / (1 - p), rounded once from fp32 (the plain outputs were rounded before the scaling: one ulp)
+    hk, gk = h[keep].float(), g[keep].float()
+    assert rel_err(hk.cpu(), (h_ref[keep].float() * inv).cpu()) < 2 * 2 ** -8 and rel_err(gk.cpu(), (g_ref[keep].float() * inv).cpu()) < 2 * 2 ** -8
+
+
 # ------------------------------------------------------------------------------------------- attention
 @pytest.fixture
 def attn_variant(request):
