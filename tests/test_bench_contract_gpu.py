@@ -77,14 +77,24 @@ def test_bench_reports_the_exchange_wait_on_the_forced_exchange_path():
     assert abs(rk["ms_per_step"][0] - d["ms_per_step"]) < 0.2 * d["ms_per_step"]
 
 
-def test_bench_default_line_through_the_multi_rank_path_on_one_gpu():
+@pytest.mark.parametrize("launcher", ["self", "torch.distributed.run"])
+def test_bench_default_line_through_the_multi_rank_path_on_one_gpu(launcher):
     """The driver's scaling run is `bench.py --gpus N` with DEFAULT flags — parity checks on rank 0 included — and no run of it had ever
     executed with more than one rank (the other multi-rank tests pass --no-parity).  `--rehearse-on-one-gpu` puts every rank on cuda:0
     over gloo (RCCL refuses two ranks on one device) and leaves everything else as the real N > 1 path: rendezvous, per-rank batches,
     four graph segments with the gradient exchange between them, MAX over ranks, the per-rank arrays — and rank 0's parity engines, which
     must be rank-LOCAL (round 6: they were built with process_group=None = the default group, i.e. rank 0 alone would have issued
     collectives and the job would have hung).  Three ranks: a world size that is neither 1 nor 2."""
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--rehearse-on-one-gpu", "--steps", "3", "--warmup", "2", "--no-peak-probe"]
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "3", "--rehearse-on-one-gpu", "--steps", "3", "--warmup", "2", "--no-peak-probe"]
+    if launcher == "self":
+        cmd = [sys.executable] + tail
+    else:       # the form the driver uses for N > 1: one rank per process under torch.distributed.run
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
+               "--master-port", str(port)] + tail
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
