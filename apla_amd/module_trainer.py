@@ -3,10 +3,12 @@ runs it — model forward, criterion, ``loss.backward()``, gradient exchange, ``
 package (``apla_amd.vit`` + ``build_apla``: every tensor op of the backbone is a HIP kernel behind a ``torch.autograd.Function``) and
 ``FlatAdamW``.
 
-``AplaTrainEngine`` (the fused, captured launch sequence) is what ``main.py`` and ``bench.py`` use; it has no dropout / stochastic
-depth and refuses a model that asks for one.  ``main.py --dr / --dpr`` (main.py:101-111 of the reference) therefore train here: same
-parameters, same optimizer semantics (two groups, one flat fp32 buffer, global-norm clip, 1/world folded into the optimizer), the
-same ``train_step(images, labels, lr=)`` / ``grad_norm`` surface, ~0.6 of the fused step's speed (tools/module_path_bench.py).
+``AplaTrainEngine`` (the fused, captured launch sequence) is what ``main.py`` and ``bench.py`` use.  Until round 5 it had no dropout /
+stochastic depth and ``main.py --dr / --dpr`` (main.py:101-111 of the reference) trained here; since round 6 the engine takes both and
+this trainer is what ``main.py --module_path`` selects, or what a model the engine refuses falls back to: same parameters, same optimizer
+semantics (two groups, one flat fp32 buffer, global-norm clip, 1/world folded into the optimizer), the same ``train_step(images,
+labels, lr=)`` / ``grad_norm`` surface, 0.89 of the fused step's speed without regularisation, 0.77 with ``--dr 0.1``
+(profiles/r06_d_dropout_bench.md).
 """
 from typing import Optional
 
