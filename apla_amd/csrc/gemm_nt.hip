@@ -432,6 +432,11 @@ inline Sched pick_schedule(int epi, int out_dtype, int M, int N, int K, int lda,
     // output / second-operand image: the 4-wave persistent kernel's GELU / GELU_FWD / MUL / SwiGLU epilogues (checked by
     // gemm_nt_impl) — except the two-output GELU above 40 000 rows, which the automatic rule runs on the ping-pong kernel: its
     // line-store epilogue writes the images as well (round 3: config 3's fc2 read a row-major h, 552 us against dfc1's 474 us)
+    // (round 6: at K <= 768 — the packed student batch of the self-supervised step, M = 58 496, N = 3072 — the tile-alternating kernel, whose
+    // service waves run the epilogue under the partner group's products, beats the ping-pong kernel's exposed epilogue: 391 vs 432 us,
+    // 437 on the 4-wave kernel; at K = 1024 (ViT-L, M = 65 792, N = 4096) the ping-pong kernel stays ahead: 693 vs 721 / 759 us)
+    if (epi == APLA_EPI_GELU && M > 40000 && g_variant == 4 && K <= 768 && apla_gemm_tp_covers(M, N, K, lda, ldw, epi, out_dtype, w_panel))
+      return {4, 0};
     if (epi == APLA_EPI_GELU && M > 40000 && (g_variant == 4 || g_variant == 9) &&
         apla_gemm_pp2_covers(M, N, K, lda, ldw, epi, out_dtype))
       return {2, 0};

@@ -640,8 +640,10 @@ class _MlpGeluFn(torch.autograd.Function):
         _require_cuda(x, "mlp")
         x2 = _as2d_bf16(x)
         M, F = x2.shape[0], w1.shape[0]
-        gp = torch.empty(M, F, device=x.device, dtype=_h())
         h = _hidden_buffer(M, F, w2.shape[0], ops.EPI_GELU, x.device)   # a K-panel image where fc1's epilogue can write one
+        # GELU' is private to this epilogue and the backward's MUL epilogue: an image whenever h is one (as the fused engine keeps it) —
+        # whole-line stores / loads, and what lets the dispatch take the tile-alternating kernel for the packed student batch (round 6)
+        gp = torch.empty(F // 32, M, 32, device=x.device, dtype=_h()) if h.ndim == 3 else torch.empty(M, F, device=x.device, dtype=_h())
         w1h = w_bf16(w1)
         if _IMAGES and ops.gemm_panel_ok(M, F, w1.shape[1], ops.EPI_GELU):   # the two-output GELU above 40 000 rows: ping-pong kernel
             w1h = CACHE.get(w1, "bf16_img", lambda: ops.k_panels(w1h))
@@ -657,7 +659,7 @@ class _MlpGeluFn(torch.autograd.Function):
         if w1.requires_grad or w2.requires_grad or (ctx.has_gamma and gamma.requires_grad):
             raise NotImplementedError("trainable MLP weights / LayerScale are outside the APLA path")
         w2t = _scaled_w_t(w2, gamma) if ctx.has_gamma else w_bf16_t(w2)
-        M, F = gp.shape
+        M, F = (gp.shape[1], gp.shape[0] * 32) if gp.ndim == 3 else gp.shape
         da = _hidden_buffer(M, F, w1.shape[1], ops.EPI_MUL, dy.device)
         ops.gemm_nt(_as2d_bf16(dy), w2t, epilogue=ops.EPI_MUL, aux_in=gp, out=da)
         dx = ops.gemm_nt(da, _img(w1, "bf16_t", lambda: w1.detach().t().to(_h()).contiguous(), M))
