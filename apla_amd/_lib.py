@@ -5,7 +5,7 @@ returns an error, an exception is raised.  Nothing here imports the CPU oracle.
 """
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_long, c_uint, c_ulonglong, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int, c_long, c_uint, c_ulonglong, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 # bf16 operands (default).  APLA_LIB=<path> substitutes another build of the library (tools/build_ablations.sh: A/B timing)
@@ -97,6 +97,7 @@ SIGNATURES = {
                                             c_int, c_void_p]),
     "apla_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_float, c_float, c_float,
                                 c_float, c_float, c_int, c_float, c_float, c_void_p, c_void_p]),
+    "apla_ema_update": (c_int, [c_void_p, c_void_p, c_long, c_double, c_void_p]),
     "apla_grad_sumsq": (c_int, [c_void_p, c_long, c_float, c_void_p, c_void_p]),
     "apla_adamw_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_float, c_float, c_float,
                                  c_float, c_float, c_int, c_float, c_float, c_void_p, c_void_p]),
@@ -116,7 +117,10 @@ SIGNATURES = {
     "apla_assemble_tokens": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                      c_void_p]),
     "apla_weight_norm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "apla_weight_norm_fwd_t": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "apla_weight_norm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "apla_koleo_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "apla_koleo_bwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "apla_dropout_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_long, c_float, c_ulonglong, c_ulonglong, c_void_p]),
     "apla_dropout_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_long, c_float, c_void_p]),
     "apla_scale_samples": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_long, c_long, c_void_p]),

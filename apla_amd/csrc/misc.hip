@@ -934,12 +934,254 @@ extern "C" int apla_weight_norm_fwd(const float* v, const float* g, void* w_h16,
   return APLA_OK;
 }
 
+// The same with W^T [D, K] written beside W (the dX GEMM of the prototype layer reads W through its transposed copy; torch's
+// .t().contiguous() of the [65 536, 256] matrix takes 73 us per iteration, this kernel's extra store ~10): a workgroup takes 64 rows,
+// one wave per row as above with the 16-bit row also kept in LDS, then the tile leaves column by column in 128-byte runs of 64 rows.
+__global__ __launch_bounds__(256) void weight_norm_fwd_t_kernel(const float* __restrict__ v, const float* __restrict__ g, bf16* __restrict__ w,
+                                                                bf16* __restrict__ wt, float* __restrict__ norm, int K, int D) {
+  extern __shared__ bf16 s_tile[];   // [64][D + 8]: rows 16 bytes apart modulo the banks
+  const int ldt = D + 8, r0 = blockIdx.x * 64, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int rr = wave; rr < 64; rr += 4) {
+    const int row = r0 + rr;
+    const float* vr = v + (size_t)row * D;
+    float ss = 0.f;
+    for (int c = lane * 4; c < D; c += 256) {
+      const f32x4 a = *(const f32x4*)(vr + c);
+      ss += a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3];
+    }
+    const float n = sqrtf(wave_sum(ss));
+    const float sc = g[row] / n;
+    for (int c = lane * 4; c < D; c += 256) {
+      const f32x4 a = *(const f32x4*)(vr + c) * sc;
+      const bf16x4 h = pack4(a[0], a[1], a[2], a[3]);
+      *(bf16x4*)(w + (size_t)row * D + c) = h;
+      *(bf16x4*)(s_tile + rr * ldt + c) = h;
+    }
+    if (lane == 0) norm[row] = n;
+  }
+  __syncthreads();
+  const int sub = threadIdx.x & 7;   // 8 threads per column: rows sub * 8 .. sub * 8 + 7
+  for (int c = threadIdx.x >> 3; c < D; c += 32) {
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = s_tile[(sub * 8 + e) * ldt + c];
+    *(bf16x8*)(wt + (size_t)c * K + r0 + sub * 8) = o;
+  }
+}
+
+extern "C" int apla_weight_norm_fwd_t(const float* v, const float* g, void* w_h16, void* wt_h16, float* norm, int K, int D, hipStream_t stream) {
+  if (wt_h16 == nullptr) return apla_weight_norm_fwd(v, g, w_h16, norm, K, D, stream);
+  APLA_REQUIRE(v && g && w_h16 && norm && K > 0 && K % 64 == 0 && D > 0 && D % 4 == 0 && D <= 1024,
+               "apla_weight_norm_fwd_t: need K %% 64 == 0, D %% 4 == 0, D <= 1024 (K=%d D=%d)", K, D);
+  APLA_REQUIRE(apla_aligned16(v) && apla_aligned16(w_h16) && apla_aligned16(wt_h16), "apla_weight_norm_fwd_t: pointers must be 16-byte aligned");
+  hipLaunchKernelGGL(weight_norm_fwd_t_kernel, dim3(K / 64), dim3(256), (size_t)64 * (D + 8) * 2, stream, v, g, (bf16*)w_h16, (bf16*)wt_h16,
+                     norm, K, D);
+  APLA_CHECK_LAUNCH("apla_weight_norm_fwd_t");
+  return APLA_OK;
+}
+
 extern "C" int apla_weight_norm_bwd(const float* dw, const float* v, const float* g, const float* norm, float* dv, float* dg, int K, int D,
                                     hipStream_t stream) {
   APLA_REQUIRE(dw && v && g && norm && dv && K > 0 && D > 0 && D % 4 == 0, "apla_weight_norm_bwd: need D %% 4 == 0 (K=%d D=%d)", K, D);
   APLA_REQUIRE(apla_aligned16(dw) && apla_aligned16(v) && apla_aligned16(dv), "apla_weight_norm_bwd: pointers must be 16-byte aligned");
   hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3((K + 3) / 4), dim3(256), 0, stream, dw, v, g, norm, dv, dg, K, D);
   APLA_CHECK_LAUNCH("apla_weight_norm_bwd");
+  return APLA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ KoLeo regulariser
+// KoLeoLoss (self_supervised/dinov2/loss/koleo_loss.py:17-45) of G groups of B rows (the two global crops, models.py:410-413), fp32:
+//   xn = x / max(||x||, eps);  j(i) = argmax_{j != i} xn_i . xn_j (within the group);  d_i = ||xn_i - xn_j(i) + 1e-8||;
+//   loss_g = -mean_i log(d_i + eps);  out[g] = loss_g, out[G] = sum_g loss_g.
+// torch runs ~30 small kernels per group forward and as many backward (a [B, B] product, a diagonal fill, a max, a gather, the pairwise
+// distance, the log and the mean: 0.3 ms of a 42 ms iteration at 4 us each); here one workgroup per row does the row's search and its
+// distance, the last workgroup to finish adds the terms in a fixed order (a ticket in `counter`, which it resets), and one backward
+// launch turns d(out[G]) into dx: the gradient of row i collects its own term and those of the rows whose neighbour it is, then goes
+// through the normalisation.
+// The neighbour is the row at the smallest ||xn_i - xn_j||^2, taken directly: for unit vectors that IS the largest inner product the
+// reference searches (d^2 = 2 - 2 xn_i . xn_j), but it keeps its meaning when the rows of a group nearly coincide — CLS tokens at
+// initialisation sit 1e-4 apart, their fp32 inner products all round to 1 - {0, 1} ulp, and the reference's argmax then follows the
+// rounding of its GEMM, not the geometry (no two implementations of that product agree there; away from that regime the choice is the same).
+// (A row whose norm is under eps stays shorter than 1 after the division; its distance is corrected by 1 - ||xn_j||^2 so that the
+// order is still the order of the inner products.)
+// sum of squares of one row, one wave, the same roundings at every call site (a row's norm is taken in several places and must be ONE value)
+template <typename T>
+__device__ __forceinline__ float koleo_row_ss(const T* __restrict__ p, int D, int lane) {
+#pragma clang fp contract(off)
+  float ss = 0.f;
+  for (int c = lane * 4; c < D; c += 256) {
+    const f32x4 a = Vec4IO<T>::load(p + c);
+    ss = ss + a[0] * a[0];
+    ss = ss + a[1] * a[1];
+    ss = ss + a[2] * a[2];
+    ss = ss + a[3] * a[3];
+  }
+  return wave_sum(ss);
+}
+
+// xn_i - xn_j with each product rounded on its own (no fma contraction: identical rows must give exactly 0, as torch's separate passes do)
+__device__ __forceinline__ f32x4 koleo_diff(f32x4 a, float ia, f32x4 b, float ib) {
+#pragma clang fp contract(off)   // (hip's __fmul_rn / __fsub_rn are plain operators: they would still contract into one fma)
+  const f32x4 pa = a * ia, pb = b * ib;
+  return pa - pb;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void koleo_fwd_kernel(const T* __restrict__ x, int G, int B, int D, float eps, int* __restrict__ nn_idx,
+                                                        float* __restrict__ dist, float* __restrict__ nrm, float* __restrict__ terms,
+                                                        float* __restrict__ out, int* __restrict__ counter) {
+  __shared__ float s_val[4];
+  __shared__ int s_idx[4];
+  __shared__ float s_red[4];
+  __shared__ int s_last;
+  const int row = blockIdx.x, g = row / B, i = row - g * B, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const T* xg = x + (size_t)g * B * D;
+  const T* xi = xg + (size_t)i * D;
+  const float ni = __fsqrt_rn(koleo_row_ss(xi, D, lane)), inv_i = __frcp_rn(fmaxf(ni, eps));   // (explicitly rounded: no rsqrt fusion)
+  float best = 3.4e38f;
+  int bj = (i == 0 && B > 1) ? 1 : 0;
+  for (int j = wave; j < B; j += 4) {
+    if (j == i) continue;
+    const T* xj = xg + (size_t)j * D;
+    const float ssj = koleo_row_ss(xj, D, lane), nj = __fsqrt_rn(ssj), inv_j = __frcp_rn(fmaxf(nj, eps));
+    float q = 0.f;
+    for (int c = lane * 4; c < D; c += 256) {
+      const f32x4 t = koleo_diff(Vec4IO<T>::load(xi + c), inv_i, Vec4IO<T>::load(xj + c), inv_j);
+      q += t[0] * t[0] + t[1] * t[1] + t[2] * t[2] + t[3] * t[3];
+    }
+    q = wave_sum(q);
+    if (!(nj > eps)) q += 1.f - ssj * inv_j * inv_j;   // a row under the clamp is not a unit vector: rank it by its inner product all the same
+    if (q < best) { best = q; bj = j; }    // ascending j within the wave: the first minimum stays
+  }
+  if (lane == 0) { s_val[wave] = best; s_idx[wave] = bj; }
+  __syncthreads();
+  best = s_val[0]; bj = s_idx[0];
+#pragma unroll
+  for (int w = 1; w < 4; ++w)
+    if (s_val[w] < best || (s_val[w] == best && s_idx[w] < bj)) { best = s_val[w]; bj = s_idx[w]; }
+  if (B == 1) bj = 0;   // torch.max over the one-element row [-1] picks the row itself
+  const T* xj = xg + (size_t)bj * D;
+  const float inv_j = __frcp_rn(fmaxf(__fsqrt_rn(koleo_row_ss(xj, D, lane)), eps));
+  float d2 = 0.f;
+  for (int c = threadIdx.x * 4; c < D; c += 1024) {
+    const f32x4 df = koleo_diff(Vec4IO<T>::load(xi + c), inv_i, Vec4IO<T>::load(xj + c), inv_j);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float t = __fadd_rn(df[e], 1e-8f);    // nn.PairwiseDistance adds its eps to the difference
+      d2 += t * t;
+    }
+  }
+  d2 = wave_sum(d2);
+  if (lane == 0) s_red[wave] = d2;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float d = sqrtf(s_red[0] + s_red[1] + s_red[2] + s_red[3]);
+    nn_idx[row] = bj;
+    dist[row] = d;
+    nrm[row] = ni;
+    terms[row] = -logf(d + eps);
+    __threadfence();
+    s_last = atomicAdd(counter, 1) == (int)gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  if (wave == 0) {   // the last workgroup: every term is written; one wave adds them group by group in a fixed order
+    const volatile float* tv = terms;
+    float total = 0.f;
+    for (int gg = 0; gg < G; ++gg) {
+      float a = 0.f;
+      for (int r = lane; r < B; r += 64) a += tv[gg * B + r];
+      a = wave_sum(a) / (float)B;
+      if (lane == 0) out[gg] = a;
+      total += a;
+    }
+    if (lane == 0) { out[G] = total; *counter = 0; }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void koleo_bwd_kernel(const T* __restrict__ x, int B, int D, float eps, const int* __restrict__ nn_idx,
+                                                        const float* __restrict__ dist, const float* __restrict__ nrm,
+                                                        const float* __restrict__ gout, T* __restrict__ dx) {
+#pragma clang fp contract(off)       // each term rounded on its own: a row that is its own neighbour (B == 1) must get exactly 0, as in torch
+  extern __shared__ float s_dyn[];   // per row of the group: coefficient -g / (B (d + eps) d), 1 / max(n, eps); then the neighbour index
+  float* s_coef = s_dyn;
+  float* s_inv = s_dyn + B;
+  int* s_nn = (int*)(s_dyn + 2 * B);
+  __shared__ float s_red[4];
+  const int row = blockIdx.x, g = row / B, i = row - g * B, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const float go = gout[0];
+  for (int r = threadIdx.x; r < B; r += 256) {
+    const float d = dist[g * B + r];
+    s_coef[r] = -go / ((float)B * (d + eps) * d);
+    s_inv[r] = __frcp_rn(fmaxf(nrm[g * B + r], eps));
+    s_nn[r] = nn_idx[g * B + r];
+  }
+  __syncthreads();
+  const T* xg = x + (size_t)g * B * D;
+  const T* xi = xg + (size_t)i * D;
+  const float inv_i = s_inv[i], ni = nrm[row];
+  f32x4 acc[4];   // d(loss) / d(xn_i), D <= 4096
+  float dot = 0.f;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int c = threadIdx.x * 4 + m * 1024;
+    acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (c >= D) continue;
+    const f32x4 xa = Vec4IO<T>::load(xi + c);
+    const f32x4 a = xa * inv_i;
+    {
+      const int j = s_nn[i];
+      const f32x4 df = koleo_diff(xa, inv_i, Vec4IO<T>::load(xg + (size_t)j * D + c), s_inv[j]);
+      acc[m] += (df + 1e-8f) * s_coef[i];
+    }
+    for (int k = 0; k < B; ++k) {
+      if (s_nn[k] != i) continue;   // (k == i only when B == 1: the two terms of the row cancel, as in torch)
+      const f32x4 df = koleo_diff(Vec4IO<T>::load(xg + (size_t)k * D + c), s_inv[k], xa, inv_i);
+      acc[m] -= (df + 1e-8f) * s_coef[k];
+    }
+    dot += acc[m][0] * a[0] + acc[m][1] * a[1] + acc[m][2] * a[2] + acc[m][3] * a[3];
+  }
+  dot = wave_sum(dot);
+  if (lane == 0) s_red[wave] = dot;
+  __syncthreads();
+  dot = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+  const bool clamped = !(ni > eps);     // F.normalize divides by clamp_min(n, eps): no gradient through a clamped norm
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int c = threadIdx.x * 4 + m * 1024;
+    if (c >= D) continue;
+    const f32x4 a = Vec4IO<T>::load(xi + c) * inv_i;
+    Vec4IO<T>::store(dx + (size_t)row * D + c, clamped ? acc[m] * inv_i : (acc[m] - a * dot) * inv_i);
+  }
+}
+
+extern "C" int apla_koleo_fwd(const void* x, int dtype, int G, int B, int D, float eps, int* nn_idx, float* dist, float* nrm, float* terms,
+                              float* out, int* counter, hipStream_t stream) {
+  APLA_REQUIRE(x && nn_idx && dist && nrm && terms && out && counter && G > 0 && B > 0 && D > 0 && D % 4 == 0 && (long)G * B <= (1 << 20),
+               "apla_koleo_fwd: need G, B > 0 and D %% 4 == 0 (G=%d B=%d D=%d)", G, B, D);
+  APLA_REQUIRE((((uintptr_t)x) & 15) == 0 && (dtype == APLA_F32 || dtype == APLA_H16), "apla_koleo_fwd: x fp32 or the build's 16-bit type, 16-byte aligned");
+  if (dtype == APLA_F32)
+    hipLaunchKernelGGL(koleo_fwd_kernel<float>, dim3(G * B), dim3(256), 0, stream, (const float*)x, G, B, D, eps, nn_idx, dist, nrm, terms, out, counter);
+  else
+    hipLaunchKernelGGL(koleo_fwd_kernel<bf16>, dim3(G * B), dim3(256), 0, stream, (const bf16*)x, G, B, D, eps, nn_idx, dist, nrm, terms, out, counter);
+  APLA_CHECK_LAUNCH("apla_koleo_fwd");
+  return APLA_OK;
+}
+
+extern "C" int apla_koleo_bwd(const void* x, int dtype, int G, int B, int D, float eps, const int* nn_idx, const float* dist, const float* nrm,
+                              const float* gout, void* dx, hipStream_t stream) {
+  APLA_REQUIRE(x && nn_idx && dist && nrm && gout && dx && G > 0 && B > 0 && B <= 4096 && D > 0 && D % 4 == 0 && D <= 4096,
+               "apla_koleo_bwd: need G > 0, 0 < B <= 4096, D %% 4 == 0, D <= 4096 (G=%d B=%d D=%d)", G, B, D);
+  APLA_REQUIRE((((uintptr_t)x) & 15) == 0 && (((uintptr_t)dx) & 15) == 0 && (dtype == APLA_F32 || dtype == APLA_H16),
+               "apla_koleo_bwd: x / dx fp32 or the build's 16-bit type, 16-byte aligned");
+  const size_t lds = (size_t)B * 12;
+  if (dtype == APLA_F32)
+    hipLaunchKernelGGL(koleo_bwd_kernel<float>, dim3(G * B), dim3(256), lds, stream, (const float*)x, B, D, eps, nn_idx, dist, nrm, gout, (float*)dx);
+  else
+    hipLaunchKernelGGL(koleo_bwd_kernel<bf16>, dim3(G * B), dim3(256), lds, stream, (const bf16*)x, B, D, eps, nn_idx, dist, nrm, gout, (bf16*)dx);
+  APLA_CHECK_LAUNCH("apla_koleo_bwd");
   return APLA_OK;
 }
 

@@ -225,3 +225,31 @@ extern "C" int apla_adamw_step(float* params, float* grads, float* exp_avg, floa
   APLA_CHECK_LAUNCH("apla_adamw_step[update]");
   return APLA_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ EMA teacher
+// teacher = m * teacher + (1 - m) * student over one flat range (self_supervised/dinov2/models.py:443-453 runs torch._foreach_mul_ then
+// torch._foreach_add_(alpha = 1 - m) over the parameter lists: two passes over the teacher, 126 us at config 4; one pass here).  The
+// rounding is theirs: the product t * m rounded to fp32 (the first pass stores it), then one fused multiply-add with the student.
+__global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ t, const float* __restrict__ s, long n, float m, float om) {
+  const long stride = (long)gridDim.x * 1024;
+  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+    if (i + 4 <= n) {
+      f32x4 a = *(const f32x4*)(t + i);
+      const f32x4 b = *(const f32x4*)(s + i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[e] = __fmaf_rn(b[e], om, __fmul_rn(a[e], m));
+      *(f32x4*)(t + i) = a;
+    } else {
+      for (long k = i; k < n; ++k) t[k] = __fmaf_rn(s[k], om, __fmul_rn(t[k], m));
+    }
+  }
+}
+
+extern "C" int apla_ema_update(float* teacher, const float* student, long n, double m, hipStream_t stream) {
+  APLA_REQUIRE(teacher && student && n > 0 && apla_aligned16(teacher) && apla_aligned16(student), "apla_ema_update: two 16-byte aligned fp32 ranges expected");
+  long blocks = (n + 1023) / 1024;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(ema_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, teacher, student, n, (float)m, (float)(1.0 - m));   // torch casts the two Python scalars m and 1 - m
+  APLA_CHECK_LAUNCH("apla_ema_update");
+  return APLA_OK;
+}

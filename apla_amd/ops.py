@@ -865,14 +865,20 @@ def assemble_tokens(patches: torch.Tensor, cls_token: torch.Tensor, pos: torch.T
     return out
 
 
-def weight_norm_fwd(v: torch.Tensor, g: torch.Tensor):
-    """(W 16-bit [K, D], row norms fp32 [K]) of torch.nn.utils.weight_norm(dim=0): W = v * g / ||v|| (include/apla_hip.h)."""
+def weight_norm_fwd(v: torch.Tensor, g: torch.Tensor, transposed: bool = False):
+    """(W 16-bit [K, D], row norms fp32 [K]) of torch.nn.utils.weight_norm(dim=0): W = v * g / ||v|| (include/apla_hip.h); with
+    ``transposed`` (W, norms, W^T 16-bit [D, K]) from the same launch where the kernel covers it (K % 64 == 0, D <= 1024; else W^T is None)."""
     _req(v, torch.float32, "v", 2), _req(g, torch.float32, "g")
     K, D = v.shape
     if not v.is_contiguous() or g.numel() != K or not g.is_contiguous() or D % 4:
         raise ValueError("weight_norm_fwd: contiguous v [K, D] with D % 4 == 0 and g with K entries expected")
     w = torch.empty(K, D, device=v.device, dtype=half())
     norm = torch.empty(K, device=v.device, dtype=torch.float32)
+    if transposed:
+        wt = torch.empty(D, K, device=v.device, dtype=half()) if K % 64 == 0 and D <= 1024 else None
+        check(lib().apla_weight_norm_fwd_t(v.data_ptr(), g.data_ptr(), w.data_ptr(), _ptr(wt), norm.data_ptr(), K, D, _stream()),
+              "apla_weight_norm_fwd_t")
+        return w, norm, wt
     check(lib().apla_weight_norm_fwd(v.data_ptr(), g.data_ptr(), w.data_ptr(), norm.data_ptr(), K, D, _stream()), "apla_weight_norm_fwd")
     return w, norm
 
@@ -888,6 +894,50 @@ def weight_norm_bwd(dw: torch.Tensor, v: torch.Tensor, g: torch.Tensor, norm: to
     check(lib().apla_weight_norm_bwd(dw.data_ptr(), v.data_ptr(), g.data_ptr(), norm.data_ptr(), dv.data_ptr(), _ptr(dg), K, D, _stream()),
           "apla_weight_norm_bwd")
     return dv, dg
+
+
+def ema_update(teacher: torch.Tensor, student: torch.Tensor, m: float):
+    """teacher = m * teacher + (1 - m) * student in place over two flat fp32 buffers (include/apla_hip.h:apla_ema_update)."""
+    _req(teacher, torch.float32, "teacher", 1), _req(student, torch.float32, "student", 1)
+    if teacher.numel() != student.numel() or not (teacher.is_contiguous() and student.is_contiguous()):
+        raise ValueError("ema_update: two contiguous flat buffers of one size expected")
+    check(lib().apla_ema_update(teacher.data_ptr(), student.data_ptr(), teacher.numel(), float(m), _stream()), "apla_ema_update")
+    return teacher
+
+
+_KOLEO_TICKET = {}   # device index -> the int32 ticket of apla_koleo_fwd (0 between launches; launches of one device are stream-ordered)
+
+
+def koleo_fwd(x: torch.Tensor, groups: int, eps: float = 1e-8):
+    """KoLeoLoss of ``groups`` equal groups of rows of x [G*B, D] (fp32 or the build's 16-bit type): (out fp32 [G + 1] — the group losses
+    and their sum —, saved = (nn_idx, dist, nrm)) — include/apla_hip.h:apla_koleo_fwd."""
+    _req(x, None, "x", 2)
+    R, D = x.shape
+    if x.dtype not in (torch.float32, half()) or not x.is_contiguous() or groups <= 0 or R % groups or D % 4 or R == 0:
+        raise ValueError("koleo_fwd: contiguous x [G*B, D] (fp32 or the build's 16-bit type) with D % 4 == 0 expected")
+    dev = x.device
+    ticket = _KOLEO_TICKET.get(dev.index)
+    if ticket is None:
+        ticket = _KOLEO_TICKET[dev.index] = torch.zeros(1, device=dev, dtype=torch.int32)
+    nn_idx = torch.empty(R, device=dev, dtype=torch.int32)
+    f = torch.empty(3, R, device=dev, dtype=torch.float32)    # dist, nrm, terms
+    out = torch.empty(groups + 1, device=dev, dtype=torch.float32)
+    check(lib().apla_koleo_fwd(x.data_ptr(), _DT[x.dtype], groups, R // groups, D, eps, nn_idx.data_ptr(), f[0].data_ptr(), f[1].data_ptr(),
+                               f[2].data_ptr(), out.data_ptr(), ticket.data_ptr(), _stream()), "apla_koleo_fwd")
+    return out, (nn_idx, f[0], f[1])
+
+
+def koleo_bwd(x: torch.Tensor, groups: int, saved, gout: torch.Tensor, eps: float = 1e-8):
+    """dx (x's type) = gout * d(sum of the group losses) / dx; ``gout``: one fp32 element on the device."""
+    nn_idx, dist, nrm = saved
+    _req(gout, torch.float32, "gout")
+    R, D = x.shape
+    if gout.numel() != 1 or nn_idx.numel() != R:
+        raise ValueError("koleo_bwd: one gradient element and the saved tensors of koleo_fwd expected")
+    dx = torch.empty_like(x)
+    check(lib().apla_koleo_bwd(x.data_ptr(), _DT[x.dtype], groups, R // groups, D, eps, nn_idx.data_ptr(), dist.data_ptr(), nrm.data_ptr(),
+                               gout.data_ptr(), dx.data_ptr(), _stream()), "apla_koleo_bwd")
+    return dx
 
 
 def dropout_fwd(x: torch.Tensor, p: float, seed: int, offset: int = 0, *, out: Optional[torch.Tensor] = None, keep: Optional[torch.Tensor] = None):

@@ -6,7 +6,8 @@
   three MLP layers and the [K, 256] prototype gradient (the few thousand token rows are its reduction axis) on the TN MFMA kernel
   (`apla_proj_dw`: dW = dy^T x with fp32 accumulation; round 1 ran the prototype gradient as an fp32 vendor GEMM, 1.3 ms per
   iteration).
-* ``KoLeoLoss`` — dinov2/loss/koleo_loss.py:17-45 (a [B, B] nearest-neighbour search on the CLS tokens: torch ops, fp32).
+* ``KoLeoLoss`` — dinov2/loss/koleo_loss.py:17-45 (a nearest-neighbour search among the CLS tokens of one crop, fp32): one HIP launch
+  forward, one backward (`apla_koleo_fwd` / `apla_koleo_bwd`), both crops of models.py:410-413 in the same launch.
 * ``update_teacher`` — dinov2/models.py:443-453: teacher = m * teacher + (1 - m) * student over the trainable tensors.
 """
 import torch
@@ -17,12 +18,15 @@ from .. import functional as AF
 from .. import ops
 
 
-def _normed_weight(v, g):
-    """(W 16-bit, row norms | None) of the weight-normalised prototype layer: one kernel (apla_weight_norm_fwd) where it applies."""
+def _normed_weight(v, g, transposed=False):
+    """(W 16-bit, row norms | None, W^T 16-bit | None) of the weight-normalised prototype layer: one kernel (apla_weight_norm_fwd[_t])
+    where it applies.  W^T is what the dX GEMM reads; without it the backward transposes W itself."""
     if v.is_cuda and v.dtype == torch.float32 and v.ndim == 2 and v.shape[1] % 4 == 0 and v.is_contiguous():
-        return ops.weight_norm_fwd(v.detach(), g.detach().reshape(-1).contiguous())
+        if transposed:
+            return ops.weight_norm_fwd(v.detach(), g.detach().reshape(-1).contiguous(), transposed=True)
+        return (*ops.weight_norm_fwd(v.detach(), g.detach().reshape(-1).contiguous()), None)
     W = v.detach() * (g.detach() / v.detach().norm(dim=1, keepdim=True))
-    return W.to(ops.half()).contiguous(), None
+    return W.to(ops.half()).contiguous(), None, None
 
 
 def _normed_weight_grads(dW, v, g, norm, need_v, need_g):
@@ -43,19 +47,20 @@ class _ProtoLinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, v, g):
         x2 = AF._as2d_bf16(x)
-        Wh, norm = _normed_weight(v, g)
+        Wh, norm, WhT = _normed_weight(v, g, transposed=x.requires_grad)
         y = ops.gemm_nt(x2, Wh)
-        ctx.save_for_backward(x2, Wh, v, g, norm)
+        ctx.save_for_backward(x2, Wh, v, g, norm, WhT)
         ctx.shape = x.shape
         return y.reshape(*x.shape[:-1], Wh.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
-        x2, Wh, v, g, norm = ctx.saved_tensors
+        x2, Wh, v, g, norm, WhT = ctx.saved_tensors
         dy2 = AF._as2d_bf16(dy)
         dx = dv = dg = None
         if ctx.needs_input_grad[0]:   # [rows, 256] = dy [rows, K] W [K, 256]: 35 tiles with a 65 536-long reduction -> split along K
-            WhT = Wh.t().contiguous()
+            if WhT is None:
+                WhT = Wh.t().contiguous()
             gemm = ops.gemm_nt_splitk if ops.gemm_splitk_wanted(dy2.shape[0], WhT.shape[0], WhT.shape[1]) else ops.gemm_nt
             dx = gemm(dy2, WhT).reshape(ctx.shape)
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
@@ -85,7 +90,7 @@ class _ProtoLosses(torch.autograd.Function):
         from .losses import _PRESCALE, launch_distill_ce
         P = _PRESCALE
         x2 = AF._as2d_bf16(x)
-        Wh, norm = _normed_weight(v, g)
+        Wh, norm, WhT = _normed_weight(v, g, transposed=x.requires_grad)
         y = ops.gemm_nt(x2, Wh)
         rows, K = y.shape
         need = x.requires_grad or v.requires_grad or g.requires_grad
@@ -103,19 +108,20 @@ class _ProtoLosses(torch.autograd.Function):
             covered = b
         if need and covered < rows:
             dy[covered:].zero_()
-        ctx.save_for_backward(x2, Wh, dy, _row_term_index(rows, tuple(spans), y.device), v, g, norm)
+        ctx.save_for_backward(x2, Wh, dy, _row_term_index(rows, tuple(spans), y.device), v, g, norm, WhT)
         ctx.meta = (x.shape, P)
         res = torch.stack([o if torch.is_tensor(o) else y.new_zeros((), dtype=torch.float32) for o in out])
         return res if P == 1.0 else res / P
 
     @staticmethod
     def backward(ctx, gout):
-        x2, Wh, dy, idx, v, g, norm = ctx.saved_tensors
+        x2, Wh, dy, idx, v, g, norm, WhT = ctx.saved_tensors
         shape, P = ctx.meta
         r = (gout if P == 1.0 else gout / P).float().index_select(0, idx).unsqueeze(1)   # [rows, 1]: the upstream scalar of each row's term
         dx = dv = dg = None
         if ctx.needs_input_grad[0]:   # [rows, 256] = dy [rows, K] W [K, 256]: a 65 536-long reduction -> split along K
-            WhT = Wh.t().contiguous()
+            if WhT is None:
+                WhT = Wh.t().contiguous()
             gemm = ops.gemm_nt_splitk if ops.gemm_splitk_wanted(dy.shape[0], WhT.shape[0], WhT.shape[1]) else ops.gemm_nt
             dx = (gemm(dy, WhT).float() * r).reshape(shape)
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
@@ -197,24 +203,36 @@ class DINOHead(nn.Module):
         return _ProtoLinear.apply(self.bottleneck(x), self.last_layer.weight_v, self.last_layer.weight_g)
 
 
+class _KoLeoFn(torch.autograd.Function):
+    """Sum over `groups` equal row groups of KoLeoLoss: apla_koleo_fwd / apla_koleo_bwd, one launch each."""
+
+    @staticmethod
+    def forward(ctx, x, groups, eps):
+        x = x.contiguous()
+        out, saved = ops.koleo_fwd(x, groups, eps)
+        ctx.save_for_backward(x, *saved)
+        ctx.groups, ctx.eps = groups, eps
+        return out[groups]
+
+    @staticmethod
+    def backward(ctx, g):
+        x, *saved = ctx.saved_tensors
+        return ops.koleo_bwd(x, ctx.groups, saved, g.float().reshape(1), ctx.eps), None, None
+
+
 class KoLeoLoss(nn.Module):
-    """Kozachenko-Leonenko entropic regulariser (Sablayrolles et al. 2018), koleo_loss.py:17-45."""
+    """Kozachenko-Leonenko entropic regulariser (Sablayrolles et al. 2018), koleo_loss.py:17-45: normalise, nearest other row by inner
+    product, -mean log of the distance to it.  On the GPU one HIP launch forward and one backward (apla_koleo_fwd: torch runs ~60 small
+    kernels for the two crops of an iteration); ``grouped(x, n)`` = sum(self(c) for c in x.chunk(n)) as models.py:410-413 calls it."""
 
-    def __init__(self):
-        super().__init__()
-        self.pdist = nn.PairwiseDistance(2, eps=1e-8)
-
-    def pairwise_NNs_inner(self, x):
-        dots = torch.mm(x, x.t())
-        n = x.shape[0]
-        dots.view(-1)[:: (n + 1)].fill_(-1)
-        return torch.max(dots, dim=1)[1]
+    def grouped(self, student_output, groups: int, eps=1e-8):
+        if student_output.shape[0] % groups:
+            raise ValueError("KoLeoLoss.grouped: the rows do not split into equal groups")
+        x = student_output if student_output.dtype in (torch.float32, ops.half()) else student_output.float()
+        return _KoLeoFn.apply(x, groups, eps)
 
     def forward(self, student_output, eps=1e-8):
-        x = F.normalize(student_output.float(), eps=eps, p=2, dim=-1)
-        with torch.no_grad():
-            idx = self.pairwise_NNs_inner(x.detach().clone())
-        return -torch.log(self.pdist(x, x[idx]) + eps).mean()
+        return self.grouped(student_output, 1, eps)
 
 
 @torch.no_grad()

@@ -20,6 +20,7 @@ from functools import partial
 import torch
 from torch import nn
 
+from .. import ops
 from ..apla import build_apla
 from ..models import AttrDict
 from .backbone import DinoVisionTransformer
@@ -214,7 +215,7 @@ class DINOv2(nn.Module):
             loss_dict["dino_global_crops_loss"] = l
             total = total + self.dino_loss_weight * l
             if self.do_koleo:
-                kl = self.model_params.dinov2.dino.koleo_loss_weight * sum(self.koleo_loss(p) for p in s_glob_cls.chunk(2))
+                kl = self.model_params.dinov2.dino.koleo_loss_weight * self.koleo_loss.grouped(s_glob_cls, 2)
                 total = total + kl
                 loss_dict["koleo_loss"] = kl / loss_scales
             l = sums[2] * loss_scales * (1.0 / n_global)
@@ -235,7 +236,7 @@ class DINOv2(nn.Module):
             loss_dict["dino_global_crops_loss"] = l
             total = total + self.dino_loss_weight * l
             if self.do_koleo:   # per global crop: never between two views of one image
-                kl = self.model_params.dinov2.dino.koleo_loss_weight * sum(self.koleo_loss(p) for p in s_glob_cls.chunk(2))
+                kl = self.model_params.dinov2.dino.koleo_loss_weight * self.koleo_loss.grouped(s_glob_cls, 2)
                 total = total + kl
                 loss_dict["koleo_loss"] = kl / loss_scales
         if do_ibot:
@@ -245,17 +246,43 @@ class DINOv2(nn.Module):
             total = total + self.ibot_loss_weight * l
         return total, loss_dict
 
+    def _ema_pairs(self):
+        return [(ps, pt) for k in self.student.keys() for ps, pt in zip(self.student[k].parameters(), self.teacher[k].parameters())
+                if ps.requires_grad]
+
+    @torch.no_grad()
+    def flatten_teacher(self, optimizer) -> bool:
+        """Move the teacher's copies of the tensors ``optimizer`` (a FlatAdamW over the student) updates into ONE flat fp32 buffer laid
+        out like ``optimizer.flat``; ``update_teacher`` is then one launch over the two buffers (apla_ema_update) instead of two
+        torch._foreach passes over ~100 tensors.  False (nothing changed) if the two parameter lists do not line up."""
+        pairs = self._ema_pairs()
+        if (len(pairs) != len(optimizer.params) or any(a is not b for (a, _), b in zip(pairs, optimizer.params))
+                or any(pt.dtype != torch.float32 or pt.shape != ps.shape or pt.device != ps.device for ps, pt in pairs)):
+            return False
+        flat = torch.empty_like(optimizer.flat)
+        for (_, pt), a, b in zip(pairs, optimizer.offsets[:-1], optimizer.offsets[1:]):
+            flat[a:b].copy_(pt.detach().reshape(-1))
+            pt.data = flat[a:b].view(pt.shape)
+        self._ema_flat = (flat, optimizer.flat, list(optimizer.offsets), [pt for _, pt in pairs], [ps for ps, _ in pairs])
+        return True
+
     @torch.no_grad()
     def update_teacher(self, m):
         """teacher = m * teacher + (1 - m) * student (models.py:443-453).  The reference walks every parameter; frozen
         tensors are identical in both networks, so only the trainable ones are touched here (same result, and the frozen
-        copies stay bit-identical instead of collecting rounding noise)."""
-        t_list, s_list = [], []
-        for k in self.student.keys():
-            for ps, pt in zip(self.student[k].parameters(), self.teacher[k].parameters()):
-                if ps.requires_grad:
-                    t_list.append(pt)
-                    s_list.append(ps.detach())
+        copies stay bit-identical instead of collecting rounding noise).  After ``flatten_teacher`` one kernel does it."""
+        bound = getattr(self, "_ema_flat", None)
+        if bound is not None:
+            t_flat, s_flat, offs, t_params, s_params = bound
+            tb, sb = t_flat.data_ptr(), s_flat.data_ptr()
+            if all(pt.data_ptr() == tb + 4 * a and ps.data_ptr() == sb + 4 * a for pt, ps, a in zip(t_params, s_params, offs)):
+                ops.ema_update(t_flat, s_flat, m)
+                for pt in t_params:      # written through a raw pointer: the 16-bit weight caches key on the tensor version
+                    torch.autograd.graph.increment_version(pt)
+                return len(t_params)
+            self._ema_flat = None        # someone re-homed a tensor (load_state_dict(assign=True), .to(...)): back to the lists
+        pairs = self._ema_pairs()
+        t_list, s_list = [pt for _, pt in pairs], [ps.detach() for ps, _ in pairs]
         torch._foreach_mul_(t_list, m)
         torch._foreach_add_(t_list, s_list, alpha=1 - m)
         return len(t_list)

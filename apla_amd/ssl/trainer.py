@@ -54,6 +54,7 @@ class Dinov2Trainer:
             warmup_teacher_temp_epochs=warmup_teacher_temp_epochs, freeze_last_layer_epochs=freeze_last_layer_epochs,
             iters_per_epoch=iters_per_epoch, total_iters=self.total_iters)
         self.optimizer = FlatAdamW(model.student.named_parameters(), lr=lr, weight_decay=weight_decay)
+        model.flatten_teacher(self.optimizer)    # the EMA as one launch over two flat buffers (models.update_teacher)
         self.pg = process_group
         self.world = GradExchanger.world_of(process_group)
         self._setup_exchange(exchange_chunk_mb, force_exchange)

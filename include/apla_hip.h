@@ -376,6 +376,11 @@ int apla_adamw_apply(float* params, float* grads, float* exp_avg, float* exp_avg
                      long n, float lr, float weight_decay, float beta1, float beta2, float eps, int step,
                      float max_norm, float grad_scale, float* norm_ws, hipStream_t stream);
 
+/* The EMA teacher of the self-supervised step (self_supervised/dinov2/models.py:443-453: torch._foreach_mul_(teacher, m) then
+ * torch._foreach_add_(teacher, student, alpha = 1 - m)) over one flat fp32 range, in one pass: teacher[i] = fma(student[i], 1 - m,
+ * round(teacher[i] * m)), the roundings of the two torch passes (m and 1 - m, taken in double, each cast to fp32 as torch casts its scalars). */
+int apla_ema_update(float* teacher, const float* student, long n, double m, hipStream_t stream);
+
 /* The same step under DYNAMIC loss scaling — torch.cuda.amp.GradScaler (defaults/trainer.py:129-138:
  * scaler.scale(loss).backward(); unscale_; clip; scaler.step; scaler.update) without a host round trip.  The gradients in
  * `grads` carry the current loss scale; `scaler` is a device float[8]: [0..2] and [3..5] are two slots of {scale,
@@ -410,6 +415,21 @@ int apla_assemble_tokens_masked(const void* patches, int ldp, const float* cls_t
 int apla_weight_norm_fwd(const float* v, const float* g, void* w_h16, float* norm, int K, int D, hipStream_t stream);
 int apla_weight_norm_bwd(const float* dw, const float* v, const float* g, const float* norm, float* dv, float* dg, int K, int D,
                          hipStream_t stream);
+/* apla_weight_norm_fwd with W^T [D, K] (16-bit, row-major) written beside W: what the layer's dX GEMM reads (dx = dy W through
+ * apla_gemm_nt on W^T).  K % 64 == 0, D <= 1024; wt_h16 == NULL is apla_weight_norm_fwd. */
+int apla_weight_norm_fwd_t(const float* v, const float* g, void* w_h16, void* wt_h16, float* norm, int K, int D, hipStream_t stream);
+
+/* KoLeoLoss (self_supervised/dinov2/loss/koleo_loss.py:17-45) on G groups of B rows, as models.py:410-413 sums it over the two global
+ * crops: xn = x / max(||x||, eps), j(i) = the other row of the group with the largest xn_i . xn_j, d_i = ||xn_i - xn_j(i) + 1e-8||,
+ * loss_g = -mean_i log(d_i + eps).
+ *   apla_koleo_fwd : out[g] = loss_g (g < G), out[G] = sum_g loss_g; nn_idx / dist / nrm (||x_i||) / terms: [G*B] saved for the backward
+ *                    (terms is scratch); `counter`: one int32 that is 0 before the first call (the kernel leaves it 0).
+ *   apla_koleo_bwd : dx = d(out[G]) / dx * gout[0]   (gout: one fp32 in device memory; dx in x's type)
+ * x [G*B, D] row-major, fp32 or the build's 16-bit type (`dtype`), D % 4 == 0 (backward: D <= 4096, B <= 4096). */
+int apla_koleo_fwd(const void* x, int dtype, int G, int B, int D, float eps, int* nn_idx, float* dist, float* nrm, float* terms,
+                   float* out, int* counter, hipStream_t stream);
+int apla_koleo_bwd(const void* x, int dtype, int G, int B, int D, float eps, const int* nn_idx, const float* dist, const float* nrm,
+                   const float* gout, void* dx, hipStream_t stream);
 
 /* Dropout and stochastic depth of the module path (utils/transformers/vit.py:74-93 DropPath, :152-168 Mlp.drop; apla/appla_attn.py:82
  * proj_drop; all shipped configurations use 0, main.py:101-111 can set them).

@@ -1384,7 +1384,7 @@ def test_dropout_kernels_and_the_oracle_mask(ops, dtype, p, n):
     assert torch.equal(ops.scale_samples(xs, sc).float().cpu(), (xs.float() * sc[:, None, None]).to(dtype).float().cpu())
 
 
-@pytest.mark.parametrize("K,D", [(65536, 256), (515, 64), (3, 1024)])
+@pytest.mark.parametrize("K,D", [(65536, 256), (515, 64), (3, 1024), (192, 1024), (128, 36)])
 def test_weight_norm_kernels(ops, K, D):
     """apla_weight_norm_fwd / _bwd against torch.nn.utils.weight_norm's own arithmetic in float64 (dinov2 dino_head.py:27-28: the
     prototype layer W = v g / ||v||, dim = 0): W in the 16-bit operand type, dv and dg from an fp32 dW."""
@@ -1401,3 +1401,7 @@ def test_weight_norm_kernels(ops, K, D):
     assert rel_err(dv.cpu(), vd.grad) < 2e-5 and rel_err(dg.cpu(), gd.grad.reshape(-1)) < 2e-5
     dv2, none = ops.weight_norm_bwd(dev(dW), dev(v), dev(g).reshape(-1), norm, want_dg=False)
     assert none is None and torch.equal(dv2, dv)
+    # the launch that writes W^T beside W (what the dX GEMM reads): the same bits, transposed; None where the kernel does not apply
+    W2, norm2, WT = ops.weight_norm_fwd(dev(v), dev(g).reshape(-1), transposed=True)
+    assert torch.equal(W2, W) and torch.equal(norm2, norm)
+    assert (WT is None) == (K % 64 != 0) and (WT is None or (tuple(WT.shape) == (D, K) and torch.equal(WT, W.t().contiguous())))

@@ -37,6 +37,76 @@ def test_koleo_matches_reference():
     assert abs(float(loss) - float(g["koleo.loss"])) < 1e-5 and rel_err(x.grad.cpu(), g["koleo.dx"]) < 1e-4
 
 
+@pytest.mark.parametrize("G,B,D,dtype", [(2, 64, 768, torch.float32), (1, 7, 1024, torch.float32), (3, 130, 384, torch.float32),
+                                          (2, 1, 64, torch.float32), (2, 64, 768, None), (1, 300, 4096, torch.float32)])
+def test_koleo_kernel_against_the_oracle_in_groups(G, B, D, dtype):
+    """apla_koleo_fwd / _bwd (one launch each for all groups) against oracle/ssl_oracle.py:_koleo per chunk, as models.py:410-413 sums it:
+    loss, the neighbour choice (through the gradient) and the gradient; a one-row group (its own neighbour), ragged B, D up to the limit,
+    the 16-bit input type, a close pair of rows."""
+    from apla_amd import ops
+    from apla_amd.ssl import KoLeoLoss
+    from oracle.ssl_oracle import _koleo
+    dtype = dtype or ops.half()
+    torch.manual_seed(G * 1000 + B)
+    x = torch.randn(G * B, D)
+    if B > 4:
+        x[3] = x[1] + 0.02 * torch.randn(D)     # a close pair: each is the other's neighbour
+    x = x.to(dtype)
+    xd = x.cuda().requires_grad_(True)
+    loss = KoLeoLoss().grouped(xd, G)
+    (loss * 0.37).backward()
+    xr = x.float().requires_grad_(True)
+    ref = sum(_koleo(c) for c in xr.chunk(G))
+    (ref * 0.37).backward()
+    assert abs(float(loss) - float(ref)) < 2e-5 * max(1.0, abs(float(ref)))
+    tol = 1e-4 if dtype == torch.float32 else 1e-2
+    assert xd.grad.dtype == dtype and rel_err(xd.grad.float().cpu(), xr.grad) < tol
+    out, _ = ops.koleo_fwd(xd.detach(), G)
+    assert abs(float(out[:G].sum()) - float(out[G])) < 1e-5 and int(ops._KOLEO_TICKET[xd.device.index]) == 0
+
+
+def test_koleo_kernel_on_clamped_norms_and_a_duplicate():
+    """The degenerate inputs of koleo_loss.py:17-45: a row whose norm is under eps (F.normalize's clamp: divided by eps, its gradient
+    goes through 1 / eps and not through the norm), a zero row (at distance 1 from every unit row: the loss is defined, the neighbour is
+    not) and an exact duplicate (distance ||1e-8|| = 1e-8 sqrt(D): the largest loss term)."""
+    from apla_amd.ssl import KoLeoLoss
+    from oracle.ssl_oracle import _koleo
+    torch.manual_seed(5)
+    x = torch.randn(6, 64)
+    x[4] = 1e-10 * torch.randn(64)
+    xd = x.cuda().requires_grad_(True)
+    loss = KoLeoLoss()(xd)
+    loss.backward()
+    xr = x.clone().requires_grad_(True)
+    ref = _koleo(xr)
+    ref.backward()
+    assert abs(float(loss) - float(ref)) < 1e-5
+    keep = [0, 1, 2, 3, 5]
+    assert rel_err(xd.grad[keep].cpu(), xr.grad[keep]) < 1e-4 and rel_err(xd.grad[4].cpu(), xr.grad[4]) < 1e-4
+    with torch.no_grad():
+        x[4] = 0.0
+        assert abs(float(KoLeoLoss()(x.cuda())) - float(_koleo(x))) < 1e-5
+        x[4] = x[2]
+        assert abs(float(KoLeoLoss()(x.cuda())) - float(_koleo(x))) < 1e-4
+
+
+def test_koleo_neighbour_when_rows_nearly_coincide():
+    """CLS tokens at initialisation: rows 1e-4 apart after normalisation, where every fp32 inner product rounds to 1 and the reference's
+    argmax follows its GEMM's rounding.  The kernel searches by distance, so it must find the float64 nearest neighbour (and the loss of
+    that choice), in both input types."""
+    from apla_amd import ops
+    torch.manual_seed(9)
+    base = torch.randn(1, 768)
+    x = (base + 3e-3 * torch.randn(64, 768)).to(ops.half()).float()     # the values the 16-bit input carries
+    xn = torch.nn.functional.normalize(x.double(), dim=-1)
+    dist = torch.cdist(xn, xn)
+    dist.fill_diagonal_(float("inf"))
+    want = -torch.log(dist.min(dim=1).values + 1e-8).mean()
+    for dt in (torch.float32, ops.half()):
+        out, (idx, d, _) = ops.koleo_fwd(x.to(dt).cuda(), 1)
+        assert torch.equal(idx.cpu().long(), dist.argmin(dim=1)) and abs(float(out[0]) - float(want)) < 1e-3 * abs(float(want))
+
+
 def _student(seed=0):
     from functools import partial
     from apla_amd.apla import build_apla

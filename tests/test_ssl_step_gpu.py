@@ -202,6 +202,39 @@ def test_fp16_dynamic_loss_scale_skips_and_backs_off():
     assert np.isfinite(float(tr.loss))
 
 
+def test_teacher_ema_as_one_launch_equals_the_foreach_route():
+    """DINOv2.update_teacher after Dinov2Trainer has re-homed the teacher's trainable tensors in one flat buffer (apla_ema_update, one
+    launch) against models.py:443-453's torch._foreach_mul_ / _foreach_add_ on a twin: bit-identical (the kernel rounds the way the two
+    passes do), frozen tensors untouched, the 16-bit weight caches invalidated; and the list route again once a tensor was re-homed."""
+    from apla_amd import functional as AF
+    from apla_amd.ssl import Dinov2Trainer
+    g = load_golden("g12_ssl_step_apla.npz")
+    model, twin = build_from_golden(g, "apla"), build_from_golden(g, "apla")
+    Dinov2Trainer(model, iters_per_epoch=1, epochs=2)
+    assert model._ema_flat is not None and getattr(twin, "_ema_flat", None) is None
+    tp = dict(model.teacher.named_parameters())
+    some = next(p for n, p in tp.items() if p.ndim == 2 and dict(model.student.named_parameters())[n].requires_grad)
+    cached = AF.w_bf16(some)
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    with torch.no_grad():
+        for (n, p), (_, q) in zip(model.student.named_parameters(), twin.student.named_parameters()):
+            if p.requires_grad:
+                d = torch.randn(p.shape, device="cuda", generator=gen) * 0.05
+                p.add_(d), q.add_(d)
+    before = {n: p.detach().clone() for n, p in tp.items()}
+    for m in (0.994, 0.9):
+        assert model.update_teacher(m) == twin.update_teacher(m) > 0
+    for (n, p), (_, q) in zip(model.teacher.named_parameters(), twin.teacher.named_parameters()):
+        assert torch.equal(p, q), (n, float((p - q).abs().max()), float(q.abs().max()))
+    sp = dict(model.student.named_parameters())
+    assert all(torch.equal(p, before[n]) for n, p in tp.items() if not sp[n].requires_grad)
+    assert AF.w_bf16(some) is not cached and torch.equal(AF.w_bf16(some), some.detach().to(cached.dtype))
+    some.data = some.data.clone()                       # a re-homed tensor: the flat route must notice and leave
+    assert model.update_teacher(0.9) == twin.update_teacher(0.9) and model._ema_flat is None
+    for (n, p), (_, q) in zip(model.teacher.named_parameters(), twin.teacher.named_parameters()):
+        assert torch.equal(p, q), n
+
+
 def test_flat_adamw_matches_torch_adamw():
     """FlatAdamW (apla_grad_sumsq + apla_adamw_apply) against torch.optim.AdamW + clip_grad_norm_ with the reference's two
     parameter groups, including a tensor skipped for the first two steps (its step count starts late)."""
