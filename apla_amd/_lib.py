@@ -108,6 +108,8 @@ SIGNATURES = {
     "apla_softmax_center": (c_int, [c_void_p, c_int, c_long, c_void_p, c_float, c_void_p, c_long, c_int, c_int, c_void_p]),
     "apla_distill_ce": (c_int, [c_void_p, c_int, c_long, c_void_p, c_long, c_float, c_void_p, c_float, c_void_p, c_long, c_int,
                                 c_void_p, c_int, c_int, c_void_p]),
+    "apla_distill_ce_bcast": (c_int, [c_void_p, c_int, c_long, c_void_p, c_long, c_int, c_float, c_void_p, c_float, c_void_p, c_int, c_long,
+                                      c_int, c_void_p, c_int, c_int, c_void_p]),
     "apla_distill_ce_ex": (c_int, [c_void_p, c_int, c_long, c_void_p, c_long, c_float, c_void_p, c_float, c_void_p, c_int, c_long, c_int,
                                    c_void_p, c_int, c_int, c_void_p]),
     "apla_distill_ce_centered": (c_int, [c_void_p, c_int, c_long, c_void_p, c_int, c_long, c_void_p, c_float, c_float, c_void_p, c_float,

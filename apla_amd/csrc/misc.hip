@@ -351,12 +351,12 @@ template <typename ST>
 __global__ __launch_bounds__(256) void distill_ce_kernel(const ST* __restrict__ s, long lds, const float* __restrict__ t, long ldt,
                                                          float inv_temp, const float* __restrict__ row_weight, float weight,
                                                          float* __restrict__ ds, long ldds, int accumulate,
-                                                         float* __restrict__ row_loss, int K) {
+                                                         float* __restrict__ row_loss, int K, int t_rows) {
   __shared__ float red[4];
   __shared__ float bc;
   const int r = blockIdx.x;
   const ST* sr = s + (long)r * lds;
-  const float* tr = t + (long)r * ldt;
+  const float* tr = t + (long)(r % t_rows) * ldt;
   const float w = row_weight != nullptr ? row_weight[r] * weight : weight;
   float mx = -INFINITY;
   for (int k = threadIdx.x; k < K; k += 256) mx = fmaxf(mx, ldf(sr, k) * inv_temp);
@@ -487,11 +487,11 @@ template <typename ST, typename GT>
 __global__ __launch_bounds__(256) void distill_ce_wide_kernel(const ST* __restrict__ s, long lds, const float* __restrict__ t, long ldt,
                                                               float inv_temp, const float* __restrict__ row_weight, float weight,
                                                               GT* __restrict__ ds, long ldds, int accumulate,
-                                                              float* __restrict__ row_loss, int K, int slice) {
+                                                              float* __restrict__ row_loss, int K, int slice, int t_rows) {
   __shared__ float red[8];
   const int r = blockIdx.y;
   const ST* sr = s + (long)r * lds;
-  const float* tr = t + (long)r * ldt;
+  const float* tr = t + (long)(r % t_rows) * ldt;   // t_rows < R: the targets repeat (the local crops of DINOLoss.forward share theirs)
   const float w = row_weight != nullptr ? row_weight[r] * weight : weight;
   float m = -INFINITY, sm = 0.f, dot = 0.f, tsum = 0.f;
   for (int k = threadIdx.x * 8; k < K; k += 2048) {
@@ -715,11 +715,11 @@ extern "C" int apla_softmax_center(const void* x, int x_dtype, long ldx, const f
   return APLA_OK;
 }
 
-extern "C" int apla_distill_ce_ex(const void* student, int s_dtype, long lds, const float* teacher_probs, long ldt, float inv_temp,
-                                  const float* row_weight, float weight, void* dstudent, int ds_dtype, long ldds, int accumulate,
-                                  float* row_loss, int R, int K, hipStream_t stream) {
-  APLA_REQUIRE(student && teacher_probs && row_loss && R > 0 && K > 0 && lds >= K && ldt >= K && inv_temp > 0.f &&
-               (dstudent == nullptr || ldds >= K), "apla_distill_ce: bad arguments");
+extern "C" int apla_distill_ce_bcast(const void* student, int s_dtype, long lds, const float* teacher_probs, long ldt, int t_rows,
+                                     float inv_temp, const float* row_weight, float weight, void* dstudent, int ds_dtype, long ldds,
+                                     int accumulate, float* row_loss, int R, int K, hipStream_t stream) {
+  APLA_REQUIRE(student && teacher_probs && row_loss && R > 0 && K > 0 && lds >= K && ldt >= K && inv_temp > 0.f && t_rows > 0 &&
+               t_rows <= R && (dstudent == nullptr || ldds >= K), "apla_distill_ce: bad arguments");
   APLA_REQUIRE((s_dtype == APLA_F32 || s_dtype == APLA_H16) && (dstudent == nullptr || ds_dtype == APLA_F32 || ds_dtype == APLA_H16),
                "apla_distill_ce: unsupported dtype (student %d, gradient %d)", s_dtype, ds_dtype);
   const bool g16 = dstudent != nullptr && ds_dtype == APLA_H16;
@@ -730,17 +730,24 @@ extern "C" int apla_distill_ce_ex(const void* student, int s_dtype, long lds, co
   if (wide) {
     int slice = K;
     const int S = dstudent != nullptr ? wide_row_split(R, K, &slice) : 1;
-#define DCE_WIDE(ST, GT) hipLaunchKernelGGL((distill_ce_wide_kernel<ST, GT>), dim3(S, R), dim3(256), 0, stream, (const ST*)student, lds, teacher_probs, ldt, inv_temp, row_weight, weight, (GT*)dstudent, ldds, accumulate, row_loss, K, slice)
+#define DCE_WIDE(ST, GT) hipLaunchKernelGGL((distill_ce_wide_kernel<ST, GT>), dim3(S, R), dim3(256), 0, stream, (const ST*)student, lds, teacher_probs, ldt, inv_temp, row_weight, weight, (GT*)dstudent, ldds, accumulate, row_loss, K, slice, t_rows)
     if (s_dtype == APLA_F32) { if (g16) DCE_WIDE(float, bf16); else DCE_WIDE(float, float); }
     else { if (g16) DCE_WIDE(bf16, bf16); else DCE_WIDE(bf16, float); }
 #undef DCE_WIDE
     APLA_CHECK_LAUNCH("apla_distill_ce");
     return APLA_OK;
   }
-  if (s_dtype == APLA_F32) hipLaunchKernelGGL(distill_ce_kernel<float>, dim3(R), dim3(256), 0, stream, (const float*)student, lds, teacher_probs, ldt, inv_temp, row_weight, weight, (float*)dstudent, ldds, accumulate, row_loss, K);
-  else hipLaunchKernelGGL(distill_ce_kernel<bf16>, dim3(R), dim3(256), 0, stream, (const bf16*)student, lds, teacher_probs, ldt, inv_temp, row_weight, weight, (float*)dstudent, ldds, accumulate, row_loss, K);
+  if (s_dtype == APLA_F32) hipLaunchKernelGGL(distill_ce_kernel<float>, dim3(R), dim3(256), 0, stream, (const float*)student, lds, teacher_probs, ldt, inv_temp, row_weight, weight, (float*)dstudent, ldds, accumulate, row_loss, K, t_rows);
+  else hipLaunchKernelGGL(distill_ce_kernel<bf16>, dim3(R), dim3(256), 0, stream, (const bf16*)student, lds, teacher_probs, ldt, inv_temp, row_weight, weight, (float*)dstudent, ldds, accumulate, row_loss, K, t_rows);
   APLA_CHECK_LAUNCH("apla_distill_ce");
   return APLA_OK;
+}
+
+extern "C" int apla_distill_ce_ex(const void* student, int s_dtype, long lds, const float* teacher_probs, long ldt, float inv_temp,
+                                  const float* row_weight, float weight, void* dstudent, int ds_dtype, long ldds, int accumulate,
+                                  float* row_loss, int R, int K, hipStream_t stream) {
+  return apla_distill_ce_bcast(student, s_dtype, lds, teacher_probs, ldt, R, inv_temp, row_weight, weight, dstudent, ds_dtype, ldds,
+                               accumulate, row_loss, R, K, stream);
 }
 
 extern "C" int apla_distill_ce(const void* student, int s_dtype, long lds, const float* teacher_probs, long ldt, float inv_temp,

@@ -95,22 +95,22 @@ class _ProtoLosses(torch.autograd.Function):
         rows, K = y.shape
         need = x.requires_grad or v.requires_grad or g.requires_grad
         dy = torch.empty_like(y) if need else None
-        spans = []
-        out, covered = [0] * n_out, 0
+        row_loss = torch.zeros(rows, device=y.device, dtype=torch.float32)    # every term writes its rows; rows no term covers stay 0
+        spans, covered = [], 0
         for (oi, a, b, target, temp, rw, weight) in sorted(terms, key=lambda t: t[1]):
-            if a < covered or b > rows or a >= b:
+            if a < covered or b > rows or a >= b or not 0 <= oi < n_out:
                 raise ValueError("proto_losses: terms must cover disjoint row ranges")
             if need and a > covered:
                 dy[covered:a].zero_()
-            row_loss, _ = launch_distill_ce(y[a:b], target, temp, rw, weight * P, need, ds=dy[a:b] if need else None)
-            out[oi] = out[oi] + row_loss.sum()
+            launch_distill_ce(y[a:b], target, temp, rw, weight * P, need, ds=dy[a:b] if need else None, row_loss=row_loss[a:b])
             spans.append((oi, a, b))
             covered = b
         if need and covered < rows:
             dy[covered:].zero_()
-        ctx.save_for_backward(x2, Wh, dy, _row_term_index(rows, tuple(spans), y.device), v, g, norm, WhT)
+        idx, member = _row_term_index(rows, tuple(spans), n_out, y.device)
+        ctx.save_for_backward(x2, Wh, dy, idx, v, g, norm, WhT)
         ctx.meta = (x.shape, P)
-        res = torch.stack([o if torch.is_tensor(o) else y.new_zeros((), dtype=torch.float32) for o in out])
+        res = (member * row_loss).sum(dim=1)     # [n_out]: one masked row sum per output, in a fixed order
         return res if P == 1.0 else res / P
 
     @staticmethod
@@ -139,19 +139,22 @@ class _ProtoLosses(torch.autograd.Function):
 _ROW_INDEX_CACHE = {}
 
 
-def _row_term_index(rows, spans, device):
-    """int64 [rows]: the output index of the term covering each row (0 for uncovered rows: their gradient is zero anyway).  Cached on
-    the device per layout (the number of masked patches varies from batch to batch; the cache is small and bounded)."""
-    key = (rows, spans, str(device))
-    idx = _ROW_INDEX_CACHE.get(key)
-    if idx is None:
+def _row_term_index(rows, spans, n_out, device):
+    """(int64 [rows]: the output index of the term covering each row — 0 for uncovered rows: their gradient is zero anyway —,
+    fp32 [n_out, rows]: 1 where the row belongs to the output, else 0).  Cached on the device per layout (the number of masked patches
+    varies from batch to batch; the cache is small and bounded)."""
+    key = (rows, spans, n_out, str(device))
+    ent = _ROW_INDEX_CACHE.get(key)
+    if ent is None:
         if len(_ROW_INDEX_CACHE) >= 256:
             _ROW_INDEX_CACHE.clear()
         host = torch.zeros(rows, dtype=torch.long)
+        member = torch.zeros(n_out, rows, dtype=torch.float32)
         for oi, a, b in spans:
             host[a:b] = oi
-        idx = _ROW_INDEX_CACHE[key] = host.to(device)
-    return idx
+            member[oi, a:b] = 1.0
+        ent = _ROW_INDEX_CACHE[key] = (host.to(device), member.to(device))
+    return ent
 
 
 def proto_losses(x, v, g, n_out, terms):

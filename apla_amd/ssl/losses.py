@@ -80,10 +80,12 @@ class CenteredTeacher:
         return logits.is_cuda and logits.dtype in (ops.half(), torch.float32) and K % 8 == 0 and logits.stride(-1) == 1
 
 
-def launch_distill_ce(s, target, temp, row_weight, weight, want_grad, ds=None):
+def launch_distill_ce(s, target, temp, row_weight, weight, want_grad, ds=None, row_loss=None):
     """One launch of the fused cross-entropy over the rows of `s` ([..., K], 16-bit or fp32): `target` is a probability tensor of the
-    same shape or a CenteredTeacher.  Returns (row_loss fp32 [R], ds or None); ds[r, :] = d(sum_r row_loss) / d s[r, :], in the student's
-    16-bit type when it has one (written into `ds` if given: a [R, K] row slice of a larger buffer), else fp32."""
+    same shape — or of R / n rows, which then repeat (row r reads target row r % (R / n): the local crops of DINOLoss.forward share
+    their targets) — or a CenteredTeacher.  Returns (row_loss fp32 [R], ds or None); ds[r, :] = d(sum_r row_loss) / d s[r, :], in the
+    student's 16-bit type when it has one (written into `ds` if given: a [R, K] row slice of a larger buffer), else fp32; `row_loss`:
+    the caller's fp32 [R] slice to write the row losses into."""
     K = s.shape[-1]
     s2 = s.reshape(-1, K)
     s2 = s2 if s2.stride(-1) == 1 else s2.contiguous()
@@ -107,14 +109,18 @@ def launch_distill_ce(s, target, temp, row_weight, weight, want_grad, ds=None):
         # the gradient in the student's own dtype (what backward returns anyway): a 16-bit student saves the fp32 round trip of a
         # [rows, 65 536] tensor (iBOT: 1.3 GB written, re-read, scaled and cast per iteration)
         g16 = s2.dtype == ops.half() and K % 8 == 0 and s2.stride(0) % 8 == 0 and t2.stride(0) % 4 == 0
-    if t2.shape != s2.shape:
+    t_rows = t2.shape[0]
+    if t2.shape[1] != K or t_rows == 0 or R % t_rows or (centered and t_rows != R):
         raise ValueError(f"distill_ce: student {tuple(s2.shape)} vs teacher {tuple(t2.shape)}")
     if ds is not None:
         if not g16 or ds.dtype != s2.dtype or tuple(ds.shape) != (R, K) or ds.stride(1) != 1:
             raise ValueError("distill_ce: the caller's gradient rows need the student's 16-bit type and shape")
     elif want_grad:
         ds = torch.empty(R, K, device=s.device, dtype=s2.dtype if g16 else torch.float32)
-    row_loss = torch.empty(R, device=s.device, dtype=torch.float32)
+    if row_loss is None:
+        row_loss = torch.empty(R, device=s.device, dtype=torch.float32)
+    elif row_loss.dtype != torch.float32 or tuple(row_loss.shape) != (R,) or not row_loss.is_contiguous():
+        raise ValueError("distill_ce: the caller's row losses must be a contiguous fp32 [rows] slice")
     ds_dt = ops._DT[ds.dtype] if ds is not None else ops._DT[torch.float32]
     ld_ds = ds.stride(0) if ds is not None else K
     if centered:
@@ -123,9 +129,9 @@ def launch_distill_ce(s, target, temp, row_weight, weight, want_grad, ds=None):
                                              c.data_ptr(), 1.0 / float(temp), 1.0 / target.temp, ops._ptr(rw), float(weight), ops._ptr(ds),
                                              ds_dt, ld_ds, row_loss.data_ptr(), R, K, ops._stream()), "apla_distill_ce_centered")
     else:
-        check(lib().apla_distill_ce_ex(s2.data_ptr(), ops._DT[s2.dtype], s2.stride(0), t2.data_ptr(), t2.stride(0), 1.0 / float(temp),
-                                       ops._ptr(rw), float(weight), ops._ptr(ds), ds_dt, ld_ds, 0, row_loss.data_ptr(), R, K, ops._stream()),
-              "apla_distill_ce")
+        check(lib().apla_distill_ce_bcast(s2.data_ptr(), ops._DT[s2.dtype], s2.stride(0), t2.data_ptr(), t2.stride(0), t_rows,
+                                          1.0 / float(temp), ops._ptr(rw), float(weight), ops._ptr(ds), ds_dt, ld_ds, 0, row_loss.data_ptr(),
+                                          R, K, ops._stream()), "apla_distill_ce")
     return row_loss, ds
 
 

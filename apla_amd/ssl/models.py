@@ -56,6 +56,21 @@ def _wrap(cfg):
     return cfg
 
 
+_COEF_CACHE = {}
+
+
+def _loss_coefficients(shown, weights, device):
+    """(fp32 [n] shown * weights, fp32 [n] shown) on the device, cached per value set (schedules do not touch them)."""
+    key = (tuple(shown), tuple(weights), str(device))
+    ent = _COEF_CACHE.get(key)
+    if ent is None:
+        if len(_COEF_CACHE) >= 64:
+            _COEF_CACHE.clear()
+        ent = _COEF_CACHE[key] = (torch.tensor([a * b for a, b in zip(shown, weights)], dtype=torch.float32, device=device),
+                                  torch.tensor(list(shown), dtype=torch.float32, device=device))
+    return ent
+
+
 class DINOv2(nn.Module):
     def __init__(self, params, backbones=None, backbone_state_dict=None):
         """``backbones`` = (student, teacher, embed_dim) overrides build_model (tests use small geometries).
@@ -203,24 +218,25 @@ class DINOv2(nn.Module):
             # values as the module route below, the [rows, K] gradient written once and read by the two GEMMs only
             Bc, off = s_loc_cls.shape[0] // n_local, s_loc_cls.shape[0]
             tsum = t_dino[0].float() + t_dino[1].float()                     # DINOLoss.forward: the targets of one student view add up
-            terms = [(0, i * Bc, (i + 1) * Bc, tsum, self.dino_loss.student_temp, None, 1.0 / Bc) for i in range(n_local)]
+            # every local crop against the same Bc target rows: ONE term whose targets repeat (launch_distill_ce), not n_local launches
+            terms = [(0, 0, off, tsum, self.dino_loss.student_temp, None, 1.0 / Bc)]
             terms.append((1, off, off + s_glob_cls.shape[0], t_dino.flatten(0, 1), self.dino_loss.student_temp, None, 1.0 / s_glob_cls.shape[0]))
             off += s_glob_cls.shape[0]
             terms.append((2, off, off + n_masked, t_ibot[:n_masked], self.ibot_patch_loss.student_temp, masks_weight, 1.0 / masks.shape[0]))
             sums = proto_losses(head.bottleneck(torch.cat(head_in)), head.last_layer.weight_v, head.last_layer.weight_g, 3, terms)
-            l = sums[0] / (n_global_terms + n_local_terms)
-            loss_dict["dino_local_crops_loss"] = l
-            total = total + self.dino_loss_weight * l
-            l = sums[1] * loss_scales / (n_global_terms + n_local_terms)
-            loss_dict["dino_global_crops_loss"] = l
-            total = total + self.dino_loss_weight * l
+            # the reference's scalar bookkeeping (models.py:380-432: l = sum / (n_g + n_l); total += weight * l; ...) on the three sums at
+            # once: two small launches forward and two backward instead of a dozen each
+            n_terms = n_global_terms + n_local_terms
+            shown = (1.0 / n_terms, loss_scales / n_terms, loss_scales * (1.0 / n_global) / 2)       # what loss_dict displays
+            weights = (self.dino_loss_weight, self.dino_loss_weight, self.ibot_loss_weight * 2)       # total = sum(weights * shown * sums)
+            c_total, c_shown = _loss_coefficients(shown, weights, sums.device)
+            total = (sums * c_total).sum()
+            disp = sums.detach() * c_shown
+            loss_dict["dino_local_crops_loss"], loss_dict["dino_global_crops_loss"], loss_dict["ibot_loss"] = disp[0], disp[1], disp[2]
             if self.do_koleo:
                 kl = self.model_params.dinov2.dino.koleo_loss_weight * self.koleo_loss.grouped(s_glob_cls, 2)
                 total = total + kl
-                loss_dict["koleo_loss"] = kl / loss_scales
-            l = sums[2] * loss_scales * (1.0 / n_global)
-            loss_dict["ibot_loss"] = l / 2
-            total = total + self.ibot_loss_weight * l
+                loss_dict["koleo_loss"] = kl.detach() / loss_scales
             return total, loss_dict
         outs = head(torch.cat(head_in)).split([t.shape[0] for t in head_in])
         o_loc, o_glob = outs[0], outs[1]

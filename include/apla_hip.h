@@ -468,6 +468,11 @@ int apla_distill_ce(const void* student, int s_dtype, long lds, const float* tea
 int apla_distill_ce_ex(const void* student, int s_dtype, long lds, const float* teacher_probs, long ldt, float inv_temp,
                        const float* row_weight, float weight, void* dstudent, int ds_dtype, long ldds, int accumulate,
                        float* row_loss, int R, int K, hipStream_t stream);
+/* apla_distill_ce_ex with repeating targets: row r reads teacher_probs row r % t_rows (DINOLoss.forward, dino_clstoken_loss.py:65-77,
+ * pairs every local crop of the batch with the same teacher rows: the 8 crops of the shipped recipe are one launch of 8 x 64 rows) */
+int apla_distill_ce_bcast(const void* student, int s_dtype, long lds, const float* teacher_probs, long ldt, int t_rows, float inv_temp,
+                          const float* row_weight, float weight, void* dstudent, int ds_dtype, long ldds, int accumulate,
+                          float* row_loss, int R, int K, hipStream_t stream);
 /* apla_softmax_center + apla_distill_ce_ex in one: the targets are softmax((teacher_logits - center) * inv_temp_t), computed on the
  * fly and never written (iBOTPatchLoss.softmax_center_teacher + forward_masked, ibot_patch_loss.py:46-55, 103-121: 4 879 rows of
  * 65 536 prototypes per iteration at config 4 — 10 bytes per logit instead of 22).  K % 8 == 0, 16-byte aligned rows. */

@@ -116,9 +116,10 @@ def test_two_iterations_match_reference(tag, half):
 @pytest.mark.parametrize("half", [torch.bfloat16, torch.float16])
 def test_fused_head_losses_equal_the_module_route(half):
     """DINOv2.forward's one-node route from the bottleneck features to the three cross-entropy sums (heads._ProtoLosses) against the
-    reference-shaped route (head -> split -> DINOLoss / iBOTPatchLoss objects): identical loss values (same kernels on the same
-    rows), gradients equal up to the place the upstream scalar is applied (rows of the [rows, 256] operands instead of the [rows, K]
-    gradient)."""
+    reference-shaped route (head -> split -> DINOLoss / iBOTPatchLoss objects): the same loss values up to fp32 rounding (same kernels
+    on the same rows; the fused route adds the row losses in one masked sum and applies the bookkeeping factors of models.py:380-432 as
+    one vector), gradients equal up to the place the upstream scalar is applied (rows of the [rows, 256] operands instead of the
+    [rows, K] gradient)."""
     from apla_amd import ops as OPS
     from apla_amd.ssl.losses import grad_prescale
     g = load_golden("g12_ssl_step_apla.npz")
@@ -135,7 +136,8 @@ def test_fused_head_losses_equal_the_module_route(half):
             (loss * scale).backward()
         res[unfused] = (float(loss.detach()), {k: float(v.detach()) for k, v in ld.items()},
                         {n: p.grad.detach().float().cpu() / scale for n, p in model.student.named_parameters() if p.requires_grad})
-    assert res[True][0] == res[False][0] and res[True][1] == res[False][1]
+    assert abs(res[True][0] - res[False][0]) < 2e-6 * abs(res[True][0]) and set(res[True][1]) == set(res[False][1])
+    assert all(abs(v - res[False][1][k]) <= 2e-6 * abs(v) for k, v in res[True][1].items())
     for n, ga in res[True][2].items():
         assert rel_err(res[False][2][n], ga) < (2e-2 if half == torch.bfloat16 else 3e-3), n
 
