@@ -427,7 +427,11 @@ inline Sched pick_schedule(int epi, int out_dtype, int M, int N, int K, int lda,
   // 149.2 us on the wide 4-wave kernel; the two-output GELU and the plain stores tie or lose there: profiles/r04_tp_*)
   if (g_variant == 4 && epi == APLA_EPI_GELU_FWD && M >= 8192 && apla_gemm_tp_covers(M, N, K, lda, ldw, epi, out_dtype, w_panel)) return {4, 0};
   if (g_variant == 16 && w4_ok) return {3, 0};
+#if defined(APLA_ABL_NOW4STORE)   // (ablation build: the plain stores with a short K stay on the ping-pong kernel)
+  const bool w4_auto = g_variant == 4 && w4_ok && (epi == APLA_EPI_GELU_FWD && M >= 8192);
+#else
   const bool w4_auto = g_variant == 4 && w4_ok && ((epi == APLA_EPI_STORE && K <= 1024 && M >= 2048) || (epi == APLA_EPI_GELU_FWD && M >= 8192));
+#endif
   if (w_panel & 12) {
     // output / second-operand image: the 4-wave persistent kernel's GELU / GELU_FWD / MUL / SwiGLU epilogues (checked by
     // gemm_nt_impl) — except the two-output GELU above 40 000 rows, which the automatic rule runs on the ping-pong kernel: its

@@ -30,6 +30,7 @@ build ATT_NOEXP attention "-DAPLA_ABL_ATT_NOEXP"     # no transcendental in the 
 build ATT_NOS attention "-DAPLA_ABL_ATT_NOS"         # split kernels without the S / dP products
 build ATT_NOTR attention "-DAPLA_ABL_ATT_NOTR"       # split kernels without the transposed reads and second-stage products
 build LNGRID layernorm "-DAPLA_ABL_LNGRID"           # LayerNorm grid cap from APLA_LN_GRID
+build NOW4STORE gemm_nt "-DAPLA_ABL_NOW4STORE"       # dispatch only (results stay right): short-K plain stores on the ping-pong kernel instead of the wide 4-wave kernel (tools/ab_lib.sh)
 build NGRP gemm_pp2 "-DAPLA_ABL_NGRP"                # n-tiles per column group of the tile walk from APLA_NGRP (ping-pong kernel)
 # tile-walk sweep over all three tiled GEMM kernels (tools/l2_traffic.sh): column-group width from APLA_NGRP
 $HIPCC $FLAGS -DAPLA_ABL_NGRP -c ../csrc/gemm_nt.hip -o exp/gemm_nt_NGRPALL.o
