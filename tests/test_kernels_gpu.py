@@ -854,11 +854,12 @@ def test_gemm_wide_4wave_kernel(ops, M, N, K):
         assert ops.gemm_kernel_name(M, N, K, ops.EPI_GELU).startswith("gemm_persist_kernel<GELU")
 
 
-@pytest.mark.parametrize("M,N,K", [(25216, 768, 768), (25216, 3072, 768), (9000, 512, 1024), (4001, 256, 832), (161, 256, 768), (1, 256, 3072)])
+@pytest.mark.parametrize("M,N,K", [(25216, 768, 768), (25216, 3072, 768), (9000, 512, 1024), (4001, 256, 832), (161, 256, 768), (1, 256, 3072),
+                                   (4001, 512, 704)])
 def test_gemm_tile_alternating_kernel(ops, M, N, K):
     """gemm_tp.hip (schedule 17: 160 x 256 tiles, ONE 8-wave workgroup per CU whose two wave groups swap the compute and the service
     role per tile — the service group issues every LDS-DMA and runs the previous tile's epilogue in slices under the partner's MFMAs;
-    accumulators in the AGPR half of the register file): STORE and GELU_FWD with row-major outputs, GELU and GELU_FWD with image outputs,
+    accumulators in the AGPR half of the register file): STORE and GELU_FWD with row-major outputs, GELU, GELU_FWD and MUL with image outputs,
     row-major or K-panel-image operands, with and without bias, with CUs reserved — the bits of the other schedules (same K order, same
     epilogue arithmetic); one tile per workgroup, several tiles per workgroup (role swaps), row tails, a single row."""
     a, ad = bf(rnd(M, K, seed=141))
@@ -873,6 +874,9 @@ def test_gemm_tile_alternating_kernel(ops, M, N, K):
         g_ref = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
         h_ref = ops.gemm_nt(A, W, bias, epilogue=ops.EPI_GELU, aux_out=g_ref).clone()
         h_nb = ops.gemm_nt(A, W, None, epilogue=ops.EPI_GELU_FWD).clone()
+        g_in = dev(bf(rnd(M, N, seed=144))[0])
+        m_ref = ops.gemm_nt(A, W, bias, epilogue=ops.EPI_MUL, aux_in=g_in).clone()
+        m_nb = ops.gemm_nt(A, W, None, epilogue=ops.EPI_MUL, aux_in=g_in).clone()
         assert rel_err(ref.cpu(), base) < BF16_OUT
         ops.set_gemm_variant(17)
         assert ops.gemm_kernel_name(M, N, K, ops.EPI_GELU, out_image=True, aux_image=True).startswith("gemm_tp_kernel<GELU")
@@ -880,6 +884,9 @@ def test_gemm_tile_alternating_kernel(ops, M, N, K):
         assert not ops.gemm_kernel_name(M, N, K, ops.EPI_GELU).startswith("gemm_tp_kernel")      # row-major two-output GELU: not instantiated
         hi_ = torch.zeros(N // 32, M, 32, device="cuda", dtype=torch.bfloat16)
         gi = torch.zeros(N // 32, M, 32, device="cuda", dtype=torch.bfloat16)
+        g_img = ops.k_panels(g_in)
+        mul_tp = K // 32 >= 23          # the MUL form needs two K-steps of load lead beside its twenty half-slices
+        assert ops.gemm_kernel_name(M, N, K, ops.EPI_MUL, out_image=True, aux_image=True).startswith("gemm_tp_kernel<MUL") == mul_tp
         for Ai, Wi in ((A, W), (A, ops.k_panels(W)), (ops.k_panels(A), ops.k_panels(W))):
             for rep in range(2):    # (twice: a race would not repeat itself)
                 assert torch.equal(ops.gemm_nt(Ai, Wi, bias), ref), rep
@@ -888,12 +895,21 @@ def test_gemm_tile_alternating_kernel(ops, M, N, K):
                 assert torch.equal(hi_, ops.k_panels(h_ref)) and torch.equal(gi, ops.k_panels(g_ref)), rep
                 ops.gemm_nt(Ai, Wi, bias, epilogue=ops.EPI_GELU_FWD, out=hi_.zero_())
                 assert torch.equal(hi_, ops.k_panels(h_ref)), rep
+                if mul_tp:      # round 6: (A W^T + b) * X with X and the output as images — the second operand read two half-slices ahead
+                    ops.gemm_nt(Ai, Wi, bias, epilogue=ops.EPI_MUL, aux_in=g_img, out=hi_.zero_())
+                    assert torch.equal(hi_, ops.k_panels(m_ref)), rep
         with ops.reserved_cus(8):
             assert torch.equal(ops.gemm_nt(A, W, bias), ref)
         with ops.reserved_cus(150):      # few workgroups, many tiles each
             ops.gemm_nt(A, W, bias, epilogue=ops.EPI_GELU, aux_out=gi.zero_(), out=hi_.zero_())
             assert torch.equal(hi_, ops.k_panels(h_ref)) and torch.equal(gi, ops.k_panels(g_ref))
             assert torch.equal(ops.gemm_nt(A, W, bias), ref)
+            if mul_tp:
+                ops.gemm_nt(A, W, bias, epilogue=ops.EPI_MUL, aux_in=g_img, out=hi_.zero_())
+                assert torch.equal(hi_, ops.k_panels(m_ref))
+        if mul_tp:
+            ops.gemm_nt(A, W, None, epilogue=ops.EPI_MUL, aux_in=g_img, out=hi_.zero_())
+            assert torch.equal(hi_, ops.k_panels(m_nb))
         assert torch.equal(ops.gemm_nt(A, W, None), ref_nb)   # no bias piece in the stream
         ops.gemm_nt(A, W, None, epilogue=ops.EPI_GELU_FWD, out=hi_.zero_())
         assert torch.equal(hi_, ops.k_panels(h_nb))

@@ -63,6 +63,16 @@ def main():
                 key = ev.name + " " + str(getattr(ev, "input_shapes", ""))[:90]
                 copies[key][0] += 1
                 copies[key][1] += k.duration
+    # every runtime copy call (hipMemcpyAsync / hipMemcpyWithStream: the blit kernel of rocprofv3's table), by the operator chain above it
+    calls = collections.defaultdict(int)
+    for ev in prof.events():
+        if not ev.name.startswith("hipMemcpy"):
+            continue
+        chain, par = [], ev.cpu_parent
+        while par is not None:
+            chain.append(par.name + " " + str(getattr(par, "input_shapes", ""))[:60])
+            par = par.cpu_parent
+        calls[(ev.name, " <- ".join(chain[:3]) or "(no operator: called from Python / the library)")] += 1
     print(f"torch-launched kernels of one iteration ({args.dtype}, batch {args.batch}): {total_torch / args.steps / 1e3:.3f} ms/step of "
           f"{total_all / args.steps / 1e3:.3f} ms/step attributed device time\n")
     print("| op | launched from | launches/step | device us/step |")
@@ -73,6 +83,10 @@ def main():
         print("\nruntime device-to-device copies by operator:\n\n| op | copies/step | device us/step |\n|---|---:|---:|")
         for name, (n, us) in sorted(copies.items(), key=lambda kv: -kv[1][0])[:25]:
             print(f"| {name} | {n / args.steps:.1f} | {us / args.steps:.1f} |")
+    if calls:
+        print("\nruntime copy calls by operator chain:\n\n| call | under | calls/step |\n|---|---|---:|")
+        for (name, chain), c in sorted(calls.items(), key=lambda kv: -kv[1])[:30]:
+            print(f"| {name} | {chain} | {c / args.steps:.1f} |")
 
 
 if __name__ == "__main__":
