@@ -193,6 +193,21 @@ __device__ __forceinline__ void store_acc_T(const f32x16 (&acc)[2], bf16* rowptr
     }
 }
 
+// store_acc_T of acc + coef * x^T (x: 64 fp32 values in LDS, one rank-1 term per lane's row): the term is added on the way out, the
+// accumulator tuple itself is not modified (element-wise updates of an MFMA accumulator made hipcc copy the tuples: spills in a kernel
+// that has no register to spare)
+__device__ __forceinline__ void store_acc_T_rank1(const f32x16 (&acc)[2], bf16* rowptr, int h, float mul, float coef, const float* x) {
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 xv = *(const f32x4*)(x + 32 * dt + 8 * g + 4 * h);
+      bf16x4 v = pack4((acc[dt][4 * g] + coef * xv[0]) * mul, (acc[dt][4 * g + 1] + coef * xv[1]) * mul,
+                       (acc[dt][4 * g + 2] + coef * xv[2]) * mul, (acc[dt][4 * g + 3] + coef * xv[3]) * mul);
+      *(bf16x4*)(rowptr + 32 * dt + 8 * g + 4 * h) = v;
+    }
+}
+
 // The same store through a per-wave 4 KB LDS buffer [32 rows][64 columns], 16-byte chunk c of row r at chunk c ^ (r & 7): every
 // global store instruction then writes 8 rows x 128 B (whole lines) with 16 bytes per lane — 4 instructions per 32 x 64 tile
 // instead of 8 that touch 32-64 lines each.  In-kernel stamps showed the direct form costing 8-11k cycles per head in the fused
@@ -1580,16 +1595,79 @@ __device__ __forceinline__ void rows_landed(RowRegs& r) {
 
 constexpr int PERSIST_MAX_ROWS = 256;
 
+// ---- N = 32 NT + 1 (EXTRA): a ViT/14 at 224 pixels has 16 x 16 patches + the class token = 257 tokens, one more than eight blocks, and
+// the block-granular kernels pay a ninth block for it (attn_bwd_small_kernel<288, 4>: 560 us against 394 us at 256 tokens, 4 092 heads).
+// The persistent kernel takes the first 32 NT tokens through its blocks and the LAST token x as rank-1 corrections in plain vector
+// arithmetic (attention is symmetric in the token order):
+//   P1, wave = query block:  p[i,x], ds[i,x] of the lane's query i against key x (two 64-long dot products from the q / dO registers),
+//                            dQ_i += ds[i,x] k_x;  partial sums over the block's 32 queries of ds[i,x] q_i (-> dK_x) and p[i,x] dO_i (-> dV_x)
+//   Y,  wave = key block:    p[x,j], ds[x,j] of query x against the lane's key j (from the k / v registers read for P2),
+//                            partial sum over the block's 32 keys of ds[x,j] k_j (-> dQ_x)
+//   P2:                      dV_j += p[x,j] dO_x,  dK_j += ds[x,j] q_x
+//   after barrier Y one wave adds the eight partial sums of each of dQ_x, dK_x, dV_x in a fixed order, the (x, x) term, and stores row x.
+// Token x's q, k, v, dO (fp32), lse * log2(e) and delta live in a double-buffered 1 KB LDS record that wave 0 fills for the NEXT head
+// while the current one is in P2.  p and ds are rounded to the 16-bit operand type where the blocks round theirs.
+struct XRegs { float a, b, c; };
+__device__ __forceinline__ void xrow_prefetch(XRegs& x, const void* pa, const void* pb, const void* pc) {
+  asm volatile("global_load_dword %0, %3, off\n\tglobal_load_dword %1, %4, off\n\tglobal_load_dword %2, %5, off"
+               : "=&v"(x.a), "=&v"(x.b), "=&v"(x.c) : "v"(pa), "v"(pb), "v"(pc) : "memory");
+}
+__device__ __forceinline__ void xrow_pin(XRegs& x) { asm volatile("" : "+v"(x.a), "+v"(x.b), "+v"(x.c)); }
+__device__ __forceinline__ float h16_round(float v) { return (float)(bf16)v; }
+// v[e], e < 32: one value per lane and index; afterwards lane l holds, in v[0], the sum over the 32 lanes of its half of index l & 31
+// (butterfly: every step halves the indices a lane is responsible for; 31 exchanges instead of 160)
+// the partner lane's value for the exchange distances of the butterfly: 16 = v_permlane16_swap (below), 8 = a rotation of the 16-lane
+// row, 2 and 1 = quad permutations (data-parallel-primitive modifiers: vector ALU, no LDS crossbar — the kernel's LDS port is its
+// scarce resource), 4 = ds_bpermute
+template <int OFF>
+__device__ __forceinline__ float lane_xor(float x) {
+  if constexpr (OFF == 8) return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xf, 0xf, false));   // row_ror:8
+  else if constexpr (OFF == 2) return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, false));   // quad_perm:[2,3,0,1]
+  else if constexpr (OFF == 1) return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, false));   // quad_perm:[1,0,3,2]
+  else return __shfl_xor(x, OFF, 64);
+}
+template <int OFF>
+__device__ __forceinline__ void half_wave_reduce_step(float (&v)[32], int lane) {
+  if constexpr (OFF == 16) {   // rows 1 / 3 of v[i] trade places with rows 0 / 2 of v[16 + i]: both halves of the exchange in one instruction
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float a = v[i], b = v[16 + i];   // (inline asm: with the builtin hipcc 7.2 added the first result to itself — seen in the .s)
+      asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));   // (wait states around a lane swap whose operands a vector instruction just wrote: inline asm is not padded)
+      v[i] = a + b;
+    }
+  } else {
+    const bool up = (lane & OFF) != 0;
+#pragma unroll
+    for (int i = 0; i < OFF; ++i) {
+      const float keep = up ? v[OFF + i] : v[i], send = up ? v[i] : v[OFF + i];
+      v[i] = keep + lane_xor<OFF>(send);
+    }
+  }
+}
+__device__ __forceinline__ float half_wave_reduce32(float (&v)[32], int lane) {
+  half_wave_reduce_step<16>(v, lane);
+  half_wave_reduce_step<8>(v, lane);
+  half_wave_reduce_step<4>(v, lane);
+  half_wave_reduce_step<2>(v, lane);
+  half_wave_reduce_step<1>(v, lane);
+  return v[0];
+}
+constexpr int XA_FLOATS = 272;          // k[64] v[64] q[64] dO[64] lse2 delta (+ pad) per buffer, two buffers
+constexpr int XA_BYTES = 2 * XA_FLOATS * 4 + 3 * 8 * 64 * 4;   // + the partial sums [3][8 waves][64]
+
 // NT = 32-row blocks per sequence (compile time: the four tiles then sit at instruction-immediate distances of NT * 4 KB).
 // STAGED: the dQ / dK / dV tiles leave through a per-wave 4 KB LDS buffer as whole lines (store_acc_T_staged); the eight buffers
 // fit beside the four tiles up to seven blocks (N <= 224), the eight-block case stores directly.
 constexpr int bwdp_waves(int nt) { return nt <= 7 ? nt + 1 : 8; }   // up to seven blocks: one wave per block + the loader wave
-template <int NT, bool STAGED>
+template <int NT, bool STAGED, bool EXTRA = false>
 __global__ __launch_bounds__(64 * bwdp_waves(NT), 2) void attn_bwd_persist_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
                                                                   const bf16* __restrict__ dout, const float* __restrict__ lse,
                                                                   float* __restrict__ delta, bf16* __restrict__ dqkv, int N,
                                                                   int H, float scale, int BH) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // K, V, Q, dO tiles [32 NT][64]; lse*log2e [256]; delta [256]; store buffers
+  static_assert(!EXTRA || (NT == 8 && !STAGED), "the extra-token form exists for 8 blocks + 1 (257 tokens)");
+  const int NSEQ = N;                  // tokens of a sequence (strides); below, N = the tokens the blocks cover
+  if constexpr (EXTRA) N -= 1;
   const int tid = threadIdx.x, lane = tid & 63, h2 = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int D = H * 64;
@@ -1614,6 +1692,8 @@ __global__ __launch_bounds__(64 * bwdp_waves(NT), 2) void attn_bwd_persist_kerne
   const FragOffs fo = frag_offs(lane);
   const unsigned ka0 = lds_addr(KA);
   char* wbuf = smem + 4 * T_OFF + 2 * PERSIST_MAX_ROWS * 4 + wave * 4096;   // STAGED: this wave's store buffer
+  float* const xa_base = (float*)(smem + 4 * T_OFF + 2 * PERSIST_MAX_ROWS * 4);   // EXTRA: token x's record (two buffers), then the partial sums
+  float* const xslots = xa_base + 2 * XA_FLOATS;                                  // [3: dQ_x, dK_x, dV_x][8][64]
   STAMP_DECL
 
   // A set of two tiles is 8 * nt pieces of 1 KB (8 rows x 128 B): wave w issues pieces [(w & 3) * nt, +nt) of the first (w < 4) or
@@ -1671,17 +1751,43 @@ __global__ __launch_bounds__(64 * bwdp_waves(NT), 2) void attn_bwd_persist_kerne
   auto head_of = [&](int idx) {
     const int b = idx / H, h = idx - b * H;
     Head hd;
-    hd.base = qkv + (long)b * N * ld + h * 64;
-    hd.dobase = dout + (long)b * N * D + h * 64;
-    hd.obase = o + (long)b * N * D + h * 64;
-    hd.lsebase = lse + (long)idx * N;
-    hd.dlbase = delta + (long)idx * N;
-    hd.outbase = dqkv + (long)b * N * ld + h * 64;
+    hd.base = qkv + (long)b * NSEQ * ld + h * 64;
+    hd.dobase = dout + (long)b * NSEQ * D + h * 64;
+    hd.obase = o + (long)b * NSEQ * D + h * 64;
+    hd.lsebase = lse + (long)idx * NSEQ;
+    hd.dlbase = delta + (long)idx * NSEQ;
+    hd.outbase = dqkv + (long)b * NSEQ * ld + h * 64;
     return hd;
   };
   auto prefetch_rows = [&](RowRegs& rr, const Head& hd) {
     const int e = 8 * h2;
     rows_prefetch(rr, hd.base + (long)r * ld + e, hd.dobase + (long)r * D + e, hd.obase + (long)r * D + e, hd.lsebase + r);
+  };
+  // EXTRA, wave 0: token x of a head into registers (lanes 0-31: q | v | o pairs, lanes 32-63: k | dO pairs | lse), then — once landed —
+  // into the record `buf` as fp32 with lse * log2(e) and delta = dO_x . o_x (also written to the delta output)
+  auto xrow_request = [&](XRegs& xr, const Head& h) {
+    const int pl = lane & 31;
+    const bf16* rowq = h.base + (long)N * ld;           // row x = N (the blocks cover rows 0 .. N - 1)
+    const void* pa = h2 ? (const void*)(rowq + D + 2 * pl) : (const void*)(rowq + 2 * pl);
+    const void* pb = h2 ? (const void*)(h.dobase + (long)N * D + 2 * pl) : (const void*)(rowq + 2 * D + 2 * pl);
+    const void* pc = h2 ? (const void*)(h.lsebase + N) : (const void*)(h.obase + (long)N * D + 2 * pl);
+    xrow_prefetch(xr, pa, pb, pc);
+  };
+  auto xrow_publish = [&](const XRegs& xr, int buf, const Head& h) {
+    float* xa = xa_base + buf * XA_FLOATS;
+    const int pl = lane & 31;
+    const bf16x2 pa = __builtin_bit_cast(bf16x2, xr.a), pb = __builtin_bit_cast(bf16x2, xr.b);
+    // xa: k at 0, v at 64, q at 128, dO at 192
+    float* da = xa + (h2 ? 0 : 128) + 2 * pl;
+    float* db = xa + (h2 ? 192 : 64) + 2 * pl;
+    da[0] = (float)pa[0]; da[1] = (float)pa[1];
+    db[0] = (float)pb[0]; db[1] = (float)pb[1];
+    const float oc = __shfl(xr.c, pl, 64);              // lanes 32-63 fetch the o pair of lane - 32
+    const bf16x2 po = __builtin_bit_cast(bf16x2, oc);
+    float dl = h2 ? (float)pb[0] * (float)po[0] + (float)pb[1] * (float)po[1] : 0.f;
+#pragma unroll
+    for (int o_ = 32; o_ > 0; o_ >>= 1) dl += __shfl_xor(dl, o_, 64);
+    if (lane == 32) { xa[256] = xr.c * LOG2E; xa[257] = dl; h.dlbase[N] = dl; }
   };
 
   int idx = blockIdx.x;
@@ -1709,6 +1815,39 @@ __global__ __launch_bounds__(64 * bwdp_waves(NT), 2) void attn_bwd_persist_kerne
   }
   RowRegs rr;
   if (active) { prefetch_rows(rr, hd); rows_landed<0>(rr); }   // first head only: the rows are waited for on the spot
+  int hb = 0;                        // EXTRA: which of the two records holds token x of the current head
+  // p[x, j] and ds[x, j] of query x against this lane's key j, from the key block's k / v registers (at Y for the share of dQ_x, again
+  // behind the P2 loop for dK_j / dV_j: two registers that would otherwise live through the loop, whose budget is spent)
+  auto x_vs_key = [&](const bf16x8 (&kf_)[4], const bf16x8 (&vf_)[4], float& pk, float& dsk) {
+    const float* xa = xa_base + hb * XA_FLOATS;
+    float sx = 0.f, dpx = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const f32x4 q0 = *(const f32x4*)(xa + 128 + 16 * ks + 8 * h2), q1 = *(const f32x4*)(xa + 128 + 16 * ks + 8 * h2 + 4);
+      const f32x4 d0 = *(const f32x4*)(xa + 192 + 16 * ks + 8 * h2), d1 = *(const f32x4*)(xa + 192 + 16 * ks + 8 * h2 + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        sx += (float)kf_[ks][j] * q0[j] + (float)kf_[ks][4 + j] * q1[j];
+        dpx += (float)vf_[ks][j] * d0[j] + (float)vf_[ks][4 + j] * d1[j];
+      }
+      __builtin_amdgcn_sched_barrier(0);   // (one k-step's sixteen record values at a time: hoisted together they cost 64 registers)
+    }
+    sx += __shfl_xor(sx, 32, 64);
+    dpx += __shfl_xor(dpx, 32, 64);
+    const float p = ATT_EXP2(fmaf(sx, c, -xa[256]));
+    pk = h16_round(p);
+    dsk = h16_round(p * (dpx - xa[257]));
+  };
+  if constexpr (EXTRA) {
+    XRegs xr;
+    xrow_request(xr, hd);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    xrow_pin(xr);
+    if (wave == 0) {
+      xrow_publish(xr, 0, hd);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
   if constexpr (!LOADER) stage(hd.base + D, ld, hd.base + 2 * D, ld, KA, VA);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   STAMP(0);   // first head: rows + set A
@@ -1778,9 +1917,44 @@ __global__ __launch_bounds__(64 * bwdp_waves(NT), 2) void attn_bwd_persist_kerne
         }
       }
       STAMP(3);   // P1 loop
+      float pq = 0.f, dsq = 0.f;     // EXTRA: p[i, x], ds[i, x] of this lane's query
+      if constexpr (EXTRA) {
+        const float* xa = xa_base + hb * XA_FLOATS;
+        float sx = 0.f, dpx = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const f32x4 k0 = *(const f32x4*)(xa + 16 * ks + 8 * h2), k1 = *(const f32x4*)(xa + 16 * ks + 8 * h2 + 4);
+          const f32x4 v0 = *(const f32x4*)(xa + 64 + 16 * ks + 8 * h2), v1 = *(const f32x4*)(xa + 64 + 16 * ks + 8 * h2 + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            sx += (float)qf[ks][j] * k0[j] + (float)qf[ks][4 + j] * k1[j];
+            dpx += (float)dof[ks][j] * v0[j] + (float)dof[ks][4 + j] * v1[j];
+          }
+        }
+        sx += __shfl_xor(sx, 32, 64);
+        dpx += __shfl_xor(dpx, 32, 64);
+        const float p = ATT_EXP2(fmaf(sx, c, -lse2));
+        pq = h16_round(p);
+        dsq = h16_round(p * (dpx - dl));
+      }
       if constexpr (STAGED) store_acc_T_staged(acc_dq, wbuf, hd.outbase, ld, wave * 32, N, lane, scale);
+      else if constexpr (EXTRA) store_acc_T_rank1(acc_dq, hd.outbase + (long)r * ld, h2, scale, dsq, xa_base + hb * XA_FLOATS);   // dQ_i += ds[i,x] k_x
       else if (rvalid) store_acc_T(acc_dq, hd.outbase + (long)r * ld, h2, scale);
       STAMP(4);   // dQ stores
+      if constexpr (EXTRA) {   // this block's share of dK_x = sum_i ds[i,x] q_i and dV_x = sum_i p[i,x] dO_i
+        const int e_ = lane & 31, dd = 16 * (e_ >> 3) + 8 * h2 + (e_ & 7);
+        float v[32];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[8 * ks + j] = dsq * (float)qf[ks][j];
+        xslots[(8 + wave) * 64 + dd] = half_wave_reduce32(v, lane);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[8 * ks + j] = pq * (float)dof[ks][j];
+        xslots[(16 + wave) * 64 + dd] = half_wave_reduce32(v, lane);
+      }
     }
     // ================================================================ Y: own k / v rows out of set A, set B has landed
     bf16x8 kf[4], vf[4];
@@ -1791,6 +1965,18 @@ __global__ __launch_bounds__(64 * bwdp_waves(NT), 2) void attn_bwd_persist_kerne
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(kf[ks]), "+v"(vf[ks]));
+      if constexpr (EXTRA) {   // query x against this lane's key: p[x,j], ds[x,j]; this block's share of dQ_x = sum_j ds[x,j] k_j
+        float pxk, dsxk;
+        x_vs_key(kf, vf, pxk, dsxk);
+        const int e_ = lane & 31, dd = 16 * (e_ >> 3) + 8 * h2 + (e_ & 7);
+        float v[32];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[8 * ks + j] = dsxk * (float)kf[ks][j];
+        xslots[wave * 64 + dd] = half_wave_reduce32(v, lane);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the partial sums of this wave (P1's two as well) are in LDS before barrier Y
+      }
       // the DMA of set B is older than the dQ stores (with a loader wave this wave has no DMA to wait for)
       if constexpr (!LOADER) { if constexpr (STAGED) wait_vmcnt_upto4(tile_stores); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
     } else {
@@ -1800,6 +1986,24 @@ __global__ __launch_bounds__(64 * bwdp_waves(NT), 2) void attn_bwd_persist_kerne
     __builtin_amdgcn_s_barrier();   // every wave is done with set A; set B, lse and delta are complete
     asm volatile("" ::: "memory");
     STAMP(6);   // barrier Y
+    if constexpr (EXTRA) {
+      if (wave == NT - 1) {   // row x of dQ, dK, dV: the eight partial sums in wave order, the (x, x) term, one store each; lane = column
+        const float* xa = xa_base + hb * XA_FLOATS;
+        const float kq = xa[lane], vq = xa[64 + lane], qq = xa[128 + lane], dq_ = xa[192 + lane];
+        float sxx = qq * kq, dpxx = dq_ * vq;
+#pragma unroll
+        for (int o_ = 32; o_ > 0; o_ >>= 1) { sxx += __shfl_xor(sxx, o_, 64); dpxx += __shfl_xor(dpxx, o_, 64); }
+        const float p = ATT_EXP2(fmaf(sxx, c, -xa[256]));
+        const float pb = h16_round(p), dsb = h16_round(p * (dpxx - xa[257]));
+        float gq = dsb * kq, gk = dsb * qq, gv = pb * dq_;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) { gq += xslots[w * 64 + lane]; gk += xslots[(8 + w) * 64 + lane]; gv += xslots[(16 + w) * 64 + lane]; }
+        bf16* orow = hd.outbase + (long)N * ld + lane;
+        orow[0] = (bf16)(gq * scale);
+        orow[D] = (bf16)(gk * scale);
+        orow[2 * D] = (bf16)gv;
+      }
+    }
     const int next = idx + gridDim.x;
     const bool has_next = next < BH;
     Head hn = hd;
@@ -1880,22 +2084,36 @@ __global__ __launch_bounds__(64 * bwdp_waves(NT), 2) void attn_bwd_persist_kerne
       // have room for them), i.e. older than both tiles' stores in the vmcnt queue, and waited for behind them.  Unconditional (the
       // last head re-reads its own rows, never used): a conditional definition would keep the previous head's 49 registers alive
       // through P2.
+      float pxk = 0.f, dsxk = 0.f;   // EXTRA: query x's share of this block's keys, added on the way out: dV_j += p[x,j] dO_x, dK_j += ds[x,j] q_x
+      if constexpr (EXTRA) x_vs_key(kf, vf, pxk, dsxk);
       asm volatile("" ::: "memory");
+      XRegs xr;
+      if constexpr (EXTRA) xrow_request(xr, hn);   // token x of the next head (every wave asks, wave 0 uses it): older than the rows, landed with them
       prefetch_rows(rr, hn);
       if constexpr (STAGED) store_acc_T_staged(acc_dk, wbuf, hd.outbase + D, ld, wave * 32, N, lane, scale);
+      else if constexpr (EXTRA) store_acc_T_rank1(acc_dk, hd.outbase + (long)r * ld + D, h2, scale, dsxk, xa_base + hb * XA_FLOATS + 128);
       else if (rvalid) store_acc_T(acc_dk, hd.outbase + (long)r * ld + D, h2, scale);
       if constexpr (STAGED) store_acc_T_staged(acc_dv, wbuf, hd.outbase + 2 * D, ld, wave * 32, N, lane, 1.0f);
+      else if constexpr (EXTRA) store_acc_T_rank1(acc_dv, hd.outbase + (long)r * ld + 2 * D, h2, 1.0f, pxk, xa_base + hb * XA_FLOATS + 192);
       else if (rvalid) store_acc_T(acc_dv, hd.outbase + (long)r * ld + 2 * D, h2, 1.0f);
       STAMP(9);   // row prefetch + dK / dV stores issued
       // the rows (and, without a loader wave, set A of the next head: older still) have landed; the dK / dV stores stay in flight
       if constexpr (STAGED) { wait_vmcnt_upto8(2 * tile_stores); rows_pin(rr); } else rows_landed<16>(rr);
       STAMP(10);  // wait for rows / set A
+      if constexpr (EXTRA) {
+        xrow_pin(xr);
+        if (wave == 0 && has_next) {   // into the OTHER record: the waves still in P2 read the current one
+          xrow_publish(xr, hb ^ 1, hn);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+      }
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     if (!has_next) break;
     idx = next;
     hd = hn;
+    if constexpr (EXTRA) hb ^= 1;
   }
 #if defined(APLA_ATT_STAMPS)
   if (lane == 0 && blockIdx.x < 512) for (int k_ = 0; k_ < 16; ++k_) apla_att_dbg[(blockIdx.x * 8 + wave) * 16 + k_] = st_acc[k_];
@@ -2101,8 +2319,8 @@ static AttnKernel attn_fwd_choice(bool packed, int B, int N, int H, int variant)
 static AttnKernel attn_bwd_choice(bool packed, int B, int N, int H, int variant) {
   // uniform batch of short sequences with at least one head per CU: the persistent kernel (every load one phase ahead of its use);
   // variant 2 pins the one-workgroup-per-head kernels, variant 3 the persistent one wherever it applies (tests, A/B timing)
-  if (!packed && N <= PERSIST_MAX_ROWS && variant != 1 && variant != 2 && (variant == 3 || (long)B * H >= apla_num_cus()))
-    return ATTN_BWD_PERSIST;
+  if (!packed && (N <= PERSIST_MAX_ROWS || N == PERSIST_MAX_ROWS + 1) && variant != 1 && variant != 2 && (variant == 3 || (long)B * H >= apla_num_cus()))
+    return ATTN_BWD_PERSIST;   // (257 tokens: eight blocks + the last token as rank-1 corrections, attn_bwd_persist_kernel<8, false, true>)
   if (N <= TINY_MAX_ROWS && variant != 1) return ATTN_BWD_TINY;
   if (N <= SMALL_MAX_ROWS_BWD && variant != 1) return ATTN_BWD_SMALL;
   return ATTN_BWD_SPLIT;
@@ -2189,6 +2407,17 @@ static int launch_attn_bwd(const void* qkv, const void* o, const void* d_o, cons
                             // stagger of waves 4-7 changed nothing, profiles/r05_attn_experiments.md)
   APLA_REQUIRE(g_attn_variant >= 0 && g_attn_variant <= 3, "%s: unknown kernel variant %d", who, g_attn_variant);
   const AttnKernel kchoice = attn_bwd_choice(cu != nullptr, B, N, H, g_attn_variant);
+  if (kchoice == ATTN_BWD_PERSIST && N == PERSIST_MAX_ROWS + 1) {
+    const int BH = B * H;
+    const size_t lds = (size_t)8 * 4096 * 4 + 2 * PERSIST_MAX_ROWS * 4 + XA_BYTES;
+    auto kern = attn_bwd_persist_kernel<8, false, true>;
+    static std::atomic<unsigned long long> lds_ok{0};
+    apla_allow_lds(lds_ok, (const void*)kern, (int)lds);
+    const int G = fwdp_grid((const void*)kern, 64 * bwdp_waves(8), lds, BH);
+    hipLaunchKernelGGL(kern, dim3(G), dim3(64 * bwdp_waves(8)), lds, stream, (const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse, delta, (bf16*)dqkv, N, H, scale, BH);
+    APLA_CHECK_LAUNCH(who);
+    return APLA_OK;
+  }
   if (kchoice == ATTN_BWD_PERSIST) {
     const int NP = (N + 31) / 32 * 32, BH = B * H;
     const int nt = NP / 32;

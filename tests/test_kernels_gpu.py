@@ -1216,9 +1216,9 @@ def test_cross_entropy_soft_targets(ops):
 @pytest.mark.parametrize("B,N", [(128, 197), (96, 50), (40, 256), (64, 257), (48, 288), (30, 225), (23, 32), (60, 129), (90, 96),
                                  (512, 50), (300, 17), (120, 64), (70, 65), (400, 1)])
 def test_attn_bwd_fused_short_sequence_kernel_equals_split_kernels_at_full_occupancy(ops, B, N):
-    """The one-workgroup-per-head backward (N <= 288) and the persistent backward (N <= 256: resident workgroups of one wave per
-    32-row block + a loader wave walking their heads, every load one phase ahead of its use; up to 96 tokens two to four of them per
-    CU) against the query-/key-blocked kernels on identical inputs, with enough
+    """The one-workgroup-per-head backward (N <= 288) and the persistent backward (N <= 256, and 257 = eight blocks + one token: resident
+    workgroups of one wave per 32-row block + a loader wave walking their heads, every load one phase ahead of its use; up to 96 tokens
+    two to four of them per CU) against the query-/key-blocked kernels on identical inputs, with enough
     heads to fill the chip several times over: bitwise equal (same products in the same order), delta included, and
     reproducible.  (A first version of the fused kernel let the 64-float lse DMA pieces spill into the delta rows next to them:
     invisible at the small batches of the parity tests above, a race at full occupancy.)"""
@@ -1242,6 +1242,15 @@ def test_attn_bwd_fused_short_sequence_kernel_equals_split_kernels_at_full_occup
     finally:
         ops.set_attn_variant(old)
     for v in (2, 3, 0):
+        if N == 257 and v != 2:
+            # 8 blocks + 1: the persistent kernel takes token 256 as rank-1 corrections in vector arithmetic (round 6) — other products,
+            # another summation order: equal to the blocked kernels within the rounding of the 16-bit outputs, delta to fp32 rounding,
+            # and the same bits from the automatic choice as from the pinned variant
+            assert ops.attn_kernel_name("bwd", B, N, H).startswith("attn_bwd_persist_kernel")
+            assert torch.equal(res[v][0], res[3][0]) and torch.equal(res[v][1], res[3][1]), v
+            assert rel_err(res[v][0].float().cpu(), res[1][0].float().cpu()) < 1e-2, v
+            assert float((res[v][1] - res[1][1]).abs().max()) < 1e-4 * float(res[1][1].abs().max()), v
+            continue
         assert torch.equal(res[v][0], res[1][0]) and torch.equal(res[v][1], res[1][1]), v
     # ... and against the fp64 oracle (appla_attn.py:56-60 differentiated by hand, oracle/apla_oracle.py:attention_bwd), as the forward's
     # test does: all twelve heads of the first, a middle and the last sequence of the walk — at (128, 197) and (64, 257) the launch is
