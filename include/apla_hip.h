@@ -239,12 +239,14 @@ int apla_attn_varlen_bwd(const void* qkv, const void* o, const void* d_o, const 
 /* The attention entry points with an explicit kernel choice (`variant`; the plain entry points pass 0):
  *   0 = auto: uniform batches of up to 280 tokens with at least one head per CU use the persistent forward (resident workgroups
  *       walking their heads, K / V double-buffered by a loader wave, one row maximum per head: one wave per 32-row block up to 224
- *       tokens — several small workgroups per CU up to 96 —, four waves walking 8 or 9 blocks above) and, up to 256 tokens, the
+ *       tokens — several small workgroups per CU up to 96 —, four waves walking 8 or 9 blocks above) and, up to 256 tokens and at
+ *       257 (eight blocks + the last token as rank-1 corrections: a ViT/14 at 224 pixels), the
  *       persistent backward (every load one phase ahead of its use; several small workgroups per CU for short sequences, down to
  *       one token); other batches of up to 288 tokens the one-workgroup-per-head
  *       kernels (whole K / V of a head in LDS); longer sequences the key-/query-blocked kernels;
  *   1 = always the blocked kernels; 2 = the one-workgroup-per-head kernels (never the persistent ones); 3 = the persistent
- *       kernels wherever they apply.  The backward kernels compute bitwise the same results, and so do the blocked and the
+ *       kernels wherever they apply.  The backward kernels compute bitwise the same results (except the 257-token form of the
+ *       persistent one: other products for the last token, equal to rounding), and so do the blocked and the
  *       one-workgroup-per-head forward; the persistent forward takes ONE maximum per row instead of a running one per 64 keys and
  *       agrees with them to rounding (tests/test_kernels_gpu.py).  Bits 8.. of `variant` are ignored. */
 int apla_attn_fwd_ex(const void* qkv, void* o, float* lse, int B, int N, int H, float scale, int variant, hipStream_t stream);
