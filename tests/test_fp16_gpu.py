@@ -110,7 +110,7 @@ def test_fp16_attention_and_layernorm():
 def test_fp16_persistent_attention_kernels(B, N, H):
     """The persistent attention kernels of the fp16 build at sizes that select them (at least one head per CU): the forward (one wave
     per block / four waves walking nine blocks / several workgroups per CU) against the one-workgroup-per-head kernel and, on sampled
-    sequences, the fp64 oracle; the backward bitwise against the blocked kernels."""
+    sequences, the fp64 oracle; the backward bitwise against the blocked kernels (257 tokens: to rounding)."""
     from apla_amd import ops
     D, scale = 64 * H, 64 ** -0.5
     qkv, qkvd = hf(rnd(B * N, 3 * D, seed=41))
@@ -128,7 +128,11 @@ def test_fp16_persistent_attention_kernels(B, N, H):
             d1 = ops.attn_bwd(q, o, g, lse, B, N, H, scale).clone()
         finally:
             ops.set_attn_variant(old)
-    assert o.dtype == torch.float16 and torch.equal(d0, d1)
+    assert o.dtype == torch.float16
+    if N == 257:    # eight blocks + the last token as rank-1 corrections (both directions, round 6): other products, equal to fp16 rounding
+        assert rel_err(d0.float().cpu(), d1.float().cpu()) < 2e-3
+    else:
+        assert torch.equal(d0, d1)
     top = float(o_ref.float().abs().max())
     assert float((o.float() - o_ref.float()).abs().max()) < 4 * 2 ** -12 * top      # a few units in the last place of the largest outputs
     assert float((lse - lse_ref).abs().max()) < 2e-6 * max(1.0, float(lse_ref.abs().max()))
