@@ -78,15 +78,35 @@ constexpr int TJ = 64, TK = 128, TM = 64;  // j granule 64; output tile (64*NJ) 
 #define DW_LDSP(p) ((__attribute__((address_space(3))) void*)(p))
 #define DW_GLBP(p) ((const __attribute__((address_space(1))) void*)(p))
 constexpr int DW_MAX_BATCH = 8;
+// Ring depth of proj_dw_partial_kernel: 3 stages, one workgroup per CU — or, up to NJ = 2 and from 16 output tiles (r = 256 at D = 1024,
+// the 2048-wide layers of the DINO head), 2 stages and TWO workgroups per CU (see the kernel).  With few output tiles the token axis
+// is cut into many slabs and doubling them doubles the fp32 partials: r = 128 at D = 768 (6 tiles) lost 18-30 % that way.  (A four-stage
+// ring with one workgroup changed nothing in config 3's step; its counters show the batched launches fetching 2.4 x the algorithmic
+// bytes — the 16 tiles of a unit drift apart over 200-500 steps and lose each other in the L2 — at the same time as the
+// one-layer launches at 1.0 x: the kernel is bound by neither; profiles/r06_h_dispatch_checks.md.)
+inline int dw_group(int r) { return r % 192 == 0 ? 3 : (r % 128 == 0 ? 2 : 1); }  // 64-row granules per workgroup
+inline int dw_ring(int r, int D) {
+#if defined(APLA_ABL_DWRING3)   // diagnostic build: round 5's form at every width
+  return 3;
+#else
+  return (dw_group(r) <= 2 && (r / (TJ * dw_group(r))) * (D / TK) >= 16) ? 2 : 3;
+#endif
+}
 struct DwIn { const bf16* dyg[DW_MAX_BATCH]; const bf16* x[DW_MAX_BATCH]; };
 struct DwOut { float* dW[DW_MAX_BATCH]; float* db[DW_MAX_BATCH]; const float* row_scale[DW_MAX_BATCH]; };
 template <int N> __device__ __forceinline__ void dw_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int NJ>
+template <int NJ, int NS>
 __global__ __launch_bounds__(256) void proj_dw_partial_kernel(DwIn in, int nb, int ldx, float* __restrict__ partial, int M, int r,
                                                               int D, int rows_per_slab, int S) {
-  constexpr int STG = (NJ + 2) * 8192, NS = 3, PW = (NJ + 2) * 2;  // stage bytes; ring depth; pieces per wave per step
-  __shared__ __attribute__((aligned(16))) char smem[NS * STG];
+  // Ring depth.  A wave of this kernel issues its own LDS-DMA (~100 blocking cycles per 1 KB piece, 8-10 pieces per step) next to 16-24
+  // products and 40-56 transposed LDS reads, one wave per SIMD: the step is ISSUE-bound, not HBM-bound (round 6: 1.2-2.0 TB/s at
+  // r = 256 / 128).  Up to NJ = 2 a two-stage ring (64 KB + the 66 KB epilogue tile) lets TWO workgroups share a CU, so that one's DMA
+  // issue and barrier waits run under the other's products (NS = 2; chosen from 16 output tiles: dw_ring); NJ = 3 (r = 192: 40 KB
+  // stages) keeps three stages and one workgroup.
+  constexpr int STG = (NJ + 2) * 8192, PW = (NJ + 2) * 2;  // stage bytes; pieces per wave per step (NS: ring depth)
+  constexpr int EPI_BYTES = 64 * NJ * 132 * 4;                               // the fp32 output tile of the epilogue
+  __shared__ __attribute__((aligned(16))) char smem[NS * STG > EPI_BYTES ? NS * STG : EPI_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, h2 = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // Workgroup ids are dealt round-robin to the 8 XCDs: all (tj, tk) tiles of one unit (layer, token slab) get ids of the same
@@ -146,15 +166,15 @@ __global__ __launch_bounds__(256) void proj_dw_partial_kernel(DwIn in, int nb, i
     xb[hh] = tr_base(smem + NJ * 8192 + (wk >> 6) * 8192, wk & 63, hh, lane);
   }
   if (nsteps > 0) issue(0);
-  if (nsteps > 1) issue(1);
+  if (NS > 2 && nsteps > 1) issue(1);
   // One 64-token step.  TAIL: token rows past the end exist in this step (only the last step of the last slab of a layer);
   // BIAS: this workgroup also sums dyg's columns (the tk == 0 tiles).  Both are compile-time so that the six products of a
   // 16-row step are issued back to back (as run-time tests they put two branches between every two MFMAs).
   auto step = [&](int s, auto TAILC, auto BIASC) {
     constexpr bool TAIL = TAILC.value != 0, BIAS = BIASC.value != 0;
-    if (s + 1 < nsteps) dw_wait_vmcnt<PW>(); else dw_wait_vmcnt<0>();
+      if (NS > 2 && s + 1 < nsteps) dw_wait_vmcnt<PW>(); else dw_wait_vmcnt<0>();   // stage s has landed (NS = 3: the next one may still fly)
     __builtin_amdgcn_s_barrier();  // stage s has landed for every wave; everyone is done reading stage s-1
-    if (s + 2 < nsteps) issue(s + 2);
+    if (s + NS - 1 < nsteps) issue(s + NS - 1);
     const int valid = m_end - (m_begin + s * TM);  // token rows of this step that exist (< 64 only at the very end of M)
     // Rows past the end were fetched from a clamped address: their dyg fragment elements are forced to zero (element e
     // of a transposed fragment is token row 16*ks + 8*(e>>2) + 4*(lane>>5) + (e&3)).  No LDS writes here: a plain LDS
@@ -298,14 +318,13 @@ __global__ __launch_bounds__(256) void proj_dw_reduce_kernel(const float* __rest
   }
 }
 
-inline int dw_group(int r) { return r % 192 == 0 ? 3 : (r % 128 == 0 ? 2 : 1); }  // 64-row granules per workgroup
-
 inline int dw_slabs(int M, int r, int D, int nb = 1) {
   const int tiles = (r / (TJ * dw_group(r))) * (D / TK);
-  int S = 256 / tiles / 8 * 8;  // a multiple of 8 (one slab set per XCD), at most one workgroup per CU
+  const int cap = dw_ring(r, D) == 2 ? 512 : 256;   // workgroups resident at once
+  int S = cap / tiles / 8 * 8;  // a multiple of 8 (one slab set per XCD), as many workgroups as are resident at once
   if (tiles >= 256) return 1;   // more output tiles than CUs: no token split (every slab would cost an r x D fp32 partial)
-  if (nb > 1) {                 // units = nb * S are dealt to the XCDs one by one: any S, still at most one workgroup per CU
-    S = 256 / (tiles * nb);
+  if (nb > 1) {                 // units = nb * S are dealt to the XCDs one by one: any S, still no more workgroups than are resident
+    S = cap / (tiles * nb);
     const int max_s = (M + TM - 1) / TM;
     return S < 1 ? 1 : (S > max_s ? max_s : S);
   }
@@ -468,9 +487,12 @@ extern "C" int apla_proj_dw_batched(int nb, const void* const* dyg, const void* 
   int rows_per_slab = ((M + S - 1) / S + TM - 1) / TM * TM;
   const int nj = dw_group(r);
   const dim3 grid(U == 1 ? (r / (TJ * nj)) * (D / TK) : 8 * ((U + 7) / 8) * (r / (TJ * nj)) * (D / TK));
-  if (nj == 3) hipLaunchKernelGGL(proj_dw_partial_kernel<3>, grid, dim3(256), 0, stream, in, nb, ldx, (float*)partial, M, r, D, rows_per_slab, S);
-  else if (nj == 2) hipLaunchKernelGGL(proj_dw_partial_kernel<2>, grid, dim3(256), 0, stream, in, nb, ldx, (float*)partial, M, r, D, rows_per_slab, S);
-  else hipLaunchKernelGGL(proj_dw_partial_kernel<1>, grid, dim3(256), 0, stream, in, nb, ldx, (float*)partial, M, r, D, rows_per_slab, S);
+  const int ns = dw_ring(r, D);
+#define DW_LAUNCH(NJV, NSV) hipLaunchKernelGGL((proj_dw_partial_kernel<NJV, NSV>), grid, dim3(256), 0, stream, in, nb, ldx, (float*)partial, M, r, D, rows_per_slab, S)
+  if (nj == 3) DW_LAUNCH(3, 3);
+  else if (nj == 2) { if (ns == 2) DW_LAUNCH(2, 2); else DW_LAUNCH(2, 3); }
+  else { if (ns == 2) DW_LAUNCH(1, 2); else DW_LAUNCH(1, 3); }
+#undef DW_LAUNCH
   APLA_CHECK_LAUNCH("apla_proj_dw[partial]");
   const long n4 = (long)r * D / 4;
   hipLaunchKernelGGL(proj_dw_reduce_kernel, dim3((unsigned)((4 * n4 + 255) / 256), nb), dim3(256), 0, stream, (const float*)partial, out, nb, r, D, S, accumulate);

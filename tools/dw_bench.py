@@ -8,11 +8,11 @@ if os.environ.get("APLA_LIB"):
     _lib.LIB_PATH = os.environ["APLA_LIB"]
 from apla_amd import ops
 
-M, r, D = int(os.environ.get("DW_M", 25216)), 192, 768
+M, r, D = int(os.environ.get("DW_M", 25216)), int(os.environ.get("DW_R", 192)), int(os.environ.get("DW_D", 768))   # e.g. DW_M=65792 DW_R=256 DW_D=1024 (config 3), DW_M=58496 DW_R=128 (self-supervised student)
 dyg = torch.randn(M, r, device="cuda").to(torch.bfloat16)
 x = torch.randn(M, D, device="cuda").to(torch.bfloat16)
 dW, db = torch.zeros(r, D, device="cuda"), torch.zeros(r, device="cuda")
-ws = torch.empty(64 * (r * D + r), device="cuda")
+ws = torch.empty(256 * (r * D + r), device="cuda")
 for _ in range(3):
     ops.proj_dw(dyg, x, dW, db, workspace=ws)
 ref = dyg.float().T @ x.float()
