@@ -905,7 +905,7 @@ def ema_update(teacher: torch.Tensor, student: torch.Tensor, m: float):
     return teacher
 
 
-_KOLEO_TICKET = {}   # device index -> the int32 ticket of apla_koleo_fwd (0 between launches; launches of one device are stream-ordered)
+_KOLEO_TICKET = {}   # (device index, stream) -> the int32 ticket of apla_koleo_fwd (0 between launches: launches of one stream are ordered)
 
 
 def koleo_fwd(x: torch.Tensor, groups: int, eps: float = 1e-8):
@@ -916,9 +916,10 @@ def koleo_fwd(x: torch.Tensor, groups: int, eps: float = 1e-8):
     if x.dtype not in (torch.float32, half()) or not x.is_contiguous() or groups <= 0 or R % groups or D % 4 or R == 0:
         raise ValueError("koleo_fwd: contiguous x [G*B, D] (fp32 or the build's 16-bit type) with D % 4 == 0 expected")
     dev = x.device
-    ticket = _KOLEO_TICKET.get(dev.index)
+    tkey = (dev.index, _stream())
+    ticket = _KOLEO_TICKET.get(tkey)
     if ticket is None:
-        ticket = _KOLEO_TICKET[dev.index] = torch.zeros(1, device=dev, dtype=torch.int32)
+        ticket = _KOLEO_TICKET[tkey] = torch.zeros(1, device=dev, dtype=torch.int32)
     nn_idx = torch.empty(R, device=dev, dtype=torch.int32)
     f = torch.empty(3, R, device=dev, dtype=torch.float32)    # dist, nrm, terms
     out = torch.empty(groups + 1, device=dev, dtype=torch.float32)
