@@ -143,7 +143,11 @@ __global__ __launch_bounds__(256) void proj_dw_partial_kernel(DwIn in, int nb, i
       m = m < M ? m : M - 1;  // tail rows are zeroed in LDS after they land (below)
       const bf16* src = sub < NJ ? dyg + (size_t)m * r + j0 + sub * 64 + c * 8
                                  : x + (size_t)m * ldx + k0 + (sub - NJ) * 64 + c * 8;
+#if !defined(APLA_ABL_DW_NODMA)   // (diagnostic build: the step without its LDS-DMA)
       __builtin_amdgcn_global_load_lds(DW_GLBP(src), DW_LDSP(st + pc * 1024), 16, 0, 0);
+#else
+      asm volatile("" ::"v"(src));
+#endif
     }
   };
 
@@ -196,6 +200,9 @@ __global__ __launch_bounds__(256) void proj_dw_partial_kernel(DwIn in, int nb, i
         ahi[st][t] = tr_read<2048 * ks + 8192 * (t >> 1)>((t & 1) ? ya11 : ya01);
       });
     };
+#if defined(APLA_ABL_DW_NOMMA)     // (diagnostic build: DMA, waits and barriers only)
+    if (s >= 0) return;
+#endif
     frags(IntC<0>{});
     static_for<0, 4>([&](auto KS) {
       constexpr int ks = KS.value, st = ks & 1;
@@ -239,6 +246,9 @@ __global__ __launch_bounds__(256) void proj_dw_partial_kernel(DwIn in, int nb, i
   }
   // D[j][k]: lane col = k (lane&31), rows j = acc_row(reg, h2).  The tile goes through LDS (the ring is idle now) so that
   // the partial slab is written with 16-byte stores of whole 512-byte rows instead of 32*NJ dword stores per wave.
+#if defined(APLA_ABL_DW_NOEPI)     // (diagnostic build: no partial tile leaves the workgroup)
+  if (acc[0][0] != 123.456f) return;
+#endif
   __syncthreads();
   float* Ts = (float*)smem;  // [64*NJ][128] fp32, row pitch 132 floats (bank spread for the column-wise writes)
 #pragma unroll

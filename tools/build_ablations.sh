@@ -25,6 +25,9 @@ build NODMA gemm_pp2 "-DAPLA_ABL_NODMA"              # K loop without LDS-DMA
 build NOREADNODMA gemm_pp2 "-DAPLA_ABL_NOREAD -DAPLA_ABL_NODMA"   # MFMA + barriers only: the structure's floor
 build SAMEK gemm_pp2 "-DAPLA_ABL_SAMEK"              # LDS-DMA always from the k = 0 slice (cache-resident source)
 build DWRING3 apla_dw "-DAPLA_ABL_DWRING3"           # dW kernel with three stages and one workgroup per CU at every width (round 5's form; results stay right)
+build DW_NOMMA apla_dw "-DAPLA_ABL_DW_NOMMA"         # dW kernel: LDS-DMA, waits and barriers only (no fragment reads, no products)
+build DW_NODMA apla_dw "-DAPLA_ABL_DW_NODMA"         # dW kernel without its LDS-DMA (products on whatever the LDS holds)
+build DW_NOEPI apla_dw "-DAPLA_ABL_DW_NOEPI"         # dW kernel without the partial-tile epilogue
 build DWSLABS apla_dw "-DAPLA_ABL_DWSLABS"           # dW slab count from APLA_DW_SLABS
 # attention backward (tools/attn_split.py under rocprofv3 --kernel-trace --stats, APLA_ATTN variant 1 = split kernels)
 build ATT_NOEXP attention "-DAPLA_ABL_ATT_NOEXP"     # no transcendental in the softmax recompute
